@@ -1,0 +1,121 @@
+/*
+ * zes.h — C-ABI of the MI355X-native DEFLATE engine (drop-in for zlib.es's hot path).
+ *
+ * Every entry point replaces one interface of the reference (zprodev/zlib.es v0.6.0);
+ * the citation after "replaces:" is the reference file:line the entry point stands in for.
+ * Plain pointers and sizes only, no exceptions across the boundary: every function returns
+ * ZES_OK (0) or a negative zes_status.  zes_strerror() returns, for the reference-defined
+ * codes, the exact message string the reference throws, so a binding can rethrow it verbatim
+ * (see INTEGRATION.md for the N-API / ctypes stubs).
+ *
+ * Two families:
+ *   zes_*      — host pointers (what an FFI binding hands over); the library stages through
+ *                its own device buffers (H2D, kernels, D2H).
+ *   zes_*_dev  — device pointers (HBM-resident in/out); nothing crosses PCIe except a few
+ *                scalars.  This is what bench.py times.
+ *
+ * The product path is HIP only.  There is no CPU fallback in this library: without a usable
+ * gfx950 device every compute entry point returns ZES_E_DEVICE.
+ */
+#ifndef ZES_H
+#define ZES_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum zes_status {
+  ZES_OK = 0,
+  /* reference-defined errors (message strings identical to the reference's `throw new Error`) */
+  ZES_E_NOT_DEFLATE = -1,   /* 'Not compressed by deflate'     src/zlib.ts:15               */
+  ZES_E_BTYPE3 = -2,        /* 'Not supported BTYPE : 3'       src/inflate.ts:32            */
+  ZES_E_CORRUPT = -3,       /* 'Data is corrupted'             src/inflate.ts:50,88,166,247,276; src/deflate.ts:172,190,202,216,224 */
+  ZES_E_INSUFFICIENT = -4,  /* 'Data length is insufficient'   src/inflate.ts:35            */
+  ZES_E_LACK = -5,          /* 'Lack of data length'           src/utils/BitReadStream.ts:15, BitWriteStream.ts:15 */
+  /* engine-defined errors (no reference counterpart) */
+  ZES_E_NOSPACE = -16,      /* caller's output capacity too small; *out_len holds the size needed when known */
+  ZES_E_DEVICE = -17,       /* HIP runtime error / no gfx950 device */
+  ZES_E_ARG = -18           /* bad argument (null pointer, size overflow) */
+} zes_status;
+
+/* Geometry of the reference format (src/const.ts:7). */
+#define ZES_BLOCK_LEN 131072u
+
+/* flags for zes_inflate*: */
+#define ZES_F_DEFAULT 0u
+#define ZES_F_NO_FASTPATH 1u   /* force the general (serial, any-stream) decoder: testing aid */
+
+/* Exact reference message for a status (engine-defined codes get a descriptive string). */
+const char* zes_strerror(int status);
+
+/* Library/device lifecycle.  zes_init(device) binds the calling process to one HIP device
+ * (one process per GPU; bench.py passes LOCAL_RANK).  Idempotent.  replaces: nothing (the
+ * reference has no state); required because device scratch is pooled across calls. */
+int zes_init(int device);
+int zes_shutdown(void);
+/* Fills name (<= cap bytes) with the device's gcnArchName, *cus with its CU count. */
+int zes_device_info(char* name, int cap, int* cus, uint64_t* hbm_bytes);
+
+/* Output capacity sufficient for zes_deflate of an n-byte input.
+ * replaces: the `streamHeap` sizing in src/deflate.ts:16 (+6 for the zlib wrapper, src/zlib.ts:42). */
+int zes_deflate_bound(uint64_t n, uint64_t* cap);
+
+/* zlib-wrapped compress: out = 78 9C | raw deflate | Adler-32 BE.  Bit-exact with
+ * replaces: `export function deflate(input)` src/zlib.ts:25-49 (→ src/deflate.ts:14-39, src/lz77.ts, src/huffman.ts:55-153, src/adler32.ts).
+ * n == 0, n == 1 and n % 131072 == 1 return ZES_E_CORRUPT exactly as the reference throws. */
+int zes_deflate(const uint8_t* in, uint64_t n, uint8_t* out, uint64_t cap, uint64_t* out_len);
+int zes_deflate_dev(const uint8_t* d_in, uint64_t n, uint8_t* d_out, uint64_t cap, uint64_t* out_len);
+
+/* zlib-wrapped decompress.
+ * replaces: `export function inflate(input)` src/zlib.ts:11-23 (→ src/inflate.ts:16-292, src/huffman.ts:8-53, src/utils/BitReadStream.ts).
+ * Same accept-set and the same error for every malformed stream (checks only the CM nibble,
+ * ignores FCHECK/FDICT and the Adler-32 trailer).  On ZES_E_NOSPACE *out_len = bytes needed. */
+int zes_inflate(const uint8_t* in, uint64_t c, uint8_t* out, uint64_t cap, uint64_t* out_len, uint32_t flags);
+int zes_inflate_dev(const uint8_t* d_in, uint64_t c, uint8_t* d_out, uint64_t cap, uint64_t* out_len, uint32_t flags);
+/* Size-only pass (decodes, writes nothing to the caller): lets a binding allocate the exact
+ * result the way the reference's growable Uint8WriteStream (src/utils/Uint8WriteStream.ts:1-25) does. */
+int zes_inflate_size(const uint8_t* in, uint64_t c, uint64_t* n, uint32_t flags);
+
+/* Adler-32 of a buffer (standard value as an unsigned 32-bit).
+ * replaces: `calcAdler32` src/adler32.ts:1-10 (byte extraction at src/zlib.ts:37-40). */
+int zes_adler32(const uint8_t* in, uint64_t n, uint32_t* adler);
+int zes_adler32_dev(const uint8_t* d_in, uint64_t n, uint32_t* adler);
+
+/* Batch forms over independent buffers (configs 4/5 of BASELINE.json): count buffers, the
+ * i-th at d_in + in_off[i] with in_len[i] bytes, written to d_out + out_off[i] (capacity
+ * out_cap[i]); out_len[i] and status[i] filled per buffer.  All launches share the stream
+ * so small buffers fill the chip together.  replaces: a caller's loop over deflate()/inflate()
+ * (README.md:28-42) — the reference has no batch API. */
+int zes_deflate_batch_dev(const uint8_t* d_in, const uint64_t* in_off, const uint64_t* in_len,
+                          uint8_t* d_out, const uint64_t* out_off, const uint64_t* out_cap,
+                          uint64_t* out_len, int32_t* status, uint32_t count);
+int zes_inflate_batch_dev(const uint8_t* d_in, const uint64_t* in_off, const uint64_t* in_len,
+                          uint8_t* d_out, const uint64_t* out_off, const uint64_t* out_cap,
+                          uint64_t* out_len, int32_t* status, uint32_t count, uint32_t flags);
+
+/* Stage-level entry points (device pointers) used by the kernel parity tests; each mirrors
+ * one internal function of the reference. */
+/* replaces: generateLZ77Codes src/lz77.ts:24-119 for the block [start, start+len) of an n-byte input.
+ * tokens[i] = literal byte, or 0x80000000 | (len-3) << 16 | (dist-1) for a match. */
+int zes_stage_lz77_dev(const uint8_t* d_in, uint64_t n, uint64_t start, uint32_t len,
+                       uint32_t* h_tokens, uint32_t* ntokens);
+/* replaces: the code-length half of generateDeflateHuffmanTable src/huffman.ts:55-115.
+ * hist[nsym] symbol counts → lens[nsym] code lengths (0 = unused), limit maxlen (15 or 7). */
+int zes_stage_huff_lengths_dev(const uint32_t* h_hist, uint32_t nsym, uint32_t maxlen, uint8_t* h_lens);
+
+/* Timing of the last *_dev call's kernels, measured with HIP events on the library's own
+ * stream: name/ms pairs for bench.py's roofline leg.  Returns the number of entries. */
+typedef struct zes_ktime { const char* name; float ms; uint32_t launches; } zes_ktime;
+int zes_last_kernel_times(zes_ktime* out, int cap);
+int zes_set_profiling(int on);
+
+/* Deterministic integer-only workload generators: host side, used by bench.py,
+ * the tests and the JS fixture script alike. kind: 0 xorshift32 bytes, 1 lowent4k, 2 itext. */
+int zes_gen(uint8_t* out, uint64_t n, uint32_t kind, uint32_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZES_H */

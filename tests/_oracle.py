@@ -1,0 +1,105 @@
+"""ctypes binding of oracle/libzes_oracle.so — the CPU restatement of the reference.
+
+Test infrastructure only (see oracle/zes_oracle.c header): imported by tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the product path.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_LIB = None
+
+MESSAGES = {
+    -1: "Not compressed by deflate",
+    -2: "Not supported BTYPE : 3",
+    -3: "Data is corrupted",
+    -4: "Data length is insufficient",
+    -5: "Lack of data length",
+}
+
+
+def build():
+    so = os.path.join(ROOT, "oracle", "libzes_oracle.so")
+    src = os.path.join(ROOT, "oracle", "zes_oracle.c")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        u8p, u32p, u64p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+        L.zor_adler32.argtypes = [C.c_void_p, C.c_uint64, u32p]
+        L.zor_deflate_bound.argtypes = [C.c_uint64, u64p]
+        L.zor_deflate.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, u64p]
+        L.zor_inflate.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p), u64p]
+        L.zor_inflate_raw.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p), u64p]
+        L.zor_lz77_block.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, u32p]
+        L.zor_huff_lengths.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.zor_free.argtypes = [C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+class OracleError(Exception):
+    def __init__(self, code):
+        self.code = code
+        super().__init__(MESSAGES.get(code, "oracle error %d" % code))
+
+
+def _as_u8(data):
+    a = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def adler32(data):
+    a = _as_u8(data)
+    out = C.c_uint32()
+    lib().zor_adler32(a.ctypes.data, a.size, C.byref(out))
+    return out.value
+
+
+def deflate(data):
+    a = _as_u8(data)
+    cap = C.c_uint64()
+    lib().zor_deflate_bound(a.size, C.byref(cap))
+    out = np.empty(cap.value, dtype=np.uint8)
+    n = C.c_uint64()
+    rc = lib().zor_deflate(a.ctypes.data, a.size, out.ctypes.data, cap.value, C.byref(n))
+    if rc:
+        raise OracleError(rc)
+    return out[: n.value].copy()
+
+
+def inflate(data):
+    a = _as_u8(data)
+    p = C.c_void_p()
+    n = C.c_uint64()
+    rc = lib().zor_inflate(a.ctypes.data, a.size, C.byref(p), C.byref(n))
+    if rc:
+        raise OracleError(rc)
+    out = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(max(n.value, 1),))[: n.value].copy()
+    lib().zor_free(p)
+    return out
+
+
+def lz77_block(data, start, length):
+    a = _as_u8(data)
+    tok = np.empty(length + 4, dtype=np.uint32)
+    nt = C.c_uint32()
+    rc = lib().zor_lz77_block(a.ctypes.data, a.size, start, length, tok.ctypes.data, C.byref(nt))
+    if rc:
+        raise OracleError(rc)
+    return tok[: nt.value].copy()
+
+
+def huff_lengths(hist, maxlen):
+    h = np.ascontiguousarray(hist, dtype=np.uint32)
+    lens = np.zeros(h.size, dtype=np.uint8)
+    lib().zor_huff_lengths(h.ctypes.data, h.size, maxlen, lens.ctypes.data)
+    return lens

@@ -1,0 +1,346 @@
+#!/usr/bin/env node
+/*
+ * make_golden.js — regenerates tests/golden/*.json by RUNNING the reference (zprodev/zlib.es
+ * v0.6.0, bundle dist/cjs/zlib.js) under Node in the build container.
+ *
+ *   node tests/golden/make_golden.js [/root/reference]
+ *
+ * The reference itself is never copied: only inputs (or their generator parameters) and the
+ * outputs it produced are stored.  Internal stages (generateLZ77Codes,
+ * generateDeflateHuffmanTable) are not exported by the bundle; they are reached by evaluating
+ * the bundle text in a function scope with extra exports appended (SURVEY.md §8c) — in memory
+ * only.
+ *
+ * The three generators below restate zlib.es_amd/csrc/zes_gen.c (integer-only, SURVEY App. B);
+ * manifest.json pins sha256 of their outputs so the C and JS versions cannot drift apart.
+ */
+'use strict';
+const fs = require('fs');
+const path = require('path');
+const vm = require('vm');
+const crypto = require('crypto');
+
+const REF = process.argv[2] || '/root/reference';
+const OUT = __dirname;
+const bundlePath = path.join(REF, 'dist', 'cjs', 'zlib.js');
+const src = fs.readFileSync(bundlePath, 'utf8');
+const extra = '\n;exports.__lz=generateLZ77Codes;exports.__huff=generateDeflateHuffmanTable;' +
+  'exports.__canon=generateHuffmanTable;exports.__adler=calcAdler32;';
+const mod = {exports: {}};
+vm.runInThisContext('(function(exports,module,require){' + src + extra + '\n})', {filename: 'ref-bundle'})(
+  mod.exports, mod, require);
+const Z = mod.exports;
+
+const sha = (u8) => crypto.createHash('sha256').update(Buffer.from(u8.buffer, u8.byteOffset, u8.length)).digest('hex');
+const hex = (u8) => Buffer.from(u8.buffer, u8.byteOffset, u8.length).toString('hex');
+const fromHex = (h) => new Uint8Array(Buffer.from(h, 'hex'));
+
+/* ---- generators (mirror of zes_gen.c) ---- */
+function Xs(seed) { this.s = seed >>> 0; }
+Xs.prototype.next = function() {
+  let x = this.s;
+  x ^= x << 13; x >>>= 0;
+  x ^= x >>> 17;
+  x ^= x << 5; x >>>= 0;
+  this.s = x;
+  return x;
+};
+function genXorshift(n, seed) {
+  const g = new Xs(seed), out = new Uint8Array(n);
+  for (let i = 0; i < n; i++) out[i] = g.next() & 0xff;
+  return out;
+}
+function genLowent4k(n, seed) {
+  const pat = genXorshift(4096, seed), out = new Uint8Array(n);
+  for (let i = 0; i < n; i++) out[i] = pat[i & 4095];
+  return out;
+}
+function genItext(n, seed) {
+  const letters = 'etaoinshrdlcumwfgypbvkjxqz';
+  const V = 2048;
+  const g = new Xs(seed ? seed : 1);
+  const words = [];
+  for (let w = 0; w < V; w++) {
+    const len = 1 + (g.next() % 4) + (g.next() % 4) + (g.next() % 3);
+    const word = new Uint8Array(len);
+    for (let k = 0; k < len; k++) {
+      const a = g.next() % 26, b = g.next() % 26;
+      word[k] = letters.charCodeAt(Math.floor((a * b) / 26));
+    }
+    words.push(word);
+  }
+  const out = new Uint8Array(n);
+  let pos = 0, left = 5 + g.next() % 12, cap = true;
+  while (pos < n) {
+    const a = g.next() % V, b = g.next() % V, c = g.next() % V, d = g.next() % V;
+    const idx = Math.floor((Math.floor((Math.floor((a * b) / V) * c) / V) * d) / V);
+    const word = words[idx];
+    for (let k = 0; k < word.length && pos < n; k++) {
+      let ch = word[k];
+      if (cap && k === 0) ch -= 32;
+      out[pos++] = ch;
+    }
+    cap = false;
+    left--;
+    if (left === 0) {
+      if (pos < n) out[pos++] = 46;
+      const r = g.next() % 4;
+      if (pos < n) out[pos++] = (r === 0) ? 10 : 32;
+      cap = true;
+      left = 5 + g.next() % 12;
+    } else {
+      const r = g.next() % 16;
+      if (r === 0 && pos < n) out[pos++] = 44;
+      if (pos < n) out[pos++] = 32;
+    }
+  }
+  return out;
+}
+const GEN = [genXorshift, genLowent4k, genItext];
+const KIND = {xorshift: 0, lowent4k: 1, itext: 2};
+
+function tryCall(f) {
+  try { return {ok: f()}; } catch (e) { return {err: e.message}; }
+}
+
+/* ---- 1. reference test-suite vectors (test/index.js:7-10) + small deflate KATs ---- */
+const RAW = new Uint8Array([84, 104, 105, 115, 32, 105, 115, 32, 122, 108, 105, 98, 46, 101, 115]);
+const KAT = {
+  RAW: hex(RAW),
+  UNCOMPRESSED: hex(new Uint8Array([120, 156, 1, 15, 0, 240, 255, 84, 104, 105, 115, 32, 105, 115, 32, 122, 108, 105, 98, 46, 101, 115, 43, 35, 5, 108])),
+  FIXED: hex(new Uint8Array([120, 156, 11, 201, 200, 44, 86, 0, 162, 170, 156, 204, 36, 189, 212, 98, 0, 43, 35, 5, 108])),
+  DYNAMIC: hex(new Uint8Array([120, 156, 13, 194, 65, 9, 0, 0, 8, 3, 192, 42, 38, 48, 141, 9, 4, 193, 129, 191, 253, 150, 126, 194, 213, 130, 241, 116, 232, 28, 26, 43, 35, 5, 108])),
+};
+for (const k of ['UNCOMPRESSED', 'FIXED', 'DYNAMIC']) {
+  if (hex(Z.inflate(fromHex(KAT[k]))) !== KAT.RAW) throw new Error('reference KAT failed: ' + k);
+}
+/* "Repeat Length Limit" input of test/index.js:89-94 */
+const rep = new Uint8Array(1023);
+for (let i = 0; i < 1023; i++) rep[i] = 48 + (i % 10);
+const smallInputs = {
+  RAW: RAW,
+  AB: new Uint8Array([65, 66]),
+  ABC: new Uint8Array([65, 66, 67]),
+  AAAA: new Uint8Array([65, 65, 65, 65]),
+  zeros10: new Uint8Array(10),
+  zeros1000: new Uint8Array(1000),
+  digits1023: rep,
+  allbytes: Uint8Array.from({length: 512}, (_, i) => i & 255),
+  itext2k: genItext(2048, 7),
+  low300: genLowent4k(9000, 3).subarray(0, 300),
+  rnd777: genXorshift(777, 99),
+};
+const small = {};
+for (const k of Object.keys(smallInputs)) {
+  const o = Z.deflate(smallInputs[k]);
+  if (hex(Z.inflate(o)) !== hex(smallInputs[k])) throw new Error('roundtrip ' + k);
+  small[k] = {input: hex(smallInputs[k]), deflate: hex(o)};
+}
+/* throw cases of deflate (SURVEY A.7) */
+const throwsCases = {};
+for (const n of [0, 1]) throwsCases['n' + n] = tryCall(() => hex(Z.deflate(new Uint8Array(n)))).err || null;
+throwsCases['n131073'] = tryCall(() => hex(Z.deflate(genXorshift(131073, 1)))).err || null;
+fs.writeFileSync(path.join(OUT, 'kat.json'), JSON.stringify({kat: KAT, small: small, deflate_throws: throwsCases}, null, 1));
+
+/* ---- 2. manifest of generated workloads: deflate length + sha256 ---- */
+const manifest = [];
+function addCase(kindName, seed, n) {
+  const input = GEN[KIND[kindName]](n, seed);
+  const r = tryCall(() => Z.deflate(input));
+  const e = {kind: kindName, seed: seed, n: n, input_sha256: sha(input)};
+  if (r.err) { e.error = r.err; } else {
+    e.deflate_len = r.ok.length; e.deflate_sha256 = sha(r.ok);
+    const back = Z.inflate(r.ok);
+    if (sha(back) !== e.input_sha256) throw new Error('reference roundtrip failed');
+  }
+  manifest.push(e);
+  return e;
+}
+const big = process.env.GOLDEN_BIG === '1';
+for (const kn of ['xorshift', 'lowent4k', 'itext']) {
+  for (const n of [2, 3, 100, 4096, 65535, 65536, 131071, 131072, 131074, 131075, 262144, 300000, 1048576]) addCase(kn, 12345, n);
+}
+addCase('xorshift', 1, 131071); addCase('xorshift', 1, 131072); addCase('xorshift', 1, 131074);
+addCase('xorshift', 1, 131073);   /* throws */
+addCase('itext', 1, 4 * 1048576); addCase('lowent4k', 77, 3 * 1048576 + 17); addCase('xorshift', 5, 2 * 1048576 + 5);
+if (big) { addCase('xorshift', 12345, 64 * 1048576); addCase('itext', 12345, 64 * 1048576); addCase('lowent4k', 12345, 64 * 1048576); }
+/* zeros (SURVEY App. B) */
+const zeros = [];
+for (const n of [1000, 65535, 65536, 131072, 262144, 1048576]) {
+  const o = Z.deflate(new Uint8Array(n));
+  zeros.push({n: n, deflate_len: o.length, deflate_sha256: sha(o)});
+}
+/* keep entries from a previous GOLDEN_BIG=1 run when this run is not big */
+let prevBig = [];
+try {
+  const prev = JSON.parse(fs.readFileSync(path.join(OUT, 'manifest.json'), 'utf8'));
+  prevBig = (prev.big || []);
+} catch (e) { /* first run */ }
+const bigEntries = big ? manifest.filter((e) => e.n >= 64 * 1048576) : prevBig;
+fs.writeFileSync(path.join(OUT, 'manifest.json'), JSON.stringify(
+  {cases: manifest.filter((e) => e.n < 64 * 1048576), zeros: zeros, big: bigEntries}, null, 1));
+
+/* ---- 3. stage-level: LZ77 tokens (token = literal byte | 0x80000000|(len-3)<<16|(dist-1)) ---- */
+function lzTokens(input, start, len) {
+  const t = Z.__lz(input, start, len);
+  const out = new Uint32Array(t.length);
+  for (let i = 0; i < t.length; i++) {
+    out[i] = (t[i].length === 1) ? t[i][0] : ((0x80000000 | ((t[i][2] - 3) << 16) | (t[i][3] - 1)) >>> 0);
+  }
+  return out;
+}
+const lz = [];
+function addLz(kindName, seed, n, start, len, full) {
+  const input = GEN[KIND[kindName]](n, seed);
+  const tk = lzTokens(input, start, len);
+  const e = {kind: kindName, seed: seed, n: n, start: start, len: len, ntokens: tk.length,
+    tokens_sha256: sha(new Uint8Array(tk.buffer))};
+  if (full) e.tokens = Array.from(tk);
+  lz.push(e);
+}
+addLz('itext', 7, 3000, 0, 3000, true);
+addLz('lowent4k', 3, 9000, 0, 9000, true);
+addLz('xorshift', 9, 2000, 0, 2000, true);
+addLz('itext', 12345, 300000, 0, 131072, false);       /* halo: compares run past the block end */
+addLz('itext', 12345, 300000, 131072, 131072, false);
+addLz('itext', 12345, 300000, 262144, 37856, false);   /* final short block */
+addLz('lowent4k', 12345, 300000, 131072, 131072, false);
+addLz('lowent4k', 12345, 300000, 262144, 37856, false);
+addLz('xorshift', 12345, 262144, 131072, 131072, false);
+{ /* zeros: the early-exit rule near the end of the input (16/128 candidates) */
+  const input = new Uint8Array(70000);
+  const tk = lzTokens(input, 0, 70000);
+  lz.push({kind: 'zeros', seed: 0, n: 70000, start: 0, len: 70000, ntokens: tk.length,
+    tokens_sha256: sha(new Uint8Array(tk.buffer)), tokens: Array.from(tk)});
+}
+{ /* short period patterns: many candidates, ties resolved towards the nearest */
+  const input = new Uint8Array(5000);
+  for (let i = 0; i < 5000; i++) input[i] = 'abcabcabdabcabcabcabcabxabc'.charCodeAt(i % 27);
+  const tk = lzTokens(input, 0, 5000);
+  lz.push({kind: 'pattern27', seed: 0, n: 5000, start: 0, len: 5000, ntokens: tk.length,
+    tokens_sha256: sha(new Uint8Array(tk.buffer)), tokens: Array.from(tk)});
+}
+fs.writeFileSync(path.join(OUT, 'lz77.json'), JSON.stringify(lz));
+
+/* ---- 4. stage-level: package-merge code lengths ---- */
+const huff = [];
+function addHuff(hist, maxlen) {
+  const values = [];
+  for (let s = 0; s < hist.length; s++) for (let k = 0; k < hist[s]; k++) values.push(s);
+  const tab = Z.__huff(values, maxlen);
+  const lens = new Array(hist.length).fill(0), codes = new Array(hist.length).fill(0);
+  tab.forEach((v, k) => { lens[k] = v.bitlen; codes[k] = v.code; });
+  huff.push({hist: hist, maxlen: maxlen, lens: lens, codes: codes});
+}
+{
+  const g = new Xs(4242);
+  for (let c = 0; c < 40; c++) {
+    const nsym = [286, 30, 19][c % 3], maxlen = (c % 3 === 2) ? 7 : 15;
+    const hist = new Array(nsym).fill(0);
+    const mode = c % 5;
+    for (let s = 0; s < nsym; s++) {
+      const r = g.next();
+      if (mode === 0) hist[s] = r % 50;
+      else if (mode === 1) hist[s] = (r % 7 === 0) ? (r >>> 8) % 3000 : 0;
+      else if (mode === 2) hist[s] = 1 + (r % 2);
+      else if (mode === 3) hist[s] = (r % 3 === 0) ? 0 : (1 << ((r >>> 4) % 12));
+      else hist[s] = (r % 11 === 0) ? 5 : 0;
+    }
+    addHuff(hist, maxlen);
+  }
+  /* Fibonacci-skewed: forces the length limit */
+  for (const spec of [[30, 15], [19, 7], [286, 15]]) {
+    const hist = new Array(spec[0]).fill(0);
+    let a = 1, b = 1;
+    for (let s = 0; s < Math.min(spec[0], 24); s++) { hist[s] = a; const t = a + b; a = b; b = t; }
+    addHuff(hist, spec[1]);
+  }
+  addHuff([0, 0, 5, 0], 15);          /* one symbol */
+  addHuff([0, 0, 0, 0], 15);          /* none */
+  addHuff([3, 3], 15); addHuff([1, 1, 1], 7); addHuff([1, 1, 1, 1, 1], 7);
+  const eq = new Array(286).fill(7); addHuff(eq, 15);   /* all ties: stable-sort order matters */
+}
+fs.writeFileSync(path.join(OUT, 'huffman.json'), JSON.stringify(huff));
+
+/* ---- 5. inflate behaviour on malformed / foreign streams ---- */
+const nodeZlib = require('zlib');
+const inf = [];
+function addInf(name, u8) {
+  const r = tryCall(() => Z.inflate(u8));
+  inf.push(r.err ? {name: name, input: hex(u8), error: r.err} : {name: name, input: hex(u8), output: hex(r.ok)});
+}
+addInf('empty', new Uint8Array(0));
+addInf('one', new Uint8Array([0x78]));
+addInf('hdr_only', new Uint8Array([0x78, 0x9c]));
+addInf('not_deflate', new Uint8Array([0x77, 0x9c, 1, 2, 3]));
+addInf('btype3', new Uint8Array([0x78, 0x9c, 0x07, 0, 0, 0]));
+addInf('btype3_nonfinal', new Uint8Array([0x78, 0x9c, 0x06, 0, 0, 0]));
+addInf('stored_bad_nlen', new Uint8Array([0x78, 0x9c, 1, 5, 0, 0, 0, 1, 2, 3, 4, 5]));
+addInf('stored_trunc', new Uint8Array([0x78, 0x9c, 1, 5, 0, 250, 255, 1, 2]));
+addInf('stored_nonfinal_then_end', new Uint8Array([0x78, 0x9c, 0, 2, 0, 253, 255, 9, 8]));
+addInf('stored_empty_final', new Uint8Array([0x78, 0x9c, 1, 0, 0, 255, 255]));
+addInf('fixed_dist30', new Uint8Array([0x78, 0x9c, 0x4b, 0x04, 0x7a, 0x00, 0x00]));
+const base = {
+  dyn: Z.deflate(genItext(400, 5)),
+  dyn2: Z.deflate(genLowent4k(700, 9).subarray(0, 700)),
+  kat_dyn: fromHex(KAT.DYNAMIC), kat_fix: fromHex(KAT.FIXED), kat_unc: fromHex(KAT.UNCOMPRESSED),
+  node_fixed: new Uint8Array(nodeZlib.deflateSync(Buffer.from(genItext(300, 11)), {strategy: nodeZlib.constants.Z_FIXED})),
+  node_l9: new Uint8Array(nodeZlib.deflateSync(Buffer.from(genItext(5000, 12)), {level: 9})),
+  node_l0: new Uint8Array(nodeZlib.deflateSync(Buffer.from(genXorshift(300, 13)), {level: 0})),
+  node_zeros: new Uint8Array(nodeZlib.deflateSync(Buffer.alloc(3000), {level: 6})),
+};
+for (const k of Object.keys(base)) {
+  const b = base[k];
+  addInf(k + '_ok', b);
+  addInf(k + '_garbage_tail', Uint8Array.from([...b, 1, 2, 3, 4, 5, 6, 7]));
+  /* every truncation length of the small ones, a sample for the larger */
+  const step = b.length > 120 ? Math.ceil(b.length / 60) : 1;
+  for (let L = 2; L < b.length; L += step) addInf(k + '_trunc' + L, b.subarray(0, L));
+  /* deterministic bit flips */
+  const g = new Xs(1000 + b.length);
+  for (let t = 0; t < 40; t++) {
+    const c = Uint8Array.from(b);
+    const pos = 2 + (g.next() % (b.length - 2));
+    c[pos] ^= 1 << (g.next() % 8);
+    addInf(k + '_flip' + pos + '_' + t, c);
+  }
+}
+/* random garbage bodies behind a valid header nibble */
+{
+  const g = new Xs(31337);
+  for (let t = 0; t < 120; t++) {
+    const len = 3 + (g.next() % 60);
+    const c = new Uint8Array(len);
+    c[0] = 0x78; c[1] = 0x9c;
+    for (let i = 2; i < len; i++) c[i] = g.next() & 0xff;
+    if (t % 3 === 0) c[2] = (c[2] & 0xf8) | 5;      /* force BFINAL=1, BTYPE=2 */
+    if (t % 3 === 1) c[2] = (c[2] & 0xf8) | 3;      /* BFINAL=1, BTYPE=1 */
+    addInf('garbage' + t, c);
+  }
+}
+fs.writeFileSync(path.join(OUT, 'inflate_cases.json'), JSON.stringify(inf));
+
+/* ---- 6. foreign multi-block streams (other compressor: Node's zlib), sha-pinned ---- */
+const foreign = [];
+for (const spec of [['itext', 21, 300000, 6], ['lowent4k', 22, 200000, 1], ['xorshift', 23, 100000, 6], ['itext', 24, 1048576, 9]]) {
+  const input = GEN[KIND[spec[0]]](spec[2], spec[1]);
+  const comp = new Uint8Array(nodeZlib.deflateSync(Buffer.from(input), {level: spec[3]}));
+  const back = Z.inflate(comp);
+  if (sha(back) !== sha(input)) throw new Error('reference failed on foreign stream');
+  const name = 'foreign_' + spec[0] + '_' + spec[2] + '.zz';
+  fs.writeFileSync(path.join(OUT, name), Buffer.from(comp));
+  foreign.push({file: name, kind: spec[0], seed: spec[1], n: spec[2], output_sha256: sha(back)});
+}
+fs.writeFileSync(path.join(OUT, 'foreign.json'), JSON.stringify(foreign, null, 1));
+
+/* ---- 7. the reference suite's own binary fixtures (data, not source): sha + deflate pin ---- */
+{
+  const rawBin = new Uint8Array(fs.readFileSync(path.join(REF, 'test', 'data', 'raw.bin')));
+  const cmpBin = new Uint8Array(fs.readFileSync(path.join(REF, 'test', 'data', 'compressed.bin')));
+  const o = Z.deflate(rawBin);
+  const inflated = Z.inflate(cmpBin);
+  fs.writeFileSync(path.join(OUT, 'ref_data.json'), JSON.stringify({
+    raw_len: rawBin.length, raw_sha256: sha(rawBin), compressed_len: cmpBin.length, compressed_sha256: sha(cmpBin),
+    inflate_of_compressed_sha256: sha(inflated), deflate_of_raw_len: o.length, deflate_of_raw_sha256: sha(o)}, null, 1));
+}
+console.log('golden fixtures written to', OUT, ' cases:', manifest.length, 'inflate cases:', inf.length);
