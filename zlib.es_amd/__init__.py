@@ -1,0 +1,249 @@
+"""zlib.es_amd — Python host mirror of zlib.es's API over the MI355X DEFLATE engine.
+
+The reference's public surface is two functions (``/root/reference/src/zlib.ts:11,25``):
+
+    deflate(input: Uint8Array): Uint8Array
+    inflate(input: Uint8Array): Uint8Array
+
+both synchronous, both throwing plain ``Error`` with fixed messages.  This module keeps the
+same names, argument meaning and error strings (``ZlibEsError.args[0]`` is the reference's
+message) and routes every call through the C-ABI of ``include/zes.h`` (``libzes_hip.so``:
+hand-written gfx950 kernels).  There is no CPU implementation here: if the library is missing
+or no GPU is usable the call raises, it never falls back.
+
+The directory name contains a dot, so it cannot be imported with a plain ``import``; load it
+with ``importlib`` (see ``load()`` in ``__graft_entry__.py``) under the module name
+``zlibes_amd``.
+
+Host code in the reference's own language (TypeScript on Node over N-API) lives in
+``zlib.es_amd/host/``; this Python mirror drives the same C-ABI for pytest, bench.py and
+torch.distributed sharding.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libzes_hip.so")
+_lib = None
+
+BLOCK_MAX_BUFFER_LEN = 131072  # src/const.ts:7
+
+ZES_OK = 0
+ZES_E_NOSPACE = -16
+ZES_E_DEVICE = -17
+ZES_E_ARG = -18
+ZES_F_NO_FASTPATH = 1
+
+GEN_KINDS = {"xorshift": 0, "lowent4k": 1, "itext": 2}
+
+
+class ZlibEsError(Exception):
+    """Mirror of the reference's ``throw new Error(message)``; ``.code`` is the zes_status."""
+
+    def __init__(self, code, message):
+        super().__init__(message)
+        self.code = code
+
+
+class ZesKTime(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("ms", C.c_float), ("launches", C.c_uint32)]
+
+
+def build(force=False):
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    srcdir = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.check_call(["make", "-s", "-C", srcdir, "clean"])
+    subprocess.check_call(["make", "-s", "-j4", "-C", srcdir])
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(
+                "zlib.es_amd: %s is missing — run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback)" % _LIB_PATH)
+        L = C.CDLL(_LIB_PATH)
+        u64p, u32p, i32p = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_int32)
+        L.zes_strerror.restype = C.c_char_p
+        L.zes_strerror.argtypes = [C.c_int]
+        L.zes_init.argtypes = [C.c_int]
+        L.zes_device_info.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int), u64p]
+        L.zes_deflate_bound.argtypes = [C.c_uint64, u64p]
+        for name in ("zes_deflate", "zes_deflate_dev"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, u64p]
+        for name in ("zes_inflate", "zes_inflate_dev"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, u64p, C.c_uint32]
+        L.zes_inflate_size.argtypes = [C.c_void_p, C.c_uint64, u64p, C.c_uint32]
+        L.zes_adler32.argtypes = [C.c_void_p, C.c_uint64, u32p]
+        L.zes_adler32_dev.argtypes = [C.c_void_p, C.c_uint64, u32p]
+        L.zes_deflate_batch_dev.argtypes = [C.c_void_p, u64p, u64p, C.c_void_p, u64p, u64p, u64p, i32p, C.c_uint32]
+        L.zes_inflate_batch_dev.argtypes = [C.c_void_p, u64p, u64p, C.c_void_p, u64p, u64p, u64p, i32p, C.c_uint32,
+                                            C.c_uint32]
+        L.zes_stage_lz77_dev.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, u32p]
+        L.zes_stage_huff_lengths_dev.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.zes_last_kernel_times.argtypes = [C.POINTER(ZesKTime), C.c_int]
+        L.zes_set_profiling.argtypes = [C.c_int]
+        L.zes_gen.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32]
+        _lib = L
+    return _lib
+
+
+def strerror(code):
+    return lib().zes_strerror(code).decode()
+
+
+def _raise(code):
+    raise ZlibEsError(code, strerror(code))
+
+
+def init(device=0):
+    rc = lib().zes_init(int(device))
+    if rc:
+        _raise(rc)
+
+
+def device_info():
+    name = C.create_string_buffer(64)
+    cus = C.c_int()
+    hbm = C.c_uint64()
+    rc = lib().zes_device_info(name, 64, C.byref(cus), C.byref(hbm))
+    if rc:
+        _raise(rc)
+    return {"arch": name.value.decode(), "cus": cus.value, "hbm_bytes": hbm.value}
+
+
+def gen(kind, seed, n):
+    """Deterministic workload bytes (xorshift / lowent4k / itext), as a numpy uint8 array."""
+    out = np.empty(n, dtype=np.uint8)
+    rc = lib().zes_gen(out.ctypes.data, n, GEN_KINDS[kind] if isinstance(kind, str) else int(kind), int(seed) & 0xFFFFFFFF)
+    if rc:
+        _raise(rc)
+    return out
+
+
+def _as_u8(data):
+    if isinstance(data, np.ndarray):
+        return np.ascontiguousarray(data, dtype=np.uint8)
+    return np.frombuffer(bytes(data), dtype=np.uint8)
+
+
+def deflate_bound(n):
+    cap = C.c_uint64()
+    lib().zes_deflate_bound(n, C.byref(cap))
+    return cap.value
+
+
+# ---- host-buffer API: the drop-in pair ------------------------------------------------------
+def deflate(data):
+    """``deflate(input)`` of src/zlib.ts:25 — zlib-wrapped, bit-exact; returns a fresh uint8 array."""
+    a = _as_u8(data)
+    cap = deflate_bound(a.size)
+    out = np.empty(cap, dtype=np.uint8)
+    n = C.c_uint64()
+    rc = lib().zes_deflate(a.ctypes.data, a.size, out.ctypes.data, cap, C.byref(n))
+    if rc:
+        _raise(rc)
+    return out[: n.value].copy()
+
+
+def inflate(data, flags=0):
+    """``inflate(input)`` of src/zlib.ts:11 — same accept-set and errors as the reference."""
+    a = _as_u8(data)
+    need = C.c_uint64()
+    rc = lib().zes_inflate_size(a.ctypes.data, a.size, C.byref(need), flags)
+    if rc:
+        _raise(rc)
+    out = np.empty(max(need.value, 1), dtype=np.uint8)
+    n = C.c_uint64()
+    rc = lib().zes_inflate(a.ctypes.data, a.size, out.ctypes.data, need.value, C.byref(n), flags)
+    if rc:
+        _raise(rc)
+    return out[: n.value].copy()
+
+
+def adler32(data):
+    a = _as_u8(data)
+    out = C.c_uint32()
+    rc = lib().zes_adler32(a.ctypes.data, a.size, C.byref(out))
+    if rc:
+        _raise(rc)
+    return out.value
+
+
+# ---- HBM-resident API (torch uint8 CUDA tensors; torch is plumbing for device memory) --------
+def deflate_tensor(t, out=None):
+    """Compress a 1-D uint8 CUDA tensor; returns a view of ``out`` (allocated if None)."""
+    import torch
+
+    assert t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous()
+    cap = deflate_bound(t.numel())
+    if out is None:
+        out = torch.empty(cap, dtype=torch.uint8, device=t.device)
+    assert out.numel() >= cap
+    torch.cuda.current_stream(t.device).synchronize()  # the library runs on its own stream
+    n = C.c_uint64()
+    rc = lib().zes_deflate_dev(t.data_ptr(), t.numel(), out.data_ptr(), out.numel(), C.byref(n))
+    if rc:
+        _raise(rc)
+    return out[: n.value]
+
+
+def inflate_tensor(t, out, flags=0):
+    """Decompress a 1-D uint8 CUDA tensor into ``out``; returns the filled view of ``out``."""
+    import torch
+
+    assert t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous()
+    torch.cuda.current_stream(t.device).synchronize()
+    n = C.c_uint64()
+    rc = lib().zes_inflate_dev(t.data_ptr(), t.numel(), out.data_ptr(), out.numel(), C.byref(n), flags)
+    if rc == ZES_E_NOSPACE:
+        raise ZlibEsError(rc, "%s (need %d bytes)" % (strerror(rc), n.value))
+    if rc:
+        _raise(rc)
+    return out[: n.value]
+
+
+def adler32_tensor(t):
+    import torch
+
+    torch.cuda.current_stream(t.device).synchronize()
+    out = C.c_uint32()
+    rc = lib().zes_adler32_dev(t.data_ptr(), t.numel(), C.byref(out))
+    if rc:
+        _raise(rc)
+    return out.value
+
+
+def set_profiling(on):
+    lib().zes_set_profiling(1 if on else 0)
+
+
+def last_kernel_times():
+    arr = (ZesKTime * 32)()
+    n = lib().zes_last_kernel_times(arr, 32)
+    return [(arr[i].name.decode(), float(arr[i].ms), int(arr[i].launches)) for i in range(n)]
+
+
+# ---- stage-level entries used by the kernel parity tests -------------------------------------
+def stage_lz77_tensor(t, start, length):
+    tok = np.empty(length + 4, dtype=np.uint32)
+    nt = C.c_uint32()
+    rc = lib().zes_stage_lz77_dev(t.data_ptr(), t.numel(), start, length, tok.ctypes.data, C.byref(nt))
+    if rc:
+        _raise(rc)
+    return tok[: nt.value].copy()
+
+
+def stage_huff_lengths(hist, maxlen):
+    h = np.ascontiguousarray(hist, dtype=np.uint32)
+    lens = np.zeros(h.size, dtype=np.uint8)
+    rc = lib().zes_stage_huff_lengths_dev(h.ctypes.data, h.size, maxlen, lens.ctypes.data)
+    if rc:
+        _raise(rc)
+    return lens

@@ -1,0 +1,677 @@
+// zes_api.hip — host side of the C-ABI declared in include/zes.h.
+//
+// One process drives one GPU (zes_init(device)); all launches go to one private HIP stream.
+// Device scratch is pooled and only grows.  No CPU fallback exists here: every compute entry
+// point needs a working gfx950 device and returns ZES_E_DEVICE otherwise.
+#include "../../include/zes.h"
+#include "zes_kernels.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+extern "C" int zes_gen(uint8_t* out, uint64_t n, uint32_t kind, uint32_t seed);
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+struct KTime {
+  double ms = 0;
+  uint32_t launches = 0;
+};
+
+struct Ctx {
+  bool ready = false;
+  int device = -1;
+  hipStream_t stream = nullptr;
+  // deflate scratch
+  DevBuf bufs, blks, idx_a, idx_b, hists, codes, hdrs, adler, res;
+  // inflate scratch
+  DevBuf surv, cand, cand_sorted, counters, cres, map, resume;
+  // staging for the host-pointer API
+  DevBuf st_in, st_out;
+  void* pinned = nullptr;  // small pinned area for read-backs
+  size_t pinned_cap = 0;
+  // profiling
+  bool profiling = false;
+  std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending;
+  std::vector<std::pair<std::string, KTime>> last_times;
+  std::vector<std::string> name_pool;
+  char arch[64] = {0};
+  int cus = 0;
+  uint64_t hbm = 0;
+};
+
+Ctx g;
+std::mutex g_mu;
+
+#define HIPCHK(x)                                                                              \
+  do {                                                                                         \
+    hipError_t e_ = (x);                                                                       \
+    if (e_ != hipSuccess) {                                                                    \
+      if (getenv("ZES_DEBUG")) fprintf(stderr, "zes: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return ZES_E_DEVICE;                                                                     \
+    }                                                                                          \
+  } while (0)
+
+int ensure(DevBuf& b, size_t bytes) {
+  if (bytes <= b.cap) return ZES_OK;
+  if (b.p) HIPCHK(hipFree(b.p));
+  b.p = nullptr;
+  b.cap = 0;
+  size_t want = bytes + bytes / 8 + 4096;
+  HIPCHK(hipMalloc(&b.p, want));
+  b.cap = want;
+  return ZES_OK;
+}
+
+int init_locked(int device) {
+  if (g.ready) return (device < 0 || device == g.device) ? ZES_OK : ZES_E_ARG;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return ZES_E_DEVICE;
+  if (device < 0) device = 0;
+  if (device >= n) return ZES_E_DEVICE;
+  HIPCHK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  snprintf(g.arch, sizeof g.arch, "%s", prop.gcnArchName);
+  g.cus = prop.multiProcessorCount;
+  g.hbm = prop.totalGlobalMem;
+  HIPCHK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+  g.pinned_cap = 1 << 16;
+  HIPCHK(hipHostMalloc(&g.pinned, g.pinned_cap, hipHostMallocDefault));
+  g.device = device;
+  g.ready = true;
+  return ZES_OK;
+}
+
+// ---- kernel timing (HIP events on the library's stream) ----
+struct Timed {
+  hipEvent_t a = nullptr, b = nullptr;
+  const char* name;
+  explicit Timed(const char* n) : name(n) {
+    if (g.profiling) {
+      hipEventCreate(&a);
+      hipEventCreate(&b);
+      hipEventRecord(a, g.stream);
+    }
+  }
+  ~Timed() {
+    if (g.profiling) {
+      hipEventRecord(b, g.stream);
+      g.pending.push_back({name, {a, b}});
+    }
+  }
+};
+
+void collect_times() {
+  if (!g.profiling) return;
+  std::map<std::string, KTime> acc;
+  std::vector<std::string> order;
+  for (auto& p : g.pending) {
+    float ms = 0;
+    hipEventSynchronize(p.second.second);
+    hipEventElapsedTime(&ms, p.second.first, p.second.second);
+    if (!acc.count(p.first)) order.push_back(p.first);
+    acc[p.first].ms += ms;
+    acc[p.first].launches++;
+    hipEventDestroy(p.second.first);
+    hipEventDestroy(p.second.second);
+  }
+  g.pending.clear();
+  g.last_times.clear();
+  for (auto& n : order) g.last_times.push_back({n, acc[n]});
+}
+
+// ---- deflate ----
+bool deflate_throws(uint64_t n) { return n == 0 || n == 1 || (n % ZES_BLK) == 1; }
+uint64_t deflate_bound(uint64_t n) { return ((n < ZES_BLK / 2) ? (uint64_t)ZES_BLK : n * 2) + 6; }
+
+// Core: count buffers inside d_in / d_out.  Buffers whose status[] comes back non-zero were
+// rejected on the host (throw cases, capacity) and are skipped by the device pass.
+int deflate_batch_core(const uint8_t* d_in, const uint64_t* in_off, const uint64_t* in_len, uint8_t* d_out,
+                       const uint64_t* out_off, const uint64_t* out_cap, uint64_t* out_len, int32_t* status,
+                       uint32_t count) {
+  std::vector<ZesBuf> hb;
+  std::vector<ZesBlk> hk;
+  std::vector<uint32_t> live;
+  hb.reserve(count);
+  for (uint32_t i = 0; i < count; i++) {
+    out_len[i] = 0;
+    if (deflate_throws(in_len[i])) {
+      status[i] = ZES_E_CORRUPT;
+      continue;
+    }
+    if (out_cap[i] < deflate_bound(in_len[i])) {
+      status[i] = ZES_E_NOSPACE;
+      out_len[i] = deflate_bound(in_len[i]);
+      continue;
+    }
+    if ((out_off[i] & 15u) || (((uintptr_t)d_out) & 15u)) {
+      status[i] = ZES_E_ARG;
+      continue;
+    }
+    status[i] = ZES_OK;
+    ZesBuf b;
+    b.in_off = in_off[i];
+    b.n = in_len[i];
+    b.out_off = out_off[i];
+    b.cap = out_cap[i];
+    b.first_blk = (uint32_t)hk.size();
+    b.nblk = (uint32_t)((in_len[i] + ZES_BLK - 1) / ZES_BLK);
+    for (uint32_t k = 0; k < b.nblk; k++) {
+      ZesBlk z;
+      memset(&z, 0, sizeof z);
+      z.buf = (uint32_t)hb.size();
+      z.blk = k;
+      const uint64_t s = (uint64_t)k * ZES_BLK;
+      z.len = (uint32_t)std::min<uint64_t>(ZES_BLK, in_len[i] - s);
+      hk.push_back(z);
+    }
+    hb.push_back(b);
+    live.push_back(i);
+  }
+  if (hb.empty()) return ZES_OK;
+  const uint32_t nbuf = (uint32_t)hb.size(), nblk = (uint32_t)hk.size();
+  int rc;
+  if ((rc = ensure(g.bufs, sizeof(ZesBuf) * nbuf))) return rc;
+  if ((rc = ensure(g.blks, sizeof(ZesBlk) * nblk))) return rc;
+  if ((rc = ensure(g.idx_a, (size_t)nblk * ZES_BLK * 4))) return rc;
+  if ((rc = ensure(g.idx_b, (size_t)nblk * ZES_BLK * 4))) return rc;
+  if ((rc = ensure(g.hists, (size_t)nblk * 320 * 4))) return rc;
+  if ((rc = ensure(g.codes, (size_t)nblk * 320 * 4))) return rc;
+  if ((rc = ensure(g.hdrs, (size_t)nblk * ZES_HDR_WORDS * 4))) return rc;
+  if ((rc = ensure(g.adler, (size_t)nbuf * 16))) return rc;
+  if ((rc = ensure(g.res, sizeof(ZesRes) * nbuf))) return rc;
+  HIPCHK(hipMemcpyAsync(g.bufs.p, hb.data(), sizeof(ZesBuf) * nbuf, hipMemcpyHostToDevice, g.stream));
+  HIPCHK(hipMemcpyAsync(g.blks.p, hk.data(), sizeof(ZesBlk) * nblk, hipMemcpyHostToDevice, g.stream));
+  // the H2D sources are host vectors: make sure the copies are done before they go out of scope
+  // (pageable memcpyAsync is staged synchronously by the runtime, the sync below covers the rest)
+  ZesBuf* dbufs = (ZesBuf*)g.bufs.p;
+  ZesBlk* dblks = (ZesBlk*)g.blks.p;
+  uint32_t* idx_a = (uint32_t*)g.idx_a.p;
+  uint32_t* idx_b = (uint32_t*)g.idx_b.p;
+  unsigned long long* adler = (unsigned long long*)g.adler.p;
+  {
+    Timed t("k_zero");
+    hipLaunchKernelGGL(k_zero_u64, dim3((nbuf * 2 + 255) / 256), dim3(256), 0, g.stream, adler, nbuf * 2);
+  }
+  {
+    Timed t("k_adler");
+    for (uint32_t b = 0; b < nbuf; b++) {
+      const uint32_t nch = (uint32_t)((hb[b].n + ADLER_CHUNK - 1) / ADLER_CHUNK);
+      hipLaunchKernelGGL(k_adler, dim3(nch), dim3(ADLER_THREADS), 0, g.stream, d_in, hb[b].in_off, hb[b].n, adler + 2 * b);
+    }
+  }
+  {
+    Timed t("k_lz_sort");
+    hipLaunchKernelGGL(k_lz_sort, dim3(nblk), dim3(SORT_THREADS), 0, g.stream, d_in, dbufs, dblks, idx_a, idx_b);
+  }
+  {
+    Timed t("k_lz_match");  // match words go to idx_b (free after the sort)
+    hipLaunchKernelGGL(k_lz_match, dim3(nblk), dim3(MATCH_THREADS), 0, g.stream, d_in, dbufs, dblks, idx_a, idx_b);
+  }
+  {
+    Timed t("k_lz_parse");  // tokens go to idx_a (free after the match pass)
+    hipLaunchKernelGGL(k_lz_parse, dim3(nblk), dim3(64), 0, g.stream, d_in, dbufs, dblks, idx_b, idx_a, (uint32_t*)g.hists.p);
+  }
+  {
+    Timed t("k_huff");
+    hipLaunchKernelGGL(k_huff, dim3(nblk), dim3(HUFF_THREADS_HOST), 0, g.stream, dblks, (const uint32_t*)g.hists.p,
+                       (uint32_t*)g.codes.p, (uint32_t*)g.hdrs.p);
+  }
+  {
+    Timed t("k_layout");
+    hipLaunchKernelGGL(k_layout, dim3(nbuf), dim3(256), 0, g.stream, d_out, dbufs, dblks, adler, (ZesRes*)g.res.p);
+  }
+  {
+    Timed t("k_emit");
+    hipLaunchKernelGGL(k_emit, dim3(nblk), dim3(EMIT_THREADS), 0, g.stream, d_out, dbufs, dblks, idx_a,
+                       (const uint32_t*)g.codes.p, (const uint32_t*)g.hdrs.p);
+  }
+  HIPCHK(hipGetLastError());
+  if (sizeof(ZesRes) * nbuf > g.pinned_cap) {
+    HIPCHK(hipHostFree(g.pinned));
+    g.pinned_cap = sizeof(ZesRes) * nbuf * 2;
+    HIPCHK(hipHostMalloc(&g.pinned, g.pinned_cap, hipHostMallocDefault));
+  }
+  HIPCHK(hipMemcpyAsync(g.pinned, g.res.p, sizeof(ZesRes) * nbuf, hipMemcpyDeviceToHost, g.stream));
+  HIPCHK(hipStreamSynchronize(g.stream));
+  collect_times();
+  const ZesRes* r = (const ZesRes*)g.pinned;
+  for (uint32_t k = 0; k < nbuf; k++) {
+    out_len[live[k]] = r[k].out_len;
+    status[live[k]] = r[k].status;
+  }
+  return ZES_OK;
+}
+
+// ---- inflate ----
+int read_res(ZesRes* out) {
+  HIPCHK(hipMemcpyAsync(g.pinned, g.res.p, sizeof(ZesRes), hipMemcpyDeviceToHost, g.stream));
+  HIPCHK(hipStreamSynchronize(g.stream));
+  *out = *(const ZesRes*)g.pinned;
+  return ZES_OK;
+}
+
+// One buffer at d_in+in_off (16-byte aligned), result at d_out+out_off (16-byte aligned).
+// Returns the reference-equivalent status; *out_len = bytes produced (or needed on NOSPACE).
+int inflate_one(const uint8_t* d_in, uint64_t in_off, uint64_t c, uint8_t* d_out, uint64_t out_off, uint64_t cap,
+                uint64_t* out_len, uint32_t flags, uint8_t first_byte) {
+  *out_len = 0;
+  if (c == 0 || (first_byte & 15u) != 8u) return ZES_E_NOT_DEFLATE;  // src/zlib.ts:13-16
+  int rc;
+  if ((rc = ensure(g.res, sizeof(ZesRes)))) return rc;
+  if ((rc = ensure(g.resume, 16))) return rc;
+  ZesRes hr;
+  bool have_resume = false;
+  const bool fast_ok = !(flags & ZES_F_NO_FASTPATH) && c >= 64 && c < (1ull << 29);
+  if (fast_ok) {
+    const uint32_t surv_cap = (uint32_t)(c / 4 + 1024);
+    const uint32_t cand_cap = (uint32_t)(c / 64 + 64);
+    if ((rc = ensure(g.surv, (size_t)surv_cap * 4))) return rc;
+    if ((rc = ensure(g.cand, (size_t)cand_cap * 4))) return rc;
+    if ((rc = ensure(g.cand_sorted, (size_t)cand_cap * 4))) return rc;
+    if ((rc = ensure(g.counters, 16))) return rc;
+    HIPCHK(hipMemsetAsync(g.counters.p, 0, 16, g.stream));
+    {
+      Timed t("k_inf_scan");
+      const uint32_t nwg = (uint32_t)((c + INF_SCAN_BYTES - 1) / INF_SCAN_BYTES);
+      hipLaunchKernelGGL(k_inf_scan, dim3(nwg), dim3(INF_SCAN_THREADS), 0, g.stream, d_in, in_off, c, (uint32_t*)g.surv.p,
+                         surv_cap, (uint32_t*)g.counters.p);
+    }
+    uint32_t* hc = (uint32_t*)g.pinned;
+    HIPCHK(hipMemcpyAsync(hc, g.counters.p, 16, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    uint32_t nsurv = hc[0];
+    bool t1 = nsurv > 0 && nsurv <= surv_cap;
+    uint32_t ncand = 0;
+    if (t1) {
+      {
+        Timed t("k_inf_verify");
+        hipLaunchKernelGGL(k_inf_verify, dim3((nsurv + 63) / 64), dim3(64), 0, g.stream, d_in, in_off, c,
+                           (const uint32_t*)g.surv.p, surv_cap, (uint32_t*)g.counters.p, (uint32_t*)g.cand.p, cand_cap);
+      }
+      HIPCHK(hipMemcpyAsync(hc, g.counters.p, 16, hipMemcpyDeviceToHost, g.stream));
+      HIPCHK(hipStreamSynchronize(g.stream));
+      ncand = hc[1];
+      t1 = ncand > 0 && ncand <= cand_cap;
+    }
+    if (t1) {
+      if ((rc = ensure(g.cres, sizeof(ZesCandRes) * ncand))) return rc;
+      if ((rc = ensure(g.map, (size_t)ncand * 4))) return rc;
+      {
+        Timed t("k_inf_ranksort");
+        hipLaunchKernelGGL(k_inf_ranksort, dim3((ncand + 255) / 256), dim3(256), 0, g.stream, (const uint32_t*)g.cand.p, ncand,
+                           (uint32_t*)g.cand_sorted.p);
+      }
+      {
+        Timed t("k_inf_decode");
+        hipLaunchKernelGGL(k_inf_decode, dim3(ncand), dim3(64), 0, g.stream, d_in, in_off, c, d_out, out_off, cap,
+                           (const uint32_t*)g.cand_sorted.p, (const uint32_t*)nullptr, ncand, (ZesCandRes*)g.cres.p,
+                           (ZesRes*)g.res.p, (uint64_t*)g.resume.p, 0);
+      }
+      {
+        Timed t("k_inf_chain");
+        hipLaunchKernelGGL(k_inf_chain, dim3(1), dim3(64), 0, g.stream, (const uint32_t*)g.cand_sorted.p, ncand,
+                           (const ZesCandRes*)g.cres.p, (const uint32_t*)nullptr, ncand, (uint32_t*)g.map.p, (ZesRes*)g.res.p);
+      }
+      if ((rc = read_res(&hr))) return rc;
+      if (hr.status == 2) {  // false positives shifted the slots: decode the chain again, in order
+        const uint32_t K = hr.aux;
+        {
+          Timed t("k_inf_decode");
+          hipLaunchKernelGGL(k_inf_decode, dim3(K), dim3(64), 0, g.stream, d_in, in_off, c, d_out, out_off, cap,
+                             (const uint32_t*)g.cand_sorted.p, (const uint32_t*)g.map.p, K, (ZesCandRes*)g.cres.p,
+                             (ZesRes*)g.res.p, (uint64_t*)g.resume.p, 0);
+        }
+        {
+          Timed t("k_inf_chain");
+          hipLaunchKernelGGL(k_inf_chain, dim3(1), dim3(64), 0, g.stream, (const uint32_t*)g.cand_sorted.p, ncand,
+                             (const ZesCandRes*)g.cres.p, (const uint32_t*)g.map.p, K, (uint32_t*)g.map.p, (ZesRes*)g.res.p);
+        }
+        if ((rc = read_res(&hr))) return rc;
+      }
+      if (hr.status == 0) {
+        collect_times();
+        *out_len = hr.out_len;
+        return hr.out_len > cap ? ZES_E_NOSPACE : ZES_OK;
+      }
+    }
+  }
+  // T2: one wavefront, any valid stream
+  if (c >= 3) {
+    Timed t("k_inf_decode_seq");
+    hipLaunchKernelGGL(k_inf_decode, dim3(1), dim3(64), 0, g.stream, d_in, in_off, c, d_out, out_off, cap,
+                       (const uint32_t*)nullptr, (const uint32_t*)nullptr, 1u, (ZesCandRes*)nullptr, (ZesRes*)g.res.p,
+                       (uint64_t*)g.resume.p, 1);
+  }
+  if (c >= 3) {
+    if ((rc = read_res(&hr))) return rc;
+    if (hr.status == 0) {
+      collect_times();
+      *out_len = hr.out_len;
+      return hr.out_len > cap ? ZES_E_NOSPACE : ZES_OK;
+    }
+    have_resume = true;
+  }
+  // T3: exact restatement from the failing block on
+  {
+    Timed t("k_inf_exact");
+    hipLaunchKernelGGL(k_inf_exact, dim3(1), dim3(64), 0, g.stream, d_in, in_off, c, d_out, out_off, cap,
+                       have_resume ? (const uint64_t*)g.resume.p : (const uint64_t*)nullptr, (ZesRes*)g.res.p);
+  }
+  if ((rc = read_res(&hr))) return rc;
+  collect_times();
+  *out_len = hr.out_len;
+  return hr.status;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// C-ABI
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* zes_strerror(int status) {
+  switch (status) {
+    case ZES_OK: return "ok";
+    case ZES_E_NOT_DEFLATE: return "Not compressed by deflate";
+    case ZES_E_BTYPE3: return "Not supported BTYPE : 3";
+    case ZES_E_CORRUPT: return "Data is corrupted";
+    case ZES_E_INSUFFICIENT: return "Data length is insufficient";
+    case ZES_E_LACK: return "Lack of data length";
+    case ZES_E_NOSPACE: return "zes: output capacity too small";
+    case ZES_E_DEVICE: return "zes: HIP device error (no gfx950 device or runtime failure)";
+    case ZES_E_ARG: return "zes: bad argument";
+    default: return "zes: unknown status";
+  }
+}
+
+int zes_init(int device) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  return init_locked(device);
+}
+
+int zes_shutdown(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g.ready) return ZES_OK;
+  hipStreamSynchronize(g.stream);
+  DevBuf* all[] = {&g.bufs, &g.blks, &g.idx_a, &g.idx_b, &g.hists, &g.codes, &g.hdrs, &g.adler, &g.res, &g.surv, &g.cand,
+                   &g.cand_sorted, &g.counters, &g.cres, &g.map, &g.resume, &g.st_in, &g.st_out};
+  for (DevBuf* b : all) {
+    if (b->p) hipFree(b->p);
+    b->p = nullptr;
+    b->cap = 0;
+  }
+  if (g.pinned) hipHostFree(g.pinned);
+  g.pinned = nullptr;
+  hipStreamDestroy(g.stream);
+  g.stream = nullptr;
+  g.ready = false;
+  return ZES_OK;
+}
+
+int zes_device_info(char* name, int cap, int* cus, uint64_t* hbm_bytes) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  int rc = init_locked(-1);
+  if (rc) return rc;
+  if (name && cap > 0) snprintf(name, (size_t)cap, "%s", g.arch);
+  if (cus) *cus = g.cus;
+  if (hbm_bytes) *hbm_bytes = g.hbm;
+  return ZES_OK;
+}
+
+int zes_deflate_bound(uint64_t n, uint64_t* cap) {
+  if (!cap) return ZES_E_ARG;
+  *cap = deflate_bound(n);
+  return ZES_OK;
+}
+
+int zes_deflate_batch_dev(const uint8_t* d_in, const uint64_t* in_off, const uint64_t* in_len, uint8_t* d_out,
+                          const uint64_t* out_off, const uint64_t* out_cap, uint64_t* out_len, int32_t* status, uint32_t count) {
+  if (!in_off || !in_len || !out_off || !out_cap || !out_len || !status) return ZES_E_ARG;
+  std::lock_guard<std::mutex> lk(g_mu);
+  int rc = init_locked(-1);
+  if (rc) return rc;
+  return deflate_batch_core(d_in, in_off, in_len, d_out, out_off, out_cap, out_len, status, count);
+}
+
+int zes_deflate_dev(const uint8_t* d_in, uint64_t n, uint8_t* d_out, uint64_t cap, uint64_t* out_len) {
+  if (!out_len) return ZES_E_ARG;
+  uint64_t zero = 0;
+  int32_t st = 0;
+  int rc = zes_deflate_batch_dev(d_in, &zero, &n, d_out, &zero, &cap, out_len, &st, 1);
+  return rc ? rc : st;
+}
+
+int zes_deflate(const uint8_t* in, uint64_t n, uint8_t* out, uint64_t cap, uint64_t* out_len) {
+  if (!out_len || (!in && n) || !out) return ZES_E_ARG;
+  *out_len = 0;
+  if (deflate_throws(n)) return ZES_E_CORRUPT;
+  const uint64_t bound = deflate_bound(n);
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int rc = init_locked(-1);
+    if (rc) return rc;
+    if ((rc = ensure(g.st_in, n + 64))) return rc;
+    if ((rc = ensure(g.st_out, bound + 64))) return rc;
+    HIPCHK(hipMemcpyAsync(g.st_in.p, in, n, hipMemcpyHostToDevice, g.stream));
+    uint64_t zero = 0, dl = 0;
+    int32_t st = 0;
+    rc = deflate_batch_core((const uint8_t*)g.st_in.p, &zero, &n, (uint8_t*)g.st_out.p, &zero, &bound, &dl, &st, 1);
+    if (rc) return rc;
+    if (st) return st;
+    *out_len = dl;
+    if (dl > cap) return ZES_E_NOSPACE;
+    HIPCHK(hipMemcpyAsync(out, g.st_out.p, dl, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+  }
+  return ZES_OK;
+}
+
+int zes_inflate_dev(const uint8_t* d_in, uint64_t c, uint8_t* d_out, uint64_t cap, uint64_t* out_len, uint32_t flags) {
+  if (!out_len) return ZES_E_ARG;
+  if ((((uintptr_t)d_in) & 15u) || (((uintptr_t)d_out) & 15u)) return ZES_E_ARG;
+  std::lock_guard<std::mutex> lk(g_mu);
+  int rc = init_locked(-1);
+  if (rc) return rc;
+  uint8_t first = 0;
+  if (c) {
+    HIPCHK(hipMemcpyAsync(g.pinned, d_in, 1, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    first = *(const uint8_t*)g.pinned;
+  }
+  return inflate_one(d_in, 0, c, d_out, 0, cap, out_len, flags, first);
+}
+
+int zes_inflate_batch_dev(const uint8_t* d_in, const uint64_t* in_off, const uint64_t* in_len, uint8_t* d_out,
+                          const uint64_t* out_off, const uint64_t* out_cap, uint64_t* out_len, int32_t* status, uint32_t count,
+                          uint32_t flags) {
+  if (!in_off || !in_len || !out_off || !out_cap || !out_len || !status) return ZES_E_ARG;
+  if ((((uintptr_t)d_in) & 15u) || (((uintptr_t)d_out) & 15u)) return ZES_E_ARG;
+  std::lock_guard<std::mutex> lk(g_mu);
+  int rc = init_locked(-1);
+  if (rc) return rc;
+  // first bytes of the buffers (CM nibble check, src/zlib.ts:13), read back in groups
+  std::vector<uint8_t> firsts(count, 0);
+  const uint32_t group = 4096;
+  for (uint32_t g0 = 0; g0 < count; g0 += group) {
+    const uint32_t g1 = std::min(count, g0 + group);
+    for (uint32_t i = g0; i < g1; i++) {
+      if ((in_off[i] & 15u) || (out_off[i] & 15u)) {
+        status[i] = ZES_E_ARG;
+        continue;
+      }
+      status[i] = ZES_OK;
+      if (in_len[i]) HIPCHK(hipMemcpyAsync((uint8_t*)g.pinned + (i - g0), d_in + in_off[i], 1, hipMemcpyDeviceToHost, g.stream));
+    }
+    HIPCHK(hipStreamSynchronize(g.stream));
+    for (uint32_t i = g0; i < g1; i++) firsts[i] = ((const uint8_t*)g.pinned)[i - g0];
+  }
+  for (uint32_t i = 0; i < count; i++) {
+    if (status[i]) continue;
+    status[i] = inflate_one(d_in, in_off[i], in_len[i], d_out, out_off[i], out_cap[i], &out_len[i], flags, firsts[i]);
+    if (status[i] == ZES_E_DEVICE) return ZES_E_DEVICE;
+  }
+  return ZES_OK;
+}
+
+static int inflate_host(const uint8_t* in, uint64_t c, uint8_t* out, uint64_t cap, uint64_t* out_len, uint32_t flags,
+                        bool size_only) {
+  if (!out_len || (!in && c)) return ZES_E_ARG;
+  *out_len = 0;
+  std::lock_guard<std::mutex> lk(g_mu);
+  int rc = init_locked(-1);
+  if (rc) return rc;
+  if ((rc = ensure(g.st_in, c + 64))) return rc;
+  if (c) HIPCHK(hipMemcpyAsync(g.st_in.p, in, c, hipMemcpyHostToDevice, g.stream));
+  // decode into pooled device memory: grow-and-retry like the reference's Uint8WriteStream
+  uint64_t dcap = std::max<uint64_t>(size_only ? 0 : cap, std::max<uint64_t>(c * 4, 1 << 20));
+  for (int attempt = 0; attempt < 8; attempt++) {
+    if ((rc = ensure(g.st_out, dcap + 64))) return rc;
+    uint64_t n = 0;
+    rc = inflate_one((const uint8_t*)g.st_in.p, 0, c, (uint8_t*)g.st_out.p, 0, dcap, &n, flags, c ? in[0] : 0);
+    if (rc == ZES_E_NOSPACE && n > dcap) {
+      dcap = n;
+      if (size_only) {
+        *out_len = n;
+        return ZES_OK;
+      }
+      continue;
+    }
+    if (rc) return rc;
+    *out_len = n;
+    if (size_only) return ZES_OK;
+    if (n > cap) return ZES_E_NOSPACE;
+    if (n) HIPCHK(hipMemcpyAsync(out, g.st_out.p, n, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return ZES_OK;
+  }
+  return ZES_E_DEVICE;
+}
+
+int zes_inflate(const uint8_t* in, uint64_t c, uint8_t* out, uint64_t cap, uint64_t* out_len, uint32_t flags) {
+  return inflate_host(in, c, out, cap, out_len, flags, false);
+}
+int zes_inflate_size(const uint8_t* in, uint64_t c, uint64_t* n, uint32_t flags) {
+  return inflate_host(in, c, nullptr, 0, n, flags, true);
+}
+
+int zes_adler32_dev(const uint8_t* d_in, uint64_t n, uint32_t* adler_out) {
+  if (!adler_out) return ZES_E_ARG;
+  std::lock_guard<std::mutex> lk(g_mu);
+  int rc = init_locked(-1);
+  if (rc) return rc;
+  if ((rc = ensure(g.adler, 16))) return rc;
+  unsigned long long* acc = (unsigned long long*)g.adler.p;
+  HIPCHK(hipMemsetAsync(acc, 0, 16, g.stream));
+  if (n) {
+    Timed t("k_adler");
+    const uint32_t nch = (uint32_t)((n + ADLER_CHUNK - 1) / ADLER_CHUNK);
+    hipLaunchKernelGGL(k_adler, dim3(nch), dim3(ADLER_THREADS), 0, g.stream, d_in, (uint64_t)0, n, acc);
+  }
+  HIPCHK(hipMemcpyAsync(g.pinned, acc, 16, hipMemcpyDeviceToHost, g.stream));
+  HIPCHK(hipStreamSynchronize(g.stream));
+  collect_times();
+  const unsigned long long* h = (const unsigned long long*)g.pinned;
+  const uint32_t s1 = (uint32_t)((1ull + h[0]) % 65521ull);
+  const uint32_t s2 = (uint32_t)((n % 65521ull + h[1]) % 65521ull);
+  *adler_out = (s2 << 16) | s1;
+  return ZES_OK;
+}
+
+int zes_adler32(const uint8_t* in, uint64_t n, uint32_t* adler_out) {
+  if (!adler_out || (!in && n)) return ZES_E_ARG;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int rc = init_locked(-1);
+    if (rc) return rc;
+    if ((rc = ensure(g.st_in, n + 64))) return rc;
+    if (n) HIPCHK(hipMemcpyAsync(g.st_in.p, in, n, hipMemcpyHostToDevice, g.stream));
+  }
+  return zes_adler32_dev((const uint8_t*)g.st_in.p, n, adler_out);
+}
+
+int zes_stage_lz77_dev(const uint8_t* d_in, uint64_t n, uint64_t start, uint32_t len, uint32_t* h_tokens, uint32_t* ntokens) {
+  if (!h_tokens || !ntokens || len < 2 || len > ZES_BLK || start + len > n || (start % ZES_BLK)) return ZES_E_ARG;
+  std::lock_guard<std::mutex> lk(g_mu);
+  int rc = init_locked(-1);
+  if (rc) return rc;
+  ZesBuf b;
+  memset(&b, 0, sizeof b);
+  b.in_off = 0;
+  b.n = n;  // the halo reads up to the real input end
+  b.nblk = (uint32_t)((n + ZES_BLK - 1) / ZES_BLK);
+  ZesBlk z;
+  memset(&z, 0, sizeof z);
+  z.buf = 0;
+  z.blk = (uint32_t)(start / ZES_BLK);
+  z.len = len;
+  if ((rc = ensure(g.bufs, sizeof b))) return rc;
+  if ((rc = ensure(g.blks, sizeof z))) return rc;
+  if ((rc = ensure(g.idx_a, (size_t)ZES_BLK * 4))) return rc;
+  if ((rc = ensure(g.idx_b, (size_t)ZES_BLK * 4))) return rc;
+  if ((rc = ensure(g.hists, 320 * 4))) return rc;
+  HIPCHK(hipMemcpyAsync(g.bufs.p, &b, sizeof b, hipMemcpyHostToDevice, g.stream));
+  HIPCHK(hipMemcpyAsync(g.blks.p, &z, sizeof z, hipMemcpyHostToDevice, g.stream));
+  hipLaunchKernelGGL(k_lz_sort, dim3(1), dim3(SORT_THREADS), 0, g.stream, d_in, (const ZesBuf*)g.bufs.p, (const ZesBlk*)g.blks.p,
+                     (uint32_t*)g.idx_a.p, (uint32_t*)g.idx_b.p);
+  hipLaunchKernelGGL(k_lz_match, dim3(1), dim3(MATCH_THREADS), 0, g.stream, d_in, (const ZesBuf*)g.bufs.p,
+                     (const ZesBlk*)g.blks.p, (const uint32_t*)g.idx_a.p, (uint32_t*)g.idx_b.p);
+  hipLaunchKernelGGL(k_lz_parse, dim3(1), dim3(64), 0, g.stream, d_in, (const ZesBuf*)g.bufs.p, (ZesBlk*)g.blks.p,
+                     (const uint32_t*)g.idx_b.p, (uint32_t*)g.idx_a.p, (uint32_t*)g.hists.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(&z, g.blks.p, sizeof z, hipMemcpyDeviceToHost, g.stream));
+  HIPCHK(hipStreamSynchronize(g.stream));
+  *ntokens = z.ntok;
+  HIPCHK(hipMemcpy(h_tokens, g.idx_a.p, (size_t)z.ntok * 4, hipMemcpyDeviceToHost));
+  return ZES_OK;
+}
+
+int zes_stage_huff_lengths_dev(const uint32_t* h_hist, uint32_t nsym, uint32_t maxlen, uint8_t* h_lens) {
+  if (!h_hist || !h_lens || nsym == 0 || nsym > 288 || maxlen == 0 || maxlen > 15) return ZES_E_ARG;
+  std::lock_guard<std::mutex> lk(g_mu);
+  int rc = init_locked(-1);
+  if (rc) return rc;
+  if ((rc = ensure(g.hists, 320 * 4))) return rc;
+  if ((rc = ensure(g.codes, 320))) return rc;
+  HIPCHK(hipMemcpyAsync(g.hists.p, h_hist, nsym * 4, hipMemcpyHostToDevice, g.stream));
+  hipLaunchKernelGGL(k_huff_lengths_only, dim3(1), dim3(HUFF_THREADS_HOST), 0, g.stream, (const uint32_t*)g.hists.p, nsym, maxlen,
+                     (uint8_t*)g.codes.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(h_lens, g.codes.p, nsym, hipMemcpyDeviceToHost, g.stream));
+  HIPCHK(hipStreamSynchronize(g.stream));
+  return ZES_OK;
+}
+
+int zes_set_profiling(int on) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  g.profiling = on != 0;
+  return ZES_OK;
+}
+
+int zes_last_kernel_times(zes_ktime* out, int cap) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  int n = 0;
+  g.name_pool.clear();
+  for (auto& e : g.last_times) g.name_pool.push_back(e.first);
+  for (size_t i = 0; i < g.last_times.size() && n < cap; i++, n++) {
+    out[n].name = g.name_pool[i].c_str();
+    out[n].ms = (float)g.last_times[i].second.ms;
+    out[n].launches = g.last_times[i].second.launches;
+  }
+  return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,843 @@
+// zes_deflate.hip — gfx950 kernels of the compress direction.
+//
+// Pipeline per 131072-byte block (one workgroup per block unless noted), bit-exact with the
+// reference's src/deflate.ts + src/lz77.ts + src/huffman.ts:
+//
+//   k_lz_sort    index of the block: positions grouped by exact 3-byte key, ascending inside a
+//                group — a stable 3-pass LSD radix sort over the LDS-resident block
+//                (replaces generateLZ77IndexMap, src/lz77.ts:11-22)
+//   k_lz_match   per position: the match the reference's candidate loop would pick
+//                (src/lz77.ts:49-93; a pure function of the position)
+//   k_lz_parse   greedy chain p -> p+len | p+1, token compaction, LDS symbol histograms
+//                (src/lz77.ts:39-47,95-117; src/deflate.ts:58-77)
+//   k_huff       package-merge code lengths by parallel merge ranks, canonical codes,
+//                code-length RLE, dynamic header bits, block bit count
+//                (src/huffman.ts:55-153; src/deflate.ts:78-181)
+//   k_layout     per buffer: exclusive scan of block bit counts, zlib header + Adler trailer
+//                (src/deflate.ts:20-38; src/zlib.ts:25-49)
+//   k_emit       token bit lengths -> scan -> LDS-staged bit packing -> coalesced stores
+//                (src/deflate.ts:183-226; src/utils/BitWriteStream.ts)
+//   k_adler      Adler-32 as per-chunk (A, B) partial sums combined by u64 atomics
+//                (src/adler32.ts:1-10)
+#include "zes_common.h"
+#include "zes_kernels.h"
+
+// ------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------
+// unaligned 32-bit little-endian read from an LDS byte array (4-byte aligned base)
+__device__ static inline uint32_t lds_ld32u(const uint8_t* s, uint32_t off) {
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(s);
+  uint32_t i = off >> 2;
+  uint32_t lo = w[i], hi = w[i + 1];
+  return __builtin_amdgcn_alignbyte(hi, lo, off & 3u);
+}
+
+// cooperative copy global -> LDS of `bytes` bytes starting at g (any alignment), zero-padding
+// up to `padded` (multiple of 16).  s must be 16-byte aligned.
+__device__ static inline void stage_block(uint8_t* s, const uint8_t* g, uint32_t bytes, uint32_t padded) {
+  const uint32_t tid = threadIdx.x, nth = blockDim.x;
+  const uint32_t mis = (uint32_t)((uintptr_t)g & 15u);
+  if (mis == 0) {
+    const uint4* g4 = reinterpret_cast<const uint4*>(g);
+    uint4* s4 = reinterpret_cast<uint4*>(s);
+    const uint32_t full = bytes >> 4;
+    for (uint32_t i = tid; i < full; i += nth) s4[i] = g4[i];
+    for (uint32_t i = (full << 4) + tid; i < padded; i += nth) s[i] = i < bytes ? g[i] : (uint8_t)0;
+  } else {
+    for (uint32_t i = tid; i < padded; i += nth) s[i] = i < bytes ? g[i] : (uint8_t)0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_lz_sort: stable LSD radix sort of positions 0..cnt-1 (cnt = len-2) by the 3 key bytes.
+// LDS: the block itself (128 KiB) + per-wave digit counters.  Result in idx_a[g][0..cnt).
+// ------------------------------------------------------------------------------------------
+struct SortSmem {
+  uint8_t in[ZES_BLK + 16];
+  uint32_t hist[256];     // byte histogram of the whole block
+  uint32_t base[2][256];  // running output offset per digit (double-buffered across tiles)
+  uint16_t whist[2][SORT_WAVES][256];
+};
+
+__global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restrict__ d_in, const ZesBuf* __restrict__ bufs,
+                                                          const ZesBlk* __restrict__ blks, uint32_t* __restrict__ idx_a,
+                                                          uint32_t* __restrict__ idx_b) {
+  __shared__ __align__(16) SortSmem S;
+  const uint32_t g = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const ZesBlk bk = blks[g];
+  const ZesBuf bf = bufs[bk.buf];
+  const uint32_t T = bk.len;
+  const uint8_t* src = d_in + bf.in_off + (uint64_t)bk.blk * ZES_BLK;
+  uint32_t* A = idx_a + (uint64_t)g * ZES_BLK;
+  uint32_t* B = idx_b + (uint64_t)g * ZES_BLK;
+  const uint32_t cnt = T >= 3 ? T - 2 : 0;
+
+  stage_block(S.in, src, T, (T + 15u) & ~15u);
+  if (tid < 256) S.hist[tid] = 0;
+  __syncthreads();
+  if (cnt == 0) return;
+  for (uint32_t i = tid; i < T; i += SORT_THREADS) atomicAdd(&S.hist[S.in[i]], 1u);
+  __syncthreads();
+
+  uint32_t bsel = 0;
+  for (int pass = 0; pass < 3; pass++) {
+    const uint32_t off = 2u - (uint32_t)pass;  // least significant key byte first
+    const uint32_t* from = (pass == 1) ? A : B;
+    uint32_t* to = (pass == 1) ? B : A;
+    // exclusive scan of this pass's digit histogram: the pass sees positions [off, off+cnt),
+    // i.e. the block histogram minus `off` leading and `2-off` trailing bytes
+    if (wave == 0) {
+      uint32_t c[4];
+      uint32_t sum = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t v = lane * 4 + k;
+        uint32_t h = S.hist[v];
+        for (uint32_t e = 0; e < off; e++) h -= (S.in[e] == v);
+        for (uint32_t e = off + cnt; e < T; e++) h -= (S.in[e] == v);
+        c[k] = h;
+        sum += h;
+      }
+      uint32_t incl = sum;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(incl, d);
+        if ((int)lane >= d) incl += t;
+      }
+      uint32_t run = incl - sum;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        S.base[bsel][lane * 4 + k] = run;
+        run += c[k];
+      }
+    }
+    __syncthreads();
+    const uint32_t ntiles = (cnt + SORT_THREADS - 1) / SORT_THREADS;
+    for (uint32_t t = 0; t < ntiles; t++) {
+      uint16_t(*wh)[256] = S.whist[t & 1];
+      // zero this tile's per-wave counters: 16 waves x 256 x u16 = 8 KiB = 1024 x 8 B
+      reinterpret_cast<uint64_t*>(&wh[0][0])[tid] = 0ull;
+      const uint32_t i = t * SORT_THREADS + tid;
+      const bool valid = i < cnt;
+      uint32_t p = 0, d = 0;
+      if (valid) {
+        p = (pass == 0) ? i : from[i];
+        d = S.in[p + off];
+      }
+      // lanes of this wave holding the same digit (stable rank = lower lanes first)
+      uint64_t m = __ballot(valid);
+#pragma unroll
+      for (int b = 0; b < 8; b++) {
+        const bool bit = (d >> b) & 1u;
+        const uint64_t bal = __ballot(bit);
+        m &= bit ? bal : ~bal;
+      }
+      const uint32_t rank = (uint32_t)__popcll(m & zes_lanemask_lt());
+      __syncthreads();  // (A) counters zeroed
+      if (valid && rank == 0) wh[wave][d] = (uint16_t)__popcll(m);
+      __syncthreads();  // (B) counts visible
+      if (tid < 256) {
+        uint32_t o = 0;
+#pragma unroll
+        for (int w = 0; w < SORT_WAVES; w++) {
+          const uint32_t c = wh[w][tid];
+          wh[w][tid] = (uint16_t)o;  // offset of wave w inside this tile's run of digit tid
+          o += c;
+        }
+        S.base[bsel ^ 1][tid] = S.base[bsel][tid] + o;
+      }
+      __syncthreads();  // (C) offsets visible
+      if (valid) to[S.base[bsel][d] + wh[wave][d] + rank] = p;
+      bsel ^= 1;
+      // no barrier here: the next tile writes whist[other] and base[other-other] only after
+      // its own barriers (A)/(B), which every thread reaches after this scatter
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_lz_match: one thread per sorted slot r; candidates are the slots before r with the same key.
+// LDS: block + 258-byte halo (compares run past the block end up to the input end).
+// match_out[g][p] = ZES_TOK_MATCH | (len-3)<<16 | (dist-1), or 0 for "literal here".
+// ------------------------------------------------------------------------------------------
+struct MatchSmem {
+  uint8_t in[ZES_BLK + 288];
+};
+
+__global__ __launch_bounds__(MATCH_THREADS) void k_lz_match(const uint8_t* __restrict__ d_in, const ZesBuf* __restrict__ bufs,
+                                                            const ZesBlk* __restrict__ blks, const uint32_t* __restrict__ idx_a,
+                                                            uint32_t* __restrict__ match_out) {
+  __shared__ __align__(16) MatchSmem S;
+  const uint32_t g = blockIdx.x, tid = threadIdx.x;
+  const ZesBlk bk = blks[g];
+  const ZesBuf bf = bufs[bk.buf];
+  const uint32_t T = bk.len;
+  const uint64_t S0 = (uint64_t)bk.blk * ZES_BLK;  // block start inside the buffer
+  const uint8_t* src = d_in + bf.in_off + S0;
+  const uint64_t remain = bf.n - S0;  // bytes from block start to input end
+  const uint32_t avail = (uint32_t)(remain < (uint64_t)(T + ZES_MAXMATCH) ? remain : (uint64_t)(T + ZES_MAXMATCH));
+  const uint32_t* idx = idx_a + (uint64_t)g * ZES_BLK;
+  uint32_t* mo = match_out + (uint64_t)g * ZES_BLK;
+  const uint32_t cnt = T >= 3 ? T - 2 : 0;
+
+  stage_block(S.in, src, avail, (ZES_BLK + 288u));
+  // the last two positions of a block are always literals (src/lz77.ts:116-117)
+  if (tid < 2 && T >= 1u + tid) mo[T - 1 - tid] = 0;
+  __syncthreads();
+
+  for (uint32_t r = tid; r < cnt; r += MATCH_THREADS) {
+    const uint32_t p = idx[r];
+    const uint32_t kp = lds_ld32u(S.in, p) & 0xffffffu;
+    const uint32_t maxl = min(ZES_MAXMATCH, avail - p);  // = min(258, n - p)
+    uint32_t best = 0, bestq = 0, check = 0;
+    for (int32_t rr = (int32_t)r - 1; rr >= 0; rr--) {
+      const uint32_t q = idx[rr];
+      if ((lds_ld32u(S.in, q) & 0xffffffu) != kp) break;
+      if (p - q > ZES_WINDOW) break;                                 // src/lz77.ts:49
+      if (check >= 128u || (best >= 8u && check >= 16u)) break;      // src/lz77.ts:66-69
+      check++;
+      // L > best needs bytes 0..best equal: one dword probe at best-3 rejects most candidates
+      if (best >= maxl) continue;  // nothing can beat it; the candidate still counted
+      if (best >= 3u && lds_ld32u(S.in, q + best - 3u) != lds_ld32u(S.in, p + best - 3u)) continue;
+      uint32_t L = 3;
+      while (L < maxl) {
+        const uint32_t x = lds_ld32u(S.in, q + L) ^ lds_ld32u(S.in, p + L);
+        if (x) {
+          L += (uint32_t)__builtin_ctz(x) >> 3;
+          break;
+        }
+        L += 4;
+      }
+      L = min(L, maxl);
+      if (L > best) {
+        best = L;
+        bestq = q;
+        if (L >= ZES_MAXMATCH) break;
+      }
+    }
+    uint32_t tok = 0;
+    if (best >= 3u && p + best + 3u <= T)  // nowIndex + len <= endIndex = start + T - 3 (src/lz77.ts:95)
+      tok = ZES_TOK_MATCH | ((best - 3u) << 16) | (p - bestq - 1u);
+    mo[p] = tok;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_lz_parse: one wavefront per block walks the greedy chain 64 positions at a time
+// (v_readlane hop inside the chunk), compacts the tokens and builds both symbol histograms in LDS.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_lz_parse(const uint8_t* __restrict__ d_in, const ZesBuf* __restrict__ bufs,
+                                                 ZesBlk* __restrict__ blks, const uint32_t* __restrict__ match_in,
+                                                 uint32_t* __restrict__ tok_out, uint32_t* __restrict__ hists) {
+  __shared__ uint32_t lh[288];
+  __shared__ uint32_t dh[32];
+  const uint32_t g = blockIdx.x, lane = threadIdx.x;
+  const ZesBlk bk = blks[g];
+  const ZesBuf bf = bufs[bk.buf];
+  const uint32_t T = bk.len;
+  const uint8_t* src = d_in + bf.in_off + (uint64_t)bk.blk * ZES_BLK;
+  const uint32_t* mi = match_in + (uint64_t)g * ZES_BLK;
+  uint32_t* to = tok_out + (uint64_t)g * ZES_BLK;
+  for (uint32_t i = lane; i < 288; i += 64) lh[i] = 0;
+  if (lane < 32) dh[lane] = 0;
+  __syncthreads();
+
+  uint32_t cur = 0, ntok = 0;
+  // software prefetch of the next chunk's match words
+  uint32_t m_next = (lane < T) ? mi[lane] : 0u;
+  uint32_t c_next = 0;
+  while (cur < T) {
+    const uint32_t c = cur >> 6;
+    const uint32_t base = c << 6;
+    uint32_t m;
+    if (c == c_next) {
+      m = m_next;
+    } else {
+      m = (base + lane < T) ? mi[base + lane] : 0u;
+    }
+    c_next = c + 1;
+    m_next = (((c + 1) << 6) + lane < T) ? mi[((c + 1) << 6) + lane] : 0u;
+    const uint32_t step = (m & ZES_TOK_MATCH) ? zes_tok_len(m) : 1u;
+    uint32_t e = __builtin_amdgcn_readfirstlane(cur - base);
+    const uint32_t lim = min(64u, T - base);
+    uint64_t mask = 0;
+    while (e < lim) {  // every step is >= 1, so this ends
+      mask |= 1ull << e;
+      e += max(1u, (uint32_t)__builtin_amdgcn_readlane(step, e));
+    }
+    cur = base + e;  // > previous cur: e advanced at least once because cur - base < lim
+    if ((mask >> lane) & 1ull) {
+      const uint32_t rank = (uint32_t)__popcll(mask & zes_lanemask_lt());
+      uint32_t tv;
+      if (m & ZES_TOK_MATCH) {
+        tv = m;
+        atomicAdd(&lh[257u + zes_len_code(zes_tok_len(m))], 1u);
+        atomicAdd(&dh[zes_dist_code(zes_tok_dist(m))], 1u);
+      } else {
+        tv = src[base + lane];
+        atomicAdd(&lh[tv], 1u);
+      }
+      to[ntok + rank] = tv;
+    }
+    ntok += (uint32_t)__popcll(mask);
+  }
+  __syncthreads();
+  if (lane == 0) {
+    lh[256] = 1;  // EOB (src/deflate.ts:58)
+    blks[g].ntok = ntok;
+  }
+  __syncthreads();
+  uint32_t* hg = hists + (uint64_t)g * 320;
+  for (uint32_t i = lane; i < 288; i += 64) hg[i] = lh[i];
+  if (lane < 32) hg[288 + lane] = dh[lane];
+}
+
+// ------------------------------------------------------------------------------------------
+// k_huff: per block, 256 threads.
+// Package-merge restated as parallel merges: the reference's per-level
+// `sort(leaves ++ pairs(prev))` is a stable merge of two sorted runs (leaves first on ties), so
+// every item's slot is a binary-search rank; a code length is the number of levels whose
+// selected prefix still contains the leaf (the selected items of a level are a prefix of it).
+// ------------------------------------------------------------------------------------------
+#define HUFF_THREADS 256
+#define PM_MAXN 288
+struct HuffSmem {
+  uint32_t hist[320];           // working histogram of the current alphabet
+  uint32_t lw[PM_MAXN];         // leaf weights, ascending (count, symbol)
+  uint16_t lsym[PM_MAXN];       // symbol of sorted leaf i
+  uint32_t w[2][2 * PM_MAXN];   // merged weights of the previous / current level
+  uint32_t pk[PM_MAXN];         // packages of the current level
+  uint16_t leafpos[15][PM_MAXN];
+  uint32_t a_k[16];
+  uint8_t lens[320];            // [0..288) lit/len, [288..320) dist
+  uint8_t clens[32];
+  uint16_t codes[320];          // bit-reversed codes, same layout
+  uint16_t ccodes[32];
+  uint8_t rl_sym[320];
+  uint8_t rl_val[320];
+  uint32_t nrl;
+  uint32_t hdr[ZES_HDR_WORDS];
+  uint32_t hdr_bits;
+  uint32_t total_bits;
+  uint32_t n_nonzero;
+};
+
+__device__ static inline uint32_t lower_bound_u32(const uint32_t* a, uint32_t n, uint32_t v) {  // #{a[i] < v}
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (a[mid] < v) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+__device__ static inline uint32_t upper_bound_u32(const uint32_t* a, uint32_t n, uint32_t v) {  // #{a[i] <= v}
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (a[mid] <= v) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// Code lengths of alphabet hist[0..nsym) limited to L, into lens[0..nsym).  All threads call it.
+__device__ static void pm_lengths(HuffSmem& S, const uint32_t* hist, uint32_t nsym, uint32_t L, uint8_t* lens) {
+  const uint32_t tid = threadIdx.x;
+  __syncthreads();
+  // rank sort of the used symbols by (count, symbol)  — src/huffman.ts:67,79-85,95-99
+  uint32_t n = 0;
+  for (uint32_t j = 0; j < nsym; j++) n += (hist[j] != 0);
+  for (uint32_t s = tid; s < nsym; s += HUFF_THREADS) {
+    lens[s] = 0;
+    const uint32_t c = hist[s];
+    if (c) {
+      uint32_t rank = 0;
+      for (uint32_t j = 0; j < nsym; j++) {
+        const uint32_t cj = hist[j];
+        rank += (cj != 0) && (cj < c || (cj == c && j < s));
+      }
+      S.lw[rank] = c;
+      S.lsym[rank] = (uint16_t)s;
+    }
+  }
+  __syncthreads();
+  if (n == 0) return;  // empty table
+  if (n == 1) {        // src/huffman.ts:71-75
+    if (tid == 0) lens[S.lsym[0]] = 1;
+    __syncthreads();
+    return;
+  }
+  // level 1: the sorted leaves; odd length drops the last item (src/huffman.ts:100-102)
+  for (uint32_t i = tid; i < n; i += HUFF_THREADS) {
+    S.w[0][i] = S.lw[i];
+    S.leafpos[0][i] = (uint16_t)i;
+  }
+  uint32_t len_prev = n & ~1u;
+  uint32_t sel = 0;
+  __syncthreads();
+  for (uint32_t k = 1; k < L; k++) {
+    const uint32_t np = len_prev >> 1;
+    const uint32_t* wp = S.w[sel];
+    uint32_t* wc = S.w[sel ^ 1];
+    for (uint32_t j = tid; j < np; j += HUFF_THREADS) S.pk[j] = wp[2 * j] + wp[2 * j + 1];  // src/huffman.ts:87-94
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += HUFF_THREADS) {  // leaves precede packages on ties
+      const uint32_t pos = i + lower_bound_u32(S.pk, np, S.lw[i]);
+      wc[pos] = S.lw[i];
+      S.leafpos[k][i] = (uint16_t)pos;
+    }
+    for (uint32_t j = tid; j < np; j += HUFF_THREADS) {
+      const uint32_t pos = j + upper_bound_u32(S.lw, n, S.pk[j]);
+      wc[pos] = S.pk[j];
+    }
+    len_prev = (n + np) & ~1u;
+    sel ^= 1;
+    __syncthreads();
+  }
+  // selected prefix per level, from the last level down (src/huffman.ts:106-115)
+  if (tid == 0) {
+    uint32_t m = len_prev;
+    for (int k = (int)L - 1; k >= 0; k--) {
+      uint32_t lo = 0, hi = n;  // a = #{i : leafpos[k][i] < m}
+      while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (S.leafpos[k][mid] < m) lo = mid + 1; else hi = mid;
+      }
+      S.a_k[k] = lo;
+      m = 2u * (m - lo);
+    }
+  }
+  __syncthreads();
+  for (uint32_t i = tid; i < n; i += HUFF_THREADS) {
+    uint32_t l = 0;
+    for (uint32_t k = 0; k < L; k++) l += (S.a_k[k] > i);
+    lens[S.lsym[i]] = (uint8_t)l;
+  }
+  __syncthreads();
+}
+
+// canonical codes (src/huffman.ts:117-151), stored bit-reversed for LSB-first packing
+__device__ static void canon_codes(const uint8_t* lens, uint32_t nsym, uint16_t* codes) {
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t s = tid; s < nsym; s += HUFF_THREADS) {
+    const uint32_t l = lens[s];
+    uint32_t code = 0;
+    if (l) {
+      // first code of length l = sum over shorter lengths of count << (l - len); plus rank inside l
+      for (uint32_t j = 0; j < nsym; j++) {
+        const uint32_t lj = lens[j];
+        if (lj && lj < l) code += 1u << (l - lj);
+        else if (lj == l && j < s) code += 1u;
+      }
+      code = __brev(code) >> (32u - l);
+    }
+    codes[s] = (uint16_t)code;
+  }
+  __syncthreads();
+}
+
+__device__ static inline void hdr_put(HuffSmem& S, uint32_t& bitpos, uint32_t value, uint32_t nbits) {
+  // single-thread LSB-first append into S.hdr (zeroed beforehand)
+  const uint32_t w = bitpos >> 5, sh = bitpos & 31u;
+  S.hdr[w] |= value << sh;
+  if (sh + nbits > 32u) S.hdr[w + 1] |= value >> (32u - sh);
+  bitpos += nbits;
+}
+
+__global__ __launch_bounds__(HUFF_THREADS) void k_huff(ZesBlk* __restrict__ blks, const uint32_t* __restrict__ hists,
+                                                       uint32_t* __restrict__ codes_out, uint32_t* __restrict__ hdr_out) {
+  __shared__ HuffSmem S;
+  const uint32_t g = blockIdx.x, tid = threadIdx.x;
+  const uint32_t* hg = hists + (uint64_t)g * 320;
+  for (uint32_t i = tid; i < 320; i += HUFF_THREADS) S.hist[i] = hg[i];
+  for (uint32_t i = tid; i < ZES_HDR_WORDS; i += HUFF_THREADS) S.hdr[i] = 0;
+  if (tid == 0) S.total_bits = 0;
+  __syncthreads();
+
+  pm_lengths(S, S.hist, 286, 15, S.lens);             // src/deflate.ts:78
+  pm_lengths(S, S.hist + 288, 30, 15, S.lens + 288);  // src/deflate.ts:79
+  canon_codes(S.lens, 286, S.codes);
+  canon_codes(S.lens + 288, 30, S.codes + 288);
+
+  // code-length sequence + RLE (src/deflate.ts:81-139), serial: <= 316 entries
+  if (tid == 0) {
+    int lmax = 256, dmax = 0;
+    for (int i = 257; i < 286; i++)
+      if (S.hist[i]) lmax = i;
+    for (int i = 0; i < 30; i++)
+      if (S.hist[288 + i]) dmax = i;
+    const int HLIT = lmax + 1, HDIST = dmax + 1, ncl = HLIT + HDIST;
+    uint32_t nrl = 0;
+    auto CL = [&](int i) -> int { return i < HLIT ? S.lens[i] : S.lens[288 + i - HLIT]; };
+    for (int i = 0; i < ncl; i++) {
+      const int cl = CL(i);
+      int rep = 1;
+      while (i + 1 < ncl && cl == CL(i + 1)) {
+        rep++;
+        i++;
+        if (cl == 0) {
+          if (138 <= rep) break;
+        } else {
+          if (6 <= rep) break;
+        }
+      }
+      if (4 <= rep) {
+        if (cl == 0) {
+          S.rl_sym[nrl] = (11 <= rep) ? 18 : 17;
+        } else {
+          S.rl_sym[nrl] = (uint8_t)cl;
+          S.rl_val[nrl] = 1;
+          nrl++;
+          rep--;
+          S.rl_sym[nrl] = 16;
+        }
+        S.rl_val[nrl] = (uint8_t)rep;
+        nrl++;
+      } else {
+        for (int j = 0; j < rep; j++) {
+          S.rl_sym[nrl] = (uint8_t)cl;
+          S.rl_val[nrl] = 1;
+          nrl++;
+        }
+      }
+    }
+    S.nrl = nrl;
+    for (int i = 0; i < 32; i++) S.hist[i] = 0;  // reuse as the code-length-code histogram
+    for (uint32_t i = 0; i < nrl; i++) S.hist[S.rl_sym[i]]++;
+    // header fields that do not depend on the CL code
+    S.hdr_bits = ((uint32_t)(HLIT - 257)) | ((uint32_t)(HDIST - 1) << 5);
+  }
+  __syncthreads();
+  pm_lengths(S, S.hist, 19, 7, S.clens);  // src/deflate.ts:141
+  canon_codes(S.clens, 19, S.ccodes);
+
+  if (tid == 0) {
+    const uint32_t hl_hd = S.hdr_bits;
+    uint32_t HCLEN = 0;
+    for (uint32_t i = 0; i < 19; i++)
+      if (S.clens[kClOrder[i]]) HCLEN = i + 1;  // src/deflate.ts:143-148
+    uint32_t bp = 0;
+    hdr_put(S, bp, hl_hd, 10);                                                     // HLIT, HDIST
+    hdr_put(S, bp, (HCLEN - 4u) & 15u, 4);                                         // HCLEN
+    for (uint32_t i = 0; i < HCLEN; i++) hdr_put(S, bp, S.clens[kClOrder[i]], 3);  // src/deflate.ts:158-165
+    for (uint32_t i = 0; i < S.nrl; i++) {                                         // src/deflate.ts:167-181
+      const uint32_t v = S.rl_sym[i];
+      hdr_put(S, bp, S.ccodes[v], S.clens[v]);
+      if (v == 18) hdr_put(S, bp, S.rl_val[i] - 11u, 7);
+      else if (v == 17) hdr_put(S, bp, S.rl_val[i] - 3u, 3);
+      else if (v == 16) hdr_put(S, bp, S.rl_val[i] - 3u, 2);
+    }
+    S.hdr_bits = bp;
+  }
+  __syncthreads();
+  // block bit count straight from the histograms
+  uint32_t part = 0;
+  for (uint32_t s = tid; s < 286; s += HUFF_THREADS) {
+    uint32_t xb = (s >= 257) ? kLenXbits[s - 257] : 0u;
+    part += hg[s] * ((uint32_t)S.lens[s] + xb);
+  }
+  if (tid < 30) part += hg[288 + tid] * ((uint32_t)S.lens[288 + tid] + kDistXbits[tid]);
+  atomicAdd(&S.total_bits, part);
+  __syncthreads();
+  if (tid == 0) {
+    blks[g].hdr_bits = S.hdr_bits;
+    blks[g].bits = 3u + S.hdr_bits + S.total_bits;
+  }
+  uint32_t* cg = codes_out + (uint64_t)g * 320;
+  for (uint32_t i = tid; i < 320; i += HUFF_THREADS) cg[i] = (uint32_t)S.codes[i] | ((uint32_t)S.lens[i] << 16);
+  uint32_t* hd = hdr_out + (uint64_t)g * ZES_HDR_WORDS;
+  for (uint32_t i = tid; i < ZES_HDR_WORDS; i += HUFF_THREADS) hd[i] = S.hdr[i];
+}
+
+// stage-level entry for tests: lengths only
+__global__ __launch_bounds__(HUFF_THREADS) void k_huff_lengths_only(const uint32_t* __restrict__ hist, uint32_t nsym, uint32_t L,
+                                                                    uint8_t* __restrict__ lens_out) {
+  __shared__ HuffSmem S;
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t i = tid; i < 320; i += HUFF_THREADS) S.hist[i] = i < nsym ? hist[i] : 0u;
+  __syncthreads();
+  pm_lengths(S, S.hist, nsym, L, S.lens);
+  for (uint32_t i = tid; i < nsym; i += HUFF_THREADS) lens_out[i] = S.lens[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// k_adler: each workgroup reduces one 64 KiB chunk to (A, B) and adds its closed-form share
+//  to two u64 accumulators per buffer: acc[0] += A, acc[1] += B + A * bytesAfter.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(ADLER_THREADS) void k_adler(const uint8_t* __restrict__ d_in, uint64_t in_off, uint64_t n,
+                                                         unsigned long long* __restrict__ acc) {
+  __shared__ uint64_t sa[ADLER_THREADS / 64], sb[ADLER_THREADS / 64];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint64_t c0 = (uint64_t)blockIdx.x * ADLER_CHUNK;
+  const uint64_t clen = min((uint64_t)ADLER_CHUNK, n - c0);
+  const uint8_t* p = d_in + in_off + c0;
+  // B = sum over j of (clen - j) * b[j]  (j = offset inside the chunk)
+  uint64_t A = 0, B = 0;
+  const bool aligned = (((uintptr_t)p) & 15u) == 0;
+  for (uint64_t o = (uint64_t)tid * 16; o < clen; o += (uint64_t)ADLER_THREADS * 16) {
+    uint8_t b[16];
+    if (aligned && o + 16 <= clen) {
+      *reinterpret_cast<uint4*>(b) = *reinterpret_cast<const uint4*>(p + o);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 16; k++) b[k] = (o + k < clen) ? p[o + k] : (uint8_t)0;
+    }
+    uint32_t a = 0, w = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      a += b[k];
+      w += (uint32_t)(16 - k) * b[k];
+    }
+    // (clen - (o+k)) = (clen - o - 16) + (16 - k); bytes past the chunk end are 0 so the
+    // (possibly negative) first factor never multiplies a non-zero byte out of range
+    A += a;
+    B += (uint64_t)w + (uint64_t)a * (clen - o - 16);  // clen - o - 16 may wrap; see below
+  }
+  // note: when o + 16 > clen the term a * (clen - o - 16) wraps modulo 2^64, and so does the
+  // over-count inside w for the padding zeros: together they are still exact modulo 2^64,
+  // because (clen - o - 16) + (16 - k) = clen - o - k >= 1 for every real byte.
+  for (int d = 32; d >= 1; d >>= 1) {
+    A += __shfl_down(A, d);
+    B += __shfl_down(B, d);
+  }
+  if (lane == 0) {
+    sa[wave] = A;
+    sb[wave] = B;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    uint64_t ta = 0, tb = 0;
+    for (uint32_t w = 0; w < ADLER_THREADS / 64; w++) {
+      ta += sa[w];
+      tb += sb[w];
+    }
+    const uint64_t after = n - c0 - clen;
+    ta %= 65521u;
+    tb %= 65521u;
+    const uint64_t share = (tb + ta * (after % 65521u)) % 65521u;
+    atomicAdd(&acc[0], (unsigned long long)ta);
+    atomicAdd(&acc[1], (unsigned long long)share);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_layout: one workgroup per buffer.  Exclusive scan of the block bit counts (blocks are
+// bit-concatenated, src/deflate.ts:20-34), final zero pad (:35-37), zlib header and Adler-32
+// trailer (src/zlib.ts:28-46).  Boundary dwords of every block are zeroed here because k_emit
+// ORs into them atomically.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_layout(uint8_t* __restrict__ d_out, const ZesBuf* __restrict__ bufs,
+                                                ZesBlk* __restrict__ blks, const unsigned long long* __restrict__ adler_acc,
+                                                ZesRes* __restrict__ res) {
+  __shared__ uint64_t s_tot;
+  __shared__ uint64_t s_part[256];
+  const uint32_t b = blockIdx.x, tid = threadIdx.x;
+  const ZesBuf bf = bufs[b];
+  ZesBlk* bk = blks + bf.first_blk;
+  uint32_t* out32 = reinterpret_cast<uint32_t*>(d_out + bf.out_off);
+  {
+    // exclusive scan over the buffer's blocks: contiguous slice per thread, then a serial
+    // pass over the 256 slice sums (nblk is a few thousand at most)
+    const uint32_t per = (bf.nblk + 255u) / 256u;
+    const uint32_t lo = min(bf.nblk, tid * per), hi = min(bf.nblk, lo + per);
+    uint64_t sum = 0;
+    for (uint32_t i = lo; i < hi; i++) sum += bk[i].bits;
+    s_part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+      uint64_t off = 16;  // after the two zlib header bytes
+      for (uint32_t t = 0; t < 256; t++) {
+        const uint64_t v = s_part[t];
+        s_part[t] = off;
+        off += v;
+      }
+      s_tot = off;
+    }
+    __syncthreads();
+    uint64_t off = s_part[tid];
+    for (uint32_t i = lo; i < hi; i++) {
+      bk[i].bit_off = off;
+      off += bk[i].bits;
+    }
+  }
+  __syncthreads();
+  const uint64_t tot = s_tot;
+  const uint64_t raw_end = (tot + 7) >> 3;      // byte index just past the padded deflate data
+  const uint64_t out_len = raw_end + 4;
+  // zero every dword touched atomically: block boundary dwords and everything from the last
+  // block's final dword through the trailer
+  for (uint32_t i = tid; i < bf.nblk; i += 256) {
+    const uint64_t s = bk[i].bit_off, e = s + bk[i].bits - 1;
+    out32[s >> 5] = 0;
+    out32[e >> 5] = 0;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const uint64_t last_dw = (tot - 1) >> 5;
+    const uint64_t end_dw = (out_len * 8 - 1) >> 5;
+    for (uint64_t w = last_dw + 1; w <= end_dw; w++) out32[w] = 0;
+    __threadfence();
+    // zlib header: 0x78 0x9C (src/zlib.ts:29-34)
+    atomicOr(&out32[0], 0x9C78u);
+    const uint64_t n = bf.n;
+    const uint32_t s1 = (uint32_t)((1ull + adler_acc[2 * b + 0]) % 65521ull);
+    const uint32_t s2 = (uint32_t)((n % 65521ull + adler_acc[2 * b + 1]) % 65521ull);
+    const uint32_t ad = (s2 << 16) | s1;
+    for (int k = 0; k < 4; k++) {  // big-endian trailer (src/zlib.ts:37-40)
+      const uint64_t pos = raw_end + k;
+      const uint32_t byte = (ad >> (24 - 8 * k)) & 0xffu;
+      atomicOr(&out32[pos >> 2], byte << (8 * (pos & 3)));
+    }
+    res[b].out_len = out_len;
+    res[b].status = 0;
+    res[b].aux = ad;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_emit: one workgroup per block.  Items (3 block bits, header words, tokens, EOB) get their
+// bit offsets from a workgroup scan; bits are OR-ed into an LDS staging window and leave as
+// whole dwords.  Only the first and last dword of a block (shared with its neighbours) use
+// global atomics.
+// ------------------------------------------------------------------------------------------
+#define EMIT_ITEMS 4  // tokens per thread per tile
+#define EMIT_TILE (EMIT_THREADS * EMIT_ITEMS)
+#define EMIT_STAGE_WORDS (EMIT_TILE * 48 / 32 + 8)
+struct EmitSmem {
+  uint32_t codes[320];
+  uint32_t stage[EMIT_STAGE_WORDS];
+  uint32_t wsum[EMIT_THREADS / 64];
+  uint32_t carry;
+};
+
+__device__ static inline void stage_or(uint32_t* stage, uint32_t rel_bit, uint64_t v, uint32_t nbits) {
+  const uint32_t w = rel_bit >> 5, sh = rel_bit & 31u;
+  const uint64_t lo = v << sh;
+  atomicOr(&stage[w], (uint32_t)lo);
+  if (sh + nbits > 32u) atomicOr(&stage[w + 1], (uint32_t)(lo >> 32));
+  if (sh + nbits > 64u) atomicOr(&stage[w + 2], (uint32_t)(v >> (64u - sh)));
+}
+
+__global__ __launch_bounds__(EMIT_THREADS) void k_emit(uint8_t* __restrict__ d_out, const ZesBuf* __restrict__ bufs,
+                                                       const ZesBlk* __restrict__ blks, const uint32_t* __restrict__ tok_in,
+                                                       const uint32_t* __restrict__ codes_in, const uint32_t* __restrict__ hdr_in) {
+  __shared__ EmitSmem S;
+  const uint32_t g = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const ZesBlk bk = blks[g];
+  const ZesBuf bf = bufs[bk.buf];
+  uint32_t* out32 = reinterpret_cast<uint32_t*>(d_out + bf.out_off);
+  const uint32_t* tk = tok_in + (uint64_t)g * ZES_BLK;
+  const uint32_t* hd = hdr_in + (uint64_t)g * ZES_HDR_WORDS;
+  for (uint32_t i = tid; i < 320; i += EMIT_THREADS) S.codes[i] = codes_in[(uint64_t)g * 320 + i];
+  if (tid == 0) S.carry = 0;
+  const uint64_t blk_first_dw = bk.bit_off >> 5;
+  const uint64_t blk_last_dw = (bk.bit_off + bk.bits - 1) >> 5;
+  const bool is_final = (bk.blk + 1 == bf.nblk);
+  const uint32_t nhdr_items = 1 + ((bk.hdr_bits + 31u) >> 5);  // block bits + header words
+  const uint32_t nitems = nhdr_items + bk.ntok + 1;            // + EOB
+  uint64_t cur_bit = bk.bit_off;                               // uniform
+  __syncthreads();
+
+  for (uint32_t t0 = 0; t0 < nitems; t0 += EMIT_TILE) {
+    // 1. each thread builds its (value, nbits) items
+    uint64_t val[EMIT_ITEMS];
+    uint32_t nb[EMIT_ITEMS];
+    uint32_t mysum = 0;
+#pragma unroll
+    for (int k = 0; k < EMIT_ITEMS; k++) {
+      const uint32_t it = t0 + tid * EMIT_ITEMS + k;
+      uint64_t v = 0;
+      uint32_t b = 0;
+      if (it < nitems) {
+        if (it == 0) {  // BFINAL + BTYPE=2 (src/deflate.ts:21-28)
+          v = (is_final ? 1u : 0u) | (2u << 1);
+          b = 3;
+        } else if (it < nhdr_items) {
+          const uint32_t wi = it - 1;
+          v = hd[wi];
+          b = min(32u, bk.hdr_bits - wi * 32u);
+        } else if (it == nitems - 1) {  // EOB (src/deflate.ts:222-226)
+          const uint32_t c = S.codes[256];
+          v = c & 0xffffu;
+          b = c >> 16;
+        } else {
+          const uint32_t tv = tk[it - nhdr_items];
+          if (tv & ZES_TOK_MATCH) {  // src/deflate.ts:187-211
+            const uint32_t len = zes_tok_len(tv), dist = zes_tok_dist(tv);
+            const uint32_t lc = zes_len_code(len), dc = zes_dist_code(dist);
+            const uint32_t cl = S.codes[257 + lc], cd = S.codes[288 + dc];
+            const uint32_t ll = cl >> 16, dl = cd >> 16;
+            const uint32_t lx = kLenXbits[lc], dx = kDistXbits[dc];
+            v = (uint64_t)(cl & 0xffffu);
+            b = ll;
+            v |= (uint64_t)(len - kLenBase[lc]) << b;
+            b += lx;
+            v |= (uint64_t)(cd & 0xffffu) << b;
+            b += dl;
+            v |= (uint64_t)(dist - kDistBase[dc]) << b;
+            b += dx;
+          } else {  // literal (src/deflate.ts:212-219)
+            const uint32_t c = S.codes[tv];
+            v = c & 0xffffu;
+            b = c >> 16;
+          }
+        }
+      }
+      val[k] = v;
+      nb[k] = b;
+      mysum += b;
+    }
+    // 2. workgroup exclusive scan of mysum
+    uint32_t incl = mysum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t t = __shfl_up(incl, d);
+      if ((int)lane >= d) incl += t;
+    }
+    if (lane == 63) S.wsum[wave] = incl;
+    __syncthreads();  // also: previous tile's flush finished reading stage/carry
+    uint32_t wbase = 0, tile_bits = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < EMIT_THREADS / 64; w++) {
+      const uint32_t s = S.wsum[w];
+      if (w < wave) wbase += s;
+      tile_bits += s;
+    }
+    uint32_t rel = wbase + incl - mysum;  // bit offset of my first item inside the tile
+    // 3. zero the staging window, seed it with the carried partial dword
+    const uint32_t head = (uint32_t)(cur_bit & 31u);
+    const uint32_t nwords = (head + tile_bits + 31u) >> 5;
+    for (uint32_t i = tid; i < nwords + 1; i += EMIT_THREADS) S.stage[i] = (i == 0) ? S.carry : 0u;
+    __syncthreads();
+    // 4. OR the items in
+    rel += head;
+#pragma unroll
+    for (int k = 0; k < EMIT_ITEMS; k++) {
+      if (nb[k]) stage_or(S.stage, rel, val[k], nb[k]);
+      rel += nb[k];
+    }
+    __syncthreads();
+    // 5. flush complete dwords; the trailing partial dword is carried into the next tile
+    const uint64_t first_dw = cur_bit >> 5;
+    const uint32_t end_bits = head + tile_bits;
+    const bool last_tile = (t0 + EMIT_TILE >= nitems);
+    const uint32_t ncomplete = last_tile ? nwords : (end_bits >> 5);
+    for (uint32_t i = tid; i < ncomplete; i += EMIT_THREADS) {
+      const uint64_t gw = first_dw + i;
+      const uint32_t w = S.stage[i];
+      if (gw == blk_first_dw || gw == blk_last_dw) atomicOr(&out32[gw], w);
+      else out32[gw] = w;
+    }
+    const uint32_t carry_next = (!last_tile && (end_bits & 31u)) ? S.stage[end_bits >> 5] : 0u;
+    __syncthreads();
+    if (tid == 0) S.carry = carry_next;
+    cur_bit += tile_bits;
+  }
+}
+
+// small utility kernels ---------------------------------------------------------------------
+__global__ void k_zero_u64(unsigned long long* p, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0ull;
+}

@@ -1,0 +1,923 @@
+// zes_inflate.hip — gfx950 kernels of the decompress direction.
+//
+// Three tiers, each falling back to the next on anything unusual:
+//
+//  T1  block-parallel: reference-made streams are chains of BTYPE=2 blocks that each inflate
+//      to exactly 131072 bytes without looking behind their own start.
+//        k_inf_scan      every bit position is tested for "could start a clean dynamic block"
+//        k_inf_verify    survivors get their whole header decoded and Kraft-checked
+//        k_inf_ranksort  candidate positions in ascending order
+//        k_inf_decode    one wavefront per candidate block, 64 KiB LDS ring, lane-parallel copies
+//        k_inf_chain     walks end-bit -> next start from bit 16; accepts only a gap-free chain
+//  T2  k_inf_decode in sequential mode: one wavefront walks all blocks (stored / fixed / dynamic,
+//      32 KiB history across blocks) — any *valid* stream.
+//  T3  k_inf_exact: single-lane state-for-state restatement of the reference reader and block
+//      decoders (src/inflate.ts, src/utils/BitReadStream.ts), resumed at the block where T2 gave
+//      up — reproduces the reference's result on malformed streams (which error, or which bytes).
+#include "zes_common.h"
+#include "zes_kernels.h"
+
+#define ZES_E_NOT_DEFLATE (-1)
+#define ZES_E_BTYPE3 (-2)
+#define ZES_E_CORRUPT (-3)
+#define ZES_E_INSUFFICIENT (-4)
+#define ZES_E_LACK (-5)
+
+// ------------------------------------------------------------------------------------------
+// bit window helpers on global memory (scan/verify kernels): 64 bits starting at bit position
+// ------------------------------------------------------------------------------------------
+__device__ static inline uint64_t g_load64_le(const uint8_t* p, uint64_t byte, uint64_t nbytes) {
+  uint64_t v = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const uint64_t b = byte + k;
+    v |= (uint64_t)(b < nbytes ? p[b] : (uint8_t)0) << (8 * k);
+  }
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_inf_scan: one thread per bit position (LDS-staged chunk).  Keeps positions whose first 17
+// bits look like BTYPE=2 with HLIT<=29, HDIST<=29 and whose code-length code is Kraft-complete.
+// ------------------------------------------------------------------------------------------
+#define SCAN_BYTES INF_SCAN_BYTES  // bytes of the stream per workgroup (16384 bit positions)
+__global__ __launch_bounds__(INF_SCAN_THREADS) void k_inf_scan(const uint8_t* __restrict__ d_in, uint64_t in_off, uint64_t c,
+                                                               uint32_t* __restrict__ surv, uint32_t surv_cap,
+                                                               uint32_t* __restrict__ counters) {
+  __shared__ __align__(16) uint8_t s[SCAN_BYTES + 48];
+  const uint32_t tid = threadIdx.x;
+  const uint64_t b0 = (uint64_t)blockIdx.x * SCAN_BYTES;
+  const uint8_t* p = d_in + in_off;
+  for (uint32_t i = tid; i < SCAN_BYTES + 48; i += INF_SCAN_THREADS) s[i] = (b0 + i < c) ? p[b0 + i] : (uint8_t)0;
+  __syncthreads();
+  const uint32_t per = SCAN_BYTES * 8 / INF_SCAN_THREADS;
+  for (uint32_t k = 0; k < per; k++) {
+    const uint32_t rb = k * INF_SCAN_THREADS + tid;  // bit inside the chunk (coalesced across lanes)
+    const uint64_t abs_bit = b0 * 8 + rb;
+    if (abs_bit < 16 || abs_bit + 17 + 12 > c * 8) continue;
+    const uint32_t by = rb >> 3;
+    const uint32_t* s32 = reinterpret_cast<const uint32_t*>(s);
+    const uint32_t wi = by >> 2;
+    const uint64_t lo = (uint64_t)s32[wi] | ((uint64_t)s32[wi + 1] << 32);
+    const uint64_t hi = (uint64_t)s32[wi + 2] | ((uint64_t)s32[wi + 3] << 32);
+    const uint32_t t = ((by & 3u) << 3) + (rb & 7u);  // 0..31
+    const uint64_t bits = t ? ((lo >> t) | (hi << (64u - t))) : lo;
+    if (((bits >> 1) & 3u) != 2u) continue;
+    if (((bits >> 3) & 31u) > 29u) continue;
+    if (((bits >> 8) & 31u) > 29u) continue;
+    const uint32_t ncl = (uint32_t)((bits >> 13) & 15u) + 4u;
+    // code-length code lengths: ncl x 3 bits from bit 17 (up to 57 bits)
+    const uint64_t clb = (bits >> 17) | ((hi >> t) << 47);
+    uint32_t kraft = 0;
+    for (uint32_t i = 0; i < ncl; i++) {
+      const uint32_t l = (uint32_t)(clb >> (3 * i)) & 7u;
+      if (l) kraft += 128u >> l;
+    }
+    if (kraft != 128u) continue;
+    const uint32_t slot = atomicAdd(&counters[0], 1u);
+    if (slot < surv_cap) surv[slot] = (uint32_t)(abs_bit - 16);  // relative to bit 16 (fits u32 for c < 512 MiB)
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_inf_verify: one thread per survivor; decodes the code-length sequence and checks that the
+// lit/len code is complete with an end-of-block code and the distance code is complete, a
+// single 1-bit code, or absent.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_inf_verify(const uint8_t* __restrict__ d_in, uint64_t in_off, uint64_t c,
+                                                   const uint32_t* __restrict__ surv, uint32_t surv_cap,
+                                                   uint32_t* __restrict__ counters, uint32_t* __restrict__ cand, uint32_t cand_cap) {
+  __shared__ uint8_t cl_lut[64][128];
+  const uint32_t lane = threadIdx.x;
+  const uint32_t i = blockIdx.x * 64 + lane;
+  uint32_t ns = counters[0];
+  if (ns > surv_cap) ns = surv_cap;
+  if (i >= ns) return;
+  const uint8_t* p = d_in + in_off;
+  const uint64_t pos0 = (uint64_t)surv[i] + 16;
+  uint64_t pos = pos0;
+  auto take = [&](uint32_t k) -> uint32_t {
+    const uint64_t w = g_load64_le(p, pos >> 3, c);
+    const uint32_t v = (uint32_t)(w >> (pos & 7)) & ((1u << k) - 1u);
+    pos += k;
+    return v;
+  };
+  take(3);
+  const uint32_t HLIT = take(5) + 257, HDIST = take(5) + 1, HCLEN = take(4) + 4;
+  uint8_t cl[19];
+  for (int k = 0; k < 19; k++) cl[k] = 0;
+  for (uint32_t k = 0; k < HCLEN; k++) cl[kClOrder[k]] = (uint8_t)take(3);
+  // 7-bit LUT of the (complete) code-length code
+  uint8_t* lut = cl_lut[lane];
+  for (int k = 0; k < 128; k++) lut[k] = 0;
+  {
+    uint32_t code = 0;
+    for (uint32_t l = 1; l <= 7; l++) {
+      for (uint32_t sy = 0; sy < 19; sy++)
+        if (cl[sy] == l) {
+          const uint32_t rev = __brev(code) >> (32 - l);
+          for (uint32_t e = rev; e < 128; e += 1u << l) lut[e] = (uint8_t)(sy | (l << 5));
+          code++;
+        }
+      code <<= 1;
+    }
+  }
+  uint32_t kl = 0, kd = 0, nd = 0, dmaxlen = 0, prev = 0;
+  bool has_eob = false, ok = true;
+  const uint32_t total = HLIT + HDIST;
+  for (uint32_t k = 0; k < total && ok;) {
+    if (pos + 14 > c * 8) { ok = false; break; }
+    const uint64_t w = g_load64_le(p, pos >> 3, c);
+    const uint32_t e = lut[(uint32_t)(w >> (pos & 7)) & 127u];
+    const uint32_t l = e >> 5, sy = e & 31u;
+    if (!l) { ok = false; break; }
+    pos += l;
+    uint32_t rep = 1, val = sy;
+    if (sy == 16) {
+      if (k == 0) { ok = false; break; }
+      rep = 3 + take(2);
+      val = prev;
+    } else if (sy == 17) {
+      rep = 3 + take(3);
+      val = 0;
+    } else if (sy == 18) {
+      rep = 11 + take(7);
+      val = 0;
+    }
+    if (k + rep > total) { ok = false; break; }
+    if (val) {
+      for (uint32_t r = 0; r < rep; r++) {
+        const uint32_t idx = k + r;
+        if (idx < HLIT) {
+          kl += 32768u >> val;
+          if (idx == 256) has_eob = true;
+        } else {
+          kd += 32768u >> val;
+          nd++;
+          dmaxlen = max(dmaxlen, val);
+        }
+      }
+    }
+    prev = val;
+    k += rep;
+  }
+  if (!ok || !has_eob || kl != 32768u) return;
+  if (!(kd == 32768u || nd == 0 || (nd == 1 && dmaxlen == 1))) return;
+  const uint32_t slot = atomicAdd(&counters[1], 1u);
+  if (slot < cand_cap) cand[slot] = (uint32_t)(pos0 - 16);
+}
+
+// rank sort of the candidate list (a few hundred to a few thousand entries)
+__global__ void k_inf_ranksort(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t v = in[i];
+  uint32_t r = 0;
+  for (uint32_t j = 0; j < n; j++) {
+    const uint32_t u = in[j];
+    r += (u < v) || (u == v && j < i);
+  }
+  out[r] = v;
+}
+
+// ------------------------------------------------------------------------------------------
+// wave decoder
+// ------------------------------------------------------------------------------------------
+#define LROOT 11u
+#define DROOT 10u
+#define RING 65536u
+#define FLUSH 16384u
+#define INWIN 1024u
+
+struct InfSmem {
+  uint8_t ring[RING];
+  uint16_t lut_l[1u << LROOT];
+  uint16_t lut_d[1u << DROOT];
+  uint16_t syms_l[288];
+  uint16_t syms_d[32];
+  uint32_t first_l[16], first_d[16];
+  uint16_t cnt_l[16], cnt_d[16], offs_l[16], offs_d[16];
+  uint8_t lens[352];  // [0,288) lit/len, [288,320) dist
+  uint8_t cl_lut[128];
+  uint8_t inbuf[INWIN + 32];
+};
+
+struct WaveDec {
+  // uniform state (identical in all 64 lanes)
+  const uint8_t* in;  // buffer base (16-byte aligned)
+  uint64_t nbytes;
+  uint64_t pos;   // absolute bit position of bit 0 of bb
+  uint64_t bb;
+  uint32_t nb;    // valid bits in bb; (pos + nb) % 8 == 0
+  uint64_t win;   // byte offset held at inbuf[0]; ~0 = nothing loaded
+  uint8_t* out;   // where output byte 0 goes
+  uint64_t cap;   // bytes that may be stored at out
+  uint64_t o;     // bytes produced so far
+  uint64_t flushed;
+  uint64_t hist0; // oldest output offset a match may reach
+  uint64_t omax;  // give up once more than this many bytes were produced (slot size in T1)
+};
+
+enum { WD_OK = 0, WD_ANOMALY = 1, WD_NEEDS_HISTORY = 2 };
+
+__device__ static inline void wd_load_window(InfSmem& S, WaveDec& d, uint64_t byte) {
+  const uint32_t lane = zes_lane();
+  d.win = byte & ~15ull;
+  // 64 lanes x 16 B + 32 B tail
+  for (uint32_t k = lane; k < (INWIN + 32) / 16; k += 64) {
+    const uint64_t off = d.win + (uint64_t)k * 16;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (off + 16 <= d.nbytes) {
+      v = *reinterpret_cast<const uint4*>(d.in + off);
+    } else if (off < d.nbytes) {
+      uint8_t t[16];
+      for (int j = 0; j < 16; j++) t[j] = (off + j < d.nbytes) ? d.in[off + j] : (uint8_t)0;
+      v = *reinterpret_cast<uint4*>(t);
+    }
+    *reinterpret_cast<uint4*>(&S.inbuf[k * 16]) = v;
+  }
+}
+
+__device__ static inline uint32_t wd_ld32(InfSmem& S, WaveDec& d, uint64_t byte) {
+  if (byte < d.win || byte + 8 > d.win + INWIN + 32) wd_load_window(S, d, byte);
+  const uint32_t off = (uint32_t)(byte - d.win);
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(S.inbuf);
+  const uint32_t i = off >> 2;
+  return __builtin_amdgcn_alignbyte(w[i + 1], w[i], off & 3u);
+}
+
+__device__ static inline void wd_seek(InfSmem& S, WaveDec& d, uint64_t bit) {
+  d.pos = bit;
+  const uint32_t w = wd_ld32(S, d, bit >> 3);
+  d.bb = (uint64_t)(w >> (bit & 7));
+  d.nb = 32u - (uint32_t)(bit & 7);
+}
+__device__ static inline void wd_refill(InfSmem& S, WaveDec& d) {  // guarantees nb >= 33
+  if (d.nb <= 32u) {
+    const uint32_t w = wd_ld32(S, d, (d.pos + d.nb) >> 3);
+    d.bb |= (uint64_t)w << d.nb;
+    d.nb += 32u;
+  }
+}
+__device__ static inline uint32_t wd_take(WaveDec& d, uint32_t k) {  // k <= 16, after wd_refill
+  const uint32_t v = (uint32_t)d.bb & ((1u << k) - 1u);
+  d.bb >>= k;
+  d.nb -= k;
+  d.pos += k;
+  return v;
+}
+
+__device__ static inline void wd_flush_range(InfSmem& S, WaveDec& d, uint64_t from, uint64_t to) {
+  // ring -> global for output offsets [from, to); from is a multiple of 16
+  const uint32_t lane = zes_lane();
+  for (uint64_t off = from + (uint64_t)lane * 16; off < to; off += 64 * 16) {
+    const uint32_t r = (uint32_t)(off & (RING - 1));
+    if (off + 16 <= to && off + 16 <= d.cap) {
+      *reinterpret_cast<uint4*>(d.out + off) = *reinterpret_cast<const uint4*>(&S.ring[r]);
+    } else {
+      for (uint32_t j = 0; j < 16; j++)
+        if (off + j < to && off + j < d.cap) d.out[off + j] = S.ring[(r + j) & (RING - 1)];
+    }
+  }
+}
+__device__ static inline void wd_maybe_flush(InfSmem& S, WaveDec& d) {
+  while (d.o - d.flushed >= FLUSH) {
+    wd_flush_range(S, d, d.flushed, d.flushed + FLUSH);
+    d.flushed += FLUSH;
+  }
+}
+
+// canonical tables + root LUT for one alphabet; lens in S.lens[base .. base+nsym).
+// Returns false when the length set is over-subscribed.
+__device__ static bool wd_build(InfSmem& S, uint32_t base, uint32_t nsym, uint32_t root, uint16_t* lut, uint16_t* syms,
+                                uint32_t* first, uint16_t* cnt, uint16_t* offs) {
+  const uint32_t lane = zes_lane();
+  const uint8_t* lens = S.lens + base;
+  for (uint32_t i = lane; i < (1u << root); i += 64) lut[i] = 0;
+  // counts per length (uniform loop: nsym <= 288 broadcast reads)
+  uint32_t c[16];
+#pragma unroll
+  for (int l = 0; l < 16; l++) c[l] = 0;
+  for (uint32_t s0 = 0; s0 < nsym; s0 += 64) {
+    const uint32_t s = s0 + lane;
+    const uint32_t l = s < nsym ? lens[s] : 0u;
+#pragma unroll
+    for (int k = 1; k < 16; k++) c[k] += (uint32_t)__popcll(__ballot(l == (uint32_t)k));
+  }
+  uint32_t code = 0, off = 0, kraft = 0;
+  uint32_t fst[16], ofs[16];
+#pragma unroll
+  for (int l = 1; l < 16; l++) {
+    fst[l] = code;
+    ofs[l] = off;
+    code = (code + c[l]) << 1;
+    off += c[l];
+    kraft += c[l] << (15 - l);
+  }
+  if (kraft > 32768u) return false;
+  if (lane < 16) {
+    uint32_t f = 0, o2 = 0, cc = 0;
+#pragma unroll
+    for (int l = 1; l < 16; l++)
+      if ((int)lane == l) {
+        f = fst[l];
+        o2 = ofs[l];
+        cc = c[l];
+      }
+    first[lane] = f;
+    offs[lane] = (uint16_t)o2;
+    cnt[lane] = (uint16_t)cc;
+  }
+  // per symbol: rank inside its length, canonical code, LUT fill / sorted-symbol slot
+  for (uint32_t s0 = 0; s0 < nsym; s0 += 64) {
+    const uint32_t s = s0 + lane;
+    const uint32_t l = s < nsym ? lens[s] : 0u;
+    if (l) {
+      uint32_t rank = 0;
+      for (uint32_t j = 0; j < s; j++) rank += (lens[j] == l);
+      uint32_t f = 0, o2 = 0;
+#pragma unroll
+      for (int k = 1; k < 16; k++)
+        if ((int)l == k) {
+          f = fst[k];
+          o2 = ofs[k];
+        }
+      syms[o2 + rank] = (uint16_t)s;
+      if (l <= root) {
+        const uint32_t rev = __brev(f + rank) >> (32u - l);
+        for (uint32_t e = rev; e < (1u << root); e += 1u << l) lut[e] = (uint16_t)(s | (l << 9));
+      }
+    }
+  }
+  return true;
+}
+
+// symbol decode: root LUT, then canonical walk for codes longer than root (reference
+// src/inflate.ts:238-252 extends one bit at a time the same way).  Returns -1 if no code matches.
+__device__ static inline int wd_sym(WaveDec& d, const uint16_t* lut, uint32_t root, const uint16_t* syms,
+                                    const uint32_t* first, const uint16_t* cnt, const uint16_t* offs) {
+  const uint32_t e = lut[(uint32_t)d.bb & ((1u << root) - 1u)];
+  const uint32_t l = e >> 9;
+  if (l) {
+    d.bb >>= l;
+    d.nb -= l;
+    d.pos += l;
+    return (int)(e & 511u);
+  }
+  uint32_t code = __brev((uint32_t)d.bb & ((1u << root) - 1u)) >> (32u - root);
+  for (uint32_t len = root + 1; len <= 15u; len++) {
+    code = (code << 1) | (uint32_t)((d.bb >> (len - 1)) & 1u);
+    const uint32_t rel = code - first[len];
+    if (code >= first[len] && rel < cnt[len]) {
+      d.bb >>= len;
+      d.nb -= len;
+      d.pos += len;
+      return (int)syms[offs[len] + rel];
+    }
+  }
+  return -1;
+}
+
+// Decodes the symbols of one fixed/dynamic block whose tables are built.  Uniform control flow.
+__device__ static int wd_symbols(InfSmem& S, WaveDec& d, uint32_t droot_used) {
+  const uint32_t lane = zes_lane();
+  const uint64_t limit = d.nbytes * 8;
+  for (;;) {
+    wd_refill(S, d);
+    const int s = wd_sym(d, S.lut_l, LROOT, S.syms_l, S.first_l, S.cnt_l, S.offs_l);
+    if (s < 0) return WD_ANOMALY;
+    if (d.pos > limit) return WD_ANOMALY;
+    if (s < 256) {
+      if (lane == 0) S.ring[d.o & (RING - 1)] = (uint8_t)s;
+      d.o++;
+      if (d.o > d.omax) return WD_ANOMALY;
+      wd_maybe_flush(S, d);
+      continue;
+    }
+    if (s == 256) return WD_OK;
+    const uint32_t lc = (uint32_t)s - 257u;
+    if (lc >= 29u) return WD_ANOMALY;
+    wd_refill(S, d);
+    const uint32_t len = kLenBase[lc] + wd_take(d, kLenXbits[lc]);
+    wd_refill(S, d);
+    const int ds = wd_sym(d, S.lut_d, droot_used, S.syms_d, S.first_d, S.cnt_d, S.offs_d);
+    if (ds < 0 || ds >= 30) return WD_ANOMALY;
+    wd_refill(S, d);
+    const uint32_t dist = kDistBase[ds] + wd_take(d, kDistXbits[ds]);
+    if (d.pos > limit) return WD_ANOMALY;
+    if ((uint64_t)dist > d.o - d.hist0) return WD_NEEDS_HISTORY;  // T1: behind the block start; T2: behind the output start
+    if (d.o + len > d.omax) return WD_ANOMALY;
+    // lane-parallel copy; overlapping matches read i % dist so every source byte already exists
+    const uint64_t srcb = d.o - dist;
+    const uint32_t recip = (dist < len) ? (1048576u / dist + 1u) : 0u;
+    for (uint32_t i = lane; i < len; i += 64) {
+      uint32_t k = i;
+      if (recip) k = i - ((i * recip) >> 20) * dist;
+      const uint8_t v = S.ring[(srcb + k) & (RING - 1)];
+      S.ring[(d.o + i) & (RING - 1)] = v;
+    }
+    d.o += len;
+    wd_maybe_flush(S, d);
+  }
+}
+
+// One block starting at d.pos (bit position of BFINAL).  *bfinal receives the flag.
+__device__ static int wd_block(InfSmem& S, WaveDec& d, uint32_t* bfinal, bool dynamic_only) {
+  const uint32_t lane = zes_lane();
+  wd_refill(S, d);
+  *bfinal = wd_take(d, 1);
+  const uint32_t btype = wd_take(d, 2);
+  if (btype == 3) return WD_ANOMALY;
+  if (btype != 2 && dynamic_only) return WD_ANOMALY;
+  if (btype == 0) {  // stored (src/inflate.ts:42-55)
+    uint64_t bit = (d.pos + 7) & ~7ull;
+    if (bit + 32 > d.nbytes * 8) return WD_ANOMALY;
+    wd_seek(S, d, bit);
+    wd_refill(S, d);
+    const uint32_t LEN = wd_take(d, 16);
+    wd_refill(S, d);
+    const uint32_t NLEN = wd_take(d, 16);
+    if (LEN + NLEN != 65535u) return WD_ANOMALY;
+    const uint64_t src = d.pos >> 3;
+    if (src + LEN > d.nbytes) return WD_ANOMALY;
+    if (d.o + LEN > d.omax) return WD_ANOMALY;
+    for (uint32_t done = 0; done < LEN;) {
+      const uint32_t room = (uint32_t)(FLUSH - ((d.o - d.flushed) % FLUSH));
+      const uint32_t n = min(LEN - done, room);
+      for (uint32_t i = lane; i < n; i += 64) S.ring[(d.o + i) & (RING - 1)] = d.in[src + done + i];
+      d.o += n;
+      done += n;
+      wd_maybe_flush(S, d);
+    }
+    wd_seek(S, d, (src + LEN) * 8);
+    return WD_OK;
+  }
+  uint32_t droot = DROOT;
+  if (btype == 1) {  // fixed (src/huffman.ts:41-53; distance = 5 bits MSB-first, src/inflate.ts:107)
+    for (uint32_t i = lane; i < 288; i += 64) S.lens[i] = (uint8_t)(i <= 143 ? 8 : i <= 255 ? 9 : i <= 279 ? 7 : 8);
+    if (lane < 32) S.lens[288 + lane] = 5;
+  } else {  // dynamic header (src/inflate.ts:120-204)
+    wd_refill(S, d);
+    const uint32_t HLIT = wd_take(d, 5) + 257u;
+    const uint32_t HDIST = wd_take(d, 5) + 1u;
+    const uint32_t HCLEN = wd_take(d, 4) + 4u;
+    uint32_t mycl = 0;  // lane s holds the length of code-length symbol s
+    for (uint32_t k = 0; k < HCLEN; k++) {
+      wd_refill(S, d);
+      const uint32_t v = wd_take(d, 3);
+      if (lane == kClOrder[k]) mycl = v;
+    }
+    // 7-bit LUT of the code-length code
+    for (uint32_t i = lane; i < 128; i += 64) S.cl_lut[i] = 0;
+    uint32_t kraft = 0;
+    {
+      uint32_t code = 0;
+      for (uint32_t l = 1; l <= 7; l++) {
+        const uint64_t m = __ballot(lane < 19 && mycl == l);
+        if (lane < 19 && mycl == l) {
+          const uint32_t rank = (uint32_t)__popcll(m & zes_lanemask_lt());
+          const uint32_t rev = __brev(code + rank) >> (32u - l);
+          for (uint32_t e = rev; e < 128; e += 1u << l) S.cl_lut[e] = (uint8_t)(lane | (l << 5));
+        }
+        const uint32_t n = (uint32_t)__popcll(m);
+        kraft += n << (7 - l);
+        code = (code + n) << 1;
+      }
+    }
+    if (kraft > 128u) return WD_ANOMALY;
+    for (uint32_t i = lane; i < 352; i += 64) S.lens[i] = 0;
+    const uint32_t total = HLIT + HDIST;
+    uint32_t prev = 0;
+    for (uint32_t k = 0; k < total;) {
+      wd_refill(S, d);
+      const uint32_t e = S.cl_lut[(uint32_t)d.bb & 127u];
+      const uint32_t l = e >> 5, sy = e & 31u;
+      if (!l) return WD_ANOMALY;
+      wd_take(d, l);
+      uint32_t rep = 1, val = sy;
+      if (sy == 16) {
+        if (k == 0) return WD_ANOMALY;
+        rep = 3 + wd_take(d, 2);
+        val = prev;
+      } else if (sy == 17) {
+        rep = 3 + wd_take(d, 3);
+        val = 0;
+      } else if (sy == 18) {
+        rep = 11 + wd_take(d, 7);
+        val = 0;
+      }
+      if (k + rep > total) return WD_ANOMALY;  // the reference spills into the distance table: T3
+      if (val && lane < rep) {
+        const uint32_t idx = k + lane;
+        S.lens[idx < HLIT ? idx : 288 + (idx - HLIT)] = (uint8_t)val;
+      }
+      // the reference keeps `codelen` across 17/18 as 0 (src/inflate.ts:172-183)
+      prev = val;
+      k += rep;
+    }
+    if (d.pos > d.nbytes * 8) return WD_ANOMALY;
+  }
+  if (!wd_build(S, 0, 288, LROOT, S.lut_l, S.syms_l, S.first_l, S.cnt_l, S.offs_l)) return WD_ANOMALY;
+  if (!wd_build(S, 288, 32, droot, S.lut_d, S.syms_d, S.first_d, S.cnt_d, S.offs_d)) return WD_ANOMALY;
+  return wd_symbols(S, d, droot);
+}
+
+
+// mode 0 (T1): work item w decodes the block at cand[map ? map[w] : w] into slot w.
+// mode 1 (T2): a single wavefront decodes the whole stream from bit 16.
+__global__ __launch_bounds__(64) void k_inf_decode(const uint8_t* __restrict__ d_in, uint64_t in_off, uint64_t c,
+                                                   uint8_t* __restrict__ d_out, uint64_t out_off, uint64_t cap,
+                                                   const uint32_t* __restrict__ cand, const uint32_t* __restrict__ map,
+                                                   uint32_t nwork, ZesCandRes* __restrict__ cres, ZesRes* __restrict__ res,
+                                                   uint64_t* __restrict__ resume, int mode) {
+  __shared__ __align__(16) InfSmem S;
+  const uint32_t w = blockIdx.x, lane = threadIdx.x;
+  if (w >= nwork) return;
+  WaveDec d;
+  d.in = d_in + in_off;
+  d.nbytes = c;
+  d.win = ~0ull;
+  d.o = 0;
+  d.flushed = 0;
+  if (mode == 0) {
+    const uint32_t ci = map ? map[w] : w;
+    const uint64_t slot_off = (uint64_t)w * ZES_BLK;
+    d.out = d_out + out_off + slot_off;
+    d.cap = cap > slot_off ? min(cap - slot_off, (uint64_t)ZES_BLK) : 0;
+    d.hist0 = 0;
+    d.omax = ZES_BLK;
+    wd_seek(S, d, (uint64_t)cand[ci] + 16);
+    uint32_t bfinal = 0;
+    // hist0 = 0 with o starting at 0: a distance reaching before the block start shows up as
+    // dist > o; report it as "needs history" rather than an anomaly
+    const int rc = wd_block(S, d, &bfinal, true);
+    if (rc == WD_OK) wd_flush_range(S, d, d.flushed, d.o);
+    if (lane == 0) {
+      ZesCandRes r;
+      r.end_bit = d.pos;
+      r.out_len = (uint32_t)d.o;
+      r.flags = (rc == WD_OK ? 1u : 0u) | (bfinal ? 2u : 0u) | (rc != WD_OK ? 4u : 0u);
+      cres[w] = r;
+    }
+  } else {
+    d.out = d_out + out_off;
+    d.cap = cap;
+    d.hist0 = 0;
+    d.omax = ~0ull >> 1;
+    wd_seek(S, d, 16);
+    uint32_t bfinal = 0;
+    int rc = WD_OK;
+    uint64_t blk_bit = 16, blk_out = 0;
+    while (!bfinal) {
+      blk_bit = d.pos;
+      blk_out = d.o;
+      rc = wd_block(S, d, &bfinal, false);
+      if (rc != WD_OK) break;
+      if (!bfinal && d.pos >= d.nbytes * 8) {  // stream exhausted without a final block: T3 decides
+        rc = WD_ANOMALY;  // resume T3 at the start of the block just decoded so its reader state is exact
+        break;
+      }
+    }
+    if (rc == WD_OK) {
+      wd_flush_range(S, d, d.flushed, d.o);
+      if (lane == 0) {
+        res->out_len = d.o;
+        res->status = 0;
+        res->aux = 2;  // tier
+      }
+    } else {
+      // hand the failing block to the exact decoder: everything before it is valid output
+      wd_flush_range(S, d, d.flushed, blk_out);
+      if (lane == 0) {
+        resume[0] = blk_bit;
+        resume[1] = blk_out;
+        res->status = 1;  // continue with T3
+        res->out_len = blk_out;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_inf_chain: validates the parallel decode.  Success needs: candidate 0 at bit 16, every
+// block ok, every non-final block exactly 131072 bytes, end bit of block k == start of k+1,
+// and the k-th chain member being the k-th candidate (otherwise a remap pass is requested).
+// res->status: 0 done, 2 remap needed (chain in map_out, length in res->aux), 1 give up (T2).
+// ------------------------------------------------------------------------------------------
+__global__ void k_inf_chain(const uint32_t* __restrict__ cand, uint32_t ncand, const ZesCandRes* __restrict__ cres,
+                            const uint32_t* __restrict__ map_in, uint32_t nwork, uint32_t* __restrict__ map_out,
+                            ZesRes* __restrict__ res) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  // cres is indexed by work item; map_in (or identity) gives the candidate of each work item
+  res->status = 1;
+  res->out_len = 0;
+  res->aux = 0;
+  if (ncand == 0 || cand[0] != 0) return;
+  if (map_in) {
+    // second pass: work items are exactly the chain, only re-check sizes
+    uint64_t total = 0;
+    for (uint32_t k = 0; k < nwork; k++) {
+      const ZesCandRes r = cres[k];
+      if (!(r.flags & 1u)) return;
+      total += r.out_len;
+      if (r.flags & 2u) {
+        if (k + 1 != nwork) return;
+        res->status = 0;
+        res->out_len = total;
+        res->aux = 1;
+        return;
+      }
+      if (r.out_len != ZES_BLK) return;
+    }
+    return;
+  }
+  uint32_t j = 0, k = 0;
+  uint64_t total = 0;
+  bool identity = true;
+  for (;;) {
+    const ZesCandRes r = cres[j];
+    if (!(r.flags & 1u)) return;
+    map_out[k] = j;
+    if (j != k) identity = false;
+    k++;
+    total += r.out_len;
+    if (r.flags & 2u) break;
+    if (r.out_len != ZES_BLK) return;
+    // binary search the next start
+    const uint64_t want = r.end_bit - 16;
+    uint32_t lo = j + 1, hi = ncand;
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if ((uint64_t)cand[mid] < want) lo = mid + 1; else hi = mid;
+    }
+    if (lo >= ncand || (uint64_t)cand[lo] != want) return;
+    j = lo;
+  }
+  res->out_len = total;
+  res->aux = identity ? 1u : k;
+  res->status = identity ? 0 : 2;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_inf_exact (T3): single lane, state-for-state with the reference's BitReadStream and block
+// decoders.  Starts at a block boundary (bit position, output offset) handed over by T2, or at
+// bit 16 / offset 0.  Output goes straight to global memory (the same lane reads it back).
+// ------------------------------------------------------------------------------------------
+struct XReader {  // src/utils/BitReadStream.ts:1-50
+  const uint8_t* buf;
+  uint64_t len;
+  int64_t idx;
+  uint32_t now_bits;
+  int now_len;
+  int is_end;
+  int err;
+};
+__device__ static inline uint32_t xr_byte(const XReader& r, int64_t i) { return ((uint64_t)i < r.len) ? r.buf[i] : 0u; }
+__device__ static int xr_read(XReader& r) {  // :14-32
+  if (r.is_end) {
+    r.err = ZES_E_LACK;
+    return 0;
+  }
+  const int bit = (int)(r.now_bits & 1u);
+  if (r.now_len > 1) {
+    r.now_len--;
+    r.now_bits >>= 1;
+  } else {
+    r.idx++;
+    if ((uint64_t)r.idx < r.len) {
+      r.now_bits = r.buf[r.idx];
+      r.now_len = 8;
+    } else {
+      r.now_len = 0;
+      r.is_end = 1;
+    }
+  }
+  return bit;
+}
+__device__ static uint32_t xr_range(XReader& r, int length) {  // :33-42 (eager refill, zeros past the end)
+  while (r.now_len <= length) {
+    r.idx++;
+    r.now_bits |= xr_byte(r, r.idx) << r.now_len;
+    r.now_len += 8;
+  }
+  const uint32_t bits = r.now_bits & ((1u << length) - 1u);
+  r.now_bits >>= length;
+  r.now_len -= length;
+  return bits;
+}
+__device__ static uint32_t xr_coded(XReader& r, int length) {  // :43-49; length < 0 = empty table
+  uint32_t bits = 0;
+  if (length < 0) {
+    while (!r.err) xr_read(r);
+    return 0;
+  }
+  for (int i = 0; i < length && !r.err; i++) bits = (bits << 1) | (uint32_t)xr_read(r);
+  return bits;
+}
+
+struct XTab {  // src/huffman.ts:8-39
+  int lmin, lmax;
+  uint32_t first[16];
+  uint16_t count[16], offs[16];
+  uint16_t syms[352];
+};
+__device__ static void xt_build(XTab& t, const uint8_t* lens, int nsym) {
+  t.lmin = 99;
+  t.lmax = 0;
+  for (int l = 0; l < 16; l++) t.count[l] = 0;
+  for (int s = 0; s < nsym; s++)
+    if (lens[s]) {
+      t.count[lens[s]]++;
+      if (lens[s] < t.lmin) t.lmin = lens[s];
+      if (lens[s] > t.lmax) t.lmax = lens[s];
+    }
+  if (t.lmax == 0) {
+    t.lmin = -1;
+    return;
+  }
+  uint32_t code = 0;
+  uint16_t off = 0;
+  uint16_t fill[16];
+  for (int l = t.lmin; l <= t.lmax; l++) {
+    t.first[l] = code;
+    t.offs[l] = off;
+    fill[l] = off;
+    code += t.count[l];
+    off = (uint16_t)(off + t.count[l]);
+    code <<= 1;
+  }
+  for (int s = 0; s < nsym; s++)
+    if (lens[s]) t.syms[fill[lens[s]]++] = (uint16_t)s;
+}
+__device__ static int xt_decode(const XTab& t, XReader& r, int* err) {  // src/inflate.ts:238-252 and siblings
+  int cl = t.lmin;
+  uint32_t code = xr_coded(r, t.lmin);
+  if (r.err) {
+    *err = r.err;
+    return -1;
+  }
+  for (;;) {
+    const uint32_t rel = code - t.first[cl];
+    if (code >= t.first[cl] && rel < t.count[cl]) return t.syms[t.offs[cl] + rel];
+    if (t.lmax <= cl) {
+      *err = ZES_E_CORRUPT;
+      return -1;
+    }
+    cl++;
+    code = (code << 1) | (uint32_t)xr_read(r);
+    if (r.err) {
+      *err = r.err;
+      return -1;
+    }
+  }
+}
+
+struct XOut {
+  uint8_t* buf;
+  uint64_t cap, idx;
+  int overflow;
+};
+__device__ static inline void xo_write(XOut& o, uint8_t v) {
+  if (o.idx < o.cap) o.buf[o.idx] = v; else o.overflow = 1;
+  o.idx++;
+}
+
+__device__ static int x_symbols(XReader& r, XOut& o, const XTab& lt, const XTab* dt) {  // src/inflate.ts:78-117, 237-291
+  int err = 0;
+  while (!r.is_end) {
+    const int v = xt_decode(lt, r, &err);
+    if (v < 0) return err;
+    if (v < 256) {
+      xo_write(o, (uint8_t)v);
+      continue;
+    }
+    if (v == 256) break;
+    const int lc = v - 257;
+    const bool have_len = lc < 29;  // codes 286/287: base undefined, nothing is copied
+    uint32_t rl = have_len ? kLenBase[lc] : 0u;
+    if (have_len && kLenXbits[lc]) rl += xr_range(r, kLenXbits[lc]);
+    int dc;
+    if (!dt) {
+      dc = (int)xr_coded(r, 5);
+      if (r.err) return r.err;
+    } else {
+      dc = xt_decode(*dt, r, &err);
+      if (dc < 0) return err;
+    }
+    const bool have_dist = dc < 30;  // codes >= 30: NaN source index, zeros are written
+    uint32_t rd = have_dist ? kDistBase[dc] : 0u;
+    if (have_dist && kDistXbits[dc]) rd += xr_range(r, kDistXbits[dc]);
+    if (!have_len) continue;
+    for (uint32_t i = 0; i < rl; i++) {
+      const int64_t src = have_dist ? (int64_t)o.idx - (int64_t)rd : -1;
+      uint8_t b = 0;  // bytes beyond the capacity are lost, the length stays exact
+      if (have_dist && src >= 0 && (uint64_t)src < o.cap) b = o.buf[src];
+      xo_write(o, b);
+    }
+  }
+  return 0;
+}
+
+__global__ void k_inf_exact(const uint8_t* __restrict__ d_in, uint64_t in_off, uint64_t c, uint8_t* __restrict__ d_out,
+                            uint64_t out_off, uint64_t cap, const uint64_t* __restrict__ resume, ZesRes* __restrict__ res) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  __shared__ XTab lt, dt, ct;
+  __shared__ uint8_t llens[296], dlens[64], clens[19];
+  XReader r;
+  r.buf = d_in + in_off;
+  r.len = c;
+  r.err = 0;
+  r.is_end = 0;
+  const uint64_t bit = resume ? resume[0] : 16;
+  // state of the reference reader at a block boundary: a function of the bit position alone
+  r.idx = (int64_t)(bit >> 3);
+  r.now_len = 8 - (int)(bit & 7);
+  r.now_bits = xr_byte(r, r.idx) >> (bit & 7);
+  XOut o;
+  o.buf = d_out + out_off;
+  o.cap = cap;
+  o.idx = resume ? resume[1] : 0;
+  o.overflow = 0;
+  int bfinal = 0, rc = 0;
+  while (bfinal != 1) {  // src/inflate.ts:22-37
+    bfinal = (int)xr_range(r, 1);
+    const int btype = (int)xr_range(r, 2);
+    if (btype == 0) {  // :42-55
+      if (r.now_len < 8) xr_range(r, r.now_len);
+      uint32_t LEN = xr_range(r, 8);
+      LEN |= xr_range(r, 8) << 8;
+      uint32_t NLEN = xr_range(r, 8);
+      NLEN |= xr_range(r, 8) << 8;
+      if (LEN + NLEN != 65535u) rc = ZES_E_CORRUPT;
+      else
+        for (uint32_t i = 0; i < LEN; i++) xo_write(o, (uint8_t)xr_range(r, 8));
+    } else if (btype == 1) {  // :57-118
+      for (int i = 0; i <= 287; i++) llens[i] = (uint8_t)(i <= 143 ? 8 : i <= 255 ? 9 : i <= 279 ? 7 : 8);
+      xt_build(lt, llens, 288);
+      rc = x_symbols(r, o, lt, nullptr);
+    } else if (btype == 2) {  // :120-292
+      const int HLIT = (int)xr_range(r, 5) + 257;
+      const int HDIST = (int)xr_range(r, 5) + 1;
+      const int HCLEN = (int)xr_range(r, 4) + 4;
+      for (int i = 0; i < 19; i++) clens[i] = 0;
+      for (int i = 0; i < HCLEN; i++) clens[kClOrder[i]] = (uint8_t)xr_range(r, 3);
+      xt_build(ct, clens, 19);
+      for (int i = 0; i < 296; i++) llens[i] = 0;
+      for (int i = 0; i < 64; i++) dlens[i] = 0;
+      int repeat = 0, codelen = 0, err = 0;
+      const int total = HLIT + HDIST;
+      for (int i = 0; i < total && !rc;) {
+        const int sy = xt_decode(ct, r, &err);
+        if (sy < 0) {
+          rc = err;
+          break;
+        }
+        if (sy == 16) {
+          repeat = 3 + (int)xr_range(r, 2);
+        } else if (sy == 17) {
+          repeat = 3 + (int)xr_range(r, 3);
+          codelen = 0;
+        } else if (sy == 18) {
+          repeat = 11 + (int)xr_range(r, 7);
+          codelen = 0;
+        } else {
+          repeat = 1;
+          codelen = sy;
+        }
+        if (codelen <= 0) {
+          i += repeat;
+        } else {
+          while (repeat) {  // may run past `total`: extra symbols land in the distance table
+            if (i < HLIT) llens[i] = (uint8_t)codelen;
+            else dlens[i - HLIT] = (uint8_t)codelen;
+            i++;
+            repeat--;
+          }
+        }
+      }
+      if (!rc) {
+        xt_build(lt, llens, 288);
+        xt_build(dt, dlens, 64);
+        rc = x_symbols(r, o, lt, &dt);
+      }
+    } else {
+      rc = ZES_E_BTYPE3;
+    }
+    if (rc) break;
+    if (bfinal == 0 && r.is_end) {  // :34-36
+      rc = ZES_E_INSUFFICIENT;
+      break;
+    }
+  }
+  res->aux = 3;
+  if (rc) {
+    res->status = rc;
+    res->out_len = 0;
+  } else if (o.overflow) {
+    res->status = -16;  // ZES_E_NOSPACE; out_len is the exact size needed
+    res->out_len = o.idx;
+  } else {
+    res->status = 0;
+    res->out_len = o.idx;
+  }
+}

@@ -1,0 +1,40 @@
+// zes_kernels.h — launch geometry and kernel declarations shared by the .hip files and the host API.
+#pragma once
+#include "zes_common.h"
+
+#define SORT_THREADS 1024
+#define SORT_WAVES (SORT_THREADS / 64)
+#define MATCH_THREADS 1024
+#define EMIT_THREADS 1024
+#define HUFF_THREADS_HOST 256
+#define ADLER_THREADS 256
+#define ADLER_CHUNK 65536u
+#define INF_SCAN_THREADS 256
+#define INF_SCAN_BYTES 2048u
+
+struct ZesCandRes {
+  uint64_t end_bit;   // absolute bit just past the block's EOB
+  uint32_t out_len;
+  uint32_t flags;     // bit0 ok, bit1 bfinal
+};
+
+#ifdef __HIPCC__
+// inflate direction (zes_inflate.hip)
+__global__ void k_inf_scan(const uint8_t*, uint64_t, uint64_t, uint32_t*, uint32_t, uint32_t*);
+__global__ void k_inf_verify(const uint8_t*, uint64_t, uint64_t, const uint32_t*, uint32_t, uint32_t*, uint32_t*, uint32_t);
+__global__ void k_inf_ranksort(const uint32_t*, uint32_t, uint32_t*);
+__global__ void k_inf_decode(const uint8_t*, uint64_t, uint64_t, uint8_t*, uint64_t, uint64_t, const uint32_t*, const uint32_t*,
+                             uint32_t, ZesCandRes*, ZesRes*, uint64_t*, int);
+__global__ void k_inf_chain(const uint32_t*, uint32_t, const ZesCandRes*, const uint32_t*, uint32_t, uint32_t*, ZesRes*);
+__global__ void k_inf_exact(const uint8_t*, uint64_t, uint64_t, uint8_t*, uint64_t, uint64_t, const uint64_t*, ZesRes*);
+// deflate direction (zes_deflate.hip)
+__global__ void k_lz_sort(const uint8_t*, const ZesBuf*, const ZesBlk*, uint32_t*, uint32_t*);
+__global__ void k_lz_match(const uint8_t*, const ZesBuf*, const ZesBlk*, const uint32_t*, uint32_t*);
+__global__ void k_lz_parse(const uint8_t*, const ZesBuf*, ZesBlk*, const uint32_t*, uint32_t*, uint32_t*);
+__global__ void k_huff(ZesBlk*, const uint32_t*, uint32_t*, uint32_t*);
+__global__ void k_huff_lengths_only(const uint32_t*, uint32_t, uint32_t, uint8_t*);
+__global__ void k_adler(const uint8_t*, uint64_t, uint64_t, unsigned long long*);
+__global__ void k_layout(uint8_t*, const ZesBuf*, ZesBlk*, const unsigned long long*, ZesRes*);
+__global__ void k_emit(uint8_t*, const ZesBuf*, const ZesBlk*, const uint32_t*, const uint32_t*, const uint32_t*);
+__global__ void k_zero_u64(unsigned long long*, uint32_t);
+#endif
