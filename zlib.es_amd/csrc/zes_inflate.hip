@@ -220,7 +220,7 @@ struct WaveDec {
 
 enum { WD_OK = 0, WD_ANOMALY = 1, WD_NEEDS_HISTORY = 2 };
 
-__device__ static inline void wd_load_window(InfSmem& S, WaveDec& d, uint64_t byte) {
+__device__ __forceinline__ static void wd_load_window(InfSmem& S, WaveDec& d, uint64_t byte) {
   const uint32_t lane = zes_lane();
   d.win = byte & ~15ull;
   // 64 lanes x 16 B + 32 B tail
@@ -238,7 +238,7 @@ __device__ static inline void wd_load_window(InfSmem& S, WaveDec& d, uint64_t by
   }
 }
 
-__device__ static inline uint32_t wd_ld32(InfSmem& S, WaveDec& d, uint64_t byte) {
+__device__ __forceinline__ static uint32_t wd_ld32(InfSmem& S, WaveDec& d, uint64_t byte) {
   if (byte < d.win || byte + 8 > d.win + INWIN + 32) wd_load_window(S, d, byte);
   const uint32_t off = (uint32_t)(byte - d.win);
   const uint32_t* w = reinterpret_cast<const uint32_t*>(S.inbuf);
@@ -246,20 +246,20 @@ __device__ static inline uint32_t wd_ld32(InfSmem& S, WaveDec& d, uint64_t byte)
   return __builtin_amdgcn_alignbyte(w[i + 1], w[i], off & 3u);
 }
 
-__device__ static inline void wd_seek(InfSmem& S, WaveDec& d, uint64_t bit) {
+__device__ __forceinline__ static void wd_seek(InfSmem& S, WaveDec& d, uint64_t bit) {
   d.pos = bit;
   const uint32_t w = wd_ld32(S, d, bit >> 3);
   d.bb = (uint64_t)(w >> (bit & 7));
   d.nb = 32u - (uint32_t)(bit & 7);
 }
-__device__ static inline void wd_refill(InfSmem& S, WaveDec& d) {  // guarantees nb >= 33
+__device__ __forceinline__ static void wd_refill(InfSmem& S, WaveDec& d) {  // guarantees nb >= 33
   if (d.nb <= 32u) {
     const uint32_t w = wd_ld32(S, d, (d.pos + d.nb) >> 3);
     d.bb |= (uint64_t)w << d.nb;
     d.nb += 32u;
   }
 }
-__device__ static inline uint32_t wd_take(WaveDec& d, uint32_t k) {  // k <= 16, after wd_refill
+__device__ __forceinline__ static uint32_t wd_take(WaveDec& d, uint32_t k) {  // k <= 16, after wd_refill
   const uint32_t v = (uint32_t)d.bb & ((1u << k) - 1u);
   d.bb >>= k;
   d.nb -= k;
@@ -267,7 +267,7 @@ __device__ static inline uint32_t wd_take(WaveDec& d, uint32_t k) {  // k <= 16,
   return v;
 }
 
-__device__ static inline void wd_flush_range(InfSmem& S, WaveDec& d, uint64_t from, uint64_t to) {
+__device__ __forceinline__ static void wd_flush_range(InfSmem& S, WaveDec& d, uint64_t from, uint64_t to) {
   // ring -> global for output offsets [from, to); from is a multiple of 16
   const uint32_t lane = zes_lane();
   for (uint64_t off = from + (uint64_t)lane * 16; off < to; off += 64 * 16) {
@@ -280,7 +280,7 @@ __device__ static inline void wd_flush_range(InfSmem& S, WaveDec& d, uint64_t fr
     }
   }
 }
-__device__ static inline void wd_maybe_flush(InfSmem& S, WaveDec& d) {
+__device__ __forceinline__ static void wd_maybe_flush(InfSmem& S, WaveDec& d) {
   while (d.o - d.flushed >= FLUSH) {
     wd_flush_range(S, d, d.flushed, d.flushed + FLUSH);
     d.flushed += FLUSH;
@@ -289,7 +289,7 @@ __device__ static inline void wd_maybe_flush(InfSmem& S, WaveDec& d) {
 
 // canonical tables + root LUT for one alphabet; lens in S.lens[base .. base+nsym).
 // Returns false when the length set is over-subscribed.
-__device__ static bool wd_build(InfSmem& S, uint32_t base, uint32_t nsym, uint32_t root, uint16_t* lut, uint16_t* syms,
+__device__ __forceinline__ static bool wd_build(InfSmem& S, uint32_t base, uint32_t nsym, uint32_t root, uint16_t* lut, uint16_t* syms,
                                 uint32_t* first, uint16_t* cnt, uint16_t* offs) {
   const uint32_t lane = zes_lane();
   const uint8_t* lens = S.lens + base;
@@ -354,7 +354,7 @@ __device__ static bool wd_build(InfSmem& S, uint32_t base, uint32_t nsym, uint32
 
 // symbol decode: root LUT, then canonical walk for codes longer than root (reference
 // src/inflate.ts:238-252 extends one bit at a time the same way).  Returns -1 if no code matches.
-__device__ static inline int wd_sym(WaveDec& d, const uint16_t* lut, uint32_t root, const uint16_t* syms,
+__device__ __forceinline__ static int wd_sym(WaveDec& d, const uint16_t* lut, uint32_t root, const uint16_t* syms,
                                     const uint32_t* first, const uint16_t* cnt, const uint16_t* offs) {
   const uint32_t e = lut[(uint32_t)d.bb & ((1u << root) - 1u)];
   const uint32_t l = e >> 9;
@@ -379,7 +379,7 @@ __device__ static inline int wd_sym(WaveDec& d, const uint16_t* lut, uint32_t ro
 }
 
 // Decodes the symbols of one fixed/dynamic block whose tables are built.  Uniform control flow.
-__device__ static int wd_symbols(InfSmem& S, WaveDec& d, uint32_t droot_used) {
+__device__ __forceinline__ static int wd_symbols(InfSmem& S, WaveDec& d, uint32_t droot_used) {
   const uint32_t lane = zes_lane();
   const uint64_t limit = d.nbytes * 8;
   for (;;) {
@@ -422,7 +422,7 @@ __device__ static int wd_symbols(InfSmem& S, WaveDec& d, uint32_t droot_used) {
 }
 
 // One block starting at d.pos (bit position of BFINAL).  *bfinal receives the flag.
-__device__ static int wd_block(InfSmem& S, WaveDec& d, uint32_t* bfinal, bool dynamic_only) {
+__device__ __forceinline__ static int wd_block(InfSmem& S, WaveDec& d, uint32_t* bfinal, bool dynamic_only) {
   const uint32_t lane = zes_lane();
   wd_refill(S, d);
   *bfinal = wd_take(d, 1);
