@@ -36,7 +36,7 @@ struct Ctx {
   // deflate scratch
   DevBuf bufs, blks, idx_a, idx_b, hists, codes, hdrs, adler, res;
   // inflate scratch
-  DevBuf surv, cand, cand_sorted, counters, cres, map, resume;
+  DevBuf surv, cand, cand_sorted, counters, cres, map, resume, dbg;
   // staging for the host-pointer API
   DevBuf st_in, st_out;
   void* pinned = nullptr;  // small pinned area for read-backs
@@ -293,7 +293,7 @@ int inflate_one(const uint8_t* d_in, uint64_t in_off, uint64_t c, uint8_t* d_out
     HIPCHK(hipMemcpyAsync(hc, g.counters.p, 16, hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
     uint32_t nsurv = hc[0];
-    bool t1 = nsurv > 0 && nsurv <= surv_cap;
+    bool t1 = nsurv > 0 && nsurv <= surv_cap;  // a poisoned count (>= 2^30) fails this test
     uint32_t ncand = 0;
     if (t1) {
       {
@@ -309,34 +309,51 @@ int inflate_one(const uint8_t* d_in, uint64_t in_off, uint64_t c, uint8_t* d_out
     if (t1) {
       if ((rc = ensure(g.cres, sizeof(ZesCandRes) * ncand))) return rc;
       if ((rc = ensure(g.map, (size_t)ncand * 4))) return rc;
+      unsigned long long* dbg = nullptr;
+      if (getenv("ZES_DEBUG_PHASES")) {
+        if ((rc = ensure(g.dbg, (size_t)ncand * 64))) return rc;
+        HIPCHK(hipMemsetAsync(g.dbg.p, 0, (size_t)ncand * 64, g.stream));
+        dbg = (unsigned long long*)g.dbg.p;
+      }
       {
         Timed t("k_inf_ranksort");
         hipLaunchKernelGGL(k_inf_ranksort, dim3((ncand + 255) / 256), dim3(256), 0, g.stream, (const uint32_t*)g.cand.p, ncand,
                            (uint32_t*)g.cand_sorted.p);
       }
       {
-        Timed t("k_inf_decode");
-        hipLaunchKernelGGL(k_inf_decode, dim3(ncand), dim3(64), 0, g.stream, d_in, in_off, c, d_out, out_off, cap,
-                           (const uint32_t*)g.cand_sorted.p, (const uint32_t*)nullptr, ncand, (ZesCandRes*)g.cres.p,
-                           (ZesRes*)g.res.p, (uint64_t*)g.resume.p, 0);
+        Timed t("k_inf_block_par");
+        hipLaunchKernelGGL(k_inf_block_par, dim3(ncand), dim3(PAR_THREADS), 0, g.stream, d_in, in_off, c, d_out, out_off, cap,
+                           (const uint32_t*)g.cand_sorted.p, (const uint32_t*)nullptr, ncand, ncand, (ZesCandRes*)g.cres.p, dbg);
       }
       {
         Timed t("k_inf_chain");
-        hipLaunchKernelGGL(k_inf_chain, dim3(1), dim3(64), 0, g.stream, (const uint32_t*)g.cand_sorted.p, ncand,
+        hipLaunchKernelGGL(k_inf_chain, dim3(1), dim3(256), 0, g.stream, (const uint32_t*)g.cand_sorted.p, ncand,
                            (const ZesCandRes*)g.cres.p, (const uint32_t*)nullptr, ncand, (uint32_t*)g.map.p, (ZesRes*)g.res.p);
       }
       if ((rc = read_res(&hr))) return rc;
+      if (dbg) {  // average shader-clock cycles per phase of k_inf_block_par
+        std::vector<unsigned long long> h((size_t)ncand * 8);
+        HIPCHK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
+        double acc[8] = {0};
+        uint32_t cntd = 0;
+        for (uint32_t i = 0; i < ncand; i++) {
+          if (!h[(size_t)i * 8 + 7]) continue;
+          cntd++;
+          for (int k = 1; k < 8; k++) acc[k] += (double)(h[(size_t)i * 8 + k] - h[(size_t)i * 8 + k - 1]);
+        }
+        fprintf(stderr, "zes phases (avg cycles over %u blocks): hdr %.0f tables %.0f compose %.0f count %.0f emit %.0f resolve %.0f flush %.0f\n",
+                cntd, acc[1] / cntd, acc[2] / cntd, acc[3] / cntd, acc[4] / cntd, acc[5] / cntd, acc[6] / cntd, acc[7] / cntd);
+      }
       if (hr.status == 2) {  // false positives shifted the slots: decode the chain again, in order
         const uint32_t K = hr.aux;
         {
-          Timed t("k_inf_decode");
-          hipLaunchKernelGGL(k_inf_decode, dim3(K), dim3(64), 0, g.stream, d_in, in_off, c, d_out, out_off, cap,
-                             (const uint32_t*)g.cand_sorted.p, (const uint32_t*)g.map.p, K, (ZesCandRes*)g.cres.p,
-                             (ZesRes*)g.res.p, (uint64_t*)g.resume.p, 0);
+          Timed t("k_inf_block_par");
+          hipLaunchKernelGGL(k_inf_block_par, dim3(K), dim3(PAR_THREADS), 0, g.stream, d_in, in_off, c, d_out, out_off, cap,
+                             (const uint32_t*)g.cand_sorted.p, (const uint32_t*)g.map.p, K, ncand, (ZesCandRes*)g.cres.p, dbg);
         }
         {
           Timed t("k_inf_chain");
-          hipLaunchKernelGGL(k_inf_chain, dim3(1), dim3(64), 0, g.stream, (const uint32_t*)g.cand_sorted.p, ncand,
+          hipLaunchKernelGGL(k_inf_chain, dim3(1), dim3(256), 0, g.stream, (const uint32_t*)g.cand_sorted.p, ncand,
                              (const ZesCandRes*)g.cres.p, (const uint32_t*)g.map.p, K, (uint32_t*)g.map.p, (ZesRes*)g.res.p);
         }
         if ((rc = read_res(&hr))) return rc;

@@ -40,43 +40,74 @@ __device__ static inline uint64_t g_load64_le(const uint8_t* p, uint64_t byte, u
 // k_inf_scan: one thread per bit position (LDS-staged chunk).  Keeps positions whose first 17
 // bits look like BTYPE=2 with HLIT<=29, HDIST<=29 and whose code-length code is Kraft-complete.
 // ------------------------------------------------------------------------------------------
-#define SCAN_BYTES INF_SCAN_BYTES  // bytes of the stream per workgroup (16384 bit positions)
+#define SCAN_BYTES INF_SCAN_BYTES  // bytes of the stream per workgroup
+#define SCAN_LIST 4096u             // survivors a workgroup can stage (expected: ~0.2 % of 65536 positions)
 __global__ __launch_bounds__(INF_SCAN_THREADS) void k_inf_scan(const uint8_t* __restrict__ d_in, uint64_t in_off, uint64_t c,
                                                                uint32_t* __restrict__ surv, uint32_t surv_cap,
                                                                uint32_t* __restrict__ counters) {
-  __shared__ __align__(16) uint8_t s[SCAN_BYTES + 48];
+  // Each thread owns 32 consecutive bit positions at a time.  The fixed-field tests (BTYPE = 2,
+  // HLIT <= 29, HDIST <= 29) run on all 32 positions at once as shifted word logic; only the
+  // surviving positions (about one in five) pay for the Kraft sum of the code-length code.
+  __shared__ __align__(16) uint32_t s[SCAN_BYTES / 4 + 8];
+  __shared__ uint32_t s_list[SCAN_LIST];
+  __shared__ uint32_t s_cnt, s_base;
   const uint32_t tid = threadIdx.x;
+  if (tid == 0) s_cnt = 0;
   const uint64_t b0 = (uint64_t)blockIdx.x * SCAN_BYTES;
-  const uint8_t* p = d_in + in_off;
-  for (uint32_t i = tid; i < SCAN_BYTES + 48; i += INF_SCAN_THREADS) s[i] = (b0 + i < c) ? p[b0 + i] : (uint8_t)0;
-  __syncthreads();
-  const uint32_t per = SCAN_BYTES * 8 / INF_SCAN_THREADS;
-  for (uint32_t k = 0; k < per; k++) {
-    const uint32_t rb = k * INF_SCAN_THREADS + tid;  // bit inside the chunk (coalesced across lanes)
-    const uint64_t abs_bit = b0 * 8 + rb;
-    if (abs_bit < 16 || abs_bit + 17 + 12 > c * 8) continue;
-    const uint32_t by = rb >> 3;
-    const uint32_t* s32 = reinterpret_cast<const uint32_t*>(s);
-    const uint32_t wi = by >> 2;
-    const uint64_t lo = (uint64_t)s32[wi] | ((uint64_t)s32[wi + 1] << 32);
-    const uint64_t hi = (uint64_t)s32[wi + 2] | ((uint64_t)s32[wi + 3] << 32);
-    const uint32_t t = ((by & 3u) << 3) + (rb & 7u);  // 0..31
-    const uint64_t bits = t ? ((lo >> t) | (hi << (64u - t))) : lo;
-    if (((bits >> 1) & 3u) != 2u) continue;
-    if (((bits >> 3) & 31u) > 29u) continue;
-    if (((bits >> 8) & 31u) > 29u) continue;
-    const uint32_t ncl = (uint32_t)((bits >> 13) & 15u) + 4u;
-    // code-length code lengths: ncl x 3 bits from bit 17 (up to 57 bits)
-    const uint64_t clb = (bits >> 17) | ((hi >> t) << 47);
-    uint32_t kraft = 0;
-    for (uint32_t i = 0; i < ncl; i++) {
-      const uint32_t l = (uint32_t)(clb >> (3 * i)) & 7u;
-      if (l) kraft += 128u >> l;
+  const uint32_t* in32 = reinterpret_cast<const uint32_t*>(d_in + in_off);
+  const uint64_t ndw = (c + 3) >> 2;
+  for (uint32_t i = tid; i < SCAN_BYTES / 4 + 8; i += INF_SCAN_THREADS) {
+    const uint64_t gi = (b0 >> 2) + i;
+    uint32_t v = 0;
+    if (gi < ndw) {
+      v = in32[gi];
+      if (gi == ndw - 1 && (c & 3u)) v &= (1u << (8u * (uint32_t)(c & 3u))) - 1u;  // bytes past the end read as 0
     }
-    if (kraft != 128u) continue;
-    const uint32_t slot = atomicAdd(&counters[0], 1u);
-    if (slot < surv_cap) surv[slot] = (uint32_t)(abs_bit - 16);  // relative to bit 16 (fits u32 for c < 512 MiB)
+    s[i] = v;
   }
+  __syncthreads();
+  const uint64_t end_bits = c * 8;
+#pragma unroll 1
+  for (uint32_t k = 0; k < SCAN_BYTES / 4 / INF_SCAN_THREADS; k++) {
+    const uint32_t grp = k * INF_SCAN_THREADS + tid;  // dword of positions inside the chunk
+    const uint64_t w0 = (uint64_t)s[grp] | ((uint64_t)s[grp + 1] << 32);
+    const uint64_t w1 = (uint64_t)s[grp + 2] | ((uint64_t)s[grp + 3] << 32);
+    // bit i of m: position i has bit1 = 0, bit2 = 1 (BTYPE 2), not all of bits 4..7 (HLIT <= 29),
+    // not all of bits 9..12 (HDIST <= 29)
+    uint32_t m = (uint32_t)(~(w0 >> 1) & (w0 >> 2) & ~((w0 >> 4) & (w0 >> 5) & (w0 >> 6) & (w0 >> 7)) &
+                            ~((w0 >> 9) & (w0 >> 10) & (w0 >> 11) & (w0 >> 12)));
+    const uint64_t abs_base = b0 * 8 + (uint64_t)grp * 32;
+    while (m) {
+      const uint32_t i = (uint32_t)__builtin_ctz(m);
+      m &= m - 1u;
+      const uint64_t abs_bit = abs_base + i;
+      if (abs_bit < 16 || abs_bit + 17 + 12 > end_bits) continue;
+      const uint64_t lo = i ? ((w0 >> i) | (w1 << (64u - i))) : w0;
+      const uint64_t hi = w1 >> i;
+      const uint32_t ncl = (uint32_t)((lo >> 13) & 15u) + 4u;
+      const uint64_t clb = (lo >> 17) | (hi << 47);  // ncl x 3 bits, up to 57
+      uint32_t kraft = 0;
+      for (uint32_t j = 0; j < ncl; j++) {
+        const uint32_t l = (uint32_t)(clb >> (3 * j)) & 7u;
+        kraft += (128u >> l) & 127u;  // l = 0 contributes nothing
+      }
+      if (kraft != 128u) continue;
+      const uint32_t slot = atomicAdd(&s_cnt, 1u);  // LDS: one global atomic per workgroup below
+      if (slot < SCAN_LIST) s_list[slot] = (uint32_t)(abs_bit - 16);  // relative to bit 16 (fits u32 for c < 512 MiB)
+    }
+  }
+  __syncthreads();
+  const uint32_t n = s_cnt;
+  if (n == 0) return;
+  if (tid == 0) s_base = atomicAdd(&counters[0], n);
+  __syncthreads();
+  const uint32_t gb = s_base;
+  if (n > SCAN_LIST) {  // cannot happen for sane data (a chunk has 65536 positions); poison the count
+    if (tid == 0) atomicAdd(&counters[0], 0x40000000u);
+    return;
+  }
+  for (uint32_t i = tid; i < n; i += INF_SCAN_THREADS)
+    if (gb + i < surv_cap) surv[gb + i] = s_list[i];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -163,7 +194,7 @@ __global__ __launch_bounds__(64) void k_inf_verify(const uint8_t* __restrict__ d
   }
   if (!ok || !has_eob || kl != 32768u) return;
   if (!(kd == 32768u || nd == 0 || (nd == 1 && dmaxlen == 1))) return;
-  const uint32_t slot = atomicAdd(&counters[1], 1u);
+  const uint32_t slot = atomicAdd(&counters[1], 1u);  // rare: about one per block of the stream
   if (slot < cand_cap) cand[slot] = (uint32_t)(pos0 - 16);
 }
 
@@ -604,46 +635,71 @@ __global__ __launch_bounds__(64) void k_inf_decode(const uint8_t* __restrict__ d
 // and the k-th chain member being the k-th candidate (otherwise a remap pass is requested).
 // res->status: 0 done, 2 remap needed (chain in map_out, length in res->aux), 1 give up (T2).
 // ------------------------------------------------------------------------------------------
-__global__ void k_inf_chain(const uint32_t* __restrict__ cand, uint32_t ncand, const ZesCandRes* __restrict__ cres,
-                            const uint32_t* __restrict__ map_in, uint32_t nwork, uint32_t* __restrict__ map_out,
-                            ZesRes* __restrict__ res) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  // cres is indexed by work item; map_in (or identity) gives the candidate of each work item
-  res->status = 1;
-  res->out_len = 0;
-  res->aux = 0;
-  if (ncand == 0 || cand[0] != 0) return;
-  if (map_in) {
-    // second pass: work items are exactly the chain, only re-check sizes
-    uint64_t total = 0;
-    for (uint32_t k = 0; k < nwork; k++) {
-      const ZesCandRes r = cres[k];
-      if (!(r.flags & 1u)) return;
-      total += r.out_len;
-      if (r.flags & 2u) {
-        if (k + 1 != nwork) return;
-        res->status = 0;
-        res->out_len = total;
-        res->aux = 1;
-        return;
-      }
-      if (r.out_len != ZES_BLK) return;
-    }
-    return;
+__global__ __launch_bounds__(256) void k_inf_chain(const uint32_t* __restrict__ cand, uint32_t ncand, const ZesCandRes* __restrict__ cres,
+                                                   const uint32_t* __restrict__ map_in, uint32_t nwork, uint32_t* __restrict__ map_out,
+                                                   ZesRes* __restrict__ res) {
+  __shared__ uint32_t s_bad, s_final;
+  __shared__ unsigned long long s_total;
+  const uint32_t tid = threadIdx.x;
+  if (blockIdx.x != 0) return;
+  if (tid == 0) {
+    s_bad = 0;
+    s_final = 0xFFFFFFFFu;
+    s_total = 0;
+    res->status = 1;
+    res->out_len = 0;
+    res->aux = 0;
   }
+  __syncthreads();
+  if (ncand == 0 || cand[0] != 0) return;
+  // Fast check, all work items in parallel: item k is ok, non-final items give exactly one slot
+  // and end where item k+1 starts, the first final item closes the chain.
+  uint32_t first_final = 0xFFFFFFFFu;
+  for (uint32_t k = tid; k < nwork; k += 256)
+    if ((cres[k].flags & 3u) == 3u) {
+      first_final = k;
+      break;
+    }
+  atomicMin(&s_final, first_final);
+  __syncthreads();
+  const uint32_t K = s_final;  // index of the closing block
+  if (K != 0xFFFFFFFFu) {
+    unsigned long long part = 0;
+    uint32_t bad = 0;
+    for (uint32_t k = tid; k <= K; k += 256) {
+      const ZesCandRes r = cres[k];
+      if (!(r.flags & 1u)) bad = 1;
+      part += r.out_len;
+      if (k < K) {
+        const uint32_t nxt = map_in ? map_in[k + 1] : k + 1;
+        if (r.out_len != ZES_BLK || nxt >= ncand || (uint64_t)cand[nxt] + 16 != r.end_bit) bad = 1;
+      }
+      if (map_in == nullptr) map_out[k] = k;
+    }
+    if (bad) atomicOr(&s_bad, 1u);
+    atomicAdd(&s_total, part);
+    __syncthreads();
+    if (!s_bad) {
+      if (tid == 0) {
+        res->status = 0;
+        res->out_len = s_total;
+        res->aux = 1;
+      }
+      return;
+    }
+  }
+  if (map_in || tid != 0) return;  // a remapped pass that still fails goes to T2
+  // Slow path (false candidates between the blocks): follow end bit -> next start serially.
   uint32_t j = 0, k = 0;
   uint64_t total = 0;
-  bool identity = true;
   for (;;) {
     const ZesCandRes r = cres[j];
     if (!(r.flags & 1u)) return;
     map_out[k] = j;
-    if (j != k) identity = false;
     k++;
     total += r.out_len;
     if (r.flags & 2u) break;
     if (r.out_len != ZES_BLK) return;
-    // binary search the next start
     const uint64_t want = r.end_bit - 16;
     uint32_t lo = j + 1, hi = ncand;
     while (lo < hi) {
@@ -654,8 +710,8 @@ __global__ void k_inf_chain(const uint32_t* __restrict__ cand, uint32_t ncand, c
     j = lo;
   }
   res->out_len = total;
-  res->aux = identity ? 1u : k;
-  res->status = identity ? 0 : 2;
+  res->aux = k;
+  res->status = 2;  // the slots are shifted: decode the chain again in order
 }
 
 // ------------------------------------------------------------------------------------------

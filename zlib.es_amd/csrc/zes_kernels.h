@@ -9,8 +9,10 @@
 #define HUFF_THREADS_HOST 256
 #define ADLER_THREADS 256
 #define ADLER_CHUNK 65536u
+#define PAR_THREADS 1024
+#define PAR_WAVES (PAR_THREADS / 64)
 #define INF_SCAN_THREADS 256
-#define INF_SCAN_BYTES 2048u
+#define INF_SCAN_BYTES 8192u
 
 struct ZesCandRes {
   uint64_t end_bit;   // absolute bit just past the block's EOB
@@ -25,6 +27,8 @@ __global__ void k_inf_verify(const uint8_t*, uint64_t, uint64_t, const uint32_t*
 __global__ void k_inf_ranksort(const uint32_t*, uint32_t, uint32_t*);
 __global__ void k_inf_decode(const uint8_t*, uint64_t, uint64_t, uint8_t*, uint64_t, uint64_t, const uint32_t*, const uint32_t*,
                              uint32_t, ZesCandRes*, ZesRes*, uint64_t*, int);
+__global__ void k_inf_block_par(const uint8_t*, uint64_t, uint64_t, uint8_t*, uint64_t, uint64_t, const uint32_t*, const uint32_t*,
+                                uint32_t, uint32_t, ZesCandRes*, unsigned long long*);
 __global__ void k_inf_chain(const uint32_t*, uint32_t, const ZesCandRes*, const uint32_t*, uint32_t, uint32_t*, ZesRes*);
 __global__ void k_inf_exact(const uint8_t*, uint64_t, uint64_t, uint8_t*, uint64_t, uint64_t, const uint64_t*, ZesRes*);
 // deflate direction (zes_deflate.hip)
