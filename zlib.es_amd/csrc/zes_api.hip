@@ -222,7 +222,7 @@ int deflate_batch_core(const uint8_t* d_in, const uint64_t* in_off, const uint64
   }
   {
     Timed t("k_lz_parse");  // tokens go to idx_a (free after the match pass)
-    hipLaunchKernelGGL(k_lz_parse, dim3(nblk), dim3(64), 0, g.stream, d_in, dbufs, dblks, idx_b, idx_a, (uint32_t*)g.hists.p);
+    hipLaunchKernelGGL(k_lz_parse, dim3(nblk), dim3(PARSE_THREADS), 0, g.stream, d_in, dbufs, dblks, idx_b, idx_a, (uint32_t*)g.hists.p);
   }
   {
     Timed t("k_huff");
@@ -646,7 +646,7 @@ int zes_stage_lz77_dev(const uint8_t* d_in, uint64_t n, uint64_t start, uint32_t
                      (uint32_t*)g.idx_a.p, (uint32_t*)g.idx_b.p);
   hipLaunchKernelGGL(k_lz_match, dim3(1), dim3(MATCH_THREADS), 0, g.stream, d_in, (const ZesBuf*)g.bufs.p,
                      (const ZesBlk*)g.blks.p, (const uint32_t*)g.idx_a.p, (uint32_t*)g.idx_b.p);
-  hipLaunchKernelGGL(k_lz_parse, dim3(1), dim3(64), 0, g.stream, d_in, (const ZesBuf*)g.bufs.p, (ZesBlk*)g.blks.p,
+  hipLaunchKernelGGL(k_lz_parse, dim3(1), dim3(PARSE_THREADS), 0, g.stream, d_in, (const ZesBuf*)g.bufs.p, (ZesBlk*)g.blks.p,
                      (const uint32_t*)g.idx_b.p, (uint32_t*)g.idx_a.p, (uint32_t*)g.hists.p);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(&z, g.blks.p, sizeof z, hipMemcpyDeviceToHost, g.stream));

@@ -159,12 +159,25 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
 
 // ------------------------------------------------------------------------------------------
 // k_lz_match: one thread per sorted slot r; candidates are the slots before r with the same key.
-// LDS: block + 258-byte halo (compares run past the block end up to the input end).
+// LDS: block + 258-byte halo (compares run past the block end up to the input end),
+// bank-swizzled: lanes of a wave handle neighbouring slots = the same 3-byte key, and in
+// periodic data those positions are a multiple of the period apart (4096 B for lowent4k) —
+// unswizzled, that is a 32-way bank conflict on every read.
 // match_out[g][p] = ZES_TOK_MATCH | (len-3)<<16 | (dist-1), or 0 for "literal here".
 // ------------------------------------------------------------------------------------------
+#define MATCH_IN_DWORDS ((ZES_BLK + 288) / 4)
+#define MATCH_BACK 128u  // at most 128 candidates are ever examined (src/lz77.ts:66)
+#define MATCH_SAME 0x80000000u
 struct MatchSmem {
-  uint8_t in[ZES_BLK + 288];
+  uint32_t in[(MATCH_IN_DWORDS + 31) / 32 * 32];  // whole 32-dword rows: the swizzle permutes inside a row
+  uint32_t tile[MATCH_THREADS + MATCH_BACK];  // sorted positions of the current 1024 slots + 128 before; bit 31: same key as the slot before
 };
+
+__device__ __forceinline__ static uint32_t mswz(uint32_t i) { return i ^ ((i >> 5) & 31u) ^ ((i >> 10) & 31u); }
+__device__ __forceinline__ static uint32_t m_ld32u(const uint32_t* w, uint32_t off) {  // unaligned LE dword at byte offset
+  const uint32_t i = off >> 2;
+  return __builtin_amdgcn_alignbyte(w[mswz(i + 1)], w[mswz(i)], off & 3u);
+}
 
 __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match(const uint8_t* __restrict__ d_in, const ZesBuf* __restrict__ bufs,
                                                             const ZesBlk* __restrict__ blks, const uint32_t* __restrict__ idx_a,
@@ -182,116 +195,333 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match(const uint8_t* __res
   uint32_t* mo = match_out + (uint64_t)g * ZES_BLK;
   const uint32_t cnt = T >= 3 ? T - 2 : 0;
 
-  stage_block(S.in, src, avail, (ZES_BLK + 288u));
+  // stage block + halo (zero padded), swizzled
+  if ((((uintptr_t)src) & 15u) == 0) {
+    const uint4* g4 = reinterpret_cast<const uint4*>(src);
+    for (uint32_t i = tid; i < MATCH_IN_DWORDS / 4; i += MATCH_THREADS) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      const uint32_t b = i * 16u;
+      if (b + 16u <= avail) {
+        v = g4[i];
+      } else if (b < avail) {
+        uint32_t t[4] = {0, 0, 0, 0};
+        for (uint32_t k = 0; k < 16u && b + k < avail; k++) t[k >> 2] |= (uint32_t)src[b + k] << (8u * (k & 3u));
+        v = make_uint4(t[0], t[1], t[2], t[3]);
+      }
+      S.in[mswz(4 * i + 0)] = v.x;
+      S.in[mswz(4 * i + 1)] = v.y;
+      S.in[mswz(4 * i + 2)] = v.z;
+      S.in[mswz(4 * i + 3)] = v.w;
+    }
+  } else {
+    for (uint32_t i = tid; i < MATCH_IN_DWORDS; i += MATCH_THREADS) {
+      uint32_t t = 0;
+      for (uint32_t k = 0; k < 4u; k++)
+        if (4 * i + k < avail) t |= (uint32_t)src[4 * i + k] << (8u * k);
+      S.in[mswz(i)] = t;
+    }
+  }
   // the last two positions of a block are always literals (src/lz77.ts:116-117)
   if (tid < 2 && T >= 1u + tid) mo[T - 1 - tid] = 0;
   __syncthreads();
 
-  for (uint32_t r = tid; r < cnt; r += MATCH_THREADS) {
-    const uint32_t p = idx[r];
-    const uint32_t kp = lds_ld32u(S.in, p) & 0xffffffu;
-    const uint32_t maxl = min(ZES_MAXMATCH, avail - p);  // = min(258, n - p)
-    uint32_t best = 0, bestq = 0, check = 0;
-    for (int32_t rr = (int32_t)r - 1; rr >= 0; rr--) {
-      const uint32_t q = idx[rr];
-      if ((lds_ld32u(S.in, q) & 0xffffffu) != kp) break;
-      if (p - q > ZES_WINDOW) break;                                 // src/lz77.ts:49
-      if (check >= 128u || (best >= 8u && check >= 16u)) break;      // src/lz77.ts:66-69
-      check++;
-      // L > best needs bytes 0..best equal: one dword probe at best-3 rejects most candidates
-      if (best >= maxl) continue;  // nothing can beat it; the candidate still counted
-      if (best >= 3u && lds_ld32u(S.in, q + best - 3u) != lds_ld32u(S.in, p + best - 3u)) continue;
-      uint32_t L = 3;
-      while (L < maxl) {
-        const uint32_t x = lds_ld32u(S.in, q + L) ^ lds_ld32u(S.in, p + L);
-        if (x) {
-          L += (uint32_t)__builtin_ctz(x) >> 3;
-          break;
+  const uint32_t ntiles = (cnt + MATCH_THREADS - 1) / MATCH_THREADS;
+  for (uint32_t t = 0; t < ntiles; t++) {
+    const uint32_t r0 = t * MATCH_THREADS;
+    // tile[j] <-> slot r0 - 128 + j
+    for (uint32_t j = tid; j < MATCH_THREADS + MATCH_BACK; j += MATCH_THREADS) {
+      const int32_t r = (int32_t)r0 - (int32_t)MATCH_BACK + (int32_t)j;
+      uint32_t v = 0;
+      if (r >= 0 && (uint32_t)r < cnt) {
+        v = idx[r];
+        if (r > 0) {
+          const uint32_t kq = m_ld32u(S.in, idx[r - 1]) & 0xffffffu;
+          if ((m_ld32u(S.in, v) & 0xffffffu) == kq) v |= MATCH_SAME;
         }
-        L += 4;
       }
-      L = min(L, maxl);
-      if (L > best) {
-        best = L;
-        bestq = q;
-        if (L >= ZES_MAXMATCH) break;
-      }
+      S.tile[j] = v;
     }
-    uint32_t tok = 0;
-    if (best >= 3u && p + best + 3u <= T)  // nowIndex + len <= endIndex = start + T - 3 (src/lz77.ts:95)
-      tok = ZES_TOK_MATCH | ((best - 3u) << 16) | (p - bestq - 1u);
-    mo[p] = tok;
+    __syncthreads();
+    const uint32_t r = r0 + tid;
+    if (r < cnt) {
+      uint32_t j = tid + MATCH_BACK;
+      uint32_t e = S.tile[j];
+      const uint32_t p = e & 0x7fffffffu;
+      const uint32_t maxl = min(ZES_MAXMATCH, avail - p);  // = min(258, n - p)
+      uint32_t best = 0, bestq = 0, check = 0, pprobe = 0;
+      while (e & MATCH_SAME) {  // the slot before holds the same key
+        if (check >= 128u || (best >= 8u && check >= 16u)) break;  // src/lz77.ts:66-69
+        j--;  // never below tid: at most 128 steps back
+        e = S.tile[j];
+        const uint32_t q = e & 0x7fffffffu;
+        if (p - q > ZES_WINDOW) break;  // src/lz77.ts:49
+        check++;
+        if (best >= maxl) continue;  // nothing can beat it; the candidate still counted
+        // L > best needs bytes 0..best equal: one dword probe at best-3 rejects most candidates
+        if (best >= 3u && m_ld32u(S.in, q + best - 3u) != pprobe) continue;
+        uint32_t L = 3;
+        {
+          uint32_t qo = q + 3u, po = p + 3u;
+          uint32_t qi = qo >> 2, pi = po >> 2;
+          const uint32_t qs = qo & 3u, ps = po & 3u;
+          uint32_t qlo = S.in[mswz(qi)], plo = S.in[mswz(pi)];
+          while (L < maxl) {
+            const uint32_t qhi = S.in[mswz(qi + 1)], phi = S.in[mswz(pi + 1)];
+            const uint32_t x = __builtin_amdgcn_alignbyte(qhi, qlo, qs) ^ __builtin_amdgcn_alignbyte(phi, plo, ps);
+            if (x) {
+              L += (uint32_t)__builtin_ctz(x) >> 3;
+              break;
+            }
+            L += 4;
+            qi++;
+            pi++;
+            qlo = qhi;
+            plo = phi;
+          }
+        }
+        L = min(L, maxl);
+        if (L > best) {
+          best = L;
+          bestq = q;
+          if (L >= ZES_MAXMATCH) break;
+          if (best < maxl) pprobe = m_ld32u(S.in, p + best - 3u);
+        }
+      }
+      uint32_t tok = 0;
+      if (best >= 3u && p + best + 3u <= T)  // nowIndex + len <= endIndex = start + T - 3 (src/lz77.ts:95)
+        tok = ZES_TOK_MATCH | ((best - 3u) << 16) | (p - bestq - 1u);
+      mo[p] = tok;
+    }
+    __syncthreads();
   }
 }
 
 // ------------------------------------------------------------------------------------------
-// k_lz_parse: one wavefront per block walks the greedy chain 64 positions at a time
-// (v_readlane hop inside the chunk), compacts the tokens and builds both symbol histograms in LDS.
+// k_lz_parse: the greedy chain p -> p + len | p + 1 of one block, 1024 threads.
+// The chain is sequential, but each hop is <= 258 positions, so:
+//   A   every 64-position chunk gets its exit map by in-wave pointer doubling: for each
+//       possible entry lane, how far past the chunk the chain lands (u8, 255 = look it up)
+//   B   each wave folds its region of 128 chunks backwards (sliding window of 5 chunk maps in
+//       registers): entry offset into the region -> offset past the region
+//   C   16 region tables are chained from position 0; each wave then walks its own region once,
+//       noting the entry lane of every chunk the chain touches
+//   D   per touched chunk, the visited lanes are found by binary hop decomposition (again
+//       doubling), counted, scanned, and the tokens and both histograms written in parallel.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_lz_parse(const uint8_t* __restrict__ d_in, const ZesBuf* __restrict__ bufs,
-                                                 ZesBlk* __restrict__ blks, const uint32_t* __restrict__ match_in,
-                                                 uint32_t* __restrict__ tok_out, uint32_t* __restrict__ hists) {
-  __shared__ uint32_t lh[288];
-  __shared__ uint32_t dh[32];
-  const uint32_t g = blockIdx.x, lane = threadIdx.x;
+#define PARSE_CHUNKS (ZES_BLK / 64)        // 2048
+#define PARSE_REGION 128                    // chunks per wave
+#define PARSE_NOENTRY 0xFFu
+struct ParseSmem {
+  union {
+    uint8_t xmap[PARSE_CHUNKS][64];         // phase A-C
+    struct {
+      unsigned long long mask[PARSE_CHUNKS];  // phase D (the exit maps are dead by then)
+      uint32_t cpre[PARSE_CHUNKS];
+    } d;
+  } u;
+  uint16_t rtab[PARSE_THREADS / 64][5 * 64];  // region transfer tables (entry offsets 0..319)
+  uint8_t centry[PARSE_CHUNKS];
+  uint32_t rentry[PARSE_THREADS / 64 + 1];
+  uint32_t wsum[PARSE_THREADS / 64];
+  uint32_t lh[288];
+  uint32_t dh[32];
+};
+
+// exact landing offset past the chunk for entry lane e (slow path behind xmap code 255)
+__device__ static uint32_t parse_follow(const uint32_t* mi, uint32_t T, uint32_t chunk, uint32_t e) {
+  uint32_t cur = e;
+  while (cur < 64u) {
+    const uint32_t p = chunk * 64u + cur;
+    const uint32_t m = p < T ? mi[p] : 0u;
+    cur += (m & ZES_TOK_MATCH) ? zes_tok_len(m) : 1u;
+  }
+  return cur - 64u;
+}
+
+__global__ __launch_bounds__(PARSE_THREADS) void k_lz_parse(const uint8_t* __restrict__ d_in, const ZesBuf* __restrict__ bufs,
+                                                            ZesBlk* __restrict__ blks, const uint32_t* __restrict__ match_in,
+                                                            uint32_t* __restrict__ tok_out, uint32_t* __restrict__ hists) {
+  __shared__ __align__(16) ParseSmem S;
+  const uint32_t g = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const ZesBlk bk = blks[g];
   const ZesBuf bf = bufs[bk.buf];
   const uint32_t T = bk.len;
   const uint8_t* src = d_in + bf.in_off + (uint64_t)bk.blk * ZES_BLK;
   const uint32_t* mi = match_in + (uint64_t)g * ZES_BLK;
   uint32_t* to = tok_out + (uint64_t)g * ZES_BLK;
-  for (uint32_t i = lane; i < 288; i += 64) lh[i] = 0;
-  if (lane < 32) dh[lane] = 0;
+  const uint32_t nchunks = (T + 63u) >> 6;
+  const uint32_t nregions = (nchunks + PARSE_REGION - 1) / PARSE_REGION;
+  for (uint32_t i = tid; i < 288; i += PARSE_THREADS) S.lh[i] = 0;
+  if (tid < 32) S.dh[tid] = 0;
+  for (uint32_t i = tid; i < PARSE_CHUNKS; i += PARSE_THREADS) S.centry[i] = PARSE_NOENTRY;
+
+  // ---- A: exit map of every chunk ----
+  const uint32_t c_lo = wave * PARSE_REGION, c_hi = min(nchunks, c_lo + PARSE_REGION);
+#pragma unroll 4
+  for (uint32_t c = c_lo; c < c_hi; c++) {
+    const uint32_t p = c * 64u + lane;
+    const uint32_t m = p < T ? mi[p] : 0u;
+    uint32_t v = lane + ((m & ZES_TOK_MATCH) ? zes_tok_len(m) : 1u);
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+      const uint32_t nv = __shfl(v, (int)(v & 63u));
+      if (v < 64u) v = nv;
+    }
+    S.u.xmap[c][lane] = (uint8_t)min(v - 64u, 255u);
+  }
   __syncthreads();
 
-  uint32_t cur = 0, ntok = 0;
-  // software prefetch of the next chunk's match words
-  uint32_t m_next = (lane < T) ? mi[lane] : 0u;
-  uint32_t c_next = 0;
-  while (cur < T) {
-    const uint32_t c = cur >> 6;
-    const uint32_t base = c << 6;
-    uint32_t m;
-    if (c == c_next) {
-      m = m_next;
-    } else {
-      m = (base + lane < T) ? mi[base + lane] : 0u;
+  // ---- B: fold the region backwards.  E_k[e] = offset past the region end reached from lane e
+  //         of chunk c + k; a hop lands at most 4 chunks ahead (overshoot <= 257) ----
+  if (wave < nregions) {
+    const uint32_t nch = c_hi - c_lo;  // chunks of this region that exist
+    // beyond the region's last chunk the "offset past the region" is just the landing offset
+    uint32_t E1 = lane, E2 = 64u + lane, E3 = 128u + lane, E4 = 192u + lane, E5 = 256u + lane;
+    for (int k = (int)nch - 1; k >= 0; k--) {
+      const uint32_t c = c_lo + (uint32_t)k;
+      uint32_t ov = S.u.xmap[c][lane];
+      if (ov == 255u) ov = parse_follow(mi, T, c, lane);
+      const uint32_t d = ov >> 6, sl = ov & 63u;
+      const uint32_t a1 = __shfl(E1, (int)sl), a2 = __shfl(E2, (int)sl), a3 = __shfl(E3, (int)sl), a4 = __shfl(E4, (int)sl),
+                     a5 = __shfl(E5, (int)sl);
+      const uint32_t E0 = d == 0 ? a1 : d == 1 ? a2 : d == 2 ? a3 : d == 3 ? a4 : a5;
+      E5 = E4;
+      E4 = E3;
+      E3 = E2;
+      E2 = E1;
+      E1 = E0;
     }
-    c_next = c + 1;
-    m_next = (((c + 1) << 6) + lane < T) ? mi[((c + 1) << 6) + lane] : 0u;
-    const uint32_t step = (m & ZES_TOK_MATCH) ? zes_tok_len(m) : 1u;
-    uint32_t e = __builtin_amdgcn_readfirstlane(cur - base);
-    const uint32_t lim = min(64u, T - base);
-    uint64_t mask = 0;
-    while (e < lim) {  // every step is >= 1, so this ends
-      mask |= 1ull << e;
-      e += max(1u, (uint32_t)__builtin_amdgcn_readlane(step, e));
+    // E1..E5 now describe chunks c_lo .. c_lo+4: entry offsets 0..319 into the region
+    S.rtab[wave][lane] = (uint16_t)E1;
+    S.rtab[wave][64 + lane] = (uint16_t)E2;
+    S.rtab[wave][128 + lane] = (uint16_t)E3;
+    S.rtab[wave][192 + lane] = (uint16_t)E4;
+    S.rtab[wave][256 + lane] = (uint16_t)E5;
+  }
+  __syncthreads();
+
+  // ---- C: chain the regions, then every wave walks its own region from its true entry ----
+  if (tid == 0) {
+    uint32_t e = 0;
+    for (uint32_t r = 0; r < nregions; r++) {
+      S.rentry[r] = e;
+      e = S.rtab[r][e];
     }
-    cur = base + e;  // > previous cur: e advanced at least once because cur - base < lim
-    if ((mask >> lane) & 1ull) {
-      const uint32_t rank = (uint32_t)__popcll(mask & zes_lanemask_lt());
+  }
+  __syncthreads();
+  if (wave < nregions && lane == 0) {
+    uint32_t cur = S.rentry[wave];  // offset from the region's first position
+    const uint32_t lim = (c_hi - c_lo) * 64u;
+    while (cur < lim) {
+      const uint32_t c = c_lo + (cur >> 6), e = cur & 63u;
+      S.centry[c] = (uint8_t)e;
+      uint32_t ov = S.u.xmap[c][e];
+      if (ov == 255u) ov = parse_follow(mi, T, c, e);
+      cur = ((cur >> 6) + 1u) * 64u + ov;
+    }
+  }
+  __syncthreads();
+
+  // ---- D1: visited lanes of every touched chunk ----
+  unsigned long long mymask[2] = {0ull, 0ull};  // thread t owns chunks 2t, 2t+1 for the scan
+#pragma unroll 2
+  for (uint32_t c = c_lo; c < c_hi; c++) {
+    const uint32_t e = S.centry[c];
+    unsigned long long mk = 0ull;
+    if (e != PARSE_NOENTRY) {
+      const uint32_t p = c * 64u + lane;
+      const uint32_t m = p < T ? mi[p] : 0u;
+      uint32_t h[6], cnt = 1;
+      h[0] = lane + ((m & ZES_TOK_MATCH) ? zes_tok_len(m) : 1u);
+#pragma unroll
+      for (int r = 0; r < 5; r++) {  // h[r] = landing lane after 2^r hops (>= 64: left the chunk)
+        const uint32_t hv = __shfl(h[r], (int)(h[r] & 63u));
+        const uint32_t cv = __shfl(cnt, (int)(h[r] & 63u));
+        const bool in = h[r] < 64u;
+        h[r + 1] = in ? hv : h[r];
+        cnt = in ? cnt + cv : cnt;
+      }
+      {  // hops from h[5] on are not needed: 32+..; finish the count with one more round
+        const uint32_t cv = __shfl(cnt, (int)(h[5] & 63u));
+        if (h[5] < 64u) cnt += cv;
+      }
+      // lane i is visited iff i >= e and hopping (cnt[e] - cnt[i]) times from e lands on i
+      const uint32_t ce = __shfl(cnt, (int)e);
+      const bool cand = lane >= e && cnt <= ce;
+      const uint32_t k = cand ? ce - cnt : 0u;
+      uint32_t pos = e;
+#pragma unroll
+      for (int r = 0; r < 6; r++) {
+        const uint32_t nx = __shfl(h[r], (int)(pos & 63u));
+        if ((k >> r) & 1u) pos = nx;
+      }
+      mk = __ballot(cand && pos == lane && p < T);
+    }
+    // hand the mask to the thread that owns this chunk in the scan
+    if (lane == 0) S.u.d.mask[c] = mk;  // xmap of chunk c is dead: the walk of phase C is over
+  }
+  __syncthreads();
+  // NOTE: mask[] aliases xmap[]; chunk c's mask (8 B at c*8) overlaps xmap rows c/8 — all reads
+  // of xmap finished at the barrier above phase D1 only for the walk; D1 itself does not read xmap.
+
+  // ---- D2: token offsets = exclusive scan of the per-chunk counts ----
+  uint32_t cnt2[2];
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const uint32_t c = tid * 2 + k;
+    mymask[k] = c < nchunks ? S.u.d.mask[c] : 0ull;
+    cnt2[k] = (uint32_t)__popcll(mymask[k]);
+  }
+  const uint32_t mysum = cnt2[0] + cnt2[1];
+  uint32_t incl = mysum;
+#pragma unroll
+  for (int dlt = 1; dlt < 64; dlt <<= 1) {
+    const uint32_t t = __shfl_up(incl, dlt);
+    if ((int)lane >= dlt) incl += t;
+  }
+  if (lane == 63) S.wsum[wave] = incl;
+  __syncthreads();
+  uint32_t wbase = 0, total = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < PARSE_THREADS / 64; w++) {
+    const uint32_t sm = S.wsum[w];
+    if (w < wave) wbase += sm;
+    total += sm;
+  }
+  const uint32_t ex = wbase + incl - mysum;
+  if (tid * 2 < PARSE_CHUNKS) S.u.d.cpre[tid * 2] = ex;
+  if (tid * 2 + 1 < PARSE_CHUNKS) S.u.d.cpre[tid * 2 + 1] = ex + cnt2[0];
+  __syncthreads();
+
+  // ---- D3: tokens + histograms ----
+  for (uint32_t c = c_lo; c < c_hi; c++) {
+    const unsigned long long mk = S.u.d.mask[c];
+    if (!mk) continue;
+    if ((mk >> lane) & 1ull) {
+      const uint32_t p = c * 64u + lane;
+      const uint32_t m = mi[p];
+      const uint32_t rank = (uint32_t)__popcll(mk & zes_lanemask_lt());
       uint32_t tv;
       if (m & ZES_TOK_MATCH) {
         tv = m;
-        atomicAdd(&lh[257u + zes_len_code(zes_tok_len(m))], 1u);
-        atomicAdd(&dh[zes_dist_code(zes_tok_dist(m))], 1u);
+        atomicAdd(&S.lh[257u + zes_len_code(zes_tok_len(m))], 1u);
+        atomicAdd(&S.dh[zes_dist_code(zes_tok_dist(m))], 1u);
       } else {
-        tv = src[base + lane];
-        atomicAdd(&lh[tv], 1u);
+        tv = src[p];
+        atomicAdd(&S.lh[tv], 1u);
       }
-      to[ntok + rank] = tv;
+      to[S.u.d.cpre[c] + rank] = tv;
     }
-    ntok += (uint32_t)__popcll(mask);
   }
   __syncthreads();
-  if (lane == 0) {
-    lh[256] = 1;  // EOB (src/deflate.ts:58)
-    blks[g].ntok = ntok;
+  if (tid == 0) {
+    S.lh[256] = 1;  // EOB (src/deflate.ts:58)
+    blks[g].ntok = total;
   }
   __syncthreads();
   uint32_t* hg = hists + (uint64_t)g * 320;
-  for (uint32_t i = lane; i < 288; i += 64) hg[i] = lh[i];
-  if (lane < 32) hg[288 + lane] = dh[lane];
+  for (uint32_t i = tid; i < 288; i += PARSE_THREADS) hg[i] = S.lh[i];
+  if (tid < 32) hg[288 + tid] = S.dh[tid];
 }
 
 // ------------------------------------------------------------------------------------------

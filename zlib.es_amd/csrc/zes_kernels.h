@@ -5,6 +5,7 @@
 #define SORT_THREADS 1024
 #define SORT_WAVES (SORT_THREADS / 64)
 #define MATCH_THREADS 1024
+#define PARSE_THREADS 1024
 #define EMIT_THREADS 1024
 #define HUFF_THREADS_HOST 256
 #define ADLER_THREADS 256
