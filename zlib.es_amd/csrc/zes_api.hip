@@ -548,6 +548,7 @@ static int inflate_host(const uint8_t* in, uint64_t c, uint8_t* out, uint64_t ca
                         bool size_only) {
   if (!out_len || (!in && c)) return ZES_E_ARG;
   *out_len = 0;
+  if (c == 0 || (in[0] & 15u) != 8u) return ZES_E_NOT_DEFLATE;  // src/zlib.ts:13-16, decided before the device is touched
   std::lock_guard<std::mutex> lk(g_mu);
   int rc = init_locked(-1);
   if (rc) return rc;

@@ -1,0 +1,146 @@
+// zes_napi.cc — N-API addon: the binding between the TypeScript façade (zlib.ts) and the C-ABI of
+// include/zes.h.  Thin on purpose: argument marshalling and error translation only; every byte
+// of work happens in libzes_hip.so (HIP kernels).  Synchronous like the reference's functions
+// (src/zlib.ts:11,25).  N-API version 3 calls only (Node >= 10).
+#include <node_api.h>
+
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/zes.h"
+
+namespace {
+
+napi_value throw_status(napi_env env, int status) {
+  // plain `Error` with the reference's exact message (src/zlib.ts:15, src/inflate.ts:32,35,50,...)
+  napi_throw_error(env, nullptr, zes_strerror(status));
+  return nullptr;
+}
+
+bool get_bytes(napi_env env, napi_value v, const uint8_t** data, size_t* len) {
+  bool is_ta = false;
+  if (napi_is_typedarray(env, v, &is_ta) == napi_ok && is_ta) {
+    napi_typedarray_type type;
+    void* p = nullptr;
+    size_t n = 0;
+    napi_value ab;
+    size_t off;
+    if (napi_get_typedarray_info(env, v, &type, &n, &p, &ab, &off) != napi_ok) return false;
+    if (type != napi_uint8_array && type != napi_uint8_clamped_array && type != napi_int8_array) return false;
+    *data = static_cast<const uint8_t*>(p);
+    *len = n;
+    return true;
+  }
+  bool is_buf = false;
+  if (napi_is_buffer(env, v, &is_buf) == napi_ok && is_buf) {
+    void* p = nullptr;
+    size_t n = 0;
+    if (napi_get_buffer_info(env, v, &p, &n) != napi_ok) return false;
+    *data = static_cast<const uint8_t*>(p);
+    *len = n;
+    return true;
+  }
+  return false;
+}
+
+// fresh exact-size Uint8Array (byteOffset 0, backing length == length), like src/zlib.ts:42
+napi_value make_u8(napi_env env, const uint8_t* src, size_t n) {
+  void* dst = nullptr;
+  napi_value ab, ta;
+  if (napi_create_arraybuffer(env, n, &dst, &ab) != napi_ok) return nullptr;
+  if (n) memcpy(dst, src, n);
+  if (napi_create_typedarray(env, napi_uint8_array, n, ab, 0, &ta) != napi_ok) return nullptr;
+  return ta;
+}
+
+napi_value Deflate(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr);
+  const uint8_t* in = nullptr;
+  size_t n = 0;
+  if (argc < 1 || !get_bytes(env, argv[0], &in, &n)) {
+    napi_throw_type_error(env, nullptr, "deflate(input): input must be a Uint8Array");
+    return nullptr;
+  }
+  uint64_t cap = 0, out_len = 0;
+  zes_deflate_bound(n, &cap);
+  uint8_t* tmp = static_cast<uint8_t*>(malloc(cap));
+  if (!tmp) return throw_status(env, ZES_E_ARG);
+  const int rc = zes_deflate(in, n, tmp, cap, &out_len);
+  napi_value res = rc ? throw_status(env, rc) : make_u8(env, tmp, out_len);
+  free(tmp);
+  return res;
+}
+
+napi_value Inflate(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr);
+  const uint8_t* in = nullptr;
+  size_t c = 0;
+  if (argc < 1 || !get_bytes(env, argv[0], &in, &c)) {
+    napi_throw_type_error(env, nullptr, "inflate(input): input must be a Uint8Array");
+    return nullptr;
+  }
+  // size first (the reference grows a Uint8WriteStream instead, src/inflate.ts:17), then decode
+  // straight into the result's ArrayBuffer
+  uint64_t need = 0, out_len = 0;
+  int rc = zes_inflate_size(in, c, &need, ZES_F_DEFAULT);
+  if (rc) return throw_status(env, rc);
+  void* dst = nullptr;
+  napi_value ab, ta;
+  if (napi_create_arraybuffer(env, need, &dst, &ab) != napi_ok) return nullptr;
+  uint8_t dummy = 0;
+  rc = zes_inflate(in, c, need ? static_cast<uint8_t*>(dst) : &dummy, need, &out_len, ZES_F_DEFAULT);
+  if (rc) return throw_status(env, rc);
+  if (napi_create_typedarray(env, napi_uint8_array, out_len, ab, 0, &ta) != napi_ok) return nullptr;
+  return ta;
+}
+
+napi_value Adler32(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr);
+  const uint8_t* in = nullptr;
+  size_t n = 0;
+  if (argc < 1 || !get_bytes(env, argv[0], &in, &n)) {
+    napi_throw_type_error(env, nullptr, "adler32(input): input must be a Uint8Array");
+    return nullptr;
+  }
+  uint32_t a = 0;
+  const int rc = zes_adler32(in, n, &a);
+  if (rc) return throw_status(env, rc);
+  napi_value v;
+  napi_create_uint32(env, a, &v);
+  return v;
+}
+
+napi_value Init(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr);
+  int32_t dev = 0;
+  if (argc >= 1) napi_get_value_int32(env, argv[0], &dev);
+  const int rc = zes_init(dev);
+  if (rc) return throw_status(env, rc);
+  napi_value v;
+  napi_get_undefined(env, &v);
+  return v;
+}
+
+napi_value ModuleInit(napi_env env, napi_value exports) {
+  napi_property_descriptor props[] = {
+      {"deflate", nullptr, Deflate, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"inflate", nullptr, Inflate, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"adler32", nullptr, Adler32, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"init", nullptr, Init, nullptr, nullptr, nullptr, napi_default, nullptr},
+  };
+  napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props);
+  return exports;
+}
+
+}  // namespace
+
+NAPI_MODULE(NODE_GYP_MODULE_NAME, ModuleInit)
