@@ -198,6 +198,25 @@ def test_inflate_all_tiers_agree(z, oracle, gpu):
             assert back.numel() == n and (back.cpu().numpy() == a).all(), (kind, n, flags)
 
 
+def test_reference_made_streams_take_the_block_parallel_tier(z, oracle, gpu):
+    """Speed regressions hide behind the tiers (a T1 bug silently becomes a slow T2 run): pin the tier."""
+    import torch
+
+    for kind, seed, n in [("itext", 51, 131072 * 5 + 999), ("xorshift", 52, 131072 * 3), ("lowent4k", 53, 700000),
+                          ("itext", 54, 3000), ("itext", 55, (4 << 20) + 17)]:
+        a = z.gen(kind, seed, n)
+        comp = dev(oracle.deflate(a), gpu)
+        out = torch.empty(n, dtype=torch.uint8, device=gpu)
+        back = z.inflate_tensor(comp, out)
+        assert back.numel() == n and (back.cpu().numpy() == a).all()
+        assert z.last_inflate_tier() == 1, (kind, n)
+    raw = open(os.path.join(GOLDEN, "ref_data", "compressed.bin"), "rb").read()
+    z.inflate(raw)  # foreign stream with cross-block history
+    assert z.last_inflate_tier() == 2
+    z.inflate(bytes.fromhex(golden("kat.json")["kat"]["FIXED"]))
+    assert z.last_inflate_tier() in (2, 3)
+
+
 def test_inflate_reports_needed_size(z, oracle, gpu):
     import torch
 
@@ -241,6 +260,7 @@ def test_64mib_bit_exact_and_round_trip(z, gpu, kind):
     out = torch.empty(e["n"], dtype=torch.uint8, device=gpu)
     back = z.inflate_tensor(comp.clone(), out)
     assert back.numel() == e["n"] and bool((back == t).all())
+    assert z.last_inflate_tier() == 1
     # size-independent property: Adler-32 trailer written by the device == Adler-32 of the input
     tail = comp[-4:].cpu().numpy()
     assert int.from_bytes(tail.tobytes(), "big") == z.adler32_tensor(t)

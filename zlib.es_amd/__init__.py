@@ -220,6 +220,11 @@ def adler32_tensor(t):
     return out.value
 
 
+def last_inflate_tier():
+    """1 block-parallel, 2 sequential wavefront, 3 exact restatement."""
+    return int(lib().zes_last_inflate_tier())
+
+
 def set_profiling(on):
     lib().zes_set_profiling(1 if on else 0)
 

@@ -46,6 +46,7 @@ struct Ctx {
   std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending;
   std::vector<std::pair<std::string, KTime>> last_times;
   std::vector<std::string> name_pool;
+  int last_tier = 0;
   char arch[64] = {0};
   int cus = 0;
   uint64_t hbm = 0;
@@ -268,6 +269,7 @@ int read_res(ZesRes* out) {
 int inflate_one(const uint8_t* d_in, uint64_t in_off, uint64_t c, uint8_t* d_out, uint64_t out_off, uint64_t cap,
                 uint64_t* out_len, uint32_t flags, uint8_t first_byte) {
   *out_len = 0;
+  g.last_tier = 0;
   if (c == 0 || (first_byte & 15u) != 8u) return ZES_E_NOT_DEFLATE;  // src/zlib.ts:13-16
   int rc;
   if ((rc = ensure(g.res, sizeof(ZesRes)))) return rc;
@@ -344,6 +346,25 @@ int inflate_one(const uint8_t* d_in, uint64_t in_off, uint64_t c, uint8_t* d_out
         fprintf(stderr, "zes phases (avg cycles over %u blocks): hdr %.0f tables %.0f compose %.0f count %.0f emit %.0f resolve %.0f flush %.0f\n",
                 cntd, acc[1] / cntd, acc[2] / cntd, acc[3] / cntd, acc[4] / cntd, acc[5] / cntd, acc[6] / cntd, acc[7] / cntd);
       }
+      if (getenv("ZES_DEBUG")) {
+        fprintf(stderr, "zes T1: c=%llu nsurv=%u ncand=%u chain status=%d aux=%u out_len=%llu\n", (unsigned long long)c, nsurv, ncand,
+                hr.status, hr.aux, (unsigned long long)hr.out_len);
+        if (hr.status == 1) {
+          std::vector<ZesCandRes> hcr(ncand);
+          std::vector<uint32_t> hcand(ncand);
+          HIPCHK(hipMemcpy(hcr.data(), g.cres.p, sizeof(ZesCandRes) * ncand, hipMemcpyDeviceToHost));
+          HIPCHK(hipMemcpy(hcand.data(), g.cand_sorted.p, 4 * ncand, hipMemcpyDeviceToHost));
+          int shown = 0;
+          for (uint32_t k = 0; k < ncand && shown < 6; k++) {
+            const bool chain_ok = (k + 1 == ncand) || ((uint64_t)hcand[k + 1] + 16 == hcr[k].end_bit);
+            if (!(hcr[k].flags & 1u) || !chain_ok || (hcr[k].out_len != ZES_BLK && k + 1 != ncand)) {
+              fprintf(stderr, "  cand %u start=%u end_bit=%llu next_start=%u out_len=%u flags=%u\n", k, hcand[k] + 16,
+                      (unsigned long long)hcr[k].end_bit, k + 1 < ncand ? hcand[k + 1] + 16 : 0, hcr[k].out_len, hcr[k].flags);
+              shown++;
+            }
+          }
+        }
+      }
       if (hr.status == 2) {  // false positives shifted the slots: decode the chain again, in order
         const uint32_t K = hr.aux;
         {
@@ -360,6 +381,7 @@ int inflate_one(const uint8_t* d_in, uint64_t in_off, uint64_t c, uint8_t* d_out
       }
       if (hr.status == 0) {
         collect_times();
+        g.last_tier = 1;
         *out_len = hr.out_len;
         return hr.out_len > cap ? ZES_E_NOSPACE : ZES_OK;
       }
@@ -376,6 +398,7 @@ int inflate_one(const uint8_t* d_in, uint64_t in_off, uint64_t c, uint8_t* d_out
     if ((rc = read_res(&hr))) return rc;
     if (hr.status == 0) {
       collect_times();
+      g.last_tier = 2;
       *out_len = hr.out_len;
       return hr.out_len > cap ? ZES_E_NOSPACE : ZES_OK;
     }
@@ -389,6 +412,7 @@ int inflate_one(const uint8_t* d_in, uint64_t in_off, uint64_t c, uint8_t* d_out
   }
   if ((rc = read_res(&hr))) return rc;
   collect_times();
+  g.last_tier = 3;
   *out_len = hr.out_len;
   return hr.status;
 }
@@ -671,6 +695,11 @@ int zes_stage_huff_lengths_dev(const uint32_t* h_hist, uint32_t nsym, uint32_t m
   HIPCHK(hipMemcpyAsync(h_lens, g.codes.p, nsym, hipMemcpyDeviceToHost, g.stream));
   HIPCHK(hipStreamSynchronize(g.stream));
   return ZES_OK;
+}
+
+int zes_last_inflate_tier(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  return g.last_tier;
 }
 
 int zes_set_profiling(int on) {

@@ -34,9 +34,11 @@
 #define F_VOID 4u
 #define F_HIST 8u
 
+#define P4_WIN 512u  // output positions per bitmap window in the match resolution
+#define STAGE_DW ((ZES_BLK + ZES_BLK / 8) / 4)  // compressed bytes staged over the image + bitmap until P3
 struct ParSmem {
-  uint8_t out[ZES_BLK];
-  uint32_t bitmap[ZES_BLK / 32];
+  uint8_t out[ZES_BLK];            // P0-P2: first part of the staged compressed block (swizzled dwords)
+  uint32_t bitmap[ZES_BLK / 32];   // P0-P2: rest of the staging area; cleared before P3
   uint32_t lut_l[1u << PL_ROOT];
   uint32_t lut_d[1u << PD_ROOT];
   uint16_t syms_l[288];
@@ -45,13 +47,10 @@ struct ParSmem {
   uint16_t cnt_l[16], cnt_d[16], offs_l[16], offs_d[16];
   uint8_t lens[352];
   uint8_t cl_lut[128];
-  uint32_t wave_exit[PAR_WAVES];
-  uint32_t wave_flags[PAR_WAVES];
   uint32_t wave_sum[PAR_WAVES];
-  uint16_t mlist[704];
+  uint16_t mlist[704];                    // P4: match positions of the current 2048-byte window
   uint8_t wtab[PAR_WAVES][48];   // composed transfer table of each wave
   uint8_t wentry[PAR_WAVES];      // entry code of each wave's first segment
-  uint8_t lentry[PAR_THREADS];    // entry code of every segment
   uint32_t hdr_end, status, tail_entry, bfinal, tail_bytes, tail_end;
 };
 
@@ -68,24 +67,41 @@ __device__ __forceinline__ static uint32_t entry_d(uint32_t sym, uint32_t len) {
   return len | (3u << 8);
 }
 
+// Where a lane's bits come from: the swizzled LDS copy of the block (P0-P2) or global memory.
+struct BitSrc {
+  const uint32_t* g32;  // the buffer as dwords
+  uint32_t lastdw;      // last valid dword of the buffer
+  const uint32_t* s32;  // LDS staging area
+  uint32_t s_first;     // global dword index held at staging slot 0
+  uint32_t s_count;     // staged dwords
+};
+template <bool LDS>
+__device__ __forceinline__ static uint32_t src_ldw(const BitSrc& s, uint32_t idx) {
+  if (LDS) {
+    const uint32_t k = idx - s.s_first;
+    // lanes read at a stride of one segment (~32 dwords for random data): XOR the row index in
+    return k < s.s_count ? s.s32[k ^ ((k >> 5) & 31u)] : 0u;
+  }
+  return s.g32[idx < s.lastdw ? idx : s.lastdw];
+}
+
 struct LaneBits {
   uint64_t bb;
   uint32_t nb;
   uint32_t pos;  // bit offset of bb's bit 0 inside the buffer; (pos + nb) % 32 == 0
 };
-__device__ __forceinline__ static uint32_t lb_ldw(const uint32_t* in32, uint32_t idx, uint32_t lastdw) {
-  return in32[idx < lastdw ? idx : lastdw];
-}
-__device__ __forceinline__ static void lb_seek(LaneBits& b, const uint32_t* in32, uint32_t lastdw, uint32_t bit) {
+template <bool LDS>
+__device__ __forceinline__ static void lb_seek(LaneBits& b, const BitSrc& s, uint32_t bit) {
   const uint32_t i = bit >> 5, sh = bit & 31u;
-  const uint64_t w = (uint64_t)lb_ldw(in32, i, lastdw) | ((uint64_t)lb_ldw(in32, i + 1, lastdw) << 32);
+  const uint64_t w = (uint64_t)src_ldw<LDS>(s, i) | ((uint64_t)src_ldw<LDS>(s, i + 1) << 32);
   b.bb = w >> sh;
   b.nb = 64u - sh;
   b.pos = bit;
 }
-__device__ __forceinline__ static void lb_refill(LaneBits& b, const uint32_t* in32, uint32_t lastdw) {
+template <bool LDS>
+__device__ __forceinline__ static void lb_refill(LaneBits& b, const BitSrc& s) {
   if (b.nb <= 32u) {
-    b.bb |= (uint64_t)lb_ldw(in32, (b.pos + b.nb) >> 5, lastdw) << b.nb;
+    b.bb |= (uint64_t)src_ldw<LDS>(s, (b.pos + b.nb) >> 5) << b.nb;
     b.nb += 32u;
   }
 }
@@ -95,6 +111,57 @@ __device__ __forceinline__ static uint32_t lb_take(LaneBits& b, uint32_t k) {
   b.nb -= k;
   b.pos += k;
   return v;
+}
+
+// transfer table of a segment in registers: 64 entries x 8 bits.  Eight named words and explicit
+// select chains on purpose: an indexed array makes the compiler move the table to scratch.
+struct SegTab {
+  uint64_t a, b, c, d, e, f, g, h;
+};
+__device__ __forceinline__ static uint32_t tab_get(const SegTab& t, uint32_t o) {
+  const uint32_t wi = o >> 3;
+  // opaque copies: otherwise the select chain over fields is folded back into an indexed load
+  uint64_t a = t.a, b = t.b, c = t.c, d = t.d, e = t.e, f = t.f, g = t.g, h = t.h;
+  asm("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+  asm("" : "+v"(e), "+v"(f), "+v"(g), "+v"(h));
+  uint64_t x = a;
+  x = (wi == 1u) ? b : x;
+  x = (wi == 2u) ? c : x;
+  x = (wi == 3u) ? d : x;
+  x = (wi == 4u) ? e : x;
+  x = (wi == 5u) ? f : x;
+  x = (wi == 6u) ? g : x;
+  x = (wi == 7u) ? h : x;
+  return (uint32_t)(x >> ((o & 7u) * 8u)) & 0xffu;
+}
+__device__ __forceinline__ static void tab_set(SegTab& t, uint32_t o, uint32_t code) {  // entries start as 0, set once
+  const uint32_t wi = o >> 3;
+  const uint64_t v = (uint64_t)code << ((o & 7u) * 8u);
+  t.a |= (wi == 0u) ? v : 0ull;
+  t.b |= (wi == 1u) ? v : 0ull;
+  t.c |= (wi == 2u) ? v : 0ull;
+  t.d |= (wi == 3u) ? v : 0ull;
+  t.e |= (wi == 4u) ? v : 0ull;
+  t.f |= (wi == 5u) ? v : 0ull;
+  t.g |= (wi == 6u) ? v : 0ull;
+  t.h |= (wi == 7u) ? v : 0ull;
+}
+__device__ __forceinline__ static uint64_t bcast64(uint64_t v, uint32_t srclane) {  // srclane uniform
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)srclane);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)srclane);
+  return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+__device__ __forceinline__ static SegTab tab_bcast(const SegTab& t, uint32_t srclane) {
+  SegTab r;
+  r.a = bcast64(t.a, srclane);
+  r.b = bcast64(t.b, srclane);
+  r.c = bcast64(t.c, srclane);
+  r.d = bcast64(t.d, srclane);
+  r.e = bcast64(t.e, srclane);
+  r.f = bcast64(t.f, srclane);
+  r.g = bcast64(t.g, srclane);
+  r.h = bcast64(t.h, srclane);
+  return r;
 }
 
 // canonical walk for codes longer than the root (same bit-at-a-time extension as the reference)
@@ -122,9 +189,10 @@ __device__ __forceinline__ static int slow_sym(const LaneBits& b, uint32_t root,
 #define C_NONE 255u
 
 // One token at b.pos.  Returns its kind; literal value / (len, dist) through the references.
-__device__ __forceinline__ static uint32_t tok_step(ParSmem& S, LaneBits& b, const uint32_t* in32, uint32_t lastdw, uint32_t& val,
-                                                    uint32_t& len, uint32_t& dist) {
-  lb_refill(b, in32, lastdw);
+template <bool LDS>
+__device__ __forceinline__ static uint32_t tok_step(ParSmem& S, LaneBits& b, const BitSrc& src, uint32_t& val, uint32_t& len,
+                                                    uint32_t& dist) {
+  lb_refill<LDS>(b, src);
   uint32_t e = S.lut_l[(uint32_t)b.bb & ((1u << PL_ROOT) - 1u)];
   if ((e & 15u) == 0u) {
     uint32_t l2 = 0;
@@ -140,9 +208,9 @@ __device__ __forceinline__ static uint32_t tok_step(ParSmem& S, LaneBits& b, con
   }
   if (kind == 1u) return T_EOB;
   if (kind == 3u) return T_FAIL;
-  lb_refill(b, in32, lastdw);
+  lb_refill<LDS>(b, src);
   len = (e >> 16) + lb_take(b, (e >> 4) & 15u);
-  lb_refill(b, in32, lastdw);
+  lb_refill<LDS>(b, src);
   uint32_t ed = S.lut_d[(uint32_t)b.bb & ((1u << PD_ROOT) - 1u)];
   if ((ed & 15u) == 0u) {
     uint32_t l2 = 0;
@@ -152,84 +220,193 @@ __device__ __forceinline__ static uint32_t tok_step(ParSmem& S, LaneBits& b, con
   }
   lb_take(b, ed & 15u);
   if (((ed >> 8) & 3u) != 2u) return T_FAIL;
-  lb_refill(b, in32, lastdw);
+  lb_refill<LDS>(b, src);
   dist = (ed >> 16) + lb_take(b, (ed >> 4) & 15u);
   return T_MATCH;
 }
 
-// Transfer table of the segment [base, stop): tab[o] for o < 128 gets the exit code of the
-// trajectory passing through token boundary base+o (only o < 48 can be entries; the rest of the
-// window only detects merges early).
-__device__ __forceinline__ static void seg_table(ParSmem& S, const uint32_t* in32, uint32_t lastdw, uint32_t limit, uint32_t base,
-                                                 uint32_t stop, uint8_t* tab) {
-  uint64_t V0 = 0, V1 = 0;  // visited boundaries, offsets 0..63 and 64..127
-  for (uint32_t k = 0; k < 48u; k++) {
-    if ((V0 >> k) & 1ull) continue;
-    uint64_t M0 = 0, M1 = 0;
-    uint32_t code;
-    if (base + k >= limit) {
-      code = C_FAIL;
-      M0 = 1ull << k;
-    } else {
-      LaneBits b;
-      lb_seek(b, in32, lastdw, base + k);
-      for (;;) {
-        if (b.pos >= stop) {
-          code = b.pos - stop;  // 0..47: a token is at most 48 bits
-          break;
-        }
-        const uint32_t off = b.pos - base;
-        if (off < 64u) {
-          if ((V0 >> off) & 1ull) {
-            code = tab[off];
-            break;
-          }
-          M0 |= 1ull << off;
-        } else if (off < 128u) {
-          if ((V1 >> (off - 64u)) & 1ull) {
-            code = tab[off];
-            break;
-          }
-          M1 |= 1ull << (off - 64u);
-        }
-        uint32_t v, l, d;
-        const uint32_t kind = tok_step(S, b, in32, lastdw, v, l, d);
-        if (kind == T_EOB) {
-          code = C_EOB;
-          break;
-        }
-        if (kind == T_FAIL || b.pos > limit) {
-          code = C_FAIL;
-          break;
+// ------------------------------------------------------------------------------------------
+// Transfer table of the segment [base, stop), branch-light:
+//  (a) for each of the 64 window offsets o: where does ONE token starting at base+o end?
+//      (64 independent decodes from a register copy of the first 160 bits, fully unrolled)
+//  (b) tokens that end past the window land on at most 48 distinct offsets; only from those a
+//      full trajectory to the segment end is decoded (highest first, so a trajectory that
+//      reaches a landing point already done takes over its result)
+//  (c) table[o] = table[successor] filled from offset 63 down, every write at a static slot.
+// ------------------------------------------------------------------------------------------
+#define NX_EOB 0xFEu
+#define NX_FAIL 0xFFu
+
+// code of one litlen LUT hit (slow path for codes longer than the root); 0 = no code matches
+__device__ __forceinline__ static uint32_t lut_l_entry(ParSmem& S, uint32_t bits) {
+  uint32_t e = S.lut_l[bits & ((1u << PL_ROOT) - 1u)];
+  if ((e & 15u) == 0u) {
+    LaneBits t;
+    t.bb = bits;
+    uint32_t l2 = 0;
+    const int sy = slow_sym(t, PL_ROOT, S.syms_l, S.first_l, S.cnt_l, S.offs_l, &l2);
+    e = sy < 0 ? 0u : entry_l((uint32_t)sy, l2);
+  }
+  return e;
+}
+__device__ __forceinline__ static uint32_t lut_d_entry(ParSmem& S, uint32_t bits) {
+  uint32_t e = S.lut_d[bits & ((1u << PD_ROOT) - 1u)];
+  if ((e & 15u) == 0u) {
+    LaneBits t;
+    t.bb = bits;
+    uint32_t l2 = 0;
+    const int sy = slow_sym(t, PD_ROOT, S.syms_d, S.first_d, S.cnt_d, S.offs_d, &l2);
+    e = sy < 0 ? 0u : entry_d((uint32_t)sy, l2);
+  }
+  return e;
+}
+
+// 32 bits at relative bit r (dynamic, r < 128) of the aligned window a0..a4
+__device__ __forceinline__ static uint32_t win_bits(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4, uint32_t r) {
+  const uint32_t wi = r >> 5;
+  uint32_t lo = a0, hi = a1;
+  lo = (wi == 1u) ? a1 : lo;
+  hi = (wi == 1u) ? a2 : hi;
+  lo = (wi == 2u) ? a2 : lo;
+  hi = (wi == 2u) ? a3 : hi;
+  lo = (wi == 3u) ? a3 : lo;
+  hi = (wi == 3u) ? a4 : hi;
+  return __builtin_amdgcn_alignbit(hi, lo, r & 31u);
+}
+
+// one step of a predicated trajectory: lanes with act decode one token at b.pos (count-free)
+// returns: 0 continue, C_EOB, C_FAIL (as code+1000 so 0 stays "continue")
+template <bool LDS>
+__device__ __forceinline__ static void seg_table(ParSmem& S, const BitSrc& src, uint32_t limit, uint32_t base, uint32_t stop,
+                                                 SegTab& tab) {
+  // ---- (a) successors of the 64 window offsets ----
+  uint32_t a0, a1, a2, a3, a4;
+  {
+    const uint32_t d0 = base >> 5, bo = base & 31u;
+    const uint32_t w0 = src_ldw<LDS>(src, d0), w1 = src_ldw<LDS>(src, d0 + 1), w2 = src_ldw<LDS>(src, d0 + 2),
+                   w3 = src_ldw<LDS>(src, d0 + 3), w4 = src_ldw<LDS>(src, d0 + 4), w5 = src_ldw<LDS>(src, d0 + 5);
+    a0 = __builtin_amdgcn_alignbit(w1, w0, bo);
+    a1 = __builtin_amdgcn_alignbit(w2, w1, bo);
+    a2 = __builtin_amdgcn_alignbit(w3, w2, bo);
+    a3 = __builtin_amdgcn_alignbit(w4, w3, bo);
+    a4 = __builtin_amdgcn_alignbit(w5, w4, bo);
+  }
+  SegTab nx = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t Lmask = 0;  // landing offsets 64..111 (bit = offset - 64)
+  const uint32_t room = limit > base ? limit - base : 0u;  // bits of data from base on
+#pragma unroll 1
+  for (uint32_t o = 0; o < 64u; o++) {  // a loop, not unrolled: the body must stay small in the instruction cache
+    const uint32_t e = lut_l_entry(S, win_bits(a0, a1, a2, a3, a4, o));
+    const uint32_t kind = (e >> 8) & 3u;
+    uint32_t v = o + (e & 15u) + ((e >> 4) & 15u);
+    if (__ballot(kind == 2u)) {
+      const uint32_t ed = lut_d_entry(S, win_bits(a0, a1, a2, a3, a4, v & 127u));
+      const uint32_t v2 = v + (ed & 15u) + ((ed >> 4) & 15u);
+      const bool dbad = (((ed >> 8) & 3u) != 2u) || (ed & 15u) == 0u;
+      v = (kind == 2u) ? (dbad ? NX_FAIL : v2) : v;
+    }
+    v = (kind == 1u) ? NX_EOB : v;
+    v = (kind == 3u || (e & 15u) == 0u) ? NX_FAIL : v;
+    v = (v < 128u && v > room) ? NX_FAIL : v;
+    v = (o >= room) ? NX_FAIL : v;
+    Lmask |= (v >= 64u && v < 128u) ? (1ull << (v - 64u)) : 0ull;
+    tab_set(nx, o, v);  // v >= 1: a token has at least one bit
+  }
+
+  // ---- (b) full trajectories from the landing offsets, highest first ----
+  SegTab lt = {0, 0, 0, 0, 0, 0, 0, 0};  // exit code of landing offset 64+i at entry i
+  uint64_t Ldone = 0;
+  for (;;) {
+    const uint64_t pend = Lmask & ~Ldone;
+    const bool have = pend != 0ull;
+    if (!__ballot(have)) break;
+    const uint32_t L = have ? 63u - (uint32_t)__builtin_clzll(pend) : 0u;
+    LaneBits b;
+    lb_seek<LDS>(b, src, base + 64u + L);
+    uint32_t code = C_FAIL;
+    bool act = have && (base + 64u + L) < limit;
+    while (__ballot(act)) {
+      // token start checks
+      if (act && b.pos >= stop) {
+        code = b.pos - stop;  // 0..47
+        act = false;
+      }
+      const uint32_t rel = b.pos - base - 64u;  // landing-window offset
+      const bool hit = act && rel < 48u && ((Ldone >> rel) & 1ull);
+      if (__ballot(hit)) {
+        if (hit) {
+          code = tab_get(lt, rel);
+          act = false;
         }
       }
+      // one token for the active lanes (inactive lanes run along on stale bits, harmlessly)
+      lb_refill<LDS>(b, src);
+      const uint32_t e = lut_l_entry(S, (uint32_t)b.bb);
+      const uint32_t kind = (e >> 8) & 3u;
+      uint32_t adv = (e & 15u) + ((e >> 4) & 15u);
+      bool bad = (kind == 3u) || ((e & 15u) == 0u);
+      if (__ballot(act && kind == 2u)) {
+        // distance part: needs up to 28 more bits after the (<= 20-bit) litlen part
+        LaneBits t = b;
+        t.bb >>= adv;
+        t.nb -= adv;
+        t.pos += adv;
+        lb_refill<LDS>(t, src);
+        const uint32_t ed = lut_d_entry(S, (uint32_t)t.bb);
+        const uint32_t adv2 = (ed & 15u) + ((ed >> 4) & 15u);
+        const bool m = kind == 2u;
+        bad = bad || (m && ((((ed >> 8) & 3u) != 2u) || (ed & 15u) == 0u));
+        // commit the refill of t into b only for match lanes: recompute from t
+        if (act && m) {
+          b = t;
+          adv = adv2;
+        }
+      }
+      adv = act ? adv : 0u;
+      b.bb >>= adv;
+      b.nb -= adv;
+      b.pos += adv;
+      if (act && kind == 1u) {
+        code = C_EOB;
+        act = false;
+      }
+      if (act && (bad || b.pos > limit)) {
+        code = C_FAIL;
+        act = false;
+      }
     }
-    V0 |= M0;
-    V1 |= M1;
-    while (M0) {
-      const uint32_t o = (uint32_t)__builtin_ctzll(M0);
-      M0 &= M0 - 1ull;
-      tab[o] = (uint8_t)code;
-    }
-    while (M1) {
-      const uint32_t o = (uint32_t)__builtin_ctzll(M1);
-      M1 &= M1 - 1ull;
-      tab[64u + o] = (uint8_t)code;
+    if (have) {
+      tab_set(lt, L, code);
+      Ldone |= 1ull << L;
     }
   }
+
+  // ---- (c) table[o] from offset 63 down: successor inside the window -> its entry; landing ->
+  //          the landing's code ----
+  SegTab t = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 1
+  for (int o = 63; o >= 0; o--) {
+    const uint32_t v = tab_get(nx, (uint32_t)o);
+    const uint32_t in = tab_get(t, v & 63u);
+    const uint32_t la = tab_get(lt, (v - 64u) & 63u);
+    uint32_t c = (v < 64u) ? in : la;
+    c = (v == NX_EOB) ? C_EOB : c;
+    c = (v == NX_FAIL) ? C_FAIL : c;
+    tab_set(t, (uint32_t)o, c);
+  }
+  tab = t;
 }
 
 // Decodes tokens from bit `entry` while the token start is below `stop`.
-template <bool EMIT>
-__device__ __forceinline__ static void seg_decode(ParSmem& S, const uint32_t* in32, uint32_t lastdw, uint32_t limit, uint32_t entry,
-                                                  uint32_t stop, uint32_t out_off, uint32_t& exit_pos, uint32_t& outbytes,
-                                                  uint32_t& flags) {
+template <bool EMIT, bool LDS>
+__device__ __forceinline__ static void seg_decode(ParSmem& S, const BitSrc& src, uint32_t limit, uint32_t entry, uint32_t stop,
+                                                  uint32_t out_off, uint32_t& exit_pos, uint32_t& outbytes, uint32_t& flags) {
   LaneBits b;
-  lb_seek(b, in32, lastdw, entry);
+  lb_seek<LDS>(b, src, entry);
   uint32_t ob = 0, fl = 0;
   while (b.pos < stop) {
     uint32_t v = 0, len = 0, dist = 0;
-    const uint32_t kind = tok_step(S, b, in32, lastdw, v, len, dist);
+    const uint32_t kind = tok_step<LDS>(S, b, src, v, len, dist);
     if (kind == T_EOB) {
       fl |= F_EOB;
       break;
@@ -258,6 +435,82 @@ __device__ __forceinline__ static void seg_decode(ParSmem& S, const uint32_t* in
     if (ob > ZES_BLK) {  // more than a slot: not a reference-made block
       fl |= F_FAIL;
       break;
+    }
+  }
+  exit_pos = b.pos;
+  outbytes = ob;
+  flags = fl;
+}
+
+// Predicated form of seg_decode for the count (P2) and emit (P3) passes: one loop for the whole
+// wave, lanes drop out by clearing `act`; the rarely needed distance lookup sits behind a ballot.
+template <bool EMIT, bool LDS>
+__device__ __forceinline__ static void seg_run(ParSmem& S, const BitSrc& src, uint32_t limit, uint32_t entry, uint32_t stop, bool live,
+                                               uint32_t out_off, uint32_t& exit_pos, uint32_t& outbytes, uint32_t& flags) {
+  LaneBits b;
+  lb_seek<LDS>(b, src, live ? entry : 0u);
+  uint32_t ob = 0, fl = 0;
+  bool act = live;
+  while (__ballot(act)) {
+    if (act && b.pos >= stop) act = false;
+    lb_refill<LDS>(b, src);
+    const uint32_t e = lut_l_entry(S, (uint32_t)b.bb);
+    const uint32_t kind = (e >> 8) & 3u;
+    const uint32_t cl = e & 15u, xb = (e >> 4) & 15u;
+    uint32_t adv = cl + xb;
+    bool bad = (kind == 3u) || (cl == 0u);
+    uint32_t len = (e >> 16) + (((uint32_t)(b.bb >> cl)) & ((1u << xb) - 1u));  // length value of a match token
+    uint32_t dist = 0;
+    const bool ismatch = act && kind == 2u;
+    if (__ballot(ismatch)) {
+      LaneBits t = b;
+      t.bb >>= adv;
+      t.nb -= adv;
+      t.pos += adv;
+      lb_refill<LDS>(t, src);
+      const uint32_t ed = lut_d_entry(S, (uint32_t)t.bb);
+      const uint32_t dl = ed & 15u, dx = (ed >> 4) & 15u;
+      dist = (ed >> 16) + (((uint32_t)(t.bb >> dl)) & ((1u << dx) - 1u));
+      bad = bad || (kind == 2u && ((((ed >> 8) & 3u) != 2u) || dl == 0u));
+      if (ismatch) {  // never move a lane that has already stopped: its b.pos is the segment's exit
+        b = t;
+        adv = dl + dx;
+      }
+    }
+    adv = act ? adv : 0u;
+    b.bb >>= adv;
+    b.nb -= adv;
+    b.pos += adv;
+    if (act && kind == 1u) {
+      fl |= F_EOB;
+      act = false;
+    }
+    if (act && (bad || b.pos > limit)) {
+      fl |= F_FAIL;
+      act = false;
+    }
+    if (act) {
+      if (kind == 0u) {
+        if (EMIT) S.out[out_off + ob] = (uint8_t)(e >> 16);
+        ob += 1u;
+      } else {
+        if (EMIT) {
+          const uint32_t p = out_off + ob;
+          if (dist > p) {
+            fl |= F_HIST;  // looks behind the block start: not a reference-made block
+          } else {
+            S.out[p] = (uint8_t)(dist - 1u);
+            S.out[p + 1] = (uint8_t)((dist - 1u) >> 8);
+            S.out[p + 2] = (uint8_t)(len - 3u);
+            atomicOr(&S.bitmap[p >> 5], 1u << (p & 31u));
+          }
+        }
+        ob += len;
+      }
+      if (ob > ZES_BLK) {  // more than a slot: not a reference-made block
+        fl |= F_FAIL;
+        act = false;
+      }
     }
   }
   exit_pos = b.pos;
@@ -329,11 +582,12 @@ __device__ __forceinline__ static bool par_build(ParSmem& S, uint32_t base, uint
 }
 
 // dynamic header by wave 0 (uniform): returns false on anything T2/T3 should look at
-__device__ __forceinline__ static bool par_header(ParSmem& S, const uint32_t* in32, uint32_t lastdw, uint32_t limit, uint32_t start) {
+template <bool LDS>
+__device__ __forceinline__ static bool par_header(ParSmem& S, const BitSrc& src, uint32_t limit, uint32_t start) {
   const uint32_t lane = zes_lane();
   LaneBits b;
-  lb_seek(b, in32, lastdw, start);
-  lb_refill(b, in32, lastdw);
+  lb_seek<LDS>(b, src, start);
+  lb_refill<LDS>(b, src);
   const uint32_t bfinal = lb_take(b, 1);
   if (lb_take(b, 2) != 2u) return false;
   const uint32_t HLIT = lb_take(b, 5) + 257u;
@@ -341,7 +595,7 @@ __device__ __forceinline__ static bool par_header(ParSmem& S, const uint32_t* in
   const uint32_t HCLEN = lb_take(b, 4) + 4u;
   uint32_t mycl = 0;
   for (uint32_t k = 0; k < HCLEN; k++) {
-    lb_refill(b, in32, lastdw);
+    lb_refill<LDS>(b, src);
     const uint32_t v = lb_take(b, 3);
     if (lane == kClOrder[k]) mycl = v;
   }
@@ -367,7 +621,7 @@ __device__ __forceinline__ static bool par_header(ParSmem& S, const uint32_t* in
   const uint32_t total = HLIT + HDIST;
   uint32_t prev = 0;
   for (uint32_t k = 0; k < total;) {
-    lb_refill(b, in32, lastdw);
+    lb_refill<LDS>(b, src);
     const uint32_t e = S.cl_lut[(uint32_t)b.bb & 127u];
     const uint32_t l = e >> 5, sy = e & 31u;
     if (!l) return false;
@@ -414,7 +668,6 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __
   } while (0)
   const uint32_t w = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   if (w >= nwork) return;
-  const uint32_t* in32 = reinterpret_cast<const uint32_t*>(d_in + in_off);
   const uint32_t lastdw = (uint32_t)((c - 1) >> 2);
   const uint32_t limit = (uint32_t)(c * 8);
   const uint32_t ci = map ? map[w] : w;
@@ -426,16 +679,29 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __
   } else if (ci + 1 < ncand) {
     de_est = cand[ci + 1] + 16u;
   }
-
   STAMP(0);
-  // ---- P0: header + tables (wave 0), bitmap clear (everyone else) ----
-  if (tid == 0) S.status = 0;
-  if (wave != 0) {
-    for (uint32_t i = tid - 64; i < ZES_BLK / 32; i += PAR_THREADS - 64) S.bitmap[i] = 0;
+  // ---- P0: stage the block's compressed bytes in LDS (swizzled), header + tables by wave 0 ----
+  BitSrc src;
+  src.g32 = reinterpret_cast<const uint32_t*>(d_in + in_off);
+  src.lastdw = lastdw;
+  src.s32 = reinterpret_cast<const uint32_t*>(S.out);
+  src.s_first = start >> 5;
+  {
+    const uint64_t end_bit = min((uint64_t)limit, (uint64_t)de_est + 1280u);  // segment rounding + one token + slack
+    const uint32_t end_dw = min(lastdw, (uint32_t)((end_bit + 63u) >> 5));
+    src.s_count = end_dw - src.s_first + 1u;
+  }
+  // a block whose compressed bytes do not fit the staging area (> 144 KiB for <= 128 KiB of output)
+  // is not reference-made: leave it to T2
+  const bool use_lds = src.s_count <= STAGE_DW;
+  if (tid == 0) S.status = use_lds ? 0u : 1u;
+  if (use_lds) {
+    uint32_t* st = reinterpret_cast<uint32_t*>(S.out);
+    for (uint32_t k = tid; k < src.s_count; k += PAR_THREADS) st[k ^ ((k >> 5) & 31u)] = src.g32[src.s_first + k];
   }
   __syncthreads();
-  if (wave == 0) {
-    const bool ok = par_header(S, in32, lastdw, limit, start);
+  if (wave == 0 && use_lds) {
+    const bool ok = par_header<true>(S, src, limit, start);
     if (!ok && lane == 0) S.status = 1;
   }
   __syncthreads();
@@ -454,20 +720,21 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __
   const uint32_t span = de_est > ds ? de_est - ds : 1u;
   const uint32_t seglen = max(64u, (span + PAR_THREADS - 1) / PAR_THREADS);
 
-  // ---- P1: transfer tables (in the LDS image, 128 B per lane), then composition ----
+  // ---- P1: transfer tables in registers, then composition by lane broadcasts ----
   const uint64_t b_me64 = (uint64_t)ds + (uint64_t)tid * seglen;
   const uint32_t base = (uint32_t)(b_me64 < 0xFFFFFF00ull ? b_me64 : 0xFFFFFF00ull);
   const uint32_t stop = (uint32_t)((b_me64 + seglen) < 0xFFFFFF00ull ? (b_me64 + seglen) : 0xFFFFFF00ull);
-  uint8_t* tab = S.out + (size_t)tid * 128u;
-  seg_table(S, in32, lastdw, limit, base, stop, tab);
-  __syncthreads();
+  SegTab tab = {0, 0, 0, 0, 0, 0, 0, 0};
+  seg_table<true>(S, src, limit, base, stop, tab);
   STAMP(2);
-  if (lane < 48u) {  // composition over the 64 segments of this wave, one input offset per lane
+  {
+    // composition over the 64 segments of this wave: lane j (< 48) carries input offset j
     uint32_t cur = lane;
     for (uint32_t sgm = 0; sgm < 64u; sgm++) {
-      if (cur < 48u) cur = S.out[(size_t)(wave * 64u + sgm) * 128u + cur];
+      const SegTab ws = tab_bcast(tab, sgm);
+      if (cur < 48u) cur = tab_get(ws, cur);
     }
-    S.wtab[wave][lane] = (uint8_t)cur;
+    if (lane < 48u) S.wtab[wave][lane] = (uint8_t)cur;
   }
   __syncthreads();
   if (tid == 0) {
@@ -479,36 +746,39 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __
     S.tail_entry = e;  // state after the last segment: offset past its end, or EOB / fail
   }
   __syncthreads();
-  if (lane == 0) {  // entries of the wave's 64 segments
-    uint32_t e = S.wentry[wave];
+  uint32_t ecode;
+  {
+    uint32_t e = S.wentry[wave];  // uniform
+    uint32_t mine = C_FAIL;
     for (uint32_t sgm = 0; sgm < 64u; sgm++) {
-      S.lentry[wave * 64u + sgm] = (uint8_t)e;
-      if (e < 48u) e = S.out[(size_t)(wave * 64u + sgm) * 128u + e];
+      if (lane == sgm) mine = e;
+      const SegTab ws = tab_bcast(tab, sgm);
+      if (e < 48u) e = tab_get(ws, e);
     }
+    ecode = mine;
   }
-  __syncthreads();
-  const uint32_t ecode = S.lentry[tid];
   const uint32_t tail_code = S.tail_entry;
-  __syncthreads();  // the tables are dead from here on: the image may be written
   STAMP(3);
 
   // ---- P2: count pass from the true entries, totals, end bit, output offsets ----
-  uint32_t entry = base + ecode, exit_pos = 0, outbytes = 0, flags = F_VOID;
-  if (ecode < 48u) seg_decode<false>(S, in32, lastdw, limit, entry, stop, 0, exit_pos, outbytes, flags);
+  uint32_t entry = base + ecode, exit_pos = 0, outbytes = 0, flags = 0;
+  seg_run<false, true>(S, src, limit, entry, stop, ecode < 48u, 0, exit_pos, outbytes, flags);
+  if (ecode >= 48u) flags = F_VOID;
   if (tid == 0) {
     S.tail_bytes = 0;
     S.tail_end = 0;
   }
-  __syncthreads();
+  __syncthreads();  // every lane is done with the staged copy: the image and the bitmap are free
+  for (uint32_t i = tid; i < ZES_BLK / 32; i += PAR_THREADS) S.bitmap[i] = 0;
   // a chain that is still alive after the last segment (the end estimate was short: a false
-  // candidate sits inside this block) is finished serially by one lane
+  // candidate sits inside this block) is finished serially by one lane, from global memory
   uint32_t tail_start = 0;
   if (tail_code < 48u) {
     const uint64_t last_stop = (uint64_t)ds + (uint64_t)PAR_THREADS * seglen;
     tail_start = (uint32_t)(last_stop + tail_code);
     if (tid == 0) {
       uint32_t ex, ob, fl;
-      seg_decode<false>(S, in32, lastdw, limit, tail_start, 0xFFFFFF00u, 0, ex, ob, fl);
+      seg_decode<false, false>(S, src, limit, tail_start, 0xFFFFFF00u, 0, ex, ob, fl);
       S.tail_bytes = ob;
       S.tail_end = ex;
       if (!(fl & F_EOB) || (fl & F_FAIL)) atomicOr(&S.status, 2u);
@@ -558,15 +828,15 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __
     const uint32_t my_off = wbase + incl - outbytes;
     STAMP(4);
 
-    // ---- P3: emit ----
+    // ---- P3: emit (compressed bits from global memory: the LDS now holds the output image) ----
     uint32_t f2 = 0;
-    if (!(flags & F_VOID) && entry < stop) {
+    {
       uint32_t ex2, ob2;
-      seg_decode<true>(S, in32, lastdw, limit, entry, stop, my_off, ex2, ob2, f2);
+      seg_run<true, false>(S, src, limit, entry, stop, !(flags & F_VOID) && entry < stop, my_off, ex2, ob2, f2);
     }
     if (tid == 0 && tail_code < 48u) {
       uint32_t ex2, ob2, f3 = 0;
-      seg_decode<true>(S, in32, lastdw, limit, tail_start, 0xFFFFFF00u, seg_total, ex2, ob2, f3);
+      seg_decode<true, false>(S, src, limit, tail_start, 0xFFFFFF00u, seg_total, ex2, ob2, f3);
       f2 |= f3;
     }
     if (f2 & F_HIST) atomicOr(&S.status, 8u);
@@ -583,8 +853,11 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __
     }
 
     STAMP(5);
-    // ---- P4: match resolution, in order, by wave 0 ----
+    // ---- P4: match resolution, in order, by wave 0: a lane may copy as soon as its source lies
+    // below the first unresolved match (src/inflate.ts:287-290).  (A 16-range multi-wave variant
+    // with per-wave watermarks was measured slower: text distances stagger the ranges.) ----
     if (wave == 0) {
+      uint16_t* ml = S.mlist;
       for (uint32_t wb = 0; wb < total; wb += 2048) {
         const uint32_t wi = (wb >> 5) + lane;
         uint32_t bits = (wi < ZES_BLK / 32) ? S.bitmap[wi] : 0u;
@@ -600,26 +873,41 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __
         while (bits) {
           const uint32_t t = (uint32_t)__builtin_ctz(bits);
           bits &= bits - 1u;
-          S.mlist[slot++] = (uint16_t)((lane << 5) + t);
+          ml[slot++] = (uint16_t)((lane << 5) + t);
         }
         for (uint32_t k = 0; k < nwin; k += 64) {
           const uint32_t i = k + lane;
           const bool have = i < nwin;
           uint32_t p = 0, L = 0, D = 1;
           if (have) {
-            p = wb + S.mlist[i];
+            p = wb + ml[i];
             D = ((uint32_t)S.out[p] | ((uint32_t)S.out[p + 1] << 8)) + 1u;
             L = (uint32_t)S.out[p + 2] + 3u;
           }
-          const uint32_t srcend = min(p - D + L, p);
+          const uint32_t src = p - D;
+          const uint32_t srcend = min(src + L, p);
           uint64_t U = __ballot(have);
           while (U) {
             const uint32_t f = (uint32_t)__builtin_ctzll(U);
             const uint32_t pf = __shfl(p, (int)f);
             const bool ready = have && ((U >> lane) & 1ull) && srcend <= pf;
             if (ready) {
-              const uint32_t src = p - D;
-              for (uint32_t j = 0; j < L; j++) S.out[p + j] = S.out[src + j];
+              uint32_t j = 0;
+              if (D >= 8u) {  // 8 independent loads, then 8 stores: the LDS latency is paid once per 8 bytes
+                for (; j + 8u <= L; j += 8u) {
+                  const uint8_t t0 = S.out[src + j + 0], t1 = S.out[src + j + 1], t2 = S.out[src + j + 2], t3 = S.out[src + j + 3],
+                                t4 = S.out[src + j + 4], t5 = S.out[src + j + 5], t6 = S.out[src + j + 6], t7 = S.out[src + j + 7];
+                  S.out[p + j + 0] = t0;
+                  S.out[p + j + 1] = t1;
+                  S.out[p + j + 2] = t2;
+                  S.out[p + j + 3] = t3;
+                  S.out[p + j + 4] = t4;
+                  S.out[p + j + 5] = t5;
+                  S.out[p + j + 6] = t6;
+                  S.out[p + j + 7] = t7;
+                }
+              }
+              for (; j < L; j++) S.out[p + j] = S.out[src + j];
             }
             U &= ~__ballot(ready);
           }
