@@ -221,8 +221,16 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match(const uint8_t* __res
       S.in[mswz(i)] = t;
     }
   }
-  // the last two positions of a block are always literals (src/lz77.ts:116-117)
-  if (tid < 2 && T >= 1u + tid) mo[T - 1 - tid] = 0;
+  // Results are written in sorted-key order, i.e. scattered over the block: every 4-byte store
+  // costs a whole memory transaction (measured 8x write amplification).  Most positions have
+  // no match, so the block's result words are zero-filled with coalesced 16-byte stores first
+  // and only real matches are scattered.  This also covers the last two positions, which are
+  // always literals (src/lz77.ts:116-117).
+  {
+    uint4* mo4 = reinterpret_cast<uint4*>(mo);
+    const uint32_t n4 = (T + 3u) >> 2;
+    for (uint32_t i = tid; i < n4; i += MATCH_THREADS) mo4[i] = make_uint4(0, 0, 0, 0);
+  }
   __syncthreads();
 
   const uint32_t ntiles = (cnt + MATCH_THREADS - 1) / MATCH_THREADS;
@@ -287,10 +295,8 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match(const uint8_t* __res
           if (best < maxl) pprobe = m_ld32u(S.in, p + best - 3u);
         }
       }
-      uint32_t tok = 0;
       if (best >= 3u && p + best + 3u <= T)  // nowIndex + len <= endIndex = start + T - 3 (src/lz77.ts:95)
-        tok = ZES_TOK_MATCH | ((best - 3u) << 16) | (p - bestq - 1u);
-      mo[p] = tok;
+        mo[p] = ZES_TOK_MATCH | ((best - 3u) << 16) | (p - bestq - 1u);
     }
     __syncthreads();
   }
