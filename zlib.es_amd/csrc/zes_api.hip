@@ -300,7 +300,7 @@ int inflate_one(const uint8_t* d_in, uint64_t in_off, uint64_t c, uint8_t* d_out
     if (t1) {
       {
         Timed t("k_inf_verify");
-        hipLaunchKernelGGL(k_inf_verify, dim3((nsurv + 63) / 64), dim3(64), 0, g.stream, d_in, in_off, c,
+        hipLaunchKernelGGL(k_inf_verify, dim3(std::min<uint32_t>((nsurv + 63) / 64, 8192u)), dim3(64), 0, g.stream, d_in, in_off, c,
                            (const uint32_t*)g.surv.p, surv_cap, (uint32_t*)g.counters.p, (uint32_t*)g.cand.p, cand_cap);
       }
       HIPCHK(hipMemcpyAsync(hc, g.counters.p, 16, hipMemcpyDeviceToHost, g.stream));

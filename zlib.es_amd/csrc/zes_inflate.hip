@@ -118,136 +118,168 @@ __global__ __launch_bounds__(INF_SCAN_THREADS) void k_inf_scan(const uint8_t* __
 __global__ __launch_bounds__(64) void k_inf_verify(const uint8_t* __restrict__ d_in, uint64_t in_off, uint64_t c,
                                                    const uint32_t* __restrict__ surv, uint32_t surv_cap,
                                                    uint32_t* __restrict__ counters, uint32_t* __restrict__ cand, uint32_t cand_cap) {
-  // per-thread scratch in LDS: code-length-code lengths and the symbols sorted by (length, symbol)
+  // Persistent lanes: most survivors are rejected within ~15 code-length symbols (their codes
+  // over-subscribe at once), a few need all ~300, so a lane that is done pulls the next survivor
+  // from a shared counter (counters[2]) instead of idling until the wave's slowest lane ends.
+  // Per-thread scratch in LDS: code-length-code lengths and the symbols sorted by (length, symbol).
   __shared__ uint8_t s_cl[64][20];
   __shared__ uint8_t s_sorted[64][20];
   const uint32_t lane = threadIdx.x;
-  const uint32_t i = blockIdx.x * 64 + lane;
   uint32_t ns = counters[0];
   if (ns > surv_cap) ns = surv_cap;
-  if (i >= ns) return;
   const uint32_t* in32 = reinterpret_cast<const uint32_t*>(d_in + in_off);
   const uint32_t lastdw = (uint32_t)((c - 1) >> 2);
   const uint64_t limit = c * 8;
-  const uint64_t pos0 = (uint64_t)surv[i] + 16;
-  // 64-bit window refilled a dword at a time; (pos + nb) stays a multiple of 32
-  uint64_t bb;
-  uint32_t nb;
-  uint64_t pos = pos0;
-  {
-    const uint32_t di = (uint32_t)(pos >> 5), sh = (uint32_t)(pos & 31);
-    const uint64_t w = (uint64_t)in32[min(di, lastdw)] | ((uint64_t)in32[min(di + 1, lastdw)] << 32);
-    bb = w >> sh;
-    nb = 64u - sh;
-  }
-  auto refill = [&]() {
-    if (nb <= 32u) {
-      bb |= (uint64_t)in32[min((uint32_t)((pos + nb) >> 5), lastdw)] << nb;
-      nb += 32u;
-    }
-  };
-  auto take = [&](uint32_t k) -> uint32_t {
-    const uint32_t v = (uint32_t)bb & ((1u << k) - 1u);
-    bb >>= k;
-    nb -= k;
-    pos += k;
-    return v;
-  };
-  take(3);
-  const uint32_t HLIT = take(5) + 257, HDIST = take(5) + 1, HCLEN = take(4) + 4;
   uint8_t* cl = s_cl[lane];
   uint8_t* sorted = s_sorted[lane];
-  for (int k = 0; k < 19; k++) cl[k] = 0;
-  for (uint32_t k = 0; k < HCLEN; k++) {
-    refill();
-    cl[kClOrder[k]] = (uint8_t)take(3);
-  }
-  // canonical decode tables of the (complete) code-length code: counts per length in registers,
-  // symbols sorted by (length, symbol) in LDS
+
+  bool have = false, exhausted = false;
+  uint64_t bb = 0, pos = 0, pos0 = 0;
+  uint32_t nb = 0;
   uint32_t c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, c6 = 0, c7 = 0;
-  for (int sy = 0; sy < 19; sy++) {
-    const uint32_t l = cl[sy];
-    c1 += l == 1;
-    c2 += l == 2;
-    c3 += l == 3;
-    c4 += l == 4;
-    c5 += l == 5;
-    c6 += l == 6;
-    c7 += l == 7;
-  }
-  {
-    uint32_t o1 = 0, o2 = c1, o3 = o2 + c2, o4 = o3 + c3, o5 = o4 + c4, o6 = o5 + c5, o7 = o6 + c6;
-    for (int sy = 0; sy < 19; sy++) {
-      const uint32_t l = cl[sy];
-      if (l == 0) continue;
-      uint32_t slot;
-      if (l == 1) slot = o1++;
-      else if (l == 2) slot = o2++;
-      else if (l == 3) slot = o3++;
-      else if (l == 4) slot = o4++;
-      else if (l == 5) slot = o5++;
-      else if (l == 6) slot = o6++;
-      else slot = o7++;
-      sorted[slot] = (uint8_t)sy;
+  uint32_t HLIT = 0, total = 0, k = 0, kl = 0, kd = 0, nd = 0, dmaxlen = 0, prev = 0;
+  bool has_eob = false;
+
+  for (;;) {
+    const uint64_t idle = __ballot(!have);
+    const uint32_t nidle = (uint32_t)__popcll(idle);
+    if (!exhausted && (nidle >= 16u || nidle == 64u)) {
+      uint32_t basei = 0;
+      if (lane == 0) basei = atomicAdd(&counters[2], nidle);
+      basei = (uint32_t)__builtin_amdgcn_readfirstlane((int)basei);
+      if (basei >= ns) exhausted = true;
+      const uint32_t myi = basei + (uint32_t)__popcll(idle & zes_lanemask_lt());
+      if (!have && myi < ns) {
+        // ---- set up one survivor: fixed header fields, code-length code ----
+        pos0 = (uint64_t)surv[myi] + 16;
+        pos = pos0;
+        {
+          const uint32_t di = (uint32_t)(pos >> 5), sh = (uint32_t)(pos & 31);
+          const uint64_t w = (uint64_t)in32[min(di, lastdw)] | ((uint64_t)in32[min(di + 1, lastdw)] << 32);
+          bb = w >> sh;
+          nb = 64u - sh;
+        }
+        auto refill = [&]() {
+          if (nb <= 32u) {
+            bb |= (uint64_t)in32[min((uint32_t)((pos + nb) >> 5), lastdw)] << nb;
+            nb += 32u;
+          }
+        };
+        auto take = [&](uint32_t kk) -> uint32_t {
+          const uint32_t v = (uint32_t)bb & ((1u << kk) - 1u);
+          bb >>= kk;
+          nb -= kk;
+          pos += kk;
+          return v;
+        };
+        take(3);
+        HLIT = take(5) + 257;
+        const uint32_t HDIST = take(5) + 1, HCLEN = take(4) + 4;
+        total = HLIT + HDIST;
+        for (int q = 0; q < 19; q++) cl[q] = 0;
+        for (uint32_t q = 0; q < HCLEN; q++) {
+          refill();
+          cl[kClOrder[q]] = (uint8_t)take(3);
+        }
+        c1 = c2 = c3 = c4 = c5 = c6 = c7 = 0;
+        for (int sy = 0; sy < 19; sy++) {
+          const uint32_t l = cl[sy];
+          c1 += l == 1;
+          c2 += l == 2;
+          c3 += l == 3;
+          c4 += l == 4;
+          c5 += l == 5;
+          c6 += l == 6;
+          c7 += l == 7;
+        }
+        uint32_t o1 = 0, o2 = c1, o3 = o2 + c2, o4 = o3 + c3, o5 = o4 + c4, o6 = o5 + c5, o7 = o6 + c6;
+        for (int sy = 0; sy < 19; sy++) {
+          const uint32_t l = cl[sy];
+          if (l == 0) continue;
+          uint32_t slot;
+          if (l == 1) slot = o1++;
+          else if (l == 2) slot = o2++;
+          else if (l == 3) slot = o3++;
+          else if (l == 4) slot = o4++;
+          else if (l == 5) slot = o5++;
+          else if (l == 6) slot = o6++;
+          else slot = o7++;
+          sorted[slot] = (uint8_t)sy;
+        }
+        k = kl = kd = nd = dmaxlen = prev = 0;
+        has_eob = false;
+        have = true;
+      }
     }
-  }
-  uint32_t kl = 0, kd = 0, nd = 0, dmaxlen = 0, prev = 0;
-  bool has_eob = false, ok = true;
-  const uint32_t total = HLIT + HDIST;
-  for (uint32_t k = 0; k < total && ok;) {
-    if (pos + 14 > limit) { ok = false; break; }
-    refill();
-    // bit-at-a-time canonical walk (MSB first), at most 7 steps
-    uint32_t code = 0, first = 0, base = 0, sy = 0xFFu, len = 0;
+    if (!__ballot(have)) break;  // nothing running and nothing left to fetch
+    // ---- one code-length symbol for every running lane ----
+    if (have) {
+      bool ok = pos + 14 <= limit;
+      if (nb <= 32u) {
+        bb |= (uint64_t)in32[min((uint32_t)((pos + nb) >> 5), lastdw)] << nb;
+        nb += 32u;
+      }
+      // bit-at-a-time canonical walk (MSB first), at most 7 steps
+      uint32_t code = 0, first = 0, base = 0, sy = 0xFFu, len = 0;
 #define CL_STEP(L, CNT)                                      \
-    if (sy == 0xFFu) {                                       \
-      code = (code << 1) | (uint32_t)((bb >> ((L)-1)) & 1u); \
-      if (code - first < (CNT)) {                            \
-        sy = sorted[base + code - first];                    \
-        len = (L);                                           \
-      }                                                      \
-      first = (first + (CNT)) << 1;                          \
-      base += (CNT);                                         \
-    }
-    CL_STEP(1, c1) CL_STEP(2, c2) CL_STEP(3, c3) CL_STEP(4, c4) CL_STEP(5, c5) CL_STEP(6, c6) CL_STEP(7, c7)
+      if (sy == 0xFFu) {                                     \
+        code = (code << 1) | (uint32_t)((bb >> ((L)-1)) & 1u); \
+        if (code - first < (CNT)) {                          \
+          sy = sorted[base + code - first];                  \
+          len = (L);                                         \
+        }                                                    \
+        first = (first + (CNT)) << 1;                        \
+        base += (CNT);                                       \
+      }
+      CL_STEP(1, c1) CL_STEP(2, c2) CL_STEP(3, c3) CL_STEP(4, c4) CL_STEP(5, c5) CL_STEP(6, c6) CL_STEP(7, c7)
 #undef CL_STEP
-    if (sy == 0xFFu) { ok = false; break; }
-    take(len);
-    uint32_t rep = 1, val = sy;
-    if (sy == 16) {
-      if (k == 0) { ok = false; break; }
-      rep = 3 + take(2);
-      val = prev;
-    } else if (sy == 17) {
-      rep = 3 + take(3);
-      val = 0;
-    } else if (sy == 18) {
-      rep = 11 + take(7);
-      val = 0;
-    }
-    if (k + rep > total) { ok = false; break; }
-    if (val) {
-      for (uint32_t r = 0; r < rep; r++) {
-        const uint32_t idx = k + r;
-        if (idx < HLIT) {
-          kl += 32768u >> val;
-          if (idx == 256) has_eob = true;
-        } else {
-          kd += 32768u >> val;
-          nd++;
-          dmaxlen = max(dmaxlen, val);
+      ok = ok && sy != 0xFFu;
+      uint32_t rep = 1, val = sy, xb = 0;
+      if (sy == 16) {
+        ok = ok && k != 0;
+        xb = 2;
+        val = prev;
+      } else if (sy == 17) {
+        xb = 3;
+        val = 0;
+      } else if (sy == 18) {
+        xb = 7;
+        val = 0;
+      }
+      const uint32_t xv = ((uint32_t)(bb >> len)) & ((1u << xb) - 1u);
+      if (sy == 16 || sy == 17) rep = 3 + xv;
+      if (sy == 18) rep = 11 + xv;
+      const uint32_t adv = len + xb;
+      bb >>= adv;
+      nb -= adv;
+      pos += adv;
+      ok = ok && (k + rep <= total);
+      if (ok && val) {
+        // rep entries of length val starting at index k: split at the lit/len | distance border
+        const uint32_t nl = k < HLIT ? min(rep, HLIT - k) : 0u;
+        const uint32_t ndd = rep - nl;
+        kl += nl * (32768u >> val);
+        kd += ndd * (32768u >> val);
+        nd += ndd;
+        if (ndd) dmaxlen = max(dmaxlen, val);
+        if (k <= 256u && 256u < k + nl) has_eob = true;
+        // garbage headers over-subscribe a code within a few symbols: stop right there
+        ok = kl <= 32768u && kd <= 32768u;
+      }
+      prev = val;
+      k += rep;
+      if (!ok) {
+        have = false;
+      } else if (k >= total) {
+        have = false;
+        const bool good = has_eob && kl == 32768u && (kd == 32768u || nd == 0 || (nd == 1 && dmaxlen == 1));
+        if (good) {
+          const uint32_t slot = atomicAdd(&counters[1], 1u);  // rare: about one per block of the stream
+          if (slot < cand_cap) cand[slot] = (uint32_t)(pos0 - 16);
         }
       }
-      // garbage headers over-subscribe a code within a few symbols: stop right there
-      if (kl > 32768u || kd > 32768u) { ok = false; break; }
     }
-    prev = val;
-    k += rep;
   }
-  if (!ok || !has_eob || kl != 32768u) return;
-  if (!(kd == 32768u || nd == 0 || (nd == 1 && dmaxlen == 1))) return;
-  const uint32_t slot = atomicAdd(&counters[1], 1u);  // rare: about one per block of the stream
-  if (slot < cand_cap) cand[slot] = (uint32_t)(pos0 - 16);
 }
 
 // rank sort of the candidate list (a few hundred to a few thousand entries)

@@ -41,6 +41,8 @@ struct ParSmem {
   uint32_t bitmap[ZES_BLK / 32];   // P0-P2: rest of the staging area; cleared before P3
   uint32_t lut_l[1u << PL_ROOT];
   uint32_t lut_d[1u << PD_ROOT];
+  uint8_t len_l[1u << PL_ROOT];  // bits of the lit/len part of a token: [5:0] count, 0x40 distance follows, 0x80 use lut_l
+  uint8_t len_d[1u << PD_ROOT];  // bits of the distance part: [5:0] count, 0x80 use lut_d
   uint16_t syms_l[288];
   uint16_t syms_d[32];
   uint32_t first_l[16], first_d[16];
@@ -225,18 +227,6 @@ __device__ __forceinline__ static uint32_t tok_step(ParSmem& S, LaneBits& b, con
   return T_MATCH;
 }
 
-// ------------------------------------------------------------------------------------------
-// Transfer table of the segment [base, stop), branch-light (DESIGN.md §4.2):
-//  (a) for each of the 64 window offsets o: where does ONE token starting at base+o end?
-//      (64 independent decodes from a register copy of the first 160 bits, fully unrolled)
-//  (b) tokens that end past the window land on at most 48 distinct offsets; only from those a
-//      full trajectory to the segment end is decoded (highest first, so a trajectory that
-//      reaches a landing point already done takes over its result)
-//  (c) table[o] = table[successor] filled from offset 63 down, every write at a static slot.
-// ------------------------------------------------------------------------------------------
-#define NX_EOB 0xFEu
-#define NX_FAIL 0xFFu
-
 // code of one litlen LUT hit (slow path for codes longer than the root); 0 = no code matches
 __device__ __forceinline__ static uint32_t lut_l_entry(ParSmem& S, uint32_t bits) {
   uint32_t e = S.lut_l[bits & ((1u << PL_ROOT) - 1u)];
@@ -260,6 +250,78 @@ __device__ __forceinline__ static uint32_t lut_d_entry(ParSmem& S, uint32_t bits
   }
   return e;
 }
+
+// branch-free refill from the staged copy (a step costs the same whether or not a lane needs bits)
+__device__ __forceinline__ static void lb_refill_bf(LaneBits& b, const BitSrc& s) {
+  const bool need = b.nb <= 32u;
+  const uint32_t k = ((b.pos + b.nb) >> 5) - s.s_first;
+  const bool in = k < s.s_count;
+  const uint32_t kk = in ? k : 0u;
+  uint32_t w = s.s32[kk ^ ((kk >> 5) & 31u)];
+  w = in ? w : 0u;
+  const uint32_t sh = need ? b.nb : 0u;
+  const uint64_t add = (uint64_t)w << sh;
+  b.bb |= need ? add : 0ull;
+  b.nb += need ? 32u : 0u;
+}
+
+// Bit length of the token at b.pos for every lane (positions only, no values): byte LUTs first,
+// the full tables only behind a ballot (EOB, codes longer than the root, bad symbols).
+// On return b is positioned so that consuming `adv` more bits completes the token.
+__device__ __forceinline__ static void len_step(ParSmem& S, const BitSrc& src, LaneBits& b, bool act, uint32_t& adv, bool& eob,
+                                                bool& bad) {
+  lb_refill_bf(b, src);
+  const uint32_t a = S.len_l[(uint32_t)b.bb & ((1u << PL_ROOT) - 1u)];
+  uint32_t n = a & 63u;
+  const bool sp = (a & 0x80u) != 0u;
+  bool m = (a & 0x40u) != 0u;
+  eob = false;
+  bad = false;
+  if (__ballot(act && sp)) {
+    const uint32_t e = lut_l_entry(S, (uint32_t)b.bb);
+    const uint32_t kind = (e >> 8) & 3u;
+    if (sp) {
+      eob = kind == 1u;
+      bad = (kind == 3u) || ((e & 15u) == 0u);
+      n = (e & 15u) + ((e >> 4) & 15u);
+      m = kind == 2u;
+    }
+  }
+  if (__ballot(act && m)) {
+    LaneBits t = b;
+    t.bb >>= n;
+    t.nb -= n;
+    t.pos += n;
+    lb_refill_bf(t, src);
+    const uint32_t d = S.len_d[(uint32_t)t.bb & ((1u << PD_ROOT) - 1u)];
+    uint32_t n2 = d & 63u;
+    const bool dsp = (d & 0x80u) != 0u;
+    if (__ballot(act && m && dsp)) {
+      const uint32_t ed = lut_d_entry(S, (uint32_t)t.bb);
+      if (dsp) {
+        bad = bad || (m && ((((ed >> 8) & 3u) != 2u) || (ed & 15u) == 0u));
+        n2 = (ed & 15u) + ((ed >> 4) & 15u);
+      }
+    }
+    if (act && m) {
+      b = t;
+      n = n2;
+    }
+  }
+  adv = n;
+}
+
+// ------------------------------------------------------------------------------------------
+// Transfer table of the segment [base, stop), branch-light (DESIGN.md §4.2):
+//  (a) for each of the 64 window offsets o: where does ONE token starting at base+o end?
+//      (64 independent decodes from a register copy of the first 160 bits, fully unrolled)
+//  (b) tokens that end past the window land on at most 48 distinct offsets; only from those a
+//      full trajectory to the segment end is decoded (highest first, so a trajectory that
+//      reaches a landing point already done takes over its result)
+//  (c) table[o] = table[successor] filled from offset 63 down, every write at a static slot.
+// ------------------------------------------------------------------------------------------
+#define NX_EOB 0xFEu
+#define NX_FAIL 0xFFu
 
 // 32 bits at relative bit r (dynamic, r < 128) of the aligned window a0..a4
 __device__ __forceinline__ static uint32_t win_bits(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4, uint32_t r) {
@@ -325,48 +387,31 @@ __device__ __forceinline__ static void seg_table(ParSmem& S, const BitSrc& src, 
     lb_seek<LDS>(b, src, base + 64u + L);
     uint32_t code = C_FAIL;
     bool act = have && (base + 64u + L) < limit;
+    // (the landing-window check only matters while a trajectory is still inside that window)
     while (__ballot(act)) {
-      // token start checks
       if (act && b.pos >= stop) {
         code = b.pos - stop;  // 0..47
         act = false;
       }
       const uint32_t rel = b.pos - base - 64u;  // landing-window offset
-      const bool hit = act && rel < 48u && ((Ldone >> rel) & 1ull);
-      if (__ballot(hit)) {
-        if (hit) {
-          code = tab_get(lt, rel);
-          act = false;
+      const bool inwin = act && rel < 48u;
+      if (__ballot(inwin)) {
+        const bool hit = inwin && ((Ldone >> rel) & 1ull);
+        if (__ballot(hit)) {
+          if (hit) {
+            code = tab_get(lt, rel);
+            act = false;
+          }
         }
       }
-      // one token for the active lanes (inactive lanes run along on stale bits, harmlessly)
-      lb_refill<LDS>(b, src);
-      const uint32_t e = lut_l_entry(S, (uint32_t)b.bb);
-      const uint32_t kind = (e >> 8) & 3u;
-      uint32_t adv = (e & 15u) + ((e >> 4) & 15u);
-      bool bad = (kind == 3u) || ((e & 15u) == 0u);
-      if (__ballot(act && kind == 2u)) {
-        // distance part: needs up to 28 more bits after the (<= 20-bit) litlen part
-        LaneBits t = b;
-        t.bb >>= adv;
-        t.nb -= adv;
-        t.pos += adv;
-        lb_refill<LDS>(t, src);
-        const uint32_t ed = lut_d_entry(S, (uint32_t)t.bb);
-        const uint32_t adv2 = (ed & 15u) + ((ed >> 4) & 15u);
-        const bool m = kind == 2u;
-        bad = bad || (m && ((((ed >> 8) & 3u) != 2u) || (ed & 15u) == 0u));
-        // commit the refill of t into b only for match lanes: recompute from t
-        if (act && m) {
-          b = t;
-          adv = adv2;
-        }
-      }
+      uint32_t adv;
+      bool eob, bad;
+      len_step(S, src, b, act, adv, eob, bad);
       adv = act ? adv : 0u;
       b.bb >>= adv;
       b.nb -= adv;
       b.pos += adv;
-      if (act && kind == 1u) {
+      if (act && eob) {
         code = C_EOB;
         act = false;
       }
@@ -523,7 +568,11 @@ __device__ __forceinline__ static bool par_build(ParSmem& S, uint32_t base, uint
                                                  uint16_t* syms, uint32_t* first, uint16_t* cnt, uint16_t* offs) {
   const uint32_t lane = zes_lane();
   const uint8_t* lens = S.lens + base;
-  for (uint32_t i = lane; i < (1u << root); i += 64) lut[i] = 0;
+  uint8_t* blut = is_dist ? S.len_d : S.len_l;
+  for (uint32_t i = lane; i < (1u << root); i += 64) {
+    lut[i] = 0;
+    blut[i] = 0x80u;  // default: long code or no code -> the full tables decide
+  }
   uint32_t c[16];
 #pragma unroll
   for (int l = 0; l < 16; l++) c[l] = 0;
@@ -574,7 +623,14 @@ __device__ __forceinline__ static bool par_build(ParSmem& S, uint32_t base, uint
       if (l <= root) {
         const uint32_t rev = __brev(f + rank) >> (32u - l);
         const uint32_t ent = is_dist ? entry_d(s, l) : entry_l(s, l);
-        for (uint32_t e = rev; e < (1u << root); e += 1u << l) lut[e] = ent;
+        const uint32_t kind = (ent >> 8) & 3u;
+        uint32_t bl = (ent & 15u) + ((ent >> 4) & 15u);  // code bits + extra bits
+        if (is_dist) bl = (kind == 2u) ? bl : 0x80u;
+        else bl = (kind == 0u) ? bl : (kind == 2u) ? (bl | 0x40u) : 0x80u;  // EOB and 286/287 go the long way
+        for (uint32_t e = rev; e < (1u << root); e += 1u << l) {
+          lut[e] = ent;
+          blut[e] = (uint8_t)bl;
+        }
       }
     }
   }
@@ -892,22 +948,43 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __
             const uint32_t pf = __shfl(p, (int)f);
             const bool ready = have && ((U >> lane) & 1ull) && srcend <= pf;
             if (ready) {
-              uint32_t j = 0;
-              if (D >= 8u) {  // 8 independent loads, then 8 stores: the LDS latency is paid once per 8 bytes
-                for (; j + 8u <= L; j += 8u) {
-                  const uint8_t t0 = S.out[src + j + 0], t1 = S.out[src + j + 1], t2 = S.out[src + j + 2], t3 = S.out[src + j + 3],
-                                t4 = S.out[src + j + 4], t5 = S.out[src + j + 5], t6 = S.out[src + j + 6], t7 = S.out[src + j + 7];
-                  S.out[p + j + 0] = t0;
-                  S.out[p + j + 1] = t1;
-                  S.out[p + j + 2] = t2;
-                  S.out[p + j + 3] = t3;
-                  S.out[p + j + 4] = t4;
-                  S.out[p + j + 5] = t5;
-                  S.out[p + j + 6] = t6;
-                  S.out[p + j + 7] = t7;
+              if (D >= 8u) {
+                // rounds of 8 independent loads, then up to 8 stores: the LDS round trip is paid once
+                // per 8 bytes whatever the length (loads past the match end stay inside the LDS block)
+                uint32_t j = 0;
+                for (; j + 8u <= L; j += 8u) {  // whole rounds
+                  const uint32_t sb = src + j, pb = p + j;
+                  const uint8_t t0 = S.out[sb], t1 = S.out[sb + 1], t2 = S.out[sb + 2], t3 = S.out[sb + 3], t4 = S.out[sb + 4],
+                                t5 = S.out[sb + 5], t6 = S.out[sb + 6], t7 = S.out[sb + 7];
+                  S.out[pb] = t0;
+                  S.out[pb + 1] = t1;
+                  S.out[pb + 2] = t2;
+                  S.out[pb + 3] = t3;
+                  S.out[pb + 4] = t4;
+                  S.out[pb + 5] = t5;
+                  S.out[pb + 6] = t6;
+                  S.out[pb + 7] = t7;
                 }
+                if (j < L) {
+                  // last partial round: offsets past the match end are clamped onto its last byte, so
+                  // every load and store stays unconditional (the duplicates rewrite the same value)
+                  const uint32_t last = L - j - 1u;
+                  const uint32_t o1 = min(1u, last), o2 = min(2u, last), o3 = min(3u, last), o4 = min(4u, last), o5 = min(5u, last),
+                                 o6 = min(6u, last);
+                  const uint32_t sb = src + j, pb = p + j;
+                  const uint8_t t0 = S.out[sb], t1 = S.out[sb + o1], t2 = S.out[sb + o2], t3 = S.out[sb + o3], t4 = S.out[sb + o4],
+                                t5 = S.out[sb + o5], t6 = S.out[sb + o6];
+                  S.out[pb] = t0;
+                  S.out[pb + o1] = t1;
+                  S.out[pb + o2] = t2;
+                  S.out[pb + o3] = t3;
+                  S.out[pb + o4] = t4;
+                  S.out[pb + o5] = t5;
+                  S.out[pb + o6] = t6;
+                }
+              } else {
+                for (uint32_t j = 0; j < L; j++) S.out[p + j] = S.out[src + j];
               }
-              for (; j < L; j++) S.out[p + j] = S.out[src + j];
             }
             U &= ~__ballot(ready);
           }
