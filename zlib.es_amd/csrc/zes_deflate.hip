@@ -166,11 +166,12 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
 // match_out[g][p] = ZES_TOK_MATCH | (len-3)<<16 | (dist-1), or 0 for "literal here".
 // ------------------------------------------------------------------------------------------
 #define MATCH_IN_DWORDS ((ZES_BLK + 288) / 4)
-#define MATCH_BACK 128u  // at most 128 candidates are ever examined (src/lz77.ts:66)
 #define MATCH_SAME 0x80000000u
+#define MATCH_WAVES (MATCH_THREADS / 64)
+#define MATCH_RING 384u  // sorted-index entries a wave keeps in LDS (6 chunks of 64): a job looks back <= 128 slots
 struct MatchSmem {
   uint32_t in[(MATCH_IN_DWORDS + 31) / 32 * 32];  // whole 32-dword rows: the swizzle permutes inside a row
-  uint32_t tile[MATCH_THREADS + MATCH_BACK];  // sorted positions of the current 1024 slots + 128 before; bit 31: same key as the slot before
+  uint32_t ring[MATCH_WAVES][MATCH_RING];         // position | same-key-as-previous-slot flag (bit 31)
 };
 
 __device__ __forceinline__ static uint32_t mswz(uint32_t i) { return i ^ ((i >> 5) & 31u) ^ ((i >> 10) & 31u); }
@@ -179,11 +180,16 @@ __device__ __forceinline__ static uint32_t m_ld32u(const uint32_t* w, uint32_t o
   return __builtin_amdgcn_alignbyte(w[mswz(i + 1)], w[mswz(i)], off & 3u);
 }
 
+// Work is data dependent (0..128 candidates per position, compares of 3..258 bytes), so lanes are
+// persistent: each lane runs a small state machine (probe the next candidate | compare 4 more
+// bytes) and takes the next sorted slot of its wave's range as soon as its position is finished.
+// After staging there is no workgroup barrier: a wave owns a contiguous range of sorted slots and
+// keeps the index entries it needs in its own LDS ring.
 __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match(const uint8_t* __restrict__ d_in, const ZesBuf* __restrict__ bufs,
                                                             const ZesBlk* __restrict__ blks, const uint32_t* __restrict__ idx_a,
                                                             uint32_t* __restrict__ match_out) {
   __shared__ __align__(16) MatchSmem S;
-  const uint32_t g = blockIdx.x, tid = threadIdx.x;
+  const uint32_t g = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const ZesBlk bk = blks[g];
   const ZesBuf bf = bufs[bk.buf];
   const uint32_t T = bk.len;
@@ -231,74 +237,135 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match(const uint8_t* __res
     const uint32_t n4 = (T + 3u) >> 2;
     for (uint32_t i = tid; i < n4; i += MATCH_THREADS) mo4[i] = make_uint4(0, 0, 0, 0);
   }
-  __syncthreads();
+  __syncthreads();  // the only workgroup barrier: from here on every wave works alone
 
-  const uint32_t ntiles = (cnt + MATCH_THREADS - 1) / MATCH_THREADS;
-  for (uint32_t t = 0; t < ntiles; t++) {
-    const uint32_t r0 = t * MATCH_THREADS;
-    // tile[j] <-> slot r0 - 128 + j
-    for (uint32_t j = tid; j < MATCH_THREADS + MATCH_BACK; j += MATCH_THREADS) {
-      const int32_t r = (int32_t)r0 - (int32_t)MATCH_BACK + (int32_t)j;
-      uint32_t v = 0;
-      if (r >= 0 && (uint32_t)r < cnt) {
-        v = idx[r];
-        if (r > 0) {
-          const uint32_t kq = m_ld32u(S.in, idx[r - 1]) & 0xffffffu;
-          if ((m_ld32u(S.in, v) & 0xffffffu) == kq) v |= MATCH_SAME;
+  const uint32_t R = ((cnt + MATCH_WAVES * 64u - 1) / (MATCH_WAVES * 64u)) * 64u;
+  const uint32_t r0 = min(cnt, wave * R), r1 = min(cnt, r0 + R);
+  if (r0 >= r1) return;
+  uint32_t* ring = S.ring[wave];
+  const uint32_t rb = r0 >= 128u ? r0 - 128u : 0u;  // first slot kept in the ring (multiple of 64)
+
+  uint32_t hi = rb;           // next slot to load into the ring
+  uint32_t next = r0;         // next slot to hand out
+  uint32_t lastkey = 0;       // key of slot hi-1 (valid when hi > 0)
+  if (rb > 0) lastkey = m_ld32u(S.in, idx[rb - 1]) & 0xffffffu;
+  uint32_t pf = (hi + lane < r1) ? idx[hi + lane] : 0u;  // prefetched positions of the chunk at `hi`
+
+  // per-lane job state
+  uint32_t mode = 0;  // 0 idle, 1 probe, 2 compare
+  uint32_t jr = 0, p = 0, rp = 0, curflag = 0, best = 0, bestq = 0, check = 0, pprobe = 0, maxl = 0;
+  uint32_t q = 0;
+
+  for (;;) {
+    const uint32_t nprobe = (uint32_t)__popcll(__ballot(mode == 1u));
+    const uint64_t idle = __ballot(mode == 0u);
+    const uint32_t npend = 64u - nprobe - (uint32_t)__popcll(idle);
+    // ---- housekeeping (ring refill + slot hand-out), batched: only when >= 8 lanes are idle or
+    //      nothing can probe ----
+    if (next < r1 && ((uint32_t)__popcll(idle) >= 8u || nprobe == 0u)) {
+      if (hi < r1 && next + 64u > hi) {
+        // the chunk overwrites slots [hi-384, hi-320): every running job must have r - 128 >= hi - 320
+        const bool too_old = mode != 0u && hi >= 192u && jr < hi - 192u;
+        if (!__ballot(too_old)) {
+          const uint32_t r = hi + lane;
+          const bool valid = r < r1;
+          const uint32_t pos = pf;
+          const uint32_t key = valid ? (m_ld32u(S.in, pos) & 0xffffffu) : 0xFFFFFFFFu;
+          uint32_t pk = (uint32_t)__shfl_up((int)key, 1);
+          if (lane == 0) pk = lastkey;
+          const bool same = valid && r > 0u && key == pk;
+          ring[((hi - rb) % MATCH_RING) + lane] = pos | (same ? MATCH_SAME : 0u);
+          lastkey = (uint32_t)__shfl((int)key, 63);
+          hi += 64u;
+          pf = (hi + lane < r1) ? idx[hi + lane] : 0u;
         }
       }
-      S.tile[j] = v;
+      const uint32_t lim = min(hi, r1);
+      if (idle && next < lim) {
+        const uint32_t k = (uint32_t)__popcll(idle & zes_lanemask_lt());
+        const uint32_t navail = lim - next;
+        if (mode == 0u && k < navail) {
+          jr = next + k;
+          rp = (jr - rb) % MATCH_RING;
+          const uint32_t e = ring[rp];
+          p = e & 0x7fffffffu;
+          curflag = e >> 31;
+          best = 0;
+          bestq = 0;
+          check = 0;
+          maxl = min(ZES_MAXMATCH, avail - p);  // = min(258, n - p)
+          mode = 1u;
+        }
+        next += min((uint32_t)__popcll(idle), navail);
+      }
     }
-    __syncthreads();
-    const uint32_t r = r0 + tid;
-    if (r < cnt) {
-      uint32_t j = tid + MATCH_BACK;
-      uint32_t e = S.tile[j];
-      const uint32_t p = e & 0x7fffffffu;
-      const uint32_t maxl = min(ZES_MAXMATCH, avail - p);  // = min(258, n - p)
-      uint32_t best = 0, bestq = 0, check = 0, pprobe = 0;
-      while (e & MATCH_SAME) {  // the slot before holds the same key
-        if (check >= 128u || (best >= 8u && check >= 16u)) break;  // src/lz77.ts:66-69
-        j--;  // never below tid: at most 128 steps back
-        e = S.tile[j];
-        const uint32_t q = e & 0x7fffffffu;
-        if (p - q > ZES_WINDOW) break;  // src/lz77.ts:49
-        check++;
-        if (best >= maxl) continue;  // nothing can beat it; the candidate still counted
-        // L > best needs bytes 0..best equal: one dword probe at best-3 rejects most candidates
-        if (best >= 3u && m_ld32u(S.in, q + best - 3u) != pprobe) continue;
-        uint32_t L = 3;
-        {
-          uint32_t qo = q + 3u, po = p + 3u;
-          uint32_t qi = qo >> 2, pi = po >> 2;
-          const uint32_t qs = qo & 3u, ps = po & 3u;
-          uint32_t qlo = S.in[mswz(qi)], plo = S.in[mswz(pi)];
-          while (L < maxl) {
-            const uint32_t qhi = S.in[mswz(qi + 1)], phi = S.in[mswz(pi + 1)];
-            const uint32_t x = __builtin_amdgcn_alignbyte(qhi, qlo, qs) ^ __builtin_amdgcn_alignbyte(phi, plo, ps);
-            if (x) {
-              L += (uint32_t)__builtin_ctz(x) >> 3;
-              break;
-            }
-            L += 4;
-            qi++;
-            pi++;
-            qlo = qhi;
-            plo = phi;
-          }
-        }
-        L = min(L, maxl);
-        if (L > best) {
-          best = L;
-          bestq = q;
-          if (L >= ZES_MAXMATCH) break;
-          if (best < maxl) pprobe = m_ld32u(S.in, p + best - 3u);
-        }
+    // ---- compares, batched and run to completion: lanes whose candidate passed the probe wait in
+    //      mode 2 until 8 of them are pending (or nothing else can run) ----
+    if (npend >= 8u || (npend != 0u && nprobe == 0u)) {
+      // straight-line select code on purpose: nested if/else becomes exec-mask bookkeeping on the
+      // scalar unit, which all 16 waves of the CU share (measured: the kernel was SALU-bound)
+      bool cmp = mode == 2u;
+      uint32_t L = 3;
+      const uint32_t qo = q + 3u, po = p + 3u;
+      uint32_t qi = qo >> 2, pi = po >> 2;
+      const uint32_t qs = qo & 3u, ps = po & 3u;
+      uint32_t qlo = S.in[mswz(qi)], plo = S.in[mswz(pi)];
+      while (__ballot(cmp && L < maxl)) {  // 8 bytes per step
+        const uint32_t qm = S.in[mswz(qi + 1)], pm = S.in[mswz(pi + 1)];
+        const uint32_t qhi = S.in[mswz(qi + 2)], phi = S.in[mswz(pi + 2)];
+        const uint32_t x1 = __builtin_amdgcn_alignbyte(qm, qlo, qs) ^ __builtin_amdgcn_alignbyte(pm, plo, ps);
+        const uint32_t x2 = __builtin_amdgcn_alignbyte(qhi, qm, qs) ^ __builtin_amdgcn_alignbyte(phi, pm, ps);
+        const bool live = cmp && L < maxl;
+        const uint32_t f1 = ((uint32_t)__ffs((int)x1) - 1u) >> 3, f2 = ((uint32_t)__ffs((int)x2) - 1u) >> 3;
+        const uint32_t add = x1 ? f1 : (x2 ? 4u + f2 : 8u);
+        L += live ? add : 0u;
+        cmp = cmp && !(live && (x1 | x2));
+        qi += 2;
+        pi += 2;
+        qlo = qhi;
+        plo = phi;
       }
+      {
+        const bool c2 = mode == 2u;
+        const uint32_t Lf = min(L, maxl);
+        const bool better = c2 && Lf > best;
+        best = better ? Lf : best;
+        bestq = better ? q : bestq;
+        if (__ballot(better)) {
+          const uint32_t pw = m_ld32u(S.in, p + (best >= 3u ? best - 3u : 0u));
+          pprobe = (better && best < maxl) ? pw : pprobe;
+        }
+        mode = c2 ? ((better && Lf >= ZES_MAXMATCH) ? 3u : 1u) : mode;
+      }
+    }
+    if (!__ballot(mode != 0u)) {
+      if (next >= r1) break;
+      continue;  // nothing running: hand out more
+    }
+    // ---- probe the next candidate (the slot before, while it holds the same key); select code ----
+    {
+      const bool pr = mode == 1u;
+      const bool stop0 = !curflag || check >= 128u || (best >= 8u && check >= 16u);  // src/lz77.ts:66-69
+      const uint32_t rp2 = rp ? rp - 1u : MATCH_RING - 1u;
+      const uint32_t e = ring[rp2];
+      const uint32_t q2 = e & 0x7fffffffu;
+      const bool far = (p - q2) > ZES_WINDOW;  // src/lz77.ts:49
+      const bool adv = pr && !stop0;
+      const bool cand = adv && !far;
+      // L > best needs bytes 0..best equal: one dword probe at best-3 rejects most candidates
+      const uint32_t pw = m_ld32u(S.in, q2 + (best >= 3u ? best - 3u : 0u));
+      const bool skip = (best >= maxl) || (best >= 3u && pw != pprobe);
+      rp = adv ? rp2 : rp;
+      q = adv ? q2 : q;
+      curflag = adv ? (e >> 31) : curflag;
+      check += cand ? 1u : 0u;
+      mode = (pr && (stop0 || far)) ? 3u : ((cand && !skip) ? 2u : mode);
+    }
+    if (mode == 3u) {
       if (best >= 3u && p + best + 3u <= T)  // nowIndex + len <= endIndex = start + T - 3 (src/lz77.ts:95)
         mo[p] = ZES_TOK_MATCH | ((best - 3u) << 16) | (p - bestq - 1u);
+      mode = 0u;
     }
-    __syncthreads();
   }
 }
 
