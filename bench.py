@@ -176,6 +176,16 @@ def main():
                    "sample": "the full %d MiB %s buffer once: deflate %.2f s + inflate %.2f s, 1 thread of %d host cores"
                              % (n >> 20, kind, t2 - t1, t3 - t2, os.cpu_count() or 0),
                    "deflate_gibs": round(n / (t2 - t1) / gib, 5), "inflate_gibs": round(n / (t3 - t2) / gib, 5)}
+        # measured HBM copy bandwidth on this box (report against vendor peak and a measured copy)
+        torch.cuda.synchronize()
+        tcp = time.perf_counter()
+        for _ in range(20):
+            d_back.copy_(d_in)
+        torch.cuda.synchronize()
+        copy_gbs = 2 * n * 20 / (time.perf_counter() - tcp) / 1e9
+        if roofline:
+            roofline["measured_copy_GBs"] = round(copy_gbs, 1)
+            roofline["frac_of_measured_copy"] = round(roofline["achieved"] / copy_gbs, 5)
         line = {
             "metric": "GiB/s deflate+inflate round trip, 64 MiB buffers (uncompressed bytes / wall), bit-exact vs reference",
             "value": round(value, 4),

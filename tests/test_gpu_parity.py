@@ -146,6 +146,42 @@ def test_deflate_batch_api(z, oracle, gpu):
         assert out_len[i] == len(want) and (host[out_off[i]:out_off[i] + len(want)] == want).all(), specs[i]
 
 
+def test_inflate_batch_api(z, oracle, gpu):
+    import torch
+
+    specs = [("itext", 61, 300000), ("xorshift", 62, 131072), ("lowent4k", 63, 500000), ("itext", 64, 2)]
+    raws = [z.gen(k, s, n) for k, s, n in specs]
+    comps = [oracle.deflate(r) for r in raws]
+    comps.append(np.frombuffer(bytes([0x77, 0x9C, 1, 2, 3]), dtype=np.uint8))  # not deflate
+    comps.append(np.frombuffer(bytes([0x78, 0x9C, 7, 0, 0, 0]), dtype=np.uint8))  # BTYPE 3
+    in_off, out_off, caps = [], [], []
+    pos = opos = 0
+    for i, cdat in enumerate(comps):
+        in_off.append(pos)
+        pos += (len(cdat) + 15) // 16 * 16
+        cap = len(raws[i]) if i < len(raws) else 64
+        caps.append(cap)
+        out_off.append(opos)
+        opos += (cap + 15) // 16 * 16
+    big = np.zeros(pos, dtype=np.uint8)
+    for cdat, o in zip(comps, in_off):
+        big[o:o + len(cdat)] = cdat
+    d_in = dev(big, gpu)
+    d_out = torch.zeros(opos, dtype=torch.uint8, device=gpu)
+    cnt = len(comps)
+    arr = lambda v: (C.c_uint64 * cnt)(*v)
+    out_len = (C.c_uint64 * cnt)()
+    status = (C.c_int32 * cnt)()
+    rc = z.lib().zes_inflate_batch_dev(d_in.data_ptr(), arr(in_off), arr([len(x) for x in comps]), d_out.data_ptr(), arr(out_off),
+                                       arr(caps), out_len, status, cnt, 0)
+    assert rc == 0
+    host = d_out.cpu().numpy()
+    for i, r in enumerate(raws):
+        assert status[i] == 0 and out_len[i] == len(r)
+        assert (host[out_off[i]:out_off[i] + len(r)] == r).all(), specs[i]
+    assert status[len(raws)] == -1 and status[len(raws) + 1] == -2
+
+
 def test_deflate_capacity_is_checked(z, gpu):
     import torch
 
