@@ -279,6 +279,28 @@ def test_inflate_false_positive_block_headers_are_survivable(z, oracle, gpu):
     assert back.numel() == len(a) and (back.cpu().numpy() == a).all()
 
 
+@pytest.mark.parametrize("kind,seed", [("itext", 1093), ("xorshift", 1025)])
+def test_inflate_false_candidate_inside_a_block_stays_block_parallel(z, oracle, gpu, kind, seed):
+    """These two 1 MiB inputs compress to streams whose *bits* contain a spurious, fully valid dynamic
+    block header in the middle of a block (found on the GPU box: 9 candidates for 8 blocks).  The
+    decoder of the enclosing block must extend its end estimate past the false candidate, the chain
+    walk must drop it, and the remapped second pass must put every block in its slot — all in T1."""
+    import torch
+
+    a = z.gen(kind, seed, 1 << 20)
+    comp = dev(oracle.deflate(a), gpu)
+    out = torch.empty(len(a), dtype=torch.uint8, device=gpu)
+    z.set_profiling(True)
+    try:
+        back = z.inflate_tensor(comp, out)
+        launches = {k: n for k, _, n in z.last_kernel_times()}
+    finally:
+        z.set_profiling(False)
+    assert back.numel() == len(a) and (back.cpu().numpy() == a).all()
+    assert z.last_inflate_tier() == 1
+    assert launches.get("k_inf_block_par") == 2  # the remapped pass ran: the false candidate was really there
+
+
 # ---------------------------------------------------------------------------------------------
 # BASELINE.json sizes: 64 MiB, pinned by sha256 of the reference's own output + round trip
 # ---------------------------------------------------------------------------------------------

@@ -220,6 +220,29 @@ def adler32_tensor(t):
     return out.value
 
 
+def _batch_call(fn, d_in, in_off, in_len, d_out, out_off, out_cap, *extra):
+    import torch
+
+    cnt = len(in_off)
+    arr = lambda v: (C.c_uint64 * cnt)(*[int(x) for x in v])
+    out_len = (C.c_uint64 * cnt)()
+    status = (C.c_int32 * cnt)()
+    torch.cuda.current_stream(d_in.device).synchronize()
+    rc = fn(d_in.data_ptr(), arr(in_off), arr(in_len), d_out.data_ptr(), arr(out_off), arr(out_cap), out_len, status, cnt, *extra)
+    if rc:
+        _raise(rc)
+    return list(out_len), list(status)
+
+
+def deflate_batch_tensor(d_in, in_off, in_len, d_out, out_off, out_cap):
+    """Independent buffers inside one arena (offsets 16-byte aligned); returns (out_len[], status[])."""
+    return _batch_call(lib().zes_deflate_batch_dev, d_in, in_off, in_len, d_out, out_off, out_cap)
+
+
+def inflate_batch_tensor(d_in, in_off, in_len, d_out, out_off, out_cap, flags=0):
+    return _batch_call(lib().zes_inflate_batch_dev, d_in, in_off, in_len, d_out, out_off, out_cap, flags)
+
+
 def last_inflate_tier():
     """1 block-parallel, 2 sequential wavefront, 3 exact restatement."""
     return int(lib().zes_last_inflate_tier())

@@ -36,7 +36,7 @@ struct Ctx {
   // deflate scratch
   DevBuf bufs, blks, idx_a, idx_b, hists, codes, hdrs, adler, res;
   // inflate scratch
-  DevBuf surv, cand, cand_sorted, counters, cres, map, resume, dbg;
+  DevBuf surv, cand, cand_sorted, counters, cres, map, resume, dbg, ibufs;
   // staging for the host-pointer API
   DevBuf st_in, st_out;
   void* pinned = nullptr;  // small pinned area for read-backs
@@ -88,7 +88,7 @@ int init_locked(int device) {
   g.cus = prop.multiProcessorCount;
   g.hbm = prop.totalGlobalMem;
   HIPCHK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
-  g.pinned_cap = 1 << 16;
+  g.pinned_cap = 1 << 20;
   HIPCHK(hipHostMalloc(&g.pinned, g.pinned_cap, hipHostMallocDefault));
   g.device = device;
   g.ready = true;
@@ -208,9 +208,11 @@ int deflate_batch_core(const uint8_t* d_in, const uint64_t* in_off, const uint64
   }
   {
     Timed t("k_adler");
-    for (uint32_t b = 0; b < nbuf; b++) {
-      const uint32_t nch = (uint32_t)((hb[b].n + ADLER_CHUNK - 1) / ADLER_CHUNK);
-      hipLaunchKernelGGL(k_adler, dim3(nch), dim3(ADLER_THREADS), 0, g.stream, d_in, hb[b].in_off, hb[b].n, adler + 2 * b);
+    if (nbuf == 1) {  // one buffer: 64 KiB chunks, twice the workgroups
+      const uint32_t nch = (uint32_t)((hb[0].n + ADLER_CHUNK - 1) / ADLER_CHUNK);
+      hipLaunchKernelGGL(k_adler, dim3(nch), dim3(ADLER_THREADS), 0, g.stream, d_in, hb[0].in_off, hb[0].n, adler);
+    } else {
+      hipLaunchKernelGGL(k_adler_blocks, dim3(nblk), dim3(ADLER_THREADS), 0, g.stream, d_in, dbufs, dblks, adler);
     }
   }
   {
@@ -264,157 +266,266 @@ int read_res(ZesRes* out) {
   return ZES_OK;
 }
 
-// One buffer at d_in+in_off (16-byte aligned), result at d_out+out_off (16-byte aligned).
-// Returns the reference-equivalent status; *out_len = bytes produced (or needed on NOSPACE).
-int inflate_one(const uint8_t* d_in, uint64_t in_off, uint64_t c, uint8_t* d_out, uint64_t out_off, uint64_t cap,
-                uint64_t* out_len, uint32_t flags, uint8_t first_byte) {
-  *out_len = 0;
-  g.last_tier = 0;
-  if (c == 0 || (first_byte & 15u) != 8u) return ZES_E_NOT_DEFLATE;  // src/zlib.ts:13-16
+// pinned staging: [0, PIN_UP) read-back area, [PIN_UP, pinned_cap) upload area for the buffer table
+constexpr size_t PIN_UP = 256 << 10;
+constexpr uint32_t INF_GROUP = 4096;  // buffers per T1 group (table and read-backs fit the pinned area)
+
+struct InfJob {
+  uint64_t in_off, c, out_off, cap;
+  uint64_t out_len;
+  int status;  // reference-equivalent status once done
+  int tier;    // 0 = not decoded yet
+};
+
+bool t1_eligible(const InfJob& j, uint32_t flags) { return !(flags & ZES_F_NO_FASTPATH) && j.c >= 64 && j.c < (1ull << 29); }
+
+// T1 over a group of buffers: every launch covers all of them (scan, verify, sort, one decode work
+// item per candidate block, chain check), two host synchronisations for the whole group.  Jobs the
+// tier settles get tier = 1; the others are left for the per-buffer tiers.
+int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const uint32_t* ids, uint32_t nbuf) {
+  int rc;
+  ZesInfBuf* hb = (ZesInfBuf*)((uint8_t*)g.pinned + PIN_UP);
+  uint64_t chunks = 0, cands = 0, total_c = 0;
+  for (uint32_t i = 0; i < nbuf; i++) {
+    const InfJob& j = jobs[ids[i]];
+    ZesInfBuf& b = hb[i];
+    b.in_off = j.in_off;
+    b.c = j.c;
+    b.out_off = j.out_off;
+    b.cap = j.cap;
+    b.first_chunk = (uint32_t)chunks;
+    b.cand_base = (uint32_t)cands;
+    b.cand_cap = (uint32_t)(j.c / 64 + 64);
+    b.work_first = 0;
+    chunks += (j.c + INF_SCAN_BYTES - 1) / INF_SCAN_BYTES;
+    cands += b.cand_cap;
+    total_c += j.c;
+  }
+  if (chunks >= (1ull << 31) || cands >= (1ull << 31)) return ZES_OK;  // leave the jobs to the per-buffer tiers
+  memset(&hb[nbuf], 0, sizeof(ZesInfBuf));
+  hb[nbuf].first_chunk = (uint32_t)chunks;
+  hb[nbuf].cand_base = (uint32_t)cands;
+  const uint32_t surv_cap = (uint32_t)std::min<uint64_t>(total_c / 4 + 1024ull * nbuf, 1ull << 30);
+  const size_t cnt_bytes = 16 + (size_t)nbuf * 4;  // counters[4] followed by cnt[nbuf]
+  if ((rc = ensure(g.ibufs, sizeof(ZesInfBuf) * (nbuf + 1)))) return rc;
+  if ((rc = ensure(g.surv, (size_t)surv_cap * 8))) return rc;
+  if ((rc = ensure(g.cand, (size_t)cands * 4))) return rc;
+  if ((rc = ensure(g.cand_sorted, (size_t)cands * 4))) return rc;
+  if ((rc = ensure(g.cres, sizeof(ZesCandRes) * cands))) return rc;
+  if ((rc = ensure(g.map, (size_t)cands * 4))) return rc;
+  if ((rc = ensure(g.counters, cnt_bytes))) return rc;
+  if ((rc = ensure(g.res, sizeof(ZesRes) * nbuf))) return rc;
+  const ZesInfBuf* dbufs = (const ZesInfBuf*)g.ibufs.p;
+  uint32_t* counters = (uint32_t*)g.counters.p;
+  uint32_t* cnt = counters + 4;
+  HIPCHK(hipMemcpyAsync(g.ibufs.p, hb, sizeof(ZesInfBuf) * (nbuf + 1), hipMemcpyHostToDevice, g.stream));
+  HIPCHK(hipMemsetAsync(g.counters.p, 0, cnt_bytes, g.stream));
+  {
+    Timed t("k_inf_scan");
+    hipLaunchKernelGGL(k_inf_scan, dim3((uint32_t)chunks), dim3(INF_SCAN_THREADS), 0, g.stream, d_in, dbufs, nbuf,
+                       (unsigned long long*)g.surv.p, surv_cap, counters);
+  }
+  {
+    // persistent lanes pulling survivors from a counter: the grid only has to be large enough to fill the chip
+    Timed t("k_inf_verify");
+    const uint32_t nwg = (uint32_t)std::min<uint64_t>(total_c / 2048 + 1, 8192);
+    hipLaunchKernelGGL(k_inf_verify, dim3(nwg), dim3(64), 0, g.stream, d_in, dbufs, (const unsigned long long*)g.surv.p, surv_cap,
+                       counters, (uint32_t*)g.cand.p, cnt);
+  }
+  uint32_t* hc = (uint32_t*)g.pinned;
+  HIPCHK(hipMemcpyAsync(hc, g.counters.p, cnt_bytes, hipMemcpyDeviceToHost, g.stream));
+  HIPCHK(hipStreamSynchronize(g.stream));  // the table upload has completed too: hb may be rewritten
+  const uint32_t nsurv = hc[0];
+  if (nsurv == 0 || nsurv > surv_cap) return ZES_OK;  // nothing that looks like this format (or a poisoned count)
+  std::vector<uint32_t> ncand(nbuf);
+  uint64_t work = 0;
+  for (uint32_t i = 0; i < nbuf; i++) {
+    ncand[i] = hc[4 + i];
+    hb[i].work_first = (uint32_t)work;
+    if (ncand[i] > 0 && ncand[i] <= hb[i].cand_cap) work += ncand[i];
+  }
+  hb[nbuf].work_first = (uint32_t)work;
+  if (work == 0) return ZES_OK;
+  HIPCHK(hipMemcpyAsync(g.ibufs.p, hb, sizeof(ZesInfBuf) * (nbuf + 1), hipMemcpyHostToDevice, g.stream));
+  unsigned long long* dbg = nullptr;
+  if (getenv("ZES_DEBUG_PHASES")) {
+    if ((rc = ensure(g.dbg, (size_t)work * 64))) return rc;
+    HIPCHK(hipMemsetAsync(g.dbg.p, 0, (size_t)work * 64, g.stream));
+    dbg = (unsigned long long*)g.dbg.p;
+  }
+  {
+    Timed t("k_inf_ranksort");
+    hipLaunchKernelGGL(k_inf_ranksort, dim3(nbuf), dim3(256), 0, g.stream, dbufs, (const uint32_t*)cnt, (const uint32_t*)g.cand.p,
+                       (uint32_t*)g.cand_sorted.p);
+  }
+  {
+    Timed t("k_inf_block_par");
+    hipLaunchKernelGGL(k_inf_block_par, dim3((uint32_t)work), dim3(PAR_THREADS), 0, g.stream, d_in, d_out, dbufs, nbuf,
+                       (const uint32_t*)cnt, (const uint32_t*)g.cand_sorted.p, (const uint32_t*)nullptr, (ZesCandRes*)g.cres.p, dbg);
+  }
+  {
+    Timed t("k_inf_chain");
+    hipLaunchKernelGGL(k_inf_chain, dim3(nbuf), dim3(256), 0, g.stream, dbufs, (const uint32_t*)cnt, (const uint32_t*)g.cand_sorted.p,
+                       (const ZesCandRes*)g.cres.p, (const uint32_t*)nullptr, (uint32_t*)g.map.p, (ZesRes*)g.res.p);
+  }
+  ZesRes* hres = (ZesRes*)g.pinned;
+  HIPCHK(hipMemcpyAsync(hres, g.res.p, sizeof(ZesRes) * nbuf, hipMemcpyDeviceToHost, g.stream));
+  HIPCHK(hipStreamSynchronize(g.stream));
+  std::vector<ZesRes> r1(hres, hres + nbuf);
+  if (dbg) {  // average shader-clock cycles per phase of k_inf_block_par
+    std::vector<unsigned long long> h((size_t)work * 8);
+    HIPCHK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
+    double acc[8] = {0};
+    uint32_t cntd = 0;
+    for (uint32_t i = 0; i < work; i++) {
+      if (!h[(size_t)i * 8 + 7]) continue;
+      cntd++;
+      for (int k = 1; k < 8; k++) acc[k] += (double)(h[(size_t)i * 8 + k] - h[(size_t)i * 8 + k - 1]);
+    }
+    fprintf(stderr, "zes phases (avg cycles over %u blocks): hdr %.0f tables %.0f compose %.0f count %.0f emit %.0f resolve %.0f flush %.0f\n",
+            cntd, acc[1] / cntd, acc[2] / cntd, acc[3] / cntd, acc[4] / cntd, acc[5] / cntd, acc[6] / cntd, acc[7] / cntd);
+  }
+  if (getenv("ZES_DEBUG")) {
+    for (uint32_t i = 0, shown_b = 0; i < nbuf && shown_b < 4; i++) {
+      if (r1[i].status == 0) continue;
+      shown_b++;
+      const uint32_t nc = std::min(ncand[i], hb[i].cand_cap);
+      fprintf(stderr, "zes T1: buf %u c=%llu nsurv(all)=%u ncand=%u chain status=%d aux=%u out_len=%llu\n", ids[i],
+              (unsigned long long)hb[i].c, nsurv, ncand[i], r1[i].status, r1[i].aux, (unsigned long long)r1[i].out_len);
+      if (r1[i].status != 1 || nc == 0) continue;
+      std::vector<ZesCandRes> hcr(nc);
+      std::vector<uint32_t> hcand(nc);
+      HIPCHK(hipMemcpy(hcr.data(), (const ZesCandRes*)g.cres.p + hb[i].cand_base, sizeof(ZesCandRes) * nc, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(hcand.data(), (const uint32_t*)g.cand_sorted.p + hb[i].cand_base, 4 * (size_t)nc, hipMemcpyDeviceToHost));
+      int shown = 0;
+      for (uint32_t k = 0; k < nc && shown < 6; k++) {
+        const bool chain_ok = (k + 1 == nc) || ((uint64_t)hcand[k + 1] + 16 == hcr[k].end_bit);
+        if (!(hcr[k].flags & 1u) || !chain_ok || (hcr[k].out_len != ZES_BLK && k + 1 != nc)) {
+          fprintf(stderr, "  cand %u start=%u end_bit=%llu next_start=%u out_len=%u flags=%u\n", k, hcand[k] + 16,
+                  (unsigned long long)hcr[k].end_bit, k + 1 < nc ? hcand[k + 1] + 16 : 0, hcr[k].out_len, hcr[k].flags);
+          shown++;
+        }
+      }
+    }
+  }
+  // buffers whose candidate list holds false positives between the blocks: the chain kernel left
+  // the true chain in map[]; decode those chains again with every block in its own slot
+  uint64_t work2 = 0;
+  for (uint32_t i = 0; i < nbuf; i++) {
+    hb[i].work_first = (uint32_t)work2;
+    if (r1[i].status == 2) work2 += r1[i].aux;
+  }
+  hb[nbuf].work_first = (uint32_t)work2;
+  std::vector<ZesRes> r2;
+  if (work2) {
+    HIPCHK(hipMemcpyAsync(g.ibufs.p, hb, sizeof(ZesInfBuf) * (nbuf + 1), hipMemcpyHostToDevice, g.stream));
+    {
+      Timed t("k_inf_block_par");
+      hipLaunchKernelGGL(k_inf_block_par, dim3((uint32_t)work2), dim3(PAR_THREADS), 0, g.stream, d_in, d_out, dbufs, nbuf,
+                         (const uint32_t*)cnt, (const uint32_t*)g.cand_sorted.p, (const uint32_t*)g.map.p, (ZesCandRes*)g.cres.p,
+                         (unsigned long long*)nullptr);
+    }
+    {
+      Timed t("k_inf_chain");
+      hipLaunchKernelGGL(k_inf_chain, dim3(nbuf), dim3(256), 0, g.stream, dbufs, (const uint32_t*)cnt, (const uint32_t*)g.cand_sorted.p,
+                         (const ZesCandRes*)g.cres.p, (const uint32_t*)g.map.p, (uint32_t*)g.map.p, (ZesRes*)g.res.p);
+    }
+    HIPCHK(hipMemcpyAsync(hres, g.res.p, sizeof(ZesRes) * nbuf, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    r2.assign(hres, hres + nbuf);
+  }
+  for (uint32_t i = 0; i < nbuf; i++) {
+    const ZesRes& r = (r1[i].status == 2 && work2) ? r2[i] : r1[i];
+    if (r.status != 0) continue;
+    InfJob& j = jobs[ids[i]];
+    j.tier = 1;
+    j.out_len = r.out_len;
+    j.status = r.out_len > j.cap ? ZES_E_NOSPACE : ZES_OK;
+  }
+  return ZES_OK;
+}
+
+// T2 then T3 for one buffer the block-parallel tier did not settle.
+int inflate_slow(const uint8_t* d_in, uint8_t* d_out, InfJob& j) {
   int rc;
   if ((rc = ensure(g.res, sizeof(ZesRes)))) return rc;
   if ((rc = ensure(g.resume, 16))) return rc;
   ZesRes hr;
   bool have_resume = false;
-  const bool fast_ok = !(flags & ZES_F_NO_FASTPATH) && c >= 64 && c < (1ull << 29);
-  if (fast_ok) {
-    const uint32_t surv_cap = (uint32_t)(c / 4 + 1024);
-    const uint32_t cand_cap = (uint32_t)(c / 64 + 64);
-    if ((rc = ensure(g.surv, (size_t)surv_cap * 4))) return rc;
-    if ((rc = ensure(g.cand, (size_t)cand_cap * 4))) return rc;
-    if ((rc = ensure(g.cand_sorted, (size_t)cand_cap * 4))) return rc;
-    if ((rc = ensure(g.counters, 16))) return rc;
-    HIPCHK(hipMemsetAsync(g.counters.p, 0, 16, g.stream));
-    {
-      Timed t("k_inf_scan");
-      const uint32_t nwg = (uint32_t)((c + INF_SCAN_BYTES - 1) / INF_SCAN_BYTES);
-      hipLaunchKernelGGL(k_inf_scan, dim3(nwg), dim3(INF_SCAN_THREADS), 0, g.stream, d_in, in_off, c, (uint32_t*)g.surv.p,
-                         surv_cap, (uint32_t*)g.counters.p);
-    }
-    uint32_t* hc = (uint32_t*)g.pinned;
-    HIPCHK(hipMemcpyAsync(hc, g.counters.p, 16, hipMemcpyDeviceToHost, g.stream));
-    HIPCHK(hipStreamSynchronize(g.stream));
-    uint32_t nsurv = hc[0];
-    bool t1 = nsurv > 0 && nsurv <= surv_cap;  // a poisoned count (>= 2^30) fails this test
-    uint32_t ncand = 0;
-    if (t1) {
-      {
-        Timed t("k_inf_verify");
-        hipLaunchKernelGGL(k_inf_verify, dim3(std::min<uint32_t>((nsurv + 63) / 64, 8192u)), dim3(64), 0, g.stream, d_in, in_off, c,
-                           (const uint32_t*)g.surv.p, surv_cap, (uint32_t*)g.counters.p, (uint32_t*)g.cand.p, cand_cap);
-      }
-      HIPCHK(hipMemcpyAsync(hc, g.counters.p, 16, hipMemcpyDeviceToHost, g.stream));
-      HIPCHK(hipStreamSynchronize(g.stream));
-      ncand = hc[1];
-      t1 = ncand > 0 && ncand <= cand_cap;
-    }
-    if (t1) {
-      if ((rc = ensure(g.cres, sizeof(ZesCandRes) * ncand))) return rc;
-      if ((rc = ensure(g.map, (size_t)ncand * 4))) return rc;
-      unsigned long long* dbg = nullptr;
-      if (getenv("ZES_DEBUG_PHASES")) {
-        if ((rc = ensure(g.dbg, (size_t)ncand * 64))) return rc;
-        HIPCHK(hipMemsetAsync(g.dbg.p, 0, (size_t)ncand * 64, g.stream));
-        dbg = (unsigned long long*)g.dbg.p;
-      }
-      {
-        Timed t("k_inf_ranksort");
-        hipLaunchKernelGGL(k_inf_ranksort, dim3((ncand + 255) / 256), dim3(256), 0, g.stream, (const uint32_t*)g.cand.p, ncand,
-                           (uint32_t*)g.cand_sorted.p);
-      }
-      {
-        Timed t("k_inf_block_par");
-        hipLaunchKernelGGL(k_inf_block_par, dim3(ncand), dim3(PAR_THREADS), 0, g.stream, d_in, in_off, c, d_out, out_off, cap,
-                           (const uint32_t*)g.cand_sorted.p, (const uint32_t*)nullptr, ncand, ncand, (ZesCandRes*)g.cres.p, dbg);
-      }
-      {
-        Timed t("k_inf_chain");
-        hipLaunchKernelGGL(k_inf_chain, dim3(1), dim3(256), 0, g.stream, (const uint32_t*)g.cand_sorted.p, ncand,
-                           (const ZesCandRes*)g.cres.p, (const uint32_t*)nullptr, ncand, (uint32_t*)g.map.p, (ZesRes*)g.res.p);
-      }
-      if ((rc = read_res(&hr))) return rc;
-      if (dbg) {  // average shader-clock cycles per phase of k_inf_block_par
-        std::vector<unsigned long long> h((size_t)ncand * 8);
-        HIPCHK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
-        double acc[8] = {0};
-        uint32_t cntd = 0;
-        for (uint32_t i = 0; i < ncand; i++) {
-          if (!h[(size_t)i * 8 + 7]) continue;
-          cntd++;
-          for (int k = 1; k < 8; k++) acc[k] += (double)(h[(size_t)i * 8 + k] - h[(size_t)i * 8 + k - 1]);
-        }
-        fprintf(stderr, "zes phases (avg cycles over %u blocks): hdr %.0f tables %.0f compose %.0f count %.0f emit %.0f resolve %.0f flush %.0f\n",
-                cntd, acc[1] / cntd, acc[2] / cntd, acc[3] / cntd, acc[4] / cntd, acc[5] / cntd, acc[6] / cntd, acc[7] / cntd);
-      }
-      if (getenv("ZES_DEBUG")) {
-        fprintf(stderr, "zes T1: c=%llu nsurv=%u ncand=%u chain status=%d aux=%u out_len=%llu\n", (unsigned long long)c, nsurv, ncand,
-                hr.status, hr.aux, (unsigned long long)hr.out_len);
-        if (hr.status == 1) {
-          std::vector<ZesCandRes> hcr(ncand);
-          std::vector<uint32_t> hcand(ncand);
-          HIPCHK(hipMemcpy(hcr.data(), g.cres.p, sizeof(ZesCandRes) * ncand, hipMemcpyDeviceToHost));
-          HIPCHK(hipMemcpy(hcand.data(), g.cand_sorted.p, 4 * ncand, hipMemcpyDeviceToHost));
-          int shown = 0;
-          for (uint32_t k = 0; k < ncand && shown < 6; k++) {
-            const bool chain_ok = (k + 1 == ncand) || ((uint64_t)hcand[k + 1] + 16 == hcr[k].end_bit);
-            if (!(hcr[k].flags & 1u) || !chain_ok || (hcr[k].out_len != ZES_BLK && k + 1 != ncand)) {
-              fprintf(stderr, "  cand %u start=%u end_bit=%llu next_start=%u out_len=%u flags=%u\n", k, hcand[k] + 16,
-                      (unsigned long long)hcr[k].end_bit, k + 1 < ncand ? hcand[k + 1] + 16 : 0, hcr[k].out_len, hcr[k].flags);
-              shown++;
-            }
-          }
-        }
-      }
-      if (hr.status == 2) {  // false positives shifted the slots: decode the chain again, in order
-        const uint32_t K = hr.aux;
-        {
-          Timed t("k_inf_block_par");
-          hipLaunchKernelGGL(k_inf_block_par, dim3(K), dim3(PAR_THREADS), 0, g.stream, d_in, in_off, c, d_out, out_off, cap,
-                             (const uint32_t*)g.cand_sorted.p, (const uint32_t*)g.map.p, K, ncand, (ZesCandRes*)g.cres.p, dbg);
-        }
-        {
-          Timed t("k_inf_chain");
-          hipLaunchKernelGGL(k_inf_chain, dim3(1), dim3(256), 0, g.stream, (const uint32_t*)g.cand_sorted.p, ncand,
-                             (const ZesCandRes*)g.cres.p, (const uint32_t*)g.map.p, K, (uint32_t*)g.map.p, (ZesRes*)g.res.p);
-        }
-        if ((rc = read_res(&hr))) return rc;
-      }
-      if (hr.status == 0) {
-        collect_times();
-        g.last_tier = 1;
-        *out_len = hr.out_len;
-        return hr.out_len > cap ? ZES_E_NOSPACE : ZES_OK;
-      }
-    }
-  }
   // T2: one wavefront, any valid stream
-  if (c >= 3) {
-    Timed t("k_inf_decode_seq");
-    hipLaunchKernelGGL(k_inf_decode, dim3(1), dim3(64), 0, g.stream, d_in, in_off, c, d_out, out_off, cap,
-                       (const uint32_t*)nullptr, (const uint32_t*)nullptr, 1u, (ZesCandRes*)nullptr, (ZesRes*)g.res.p,
-                       (uint64_t*)g.resume.p, 1);
-  }
-  if (c >= 3) {
+  if (j.c >= 3) {
+    {
+      Timed t("k_inf_decode_seq");
+      hipLaunchKernelGGL(k_inf_decode, dim3(1), dim3(64), 0, g.stream, d_in, j.in_off, j.c, d_out, j.out_off, j.cap,
+                         (const uint32_t*)nullptr, (const uint32_t*)nullptr, 1u, (ZesCandRes*)nullptr, (ZesRes*)g.res.p,
+                         (uint64_t*)g.resume.p, 1);
+    }
     if ((rc = read_res(&hr))) return rc;
     if (hr.status == 0) {
-      collect_times();
-      g.last_tier = 2;
-      *out_len = hr.out_len;
-      return hr.out_len > cap ? ZES_E_NOSPACE : ZES_OK;
+      j.tier = 2;
+      j.out_len = hr.out_len;
+      j.status = hr.out_len > j.cap ? ZES_E_NOSPACE : ZES_OK;
+      return ZES_OK;
     }
     have_resume = true;
   }
   // T3: exact restatement from the failing block on
   {
     Timed t("k_inf_exact");
-    hipLaunchKernelGGL(k_inf_exact, dim3(1), dim3(64), 0, g.stream, d_in, in_off, c, d_out, out_off, cap,
+    hipLaunchKernelGGL(k_inf_exact, dim3(1), dim3(64), 0, g.stream, d_in, j.in_off, j.c, d_out, j.out_off, j.cap,
                        have_resume ? (const uint64_t*)g.resume.p : (const uint64_t*)nullptr, (ZesRes*)g.res.p);
   }
   if ((rc = read_res(&hr))) return rc;
+  j.tier = 3;
+  j.out_len = hr.out_len;
+  j.status = hr.status;
+  return ZES_OK;
+}
+
+// All jobs of a call: T1 in groups, then the stragglers one by one.  jobs[i].status must be ZES_OK
+// for the buffers to decode (anything else is left untouched).  firsts[i] = first byte of buffer i.
+int inflate_jobs(const uint8_t* d_in, uint8_t* d_out, std::vector<InfJob>& jobs, const uint8_t* firsts, uint32_t flags) {
+  g.last_tier = 0;
+  std::vector<uint32_t> ids;
+  std::vector<uint32_t> todo;
+  for (uint32_t i = 0; i < jobs.size(); i++) {
+    InfJob& j = jobs[i];
+    j.out_len = 0;
+    j.tier = 0;
+    if (j.status) continue;
+    if (j.c == 0 || (firsts[i] & 15u) != 8u) {  // src/zlib.ts:13-16
+      j.status = ZES_E_NOT_DEFLATE;
+      j.tier = -1;
+      continue;
+    }
+    todo.push_back(i);
+    if (t1_eligible(j, flags)) ids.push_back(i);
+  }
+  int rc;
+  for (size_t g0 = 0; g0 < ids.size(); g0 += INF_GROUP) {
+    const uint32_t nb = (uint32_t)std::min<size_t>(INF_GROUP, ids.size() - g0);
+    if ((rc = inflate_t1_group(d_in, d_out, jobs.data(), ids.data() + g0, nb))) return rc;
+  }
+  int worst = 0;
+  for (uint32_t i : todo) {
+    if (jobs[i].tier == 0 && (rc = inflate_slow(d_in, d_out, jobs[i]))) return rc;
+    worst = std::max(worst, jobs[i].tier);
+  }
   collect_times();
-  g.last_tier = 3;
-  *out_len = hr.out_len;
-  return hr.status;
+  g.last_tier = worst;
+  return ZES_OK;
+}
+
+// One buffer at d_in+in_off (16-byte aligned), result at d_out+out_off (16-byte aligned).
+// Returns the reference-equivalent status; *out_len = bytes produced (or needed on NOSPACE).
+int inflate_one(const uint8_t* d_in, uint64_t in_off, uint64_t c, uint8_t* d_out, uint64_t out_off, uint64_t cap,
+                uint64_t* out_len, uint32_t flags, uint8_t first_byte) {
+  std::vector<InfJob> jobs(1);
+  jobs[0] = InfJob{in_off, c, out_off, cap, 0, ZES_OK, 0};
+  int rc = inflate_jobs(d_in, d_out, jobs, &first_byte, flags);
+  if (rc) return rc;
+  *out_len = jobs[0].out_len;
+  return jobs[0].status;
 }
 
 }  // namespace
@@ -449,7 +560,7 @@ int zes_shutdown(void) {
   if (!g.ready) return ZES_OK;
   hipStreamSynchronize(g.stream);
   DevBuf* all[] = {&g.bufs, &g.blks, &g.idx_a, &g.idx_b, &g.hists, &g.codes, &g.hdrs, &g.adler, &g.res, &g.surv, &g.cand,
-                   &g.cand_sorted, &g.counters, &g.cres, &g.map, &g.resume, &g.st_in, &g.st_out};
+                   &g.cand_sorted, &g.counters, &g.cres, &g.map, &g.resume, &g.dbg, &g.ibufs, &g.st_in, &g.st_out};
   for (DevBuf* b : all) {
     if (b->p) hipFree(b->p);
     b->p = nullptr;
@@ -544,26 +655,31 @@ int zes_inflate_batch_dev(const uint8_t* d_in, const uint64_t* in_off, const uin
   std::lock_guard<std::mutex> lk(g_mu);
   int rc = init_locked(-1);
   if (rc) return rc;
-  // first bytes of the buffers (CM nibble check, src/zlib.ts:13), read back in groups
+  // first bytes of the buffers (CM nibble check, src/zlib.ts:13), gathered on the device in groups
   std::vector<uint8_t> firsts(count, 0);
-  const uint32_t group = 4096;
-  for (uint32_t g0 = 0; g0 < count; g0 += group) {
-    const uint32_t g1 = std::min(count, g0 + group);
+  if ((rc = ensure(g.ibufs, (size_t)INF_GROUP * 8 + INF_GROUP))) return rc;
+  for (uint32_t g0 = 0; g0 < count; g0 += INF_GROUP) {
+    const uint32_t g1 = std::min(count, g0 + INF_GROUP);
+    uint64_t* ho = (uint64_t*)((uint8_t*)g.pinned + PIN_UP);
     for (uint32_t i = g0; i < g1; i++) {
-      if ((in_off[i] & 15u) || (out_off[i] & 15u)) {
-        status[i] = ZES_E_ARG;
-        continue;
-      }
-      status[i] = ZES_OK;
-      if (in_len[i]) HIPCHK(hipMemcpyAsync((uint8_t*)g.pinned + (i - g0), d_in + in_off[i], 1, hipMemcpyDeviceToHost, g.stream));
+      status[i] = ((in_off[i] & 15u) || (out_off[i] & 15u)) ? ZES_E_ARG : ZES_OK;
+      ho[i - g0] = in_len[i] ? in_off[i] : 0;  // an empty buffer reads byte 0 of the arena; its result is ignored
     }
+    uint8_t* dfirst = (uint8_t*)g.ibufs.p + (size_t)INF_GROUP * 8;
+    HIPCHK(hipMemcpyAsync(g.ibufs.p, ho, (size_t)(g1 - g0) * 8, hipMemcpyHostToDevice, g.stream));
+    hipLaunchKernelGGL(k_inf_first_bytes, dim3((g1 - g0 + 255) / 256), dim3(256), 0, g.stream, d_in, (const uint64_t*)g.ibufs.p, dfirst,
+                       g1 - g0);
+    HIPCHK(hipMemcpyAsync(g.pinned, dfirst, g1 - g0, hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
-    for (uint32_t i = g0; i < g1; i++) firsts[i] = ((const uint8_t*)g.pinned)[i - g0];
+    for (uint32_t i = g0; i < g1; i++) firsts[i] = in_len[i] ? ((const uint8_t*)g.pinned)[i - g0] : 0;
   }
+  std::vector<InfJob> jobs(count);
+  for (uint32_t i = 0; i < count; i++) jobs[i] = InfJob{in_off[i], in_len[i], out_off[i], out_cap[i], 0, status[i], 0};
+  rc = inflate_jobs(d_in, d_out, jobs, firsts.data(), flags);
+  if (rc) return rc;
   for (uint32_t i = 0; i < count; i++) {
-    if (status[i]) continue;
-    status[i] = inflate_one(d_in, in_off[i], in_len[i], d_out, out_off[i], out_cap[i], &out_len[i], flags, firsts[i]);
-    if (status[i] == ZES_E_DEVICE) return ZES_E_DEVICE;
+    status[i] = jobs[i].status;
+    out_len[i] = jobs[i].out_len;
   }
   return ZES_OK;
 }

@@ -868,13 +868,12 @@ __global__ __launch_bounds__(HUFF_THREADS) void k_huff_lengths_only(const uint32
 // k_adler: each workgroup reduces one 64 KiB chunk to (A, B) and adds its closed-form share
 //  to two u64 accumulators per buffer: acc[0] += A, acc[1] += B + A * bytesAfter.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(ADLER_THREADS) void k_adler(const uint8_t* __restrict__ d_in, uint64_t in_off, uint64_t n,
-                                                         unsigned long long* __restrict__ acc) {
+// one chunk [c0, c0 + clen) of an n-byte buffer at p0
+__device__ __forceinline__ static void adler_chunk(const uint8_t* __restrict__ p0, uint64_t n, uint64_t c0, uint64_t clen,
+                                                   unsigned long long* __restrict__ acc) {
   __shared__ uint64_t sa[ADLER_THREADS / 64], sb[ADLER_THREADS / 64];
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const uint64_t c0 = (uint64_t)blockIdx.x * ADLER_CHUNK;
-  const uint64_t clen = min((uint64_t)ADLER_CHUNK, n - c0);
-  const uint8_t* p = d_in + in_off + c0;
+  const uint8_t* p = p0 + c0;
   // B = sum over j of (clen - j) * b[j]  (j = offset inside the chunk)
   uint64_t A = 0, B = 0;
   const bool aligned = (((uintptr_t)p) & 15u) == 0;
@@ -922,6 +921,21 @@ __global__ __launch_bounds__(ADLER_THREADS) void k_adler(const uint8_t* __restri
     atomicAdd(&acc[0], (unsigned long long)ta);
     atomicAdd(&acc[1], (unsigned long long)share);
   }
+}
+
+__global__ __launch_bounds__(ADLER_THREADS) void k_adler(const uint8_t* __restrict__ d_in, uint64_t in_off, uint64_t n,
+                                                         unsigned long long* __restrict__ acc) {
+  const uint64_t c0 = (uint64_t)blockIdx.x * ADLER_CHUNK;
+  adler_chunk(d_in + in_off, n, c0, min((uint64_t)ADLER_CHUNK, n - c0), acc);
+}
+
+// batch form: one workgroup per deflate block of every buffer (a block is one Adler chunk)
+__global__ __launch_bounds__(ADLER_THREADS) void k_adler_blocks(const uint8_t* __restrict__ d_in, const ZesBuf* __restrict__ bufs,
+                                                                const ZesBlk* __restrict__ blks,
+                                                                unsigned long long* __restrict__ acc) {
+  const ZesBlk bk = blks[blockIdx.x];
+  const ZesBuf bf = bufs[bk.buf];
+  adler_chunk(d_in + bf.in_off, bf.n, (uint64_t)bk.blk * ZES_BLK, bk.len, acc + 2 * (size_t)bk.buf);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -42,9 +42,26 @@ __device__ static inline uint64_t g_load64_le(const uint8_t* p, uint64_t byte, u
 // ------------------------------------------------------------------------------------------
 #define SCAN_BYTES INF_SCAN_BYTES  // bytes of the stream per workgroup
 #define SCAN_LIST 4096u             // survivors a workgroup can stage (expected: ~0.2 % of 65536 positions)
-__global__ __launch_bounds__(INF_SCAN_THREADS) void k_inf_scan(const uint8_t* __restrict__ d_in, uint64_t in_off, uint64_t c,
-                                                               uint32_t* __restrict__ surv, uint32_t surv_cap,
-                                                               uint32_t* __restrict__ counters) {
+// first byte of every buffer of a batch (CM nibble check on the host, src/zlib.ts:13)
+__global__ void k_inf_first_bytes(const uint8_t* __restrict__ d_in, const uint64_t* __restrict__ offs, uint8_t* __restrict__ out,
+                                  uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = d_in[offs[i]];
+}
+
+// buffer owning workgroup / work item x: the last entry whose first index is <= x
+__device__ __forceinline__ static uint32_t buf_of_chunk(const ZesInfBuf* bufs, uint32_t nbuf, uint32_t x) {
+  uint32_t lo = 0, hi = nbuf;
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (bufs[mid].first_chunk <= x) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(INF_SCAN_THREADS) void k_inf_scan(const uint8_t* __restrict__ d_in, const ZesInfBuf* __restrict__ bufs,
+                                                               uint32_t nbuf, unsigned long long* __restrict__ surv,
+                                                               uint32_t surv_cap, uint32_t* __restrict__ counters) {
   // Each thread owns 32 consecutive bit positions at a time.  The fixed-field tests (BTYPE = 2,
   // HLIT <= 29, HDIST <= 29) run on all 32 positions at once as shifted word logic; only the
   // surviving positions (about one in five) pay for the Kraft sum of the code-length code.
@@ -53,7 +70,9 @@ __global__ __launch_bounds__(INF_SCAN_THREADS) void k_inf_scan(const uint8_t* __
   __shared__ uint32_t s_cnt, s_base;
   const uint32_t tid = threadIdx.x;
   if (tid == 0) s_cnt = 0;
-  const uint64_t b0 = (uint64_t)blockIdx.x * SCAN_BYTES;
+  const uint32_t bi = buf_of_chunk(bufs, nbuf, blockIdx.x);
+  const uint64_t in_off = bufs[bi].in_off, c = bufs[bi].c;
+  const uint64_t b0 = (uint64_t)(blockIdx.x - bufs[bi].first_chunk) * SCAN_BYTES;
   const uint32_t* in32 = reinterpret_cast<const uint32_t*>(d_in + in_off);
   const uint64_t ndw = (c + 3) >> 2;
   for (uint32_t i = tid; i < SCAN_BYTES / 4 + 8; i += INF_SCAN_THREADS) {
@@ -107,7 +126,7 @@ __global__ __launch_bounds__(INF_SCAN_THREADS) void k_inf_scan(const uint8_t* __
     return;
   }
   for (uint32_t i = tid; i < n; i += INF_SCAN_THREADS)
-    if (gb + i < surv_cap) surv[gb + i] = s_list[i];
+    if (gb + i < surv_cap) surv[gb + i] = ((unsigned long long)bi << 32) | s_list[i];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -115,9 +134,10 @@ __global__ __launch_bounds__(INF_SCAN_THREADS) void k_inf_scan(const uint8_t* __
 // lit/len code is complete with an end-of-block code and the distance code is complete, a
 // single 1-bit code, or absent.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_inf_verify(const uint8_t* __restrict__ d_in, uint64_t in_off, uint64_t c,
-                                                   const uint32_t* __restrict__ surv, uint32_t surv_cap,
-                                                   uint32_t* __restrict__ counters, uint32_t* __restrict__ cand, uint32_t cand_cap) {
+__global__ __launch_bounds__(64) void k_inf_verify(const uint8_t* __restrict__ d_in, const ZesInfBuf* __restrict__ bufs,
+                                                   const unsigned long long* __restrict__ surv, uint32_t surv_cap,
+                                                   uint32_t* __restrict__ counters, uint32_t* __restrict__ cand,
+                                                   uint32_t* __restrict__ cnt) {
   // Persistent lanes: most survivors are rejected within ~15 code-length symbols (their codes
   // over-subscribe at once), a few need all ~300, so a lane that is done pulls the next survivor
   // from a shared counter (counters[2]) instead of idling until the wave's slowest lane ends.
@@ -127,9 +147,10 @@ __global__ __launch_bounds__(64) void k_inf_verify(const uint8_t* __restrict__ d
   const uint32_t lane = threadIdx.x;
   uint32_t ns = counters[0];
   if (ns > surv_cap) ns = surv_cap;
-  const uint32_t* in32 = reinterpret_cast<const uint32_t*>(d_in + in_off);
-  const uint32_t lastdw = (uint32_t)((c - 1) >> 2);
-  const uint64_t limit = c * 8;
+  // per-lane view of the buffer the lane's current survivor lives in
+  const uint32_t* in32 = reinterpret_cast<const uint32_t*>(d_in);
+  uint32_t lastdw = 0, mybuf = 0;
+  uint64_t limit = 0;
   uint8_t* cl = s_cl[lane];
   uint8_t* sorted = s_sorted[lane];
 
@@ -151,7 +172,12 @@ __global__ __launch_bounds__(64) void k_inf_verify(const uint8_t* __restrict__ d
       const uint32_t myi = basei + (uint32_t)__popcll(idle & zes_lanemask_lt());
       if (!have && myi < ns) {
         // ---- set up one survivor: fixed header fields, code-length code ----
-        pos0 = (uint64_t)surv[myi] + 16;
+        const unsigned long long sv = surv[myi];
+        mybuf = (uint32_t)(sv >> 32);
+        in32 = reinterpret_cast<const uint32_t*>(d_in + bufs[mybuf].in_off);
+        lastdw = (uint32_t)((bufs[mybuf].c - 1) >> 2);
+        limit = bufs[mybuf].c * 8;
+        pos0 = (uint64_t)(uint32_t)sv + 16;
         pos = pos0;
         {
           const uint32_t di = (uint32_t)(pos >> 5), sh = (uint32_t)(pos & 31);
@@ -274,25 +300,30 @@ __global__ __launch_bounds__(64) void k_inf_verify(const uint8_t* __restrict__ d
         have = false;
         const bool good = has_eob && kl == 32768u && (kd == 32768u || nd == 0 || (nd == 1 && dmaxlen == 1));
         if (good) {
-          const uint32_t slot = atomicAdd(&counters[1], 1u);  // rare: about one per block of the stream
-          if (slot < cand_cap) cand[slot] = (uint32_t)(pos0 - 16);
+          const uint32_t slot = atomicAdd(&cnt[mybuf], 1u);  // rare: about one per block of the stream
+          if (slot < bufs[mybuf].cand_cap) cand[bufs[mybuf].cand_base + slot] = (uint32_t)(pos0 - 16);
         }
       }
     }
   }
 }
 
-// rank sort of the candidate list (a few hundred to a few thousand entries)
-__global__ void k_inf_ranksort(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ out) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t v = in[i];
-  uint32_t r = 0;
-  for (uint32_t j = 0; j < n; j++) {
-    const uint32_t u = in[j];
-    r += (u < v) || (u == v && j < i);
+// rank sort of each buffer's candidate list (a few to a few thousand entries); one workgroup per buffer
+__global__ __launch_bounds__(256) void k_inf_ranksort(const ZesInfBuf* __restrict__ bufs, const uint32_t* __restrict__ cnt,
+                                                      const uint32_t* __restrict__ cand, uint32_t* __restrict__ out) {
+  const ZesInfBuf bf = bufs[blockIdx.x];
+  const uint32_t n = min(cnt[blockIdx.x], bf.cand_cap);
+  const uint32_t* in = cand + bf.cand_base;
+  uint32_t* o = out + bf.cand_base;
+  for (uint32_t i = threadIdx.x; i < n; i += 256) {
+    const uint32_t v = in[i];
+    uint32_t r = 0;
+    for (uint32_t j = 0; j < n; j++) {
+      const uint32_t u = in[j];
+      r += (u < v) || (u == v && j < i);
+    }
+    o[r] = v;
   }
-  out[r] = v;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -719,13 +750,21 @@ __global__ __launch_bounds__(64) void k_inf_decode(const uint8_t* __restrict__ d
 // and the k-th chain member being the k-th candidate (otherwise a remap pass is requested).
 // res->status: 0 done, 2 remap needed (chain in map_out, length in res->aux), 1 give up (T2).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_inf_chain(const uint32_t* __restrict__ cand, uint32_t ncand, const ZesCandRes* __restrict__ cres,
-                                                   const uint32_t* __restrict__ map_in, uint32_t nwork, uint32_t* __restrict__ map_out,
-                                                   ZesRes* __restrict__ res) {
+__global__ __launch_bounds__(256) void k_inf_chain(const ZesInfBuf* __restrict__ bufs, const uint32_t* __restrict__ cnt,
+                                                   const uint32_t* __restrict__ cand_all, const ZesCandRes* __restrict__ cres_all,
+                                                   const uint32_t* __restrict__ map_in_all, uint32_t* __restrict__ map_out_all,
+                                                   ZesRes* __restrict__ res_all) {
   __shared__ uint32_t s_bad, s_final;
   __shared__ unsigned long long s_total;
   const uint32_t tid = threadIdx.x;
-  if (blockIdx.x != 0) return;
+  const ZesInfBuf bf = bufs[blockIdx.x];
+  const uint32_t ncand = min(cnt[blockIdx.x], bf.cand_cap);
+  const uint32_t nwork = bufs[blockIdx.x + 1].work_first - bf.work_first;
+  const uint32_t* cand = cand_all + bf.cand_base;
+  const ZesCandRes* cres = cres_all + bf.cand_base;
+  const uint32_t* map_in = map_in_all ? map_in_all + bf.cand_base : nullptr;
+  uint32_t* map_out = map_out_all + bf.cand_base;
+  ZesRes* res = res_all + blockIdx.x;
   if (tid == 0) {
     s_bad = 0;
     s_final = 0xFFFFFFFFu;

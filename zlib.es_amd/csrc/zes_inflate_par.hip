@@ -712,56 +712,129 @@ __device__ __forceinline__ static bool par_header(ParSmem& S, const BitSrc& src,
   return true;
 }
 
-__global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __restrict__ d_in, uint64_t in_off, uint64_t c,
-                                                               uint8_t* __restrict__ d_out, uint64_t out_off, uint64_t cap,
-                                                               const uint32_t* __restrict__ cand, const uint32_t* __restrict__ map,
-                                                               uint32_t nwork, uint32_t ncand, ZesCandRes* __restrict__ cres,
+__global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __restrict__ d_in, uint8_t* __restrict__ d_out,
+                                                               const ZesInfBuf* __restrict__ bufs, uint32_t nbuf,
+                                                               const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ cand_all,
+                                                               const uint32_t* __restrict__ map_all, ZesCandRes* __restrict__ cres_all,
                                                                unsigned long long* __restrict__ dbg) {
   __shared__ __align__(16) ParSmem S;
 #define STAMP(i)                                                     \
   do {                                                               \
     if (dbg && threadIdx.x == 0) dbg[(size_t)blockIdx.x * 8 + (i)] = (unsigned long long)clock64(); \
   } while (0)
-  const uint32_t w = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  if (w >= nwork) return;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  // buffer of this work item: the last entry whose first work item is <= blockIdx.x
+  uint32_t bi = 0;
+  {
+    uint32_t lo = 0, hi = nbuf;
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (bufs[mid].work_first <= blockIdx.x) lo = mid; else hi = mid;
+    }
+    bi = lo;
+  }
+  const uint32_t w = blockIdx.x - bufs[bi].work_first;              // work item inside the buffer = output slot
+  const uint32_t nwork = bufs[bi + 1].work_first - bufs[bi].work_first;
+  const uint32_t ncand = min(cnt[bi], bufs[bi].cand_cap);
+  const uint32_t* cand = cand_all + bufs[bi].cand_base;
+  const uint32_t* map = map_all ? map_all + bufs[bi].cand_base : nullptr;
+  ZesCandRes* cres = cres_all + bufs[bi].cand_base;
+  const uint64_t c = bufs[bi].c;
   const uint32_t lastdw = (uint32_t)((c - 1) >> 2);
   const uint32_t limit = (uint32_t)(c * 8);
   const uint32_t ci = map ? map[w] : w;
   const uint32_t start = cand[ci] + 16u;
+  BitSrc src;
+  src.g32 = reinterpret_cast<const uint32_t*>(d_in + bufs[bi].in_off);
+  src.lastdw = lastdw;
+  src.s32 = reinterpret_cast<const uint32_t*>(S.out);
+  src.s_first = start >> 5;
+  uint32_t ds = 0, seglen = 0, base = 0, stop = 0, ecode = 0, tail_code = 0;
+  STAMP(0);
+  // P0 + P1 for one estimate of the block's end.  Returns 0 = go on, 1 = not decodable here.
+  auto stage_and_tables = [&](const uint32_t de_est) __attribute__((always_inline)) -> uint32_t {
+    // ---- P0: stage the block's compressed bytes in LDS (swizzled), header + tables by wave 0 ----
+    {
+      const uint64_t end_bit = min((uint64_t)limit, (uint64_t)de_est + 1280u);  // segment rounding + one token + slack
+      const uint32_t end_dw = min(lastdw, (uint32_t)((end_bit + 63u) >> 5));
+      src.s_count = end_dw - src.s_first + 1u;
+    }
+    // a block whose compressed bytes do not fit the staging area (> 144 KiB for <= 128 KiB of output)
+    // is not reference-made: leave it to T2
+    const bool use_lds = src.s_count <= STAGE_DW;
+    if (tid == 0) S.status = use_lds ? 0u : 1u;
+    if (use_lds) {
+      uint32_t* st = reinterpret_cast<uint32_t*>(S.out);
+      for (uint32_t k = tid; k < src.s_count; k += PAR_THREADS) st[k ^ ((k >> 5) & 31u)] = src.g32[src.s_first + k];
+    }
+    __syncthreads();
+    if (wave == 0 && use_lds) {
+      const bool ok = par_header<true>(S, src, limit, start);
+      if (!ok && lane == 0) S.status = 1;
+    }
+    __syncthreads();
+    if (S.status) return 1u;
+    STAMP(1);
+    ds = S.hdr_end;
+    const uint32_t span = de_est > ds ? de_est - ds : 1u;
+    seglen = max(64u, (span + PAR_THREADS - 1) / PAR_THREADS);
+
+    // ---- P1: transfer tables in registers, then composition by lane broadcasts ----
+    const uint64_t b_me64 = (uint64_t)ds + (uint64_t)tid * seglen;
+    base = (uint32_t)(b_me64 < 0xFFFFFF00ull ? b_me64 : 0xFFFFFF00ull);
+    stop = (uint32_t)((b_me64 + seglen) < 0xFFFFFF00ull ? (b_me64 + seglen) : 0xFFFFFF00ull);
+    SegTab tab = {0, 0, 0, 0, 0, 0, 0, 0};
+    seg_table<true>(S, src, limit, base, stop, tab);
+    STAMP(2);
+    {
+      // composition over the 64 segments of this wave: lane j (< 48) carries input offset j
+      uint32_t cur = lane;
+      for (uint32_t sgm = 0; sgm < 64u; sgm++) {
+        const SegTab ws = tab_bcast(tab, sgm);
+        if (cur < 48u) cur = tab_get(ws, cur);
+      }
+      if (lane < 48u) S.wtab[wave][lane] = (uint8_t)cur;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t e = 0;  // segment 0 starts exactly at the header end
+      for (uint32_t k = 0; k < PAR_WAVES; k++) {
+        S.wentry[k] = (uint8_t)e;
+        if (e < 48u) e = S.wtab[k][e];
+      }
+      S.tail_entry = e;  // state after the last segment: offset past its end, or EOB / fail
+    }
+    __syncthreads();
+    uint32_t e = S.wentry[wave];  // uniform
+    uint32_t mine = C_FAIL;
+    for (uint32_t sgm = 0; sgm < 64u; sgm++) {
+      if (lane == sgm) mine = e;
+      const SegTab ws = tab_bcast(tab, sgm);
+      if (e < 48u) e = tab_get(ws, e);
+    }
+    ecode = mine;
+    tail_code = S.tail_entry;
+    return 0u;
+  };
   // estimate of the block's end: the next candidate on the list (exact on a clean chain)
   uint32_t de_est = limit;
   if (map) {
     if (w + 1 < nwork) de_est = cand[map[w + 1]] + 16u;
-  } else if (ci + 1 < ncand) {
-    de_est = cand[ci + 1] + 16u;
+  } else if (ci + 1u < ncand) {
+    de_est = cand[ci + 1u] + 16u;
   }
-  STAMP(0);
-  // ---- P0: stage the block's compressed bytes in LDS (swizzled), header + tables by wave 0 ----
-  BitSrc src;
-  src.g32 = reinterpret_cast<const uint32_t*>(d_in + in_off);
-  src.lastdw = lastdw;
-  src.s32 = reinterpret_cast<const uint32_t*>(S.out);
-  src.s_first = start >> 5;
-  {
-    const uint64_t end_bit = min((uint64_t)limit, (uint64_t)de_est + 1280u);  // segment rounding + one token + slack
-    const uint32_t end_dw = min(lastdw, (uint32_t)((end_bit + 63u) >> 5));
-    src.s_count = end_dw - src.s_first + 1u;
+  uint32_t bad = stage_and_tables(de_est);
+  // The chain is still alive after the last segment: the estimate was a false candidate inside
+  // this block.  Take the candidate after it as the estimate and decode once more in parallel (a
+  // serial tail from here can cost ~10 ms); a second false candidate in the same block falls to
+  // the serial tail below.  Written as a second straight-line copy, not a loop: a back edge makes
+  // the compiler hoist invariants across the whole decoder and spill.
+  if (!bad && tail_code < 48u && !map && ci + 1u < ncand) {
+    __syncthreads();
+    de_est = ci + 2u < ncand ? cand[ci + 2u] + 16u : limit;
+    bad = stage_and_tables(de_est);
   }
-  // a block whose compressed bytes do not fit the staging area (> 144 KiB for <= 128 KiB of output)
-  // is not reference-made: leave it to T2
-  const bool use_lds = src.s_count <= STAGE_DW;
-  if (tid == 0) S.status = use_lds ? 0u : 1u;
-  if (use_lds) {
-    uint32_t* st = reinterpret_cast<uint32_t*>(S.out);
-    for (uint32_t k = tid; k < src.s_count; k += PAR_THREADS) st[k ^ ((k >> 5) & 31u)] = src.g32[src.s_first + k];
-  }
-  __syncthreads();
-  if (wave == 0 && use_lds) {
-    const bool ok = par_header<true>(S, src, limit, start);
-    if (!ok && lane == 0) S.status = 1;
-  }
-  __syncthreads();
-  if (S.status) {
+  if (bad) {
     if (tid == 0) {
       ZesCandRes r;
       r.end_bit = start;
@@ -771,49 +844,6 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __
     }
     return;
   }
-  STAMP(1);
-  const uint32_t ds = S.hdr_end;
-  const uint32_t span = de_est > ds ? de_est - ds : 1u;
-  const uint32_t seglen = max(64u, (span + PAR_THREADS - 1) / PAR_THREADS);
-
-  // ---- P1: transfer tables in registers, then composition by lane broadcasts ----
-  const uint64_t b_me64 = (uint64_t)ds + (uint64_t)tid * seglen;
-  const uint32_t base = (uint32_t)(b_me64 < 0xFFFFFF00ull ? b_me64 : 0xFFFFFF00ull);
-  const uint32_t stop = (uint32_t)((b_me64 + seglen) < 0xFFFFFF00ull ? (b_me64 + seglen) : 0xFFFFFF00ull);
-  SegTab tab = {0, 0, 0, 0, 0, 0, 0, 0};
-  seg_table<true>(S, src, limit, base, stop, tab);
-  STAMP(2);
-  {
-    // composition over the 64 segments of this wave: lane j (< 48) carries input offset j
-    uint32_t cur = lane;
-    for (uint32_t sgm = 0; sgm < 64u; sgm++) {
-      const SegTab ws = tab_bcast(tab, sgm);
-      if (cur < 48u) cur = tab_get(ws, cur);
-    }
-    if (lane < 48u) S.wtab[wave][lane] = (uint8_t)cur;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    uint32_t e = 0;  // segment 0 starts exactly at the header end
-    for (uint32_t k = 0; k < PAR_WAVES; k++) {
-      S.wentry[k] = (uint8_t)e;
-      if (e < 48u) e = S.wtab[k][e];
-    }
-    S.tail_entry = e;  // state after the last segment: offset past its end, or EOB / fail
-  }
-  __syncthreads();
-  uint32_t ecode;
-  {
-    uint32_t e = S.wentry[wave];  // uniform
-    uint32_t mine = C_FAIL;
-    for (uint32_t sgm = 0; sgm < 64u; sgm++) {
-      if (lane == sgm) mine = e;
-      const SegTab ws = tab_bcast(tab, sgm);
-      if (e < 48u) e = tab_get(ws, e);
-    }
-    ecode = mine;
-  }
-  const uint32_t tail_code = S.tail_entry;
   STAMP(3);
 
   // ---- P2: count pass from the true entries, totals, end bit, output offsets ----
@@ -996,7 +1026,8 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __
     STAMP(6);
     // ---- P5: flush ----
     const uint64_t slot_off = (uint64_t)w * ZES_BLK;
-    uint8_t* dst = d_out + out_off + slot_off;
+    uint8_t* dst = d_out + bufs[bi].out_off + slot_off;
+    const uint64_t cap = bufs[bi].cap;
     const uint64_t room = cap > slot_off ? cap - slot_off : 0;
     const uint32_t nstore = (uint32_t)min((uint64_t)total, room);
     const uint32_t full = nstore >> 4;

@@ -15,6 +15,15 @@
 #define INF_SCAN_THREADS 256
 #define INF_SCAN_BYTES 8192u
 
+// One entry per buffer of an inflate call (T1); entry [nbuf] is a sentinel carrying the totals.
+struct ZesInfBuf {
+  uint64_t in_off, c, out_off, cap;
+  uint32_t first_chunk;  // k_inf_scan: first workgroup of this buffer
+  uint32_t cand_base;    // start of the buffer's region in cand[] / cand_sorted[] / cres[] / map[]
+  uint32_t cand_cap;     // entries in that region
+  uint32_t work_first;   // k_inf_block_par: first work item of this buffer
+};
+
 struct ZesCandRes {
   uint64_t end_bit;   // absolute bit just past the block's EOB
   uint32_t out_len;
@@ -23,14 +32,15 @@ struct ZesCandRes {
 
 #ifdef __HIPCC__
 // inflate direction (zes_inflate.hip)
-__global__ void k_inf_scan(const uint8_t*, uint64_t, uint64_t, uint32_t*, uint32_t, uint32_t*);
-__global__ void k_inf_verify(const uint8_t*, uint64_t, uint64_t, const uint32_t*, uint32_t, uint32_t*, uint32_t*, uint32_t);
-__global__ void k_inf_ranksort(const uint32_t*, uint32_t, uint32_t*);
+__global__ void k_inf_first_bytes(const uint8_t*, const uint64_t*, uint8_t*, uint32_t);
+__global__ void k_inf_scan(const uint8_t*, const ZesInfBuf*, uint32_t, unsigned long long*, uint32_t, uint32_t*);
+__global__ void k_inf_verify(const uint8_t*, const ZesInfBuf*, const unsigned long long*, uint32_t, uint32_t*, uint32_t*, uint32_t*);
+__global__ void k_inf_ranksort(const ZesInfBuf*, const uint32_t*, const uint32_t*, uint32_t*);
 __global__ void k_inf_decode(const uint8_t*, uint64_t, uint64_t, uint8_t*, uint64_t, uint64_t, const uint32_t*, const uint32_t*,
                              uint32_t, ZesCandRes*, ZesRes*, uint64_t*, int);
-__global__ void k_inf_block_par(const uint8_t*, uint64_t, uint64_t, uint8_t*, uint64_t, uint64_t, const uint32_t*, const uint32_t*,
-                                uint32_t, uint32_t, ZesCandRes*, unsigned long long*);
-__global__ void k_inf_chain(const uint32_t*, uint32_t, const ZesCandRes*, const uint32_t*, uint32_t, uint32_t*, ZesRes*);
+__global__ void k_inf_block_par(const uint8_t*, uint8_t*, const ZesInfBuf*, uint32_t, const uint32_t*, const uint32_t*, const uint32_t*,
+                                ZesCandRes*, unsigned long long*);
+__global__ void k_inf_chain(const ZesInfBuf*, const uint32_t*, const uint32_t*, const ZesCandRes*, const uint32_t*, uint32_t*, ZesRes*);
 __global__ void k_inf_exact(const uint8_t*, uint64_t, uint64_t, uint8_t*, uint64_t, uint64_t, const uint64_t*, ZesRes*);
 // deflate direction (zes_deflate.hip)
 __global__ void k_lz_sort(const uint8_t*, const ZesBuf*, const ZesBlk*, uint32_t*, uint32_t*);
@@ -39,6 +49,7 @@ __global__ void k_lz_parse(const uint8_t*, const ZesBuf*, ZesBlk*, const uint32_
 __global__ void k_huff(ZesBlk*, const uint32_t*, uint32_t*, uint32_t*);
 __global__ void k_huff_lengths_only(const uint32_t*, uint32_t, uint32_t, uint8_t*);
 __global__ void k_adler(const uint8_t*, uint64_t, uint64_t, unsigned long long*);
+__global__ void k_adler_blocks(const uint8_t*, const ZesBuf*, const ZesBlk*, unsigned long long*);
 __global__ void k_layout(uint8_t*, const ZesBuf*, ZesBlk*, const unsigned long long*, ZesRes*);
 __global__ void k_emit(uint8_t*, const ZesBuf*, const ZesBlk*, const uint32_t*, const uint32_t*, const uint32_t*);
 __global__ void k_zero_u64(unsigned long long*, uint32_t);
