@@ -68,21 +68,39 @@ __global__ __launch_bounds__(INF_SCAN_THREADS) void k_inf_scan(const uint8_t* __
   __shared__ __align__(16) uint32_t s[SCAN_BYTES / 4 + 8];
   __shared__ uint32_t s_list[SCAN_LIST];
   __shared__ uint32_t s_cnt, s_base;
+  // Kraft contribution of four 3-bit code-length fields at once (units of 2^-7; a field of 0 adds
+  // nothing); saturated at 200 so that an over-full group can never sum back to exactly 128
+  __shared__ uint8_t s_kraft[4096];
   const uint32_t tid = threadIdx.x;
   if (tid == 0) s_cnt = 0;
+  for (uint32_t i = tid; i < 4096; i += INF_SCAN_THREADS) {
+    uint32_t k = 0;
+    for (uint32_t f = 0; f < 4; f++) k += (128u >> ((i >> (3 * f)) & 7u)) & 127u;
+    s_kraft[i] = (uint8_t)min(k, 200u);
+  }
   const uint32_t bi = buf_of_chunk(bufs, nbuf, blockIdx.x);
   const uint64_t in_off = bufs[bi].in_off, c = bufs[bi].c;
   const uint64_t b0 = (uint64_t)(blockIdx.x - bufs[bi].first_chunk) * SCAN_BYTES;
   const uint32_t* in32 = reinterpret_cast<const uint32_t*>(d_in + in_off);
   const uint64_t ndw = (c + 3) >> 2;
-  for (uint32_t i = tid; i < SCAN_BYTES / 4 + 8; i += INF_SCAN_THREADS) {
-    const uint64_t gi = (b0 >> 2) + i;
-    uint32_t v = 0;
-    if (gi < ndw) {
-      v = in32[gi];
-      if (gi == ndw - 1 && (c & 3u)) v &= (1u << (8u * (uint32_t)(c & 3u))) - 1u;  // bytes past the end read as 0
+  {
+    // all loads first (clamped addresses, so they are unconditional and overlap), then the masking
+    constexpr uint32_t NLD = (SCAN_BYTES / 4 + 8 + INF_SCAN_THREADS - 1) / INF_SCAN_THREADS;
+    uint32_t v[NLD];
+#pragma unroll
+    for (uint32_t j = 0; j < NLD; j++) {
+      const uint64_t gi = (b0 >> 2) + tid + j * INF_SCAN_THREADS;
+      v[j] = in32[gi < ndw ? gi : ndw - 1];
     }
-    s[i] = v;
+#pragma unroll
+    for (uint32_t j = 0; j < NLD; j++) {
+      const uint32_t i = tid + j * INF_SCAN_THREADS;
+      const uint64_t gi = (b0 >> 2) + i;
+      uint32_t x = v[j];
+      if (gi == ndw - 1 && (c & 3u)) x &= (1u << (8u * (uint32_t)(c & 3u))) - 1u;  // bytes past the end read as 0
+      if (gi >= ndw) x = 0;
+      if (i < SCAN_BYTES / 4 + 8) s[i] = x;
+    }
   }
   __syncthreads();
   const uint64_t end_bits = c * 8;
@@ -104,12 +122,11 @@ __global__ __launch_bounds__(INF_SCAN_THREADS) void k_inf_scan(const uint8_t* __
       const uint64_t lo = i ? ((w0 >> i) | (w1 << (64u - i))) : w0;
       const uint64_t hi = w1 >> i;
       const uint32_t ncl = (uint32_t)((lo >> 13) & 15u) + 4u;
-      const uint64_t clb = (lo >> 17) | (hi << 47);  // ncl x 3 bits, up to 57
-      uint32_t kraft = 0;
-      for (uint32_t j = 0; j < ncl; j++) {
-        const uint32_t l = (uint32_t)(clb >> (3 * j)) & 7u;
-        kraft += (128u >> l) & 127u;  // l = 0 contributes nothing
-      }
+      const uint64_t clb = ((lo >> 17) | (hi << 47)) & ((1ull << (3u * ncl)) - 1ull);  // ncl x 3 bits, up to 57
+      const uint32_t c_lo = (uint32_t)clb, c_hi = (uint32_t)(clb >> 32);
+      const uint32_t kraft = (uint32_t)s_kraft[c_lo & 4095u] + s_kraft[(c_lo >> 12) & 4095u] +
+                             s_kraft[((c_lo >> 24) | (c_hi << 8)) & 4095u] + s_kraft[(c_hi >> 4) & 4095u] +
+                             s_kraft[(c_hi >> 16) & 4095u];
       if (kraft != 128u) continue;
       const uint32_t slot = atomicAdd(&s_cnt, 1u);  // LDS: one global atomic per workgroup below
       if (slot < SCAN_LIST) s_list[slot] = (uint32_t)(abs_bit - 16);  // relative to bit 16 (fits u32 for c < 512 MiB)
@@ -141,125 +158,124 @@ __global__ __launch_bounds__(64) void k_inf_verify(const uint8_t* __restrict__ d
   // Persistent lanes: most survivors are rejected within ~15 code-length symbols (their codes
   // over-subscribe at once), a few need all ~300, so a lane that is done pulls the next survivor
   // from a shared counter (counters[2]) instead of idling until the wave's slowest lane ends.
-  // Per-thread scratch in LDS: code-length-code lengths and the symbols sorted by (length, symbol).
-  __shared__ uint8_t s_cl[64][20];
-  __shared__ uint8_t s_sorted[64][20];
+  //
+  // Per-lane decode table of the code-length code in LDS: 128 bytes indexed by the next 7 stream
+  // bits read MSB-first (bit-reversed window), entry = symbol | length << 5.  In that index space
+  // a canonical code is a run of consecutive entries, so the table is filled front to back in
+  // (length, symbol) order.  Dword j of lane l lives at [j][l]: conflict-free for equal j.
+  __shared__ uint32_t s_lut[32][64];
   const uint32_t lane = threadIdx.x;
   uint32_t ns = counters[0];
   if (ns > surv_cap) ns = surv_cap;
   // per-lane view of the buffer the lane's current survivor lives in
   const uint32_t* in32 = reinterpret_cast<const uint32_t*>(d_in);
   uint32_t lastdw = 0, mybuf = 0;
-  uint64_t limit = 0;
-  uint8_t* cl = s_cl[lane];
-  uint8_t* sorted = s_sorted[lane];
+  uint32_t limit = 0;
+  uint8_t* lut8 = reinterpret_cast<uint8_t*>(&s_lut[0][0]);
 
   bool have = false, exhausted = false;
-  uint64_t bb = 0, pos = 0, pos0 = 0;
-  uint32_t nb = 0;
-  uint32_t c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, c6 = 0, c7 = 0;
+  // survivors are handed to a wave in chunks (same-address atomics serialise in the L2) sized so
+  // that every wave of the grid still gets about two
+  const uint32_t chunk = min(1024u, max(64u, ((ns / (2u * gridDim.x)) + 63u) & ~63u));
+  uint32_t wnext = 0, wend = 0;
+  uint64_t bb = 0;
+  uint32_t pos = 0, pos0 = 0, nb = 0;
   uint32_t HLIT = 0, total = 0, k = 0, kl = 0, kd = 0, nd = 0, dmaxlen = 0, prev = 0;
   bool has_eob = false;
+  constexpr uint64_t M0 = 0x0049249249249249ull;  // bit 0 of each of the 19 three-bit fields
 
   for (;;) {
     const uint64_t idle = __ballot(!have);
     const uint32_t nidle = (uint32_t)__popcll(idle);
     if (!exhausted && (nidle >= 16u || nidle == 64u)) {
-      uint32_t basei = 0;
-      if (lane == 0) basei = atomicAdd(&counters[2], nidle);
-      basei = (uint32_t)__builtin_amdgcn_readfirstlane((int)basei);
-      if (basei >= ns) exhausted = true;
-      const uint32_t myi = basei + (uint32_t)__popcll(idle & zes_lanemask_lt());
-      if (!have && myi < ns) {
+      if (wnext >= wend) {  // the wave's chunk is used up: one atomic on the shared counter per chunk
+        uint32_t basei = 0;
+        if (lane == 0) basei = atomicAdd(&counters[2], chunk);
+        basei = (uint32_t)__builtin_amdgcn_readfirstlane((int)basei);
+        wnext = basei;
+        wend = min(basei + chunk, ns);
+        if (basei >= ns) {
+          exhausted = true;
+          wend = wnext;
+        }
+      }
+      const uint32_t myi = wnext + (uint32_t)__popcll(idle & zes_lanemask_lt());
+      const uint32_t wlim = wend;
+      wnext = min(wnext + nidle, wend);
+      if (!have && myi < wlim) {
         // ---- set up one survivor: fixed header fields, code-length code ----
         const unsigned long long sv = surv[myi];
         mybuf = (uint32_t)(sv >> 32);
         in32 = reinterpret_cast<const uint32_t*>(d_in + bufs[mybuf].in_off);
         lastdw = (uint32_t)((bufs[mybuf].c - 1) >> 2);
-        limit = bufs[mybuf].c * 8;
-        pos0 = (uint64_t)(uint32_t)sv + 16;
-        pos = pos0;
+        limit = (uint32_t)(bufs[mybuf].c * 8);
+        pos0 = (uint32_t)sv + 16u;
+        uint64_t clb;
         {
-          const uint32_t di = (uint32_t)(pos >> 5), sh = (uint32_t)(pos & 31);
+          // 17 header bits + up to 57 bits of code-length-code lengths, from four dwords
+          const uint32_t di = pos0 >> 5, sh = pos0 & 31u;
+          const uint64_t w0 = (uint64_t)in32[min(di, lastdw)] | ((uint64_t)in32[min(di + 1, lastdw)] << 32);
+          const uint64_t w1 = (uint64_t)in32[min(di + 2, lastdw)] | ((uint64_t)in32[min(di + 3, lastdw)] << 32);
+          const uint64_t lo = sh ? ((w0 >> sh) | (w1 << (64u - sh))) : w0;
+          const uint64_t hi = w1 >> sh;
+          HLIT = ((uint32_t)(lo >> 3) & 31u) + 257u;
+          const uint32_t HDIST = ((uint32_t)(lo >> 8) & 31u) + 1u, HCLEN = ((uint32_t)(lo >> 13) & 15u) + 4u;
+          total = HLIT + HDIST;
+          clb = ((lo >> 17) | (hi << 47)) & ((1ull << (3u * HCLEN)) - 1ull);
+          pos = pos0 + 17u + 3u * HCLEN;
+        }
+        {
+          const uint32_t di = pos >> 5, sh = pos & 31u;
           const uint64_t w = (uint64_t)in32[min(di, lastdw)] | ((uint64_t)in32[min(di + 1, lastdw)] << 32);
           bb = w >> sh;
           nb = 64u - sh;
         }
-        auto refill = [&]() {
-          if (nb <= 32u) {
-            bb |= (uint64_t)in32[min((uint32_t)((pos + nb) >> 5), lastdw)] << nb;
-            nb += 32u;
+        // lengths from transmission order into symbol order (3 bits per symbol)
+        uint64_t sl = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < 19; q++) {
+          constexpr uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};  // src/const.ts:31-35
+          sl |= ((clb >> (3u * q)) & 7ull) << (3u * order[q]);
+        }
+        // fill the table: lengths ascending, symbols ascending (the scan kernel has already checked
+        // that the lengths form a complete code, so exactly 128 entries get written)
+        uint32_t fill = 0;
+#pragma unroll 1
+        for (uint32_t L = 1; L <= 7; L++) {
+          const uint64_t x = sl ^ (M0 * L);
+          uint64_t z = ~(x | (x >> 1) | (x >> 2)) & M0;  // fields equal to L
+          while (z) {
+            const uint32_t t = (uint32_t)__builtin_ctzll(z);
+            z &= z - 1ull;
+            const uint32_t e = ((t * 11u) >> 5) | (L << 5);  // t / 3 for t <= 54
+            const uint32_t n = 128u >> L;
+            if (fill + n <= 128u) {
+              if (n >= 4u) {
+                const uint32_t v = e * 0x01010101u;
+                for (uint32_t j = 0; j < (n >> 2); j++) s_lut[(fill >> 2) + j][lane] = v;
+              } else {
+                for (uint32_t j = 0; j < n; j++) lut8[(((fill + j) >> 2) * 64u + lane) * 4u + ((fill + j) & 3u)] = (uint8_t)e;
+              }
+            }
+            fill += n;
           }
-        };
-        auto take = [&](uint32_t kk) -> uint32_t {
-          const uint32_t v = (uint32_t)bb & ((1u << kk) - 1u);
-          bb >>= kk;
-          nb -= kk;
-          pos += kk;
-          return v;
-        };
-        take(3);
-        HLIT = take(5) + 257;
-        const uint32_t HDIST = take(5) + 1, HCLEN = take(4) + 4;
-        total = HLIT + HDIST;
-        for (int q = 0; q < 19; q++) cl[q] = 0;
-        for (uint32_t q = 0; q < HCLEN; q++) {
-          refill();
-          cl[kClOrder[q]] = (uint8_t)take(3);
-        }
-        c1 = c2 = c3 = c4 = c5 = c6 = c7 = 0;
-        for (int sy = 0; sy < 19; sy++) {
-          const uint32_t l = cl[sy];
-          c1 += l == 1;
-          c2 += l == 2;
-          c3 += l == 3;
-          c4 += l == 4;
-          c5 += l == 5;
-          c6 += l == 6;
-          c7 += l == 7;
-        }
-        uint32_t o1 = 0, o2 = c1, o3 = o2 + c2, o4 = o3 + c3, o5 = o4 + c4, o6 = o5 + c5, o7 = o6 + c6;
-        for (int sy = 0; sy < 19; sy++) {
-          const uint32_t l = cl[sy];
-          if (l == 0) continue;
-          uint32_t slot;
-          if (l == 1) slot = o1++;
-          else if (l == 2) slot = o2++;
-          else if (l == 3) slot = o3++;
-          else if (l == 4) slot = o4++;
-          else if (l == 5) slot = o5++;
-          else if (l == 6) slot = o6++;
-          else slot = o7++;
-          sorted[slot] = (uint8_t)sy;
         }
         k = kl = kd = nd = dmaxlen = prev = 0;
         has_eob = false;
-        have = true;
+        have = fill == 128u;  // anything else cannot come from the scan kernel; dropped, not decoded
       }
     }
     if (!__ballot(have)) break;  // nothing running and nothing left to fetch
     // ---- one code-length symbol for every running lane ----
     if (have) {
-      bool ok = pos + 14 <= limit;
+      bool ok = pos + 14u <= limit;
       if (nb <= 32u) {
-        bb |= (uint64_t)in32[min((uint32_t)((pos + nb) >> 5), lastdw)] << nb;
+        bb |= (uint64_t)in32[min((pos + nb) >> 5, lastdw)] << nb;
         nb += 32u;
       }
-      // bit-at-a-time canonical walk (MSB first), at most 7 steps
-      uint32_t code = 0, first = 0, base = 0, sy = 0xFFu, len = 0;
-#define CL_STEP(L, CNT)                                      \
-      if (sy == 0xFFu) {                                     \
-        code = (code << 1) | (uint32_t)((bb >> ((L)-1)) & 1u); \
-        if (code - first < (CNT)) {                          \
-          sy = sorted[base + code - first];                  \
-          len = (L);                                         \
-        }                                                    \
-        first = (first + (CNT)) << 1;                        \
-        base += (CNT);                                       \
-      }
-      CL_STEP(1, c1) CL_STEP(2, c2) CL_STEP(3, c3) CL_STEP(4, c4) CL_STEP(5, c5) CL_STEP(6, c6) CL_STEP(7, c7)
-#undef CL_STEP
-      ok = ok && sy != 0xFFu;
+      const uint32_t ix = __brev((uint32_t)bb) >> 25;
+      const uint32_t ent = lut8[((ix >> 2) * 64u + lane) * 4u + (ix & 3u)];
+      const uint32_t sy = ent & 31u, len = ent >> 5;
       uint32_t rep = 1, val = sy, xb = 0;
       if (sy == 16) {
         ok = ok && k != 0;
@@ -301,7 +317,7 @@ __global__ __launch_bounds__(64) void k_inf_verify(const uint8_t* __restrict__ d
         const bool good = has_eob && kl == 32768u && (kd == 32768u || nd == 0 || (nd == 1 && dmaxlen == 1));
         if (good) {
           const uint32_t slot = atomicAdd(&cnt[mybuf], 1u);  // rare: about one per block of the stream
-          if (slot < bufs[mybuf].cand_cap) cand[bufs[mybuf].cand_base + slot] = (uint32_t)(pos0 - 16);
+          if (slot < bufs[mybuf].cand_cap) cand[bufs[mybuf].cand_base + slot] = pos0 - 16u;
         }
       }
     }

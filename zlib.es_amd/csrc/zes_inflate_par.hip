@@ -54,6 +54,7 @@ struct ParSmem {
   uint8_t wtab[PAR_WAVES][48];   // composed transfer table of each wave
   uint8_t wentry[PAR_WAVES];      // entry code of each wave's first segment
   uint32_t hdr_end, status, tail_entry, bfinal, tail_bytes, tail_end;
+  uint32_t f8lo, f8n, f8off;  // 8-bit literal codes: first code value, how many (0 = fast path off), index into syms_l
 };
 
 // LUT entry: [3:0] code length (0 = not in the root table), [7:4] extra bits, [9:8] kind
@@ -113,6 +114,19 @@ __device__ __forceinline__ static uint32_t lb_take(LaneBits& b, uint32_t k) {
   b.nb -= k;
   b.pos += k;
   return v;
+}
+
+// Incompressible data gives nearly every literal an 8-bit code.  Canonical codes of one length
+// are a contiguous range of code values and the literals come first in it, so "the next four
+// tokens are 8-bit literals" is four range tests on the bit-reversed dword: no table lookups.
+struct Lit8 {
+  uint32_t lo, n, off;  // n == 0: fast path off for this block
+};
+__device__ __forceinline__ static bool four_lit8(uint32_t w, const Lit8& f) {
+  const uint32_t r = __brev(w);
+  const bool a = ((r >> 24) - f.lo) < f.n, b = (((r >> 16) & 255u) - f.lo) < f.n, c = (((r >> 8) & 255u) - f.lo) < f.n,
+             d = ((r & 255u) - f.lo) < f.n;
+  return a & b & c & d;
 }
 
 // transfer table of a segment in registers: 64 entries x 8 bits.  Eight named words and explicit
@@ -340,7 +354,7 @@ __device__ __forceinline__ static uint32_t win_bits(uint32_t a0, uint32_t a1, ui
 // returns: 0 continue, C_EOB, C_FAIL (as code+1000 so 0 stays "continue")
 template <bool LDS>
 __device__ __forceinline__ static void seg_table(ParSmem& S, const BitSrc& src, uint32_t limit, uint32_t base, uint32_t stop,
-                                                 SegTab& tab) {
+                                                 const Lit8& f8, SegTab& tab) {
   // ---- (a) successors of the 64 window offsets ----
   uint32_t a0, a1, a2, a3, a4;
   {
@@ -389,6 +403,18 @@ __device__ __forceinline__ static void seg_table(ParSmem& S, const BitSrc& src, 
     bool act = have && (base + 64u + L) < limit;
     // (the landing-window check only matters while a trajectory is still inside that window)
     while (__ballot(act)) {
+      if (f8.n) {  // uniform: up to eight 8-bit literals at once, past the landing window and inside the segment
+#pragma unroll
+        for (int rep = 0; rep < 2; rep++) {
+          lb_refill_bf(b, src);
+          const bool fast = act && (b.pos - base) >= 112u && b.pos + 32u <= stop && b.pos + 32u <= limit &&
+                            four_lit8((uint32_t)b.bb, f8);
+          const uint32_t adv = fast ? 32u : 0u;
+          b.bb >>= adv;
+          b.nb -= adv;
+          b.pos += adv;
+        }
+      }
       if (act && b.pos >= stop) {
         code = b.pos - stop;  // 0..47
         act = false;
@@ -491,12 +517,37 @@ __device__ __forceinline__ static void seg_decode(ParSmem& S, const BitSrc& src,
 // wave, lanes drop out by clearing `act`; the rarely needed distance lookup sits behind a ballot.
 template <bool EMIT, bool LDS>
 __device__ __forceinline__ static void seg_run(ParSmem& S, const BitSrc& src, uint32_t limit, uint32_t entry, uint32_t stop, bool live,
-                                               uint32_t out_off, uint32_t& exit_pos, uint32_t& outbytes, uint32_t& flags) {
+                                               const Lit8& f8, uint32_t out_off, uint32_t& exit_pos, uint32_t& outbytes,
+                                               uint32_t& flags) {
   LaneBits b;
   lb_seek<LDS>(b, src, live ? entry : 0u);
   uint32_t ob = 0, fl = 0;
   bool act = live;
   while (__ballot(act)) {
+    if (f8.n) {  // uniform: four 8-bit literals at a time while they stay inside the segment
+#pragma unroll
+      for (int rep = 0; rep < 2; rep++) {
+        lb_refill<LDS>(b, src);
+        const uint32_t w = (uint32_t)b.bb;
+        const bool fast = act && b.pos + 32u <= stop && b.pos + 32u <= limit && ob + 4u <= ZES_BLK && four_lit8(w, f8);
+        if (EMIT && fast) {
+          const uint32_t r = __brev(w);
+          const uint32_t k0 = f8.off - f8.lo;  // wraps when off < lo; the sums below are in range again
+          const uint32_t s0 = S.syms_l[k0 + (r >> 24)], s1 = S.syms_l[k0 + ((r >> 16) & 255u)],
+                         s2 = S.syms_l[k0 + ((r >> 8) & 255u)], s3 = S.syms_l[k0 + (r & 255u)];
+          uint8_t* o = S.out + out_off + ob;
+          o[0] = (uint8_t)s0;
+          o[1] = (uint8_t)s1;
+          o[2] = (uint8_t)s2;
+          o[3] = (uint8_t)s3;
+        }
+        const uint32_t adv = fast ? 32u : 0u;
+        ob += fast ? 4u : 0u;
+        b.bb >>= adv;
+        b.nb -= adv;
+        b.pos += adv;
+      }
+    }
     if (act && b.pos >= stop) act = false;
     lb_refill<LDS>(b, src);
     const uint32_t e = lut_l_entry(S, (uint32_t)b.bb);
@@ -593,6 +644,15 @@ __device__ __forceinline__ static bool par_build(ParSmem& S, uint32_t base, uint
     kraft += c[l] << (15 - l);
   }
   if (kraft > 32768u) return false;
+  if (!is_dist) {
+    uint32_t n8 = 0;  // literals with an 8-bit code
+    for (uint32_t s0 = 0; s0 < 256u; s0 += 64) n8 += (uint32_t)__popcll(__ballot(lens[s0 + lane] == 8u));
+    if (lane == 0) {
+      S.f8lo = fst[8];
+      S.f8n = n8 >= 128u ? n8 : 0u;  // worth testing for only when most literals are 8 bits long
+      S.f8off = ofs[8];
+    }
+  }
   if (lane < 16) {
     uint32_t f = 0, o2 = 0, cc = 0;
 #pragma unroll
@@ -750,6 +810,7 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __
   src.s32 = reinterpret_cast<const uint32_t*>(S.out);
   src.s_first = start >> 5;
   uint32_t ds = 0, seglen = 0, base = 0, stop = 0, ecode = 0, tail_code = 0;
+  Lit8 f8 = {0, 0, 0};
   STAMP(0);
   // P0 + P1 for one estimate of the block's end.  Returns 0 = go on, 1 = not decodable here.
   auto stage_and_tables = [&](const uint32_t de_est) __attribute__((always_inline)) -> uint32_t {
@@ -776,6 +837,9 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __
     if (S.status) return 1u;
     STAMP(1);
     ds = S.hdr_end;
+    f8.lo = S.f8lo;
+    f8.n = S.f8n;
+    f8.off = S.f8off;
     const uint32_t span = de_est > ds ? de_est - ds : 1u;
     seglen = max(64u, (span + PAR_THREADS - 1) / PAR_THREADS);
 
@@ -784,7 +848,7 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __
     base = (uint32_t)(b_me64 < 0xFFFFFF00ull ? b_me64 : 0xFFFFFF00ull);
     stop = (uint32_t)((b_me64 + seglen) < 0xFFFFFF00ull ? (b_me64 + seglen) : 0xFFFFFF00ull);
     SegTab tab = {0, 0, 0, 0, 0, 0, 0, 0};
-    seg_table<true>(S, src, limit, base, stop, tab);
+    seg_table<true>(S, src, limit, base, stop, f8, tab);
     STAMP(2);
     {
       // composition over the 64 segments of this wave: lane j (< 48) carries input offset j
@@ -848,7 +912,7 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __
 
   // ---- P2: count pass from the true entries, totals, end bit, output offsets ----
   uint32_t entry = base + ecode, exit_pos = 0, outbytes = 0, flags = 0;
-  seg_run<false, true>(S, src, limit, entry, stop, ecode < 48u, 0, exit_pos, outbytes, flags);
+  seg_run<false, true>(S, src, limit, entry, stop, ecode < 48u, f8, 0, exit_pos, outbytes, flags);
   if (ecode >= 48u) flags = F_VOID;
   if (tid == 0) {
     S.tail_bytes = 0;
@@ -918,7 +982,7 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __
     uint32_t f2 = 0;
     {
       uint32_t ex2, ob2;
-      seg_run<true, false>(S, src, limit, entry, stop, !(flags & F_VOID) && entry < stop, my_off, ex2, ob2, f2);
+      seg_run<true, false>(S, src, limit, entry, stop, !(flags & F_VOID) && entry < stop, f8, my_off, ex2, ob2, f2);
     }
     if (tid == 0 && tail_code < 48u) {
       uint32_t ex2, ob2, f3 = 0;
