@@ -215,9 +215,33 @@ int deflate_batch_core(const uint8_t* d_in, const uint64_t* in_off, const uint64
       hipLaunchKernelGGL(k_adler_blocks, dim3(nblk), dim3(ADLER_THREADS), 0, g.stream, d_in, dbufs, dblks, adler);
     }
   }
+  const bool sort_dbg = getenv("ZES_DEBUG_PHASES") != nullptr;
+  if (sort_dbg) {
+    int rc2 = ensure(g.dbg, (size_t)nblk * 64);
+    if (rc2) return rc2;
+    HIPCHK(hipMemsetAsync(g.dbg.p, 0, (size_t)nblk * 64, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    zes_sort_set_dbg((unsigned long long*)g.dbg.p);
+  }
   {
     Timed t("k_lz_sort");
     hipLaunchKernelGGL(k_lz_sort, dim3(nblk), dim3(SORT_THREADS), 0, g.stream, d_in, dbufs, dblks, idx_a, idx_b);
+  }
+  if (sort_dbg) {  // average shader-clock cycles per step of k_lz_sort
+    HIPCHK(hipStreamSynchronize(g.stream));
+    zes_sort_set_dbg(nullptr);
+    std::vector<unsigned long long> h((size_t)nblk * 8);
+    HIPCHK(hipMemcpy(h.data(), g.dbg.p, h.size() * 8, hipMemcpyDeviceToHost));
+    double acc[8] = {0};
+    uint32_t n = 0;
+    for (uint32_t i = 0; i < nblk; i++) {
+      if (!h[(size_t)i * 8 + 7]) continue;
+      n++;
+      for (int k = 1; k < 8; k++) acc[k] += (double)(h[(size_t)i * 8 + k] - h[(size_t)i * 8 + k - 1]);
+    }
+    if (n)
+      fprintf(stderr, "zes sort steps (avg cycles over %u blocks): zero %.0f count %.0f flag %.0f compact %.0f stage %.0f pass0+1 %.0f pass2 %.0f\n", n,
+              acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[5] / n, acc[6] / n, acc[7] / n);
   }
   {
     Timed t("k_lz_match");  // match words go to idx_b (free after the sort)
@@ -349,7 +373,7 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
   HIPCHK(hipMemcpyAsync(g.ibufs.p, hb, sizeof(ZesInfBuf) * (nbuf + 1), hipMemcpyHostToDevice, g.stream));
   unsigned long long* dbg = nullptr;
   if (getenv("ZES_DEBUG_PHASES")) {
-    if ((rc = ensure(g.dbg, (size_t)work * 64))) return rc;
+    if ((rc = ensure(g.dbg, (size_t)work * 128))) return rc;
     HIPCHK(hipMemsetAsync(g.dbg.p, 0, (size_t)work * 64, g.stream));
     dbg = (unsigned long long*)g.dbg.p;
   }
@@ -373,17 +397,24 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
   HIPCHK(hipStreamSynchronize(g.stream));
   std::vector<ZesRes> r1(hres, hres + nbuf);
   if (dbg) {  // average shader-clock cycles per phase of k_inf_block_par
-    std::vector<unsigned long long> h((size_t)work * 8);
+    std::vector<unsigned long long> h((size_t)work * 16);
     HIPCHK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
-    double acc[8] = {0};
+    double acc[8] = {0}, t0[3] = {0}, t15[3] = {0};
     uint32_t cntd = 0;
     for (uint32_t i = 0; i < work; i++) {
-      if (!h[(size_t)i * 8 + 7]) continue;
+      const unsigned long long* r = &h[(size_t)i * 16];
+      if (!r[7]) continue;
       cntd++;
-      for (int k = 1; k < 8; k++) acc[k] += (double)(h[(size_t)i * 8 + k] - h[(size_t)i * 8 + k - 1]);
+      for (int k = 1; k < 8; k++) acc[k] += (double)(r[k] - r[k - 1]);
+      for (int k = 0; k < 3; k++) {  // table-phase steps relative to the end of the header phase
+        t0[k] += (double)(r[8 + k] - r[1]);
+        t15[k] += (double)(r[12 + k] - r[1]);
+      }
     }
     fprintf(stderr, "zes phases (avg cycles over %u blocks): hdr %.0f tables %.0f compose %.0f count %.0f emit %.0f resolve %.0f flush %.0f\n",
             cntd, acc[1] / cntd, acc[2] / cntd, acc[3] / cntd, acc[4] / cntd, acc[5] / cntd, acc[6] / cntd, acc[7] / cntd);
+    fprintf(stderr, "zes table steps, cycles since the header: first wave window %.0f landing %.0f fill %.0f | last wave %.0f %.0f %.0f\n",
+            t0[0] / cntd, t0[1] / cntd, t0[2] / cntd, t15[0] / cntd, t15[1] / cntd, t15[2] / cntd);
   }
   if (getenv("ZES_DEBUG")) {
     for (uint32_t i = 0, shown_b = 0; i < nbuf && shown_b < 4; i++) {

@@ -50,15 +50,52 @@ __device__ static inline void stage_block(uint8_t* s, const uint8_t* g, uint32_t
 }
 
 // ------------------------------------------------------------------------------------------
-// k_lz_sort: stable LSD radix sort of positions 0..cnt-1 (cnt = len-2) by the 3 key bytes.
-// LDS: the block itself (128 KiB) + per-wave digit counters.  Result in idx_a[g][0..cnt).
+// k_lz_sort: the positions of a block that can take part in a match, stably LSD-radix-sorted by
+// their 3 key bytes.
+//
+// Filter first: position p matters to the match finder only if another position of the block
+// has the same 3-byte key (as its candidate, or as the position it is a candidate of).  Every
+// key is hashed into 2^19 two-bit counters (128 KiB of LDS: the area that holds the block
+// afterwards); a position whose counter stays at one has a key no other position shares and is
+// dropped.  Hash collisions only keep too many positions, never too few, so the result is exact.
+// Incompressible input keeps about a fifth of its positions; text keeps nearly all (the filter
+// then costs a few percent).
+//
+// Result: idx_a[g][0..ns) sorted positions, ns in idx_a[g][ZES_BLK-1] (cnt <= ZES_BLK-2 leaves
+// that slot free).  LDS: the block itself (128 KiB) + per-wave digit counters.
 // ------------------------------------------------------------------------------------------
+// ZES_DEBUG_PHASES: cycle stamps of workgroup 0..: [g][8], set by the API through zes_sort_set_dbg()
+__device__ unsigned long long* g_sort_dbg = nullptr;
+void zes_sort_set_dbg(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sort_dbg), &p, sizeof p); }
+#define SSTAMP(i)                                                                                        \
+  do {                                                                                                   \
+    if (g_sort_dbg && threadIdx.x == 0) g_sort_dbg[(size_t)blockIdx.x * 8 + (i)] = (unsigned long long)clock64(); \
+  } while (0)
+
+#define SORT_HASH_BITS 19u
+#define SORT_OWN 128u  // consecutive positions owned by one thread in the filter phase
+#define SORT_ROUNDS 4u
+#define SORT_TILE (SORT_THREADS * SORT_ROUNDS)
 struct SortSmem {
-  uint8_t in[ZES_BLK + 16];
-  uint32_t hist[256];     // byte histogram of the whole block
-  uint32_t base[2][256];  // running output offset per digit (double-buffered across tiles)
+  uint8_t in[ZES_BLK + 16];  // filter phase: the counter table; then the staged block
+  uint32_t hist[3][256];     // digit histograms of the kept positions, one per pass
+  uint32_t base[2][256];     // running output offset per digit (double-buffered across tiles)
   uint16_t whist[2][SORT_WAVES][256];
+  uint32_t wsum[SORT_WAVES];
 };
+static_assert((1u << SORT_HASH_BITS) * 2u / 8u <= ZES_BLK, "counter table must fit the block area");
+static_assert(SORT_OWN * SORT_THREADS == ZES_BLK, "one thread per 128 positions");
+
+__device__ __forceinline__ static uint32_t sort_hash(uint32_t key24) { return (key24 * 0x9E3779B1u) >> (32u - SORT_HASH_BITS); }
+
+// 16 bytes at offset `off` of the block (zero past its end); the 16-byte path needs an aligned block
+__device__ __forceinline__ static uint4 sort_ld16(const uint8_t* __restrict__ src, bool aligned, uint32_t off, uint32_t T) {
+  if (aligned && off + 16u <= T) return *reinterpret_cast<const uint4*>(src + off);
+  uint32_t t[4] = {0, 0, 0, 0};
+  for (uint32_t k = 0; k < 16u; k++)
+    if (off + k < T) t[k >> 2] |= (uint32_t)src[off + k] << (8u * (k & 3u));
+  return make_uint4(t[0], t[1], t[2], t[3]);
+}
 
 __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restrict__ d_in, const ZesBuf* __restrict__ bufs,
                                                           const ZesBlk* __restrict__ blks, uint32_t* __restrict__ idx_a,
@@ -72,40 +109,154 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
   uint32_t* A = idx_a + (uint64_t)g * ZES_BLK;
   uint32_t* B = idx_b + (uint64_t)g * ZES_BLK;
   const uint32_t cnt = T >= 3 ? T - 2 : 0;
+  if (cnt == 0) {
+    if (tid == 0) A[ZES_BLK - 1] = 0;
+    return;
+  }
 
+  SSTAMP(0);
+  // ---- filter: which positions share their key with another position? ----
+  uint32_t* tbl = reinterpret_cast<uint32_t*>(S.in);
+  {
+    uint4* t4 = reinterpret_cast<uint4*>(S.in);
+    for (uint32_t i = tid; i < ZES_BLK / 16; i += SORT_THREADS) t4[i] = make_uint4(0, 0, 0, 0);
+    for (uint32_t i = tid; i < 4 * 3 * 256; i += SORT_THREADS) reinterpret_cast<uint32_t*>(&S.whist[0][0][0])[i] = 0;
+  }
+  __syncthreads();
+  SSTAMP(1);
+  const bool aligned = (((uintptr_t)src) & 15u) == 0;
+  const uint32_t p0 = tid * SORT_OWN;  // this thread's positions: [p0, p0 + 128) below cnt
+  // pass 1: count every key (saturating at two: bit 0 = seen, bit 1 = seen again)
+  if (p0 < cnt) {
+    uint4 cur = sort_ld16(src, aligned, p0, T);
+#pragma unroll 1
+    for (uint32_t c = 0; c < SORT_OWN / 16; c++) {
+      const uint4 nxt = sort_ld16(src, aligned, p0 + 16u * (c + 1u), T);
+      const uint32_t w[5] = {cur.x, cur.y, cur.z, cur.w, nxt.x};
+#pragma unroll
+      for (uint32_t k = 0; k < 16; k++) {
+        const uint32_t key = __builtin_amdgcn_alignbyte(w[(k >> 2) + 1], w[k >> 2], k & 3u) & 0xffffffu;
+        const uint32_t h = sort_hash(key);
+        const uint32_t sh = (h & 15u) * 2u;
+        // a plain read first: keys that repeat often (text, periodic data) are saturated early and
+        // would otherwise hammer one word with same-address atomics
+        if (p0 + 16u * c + k < cnt && !((tbl[h >> 4] >> sh) & 2u)) {
+          const uint32_t old = atomicOr(&tbl[h >> 4], 1u << sh);
+          if (((old >> sh) & 3u) == 1u) atomicOr(&tbl[h >> 4], 2u << sh);
+        }
+      }
+      cur = nxt;
+    }
+  }
+  __syncthreads();
+  SSTAMP(2);
+  // pass 2: keep the positions whose counter reached two; 128 flags per thread
+  uint32_t f0 = 0, f1 = 0, f2 = 0, f3 = 0;
+  uint32_t(*sub)[256] = reinterpret_cast<uint32_t(*)[256]>(&S.whist[0][0][0]) + 3u * (lane & 3u);  // 4 x 3 x 256 u32 = 12 KiB
+  if (p0 < cnt) {
+    uint4 cur = sort_ld16(src, aligned, p0, T);
+#pragma unroll 1
+    for (uint32_t c = 0; c < SORT_OWN / 16; c++) {
+      const uint4 nxt = sort_ld16(src, aligned, p0 + 16u * (c + 1u), T);
+      const uint32_t w[5] = {cur.x, cur.y, cur.z, cur.w, nxt.x};
+      uint32_t bits = 0;
+#pragma unroll
+      for (uint32_t k = 0; k < 16; k++) {
+        const uint32_t key = __builtin_amdgcn_alignbyte(w[(k >> 2) + 1], w[k >> 2], k & 3u) & 0xffffffu;
+        const uint32_t h = sort_hash(key);
+        const uint32_t keep = (tbl[h >> 4] >> ((h & 15u) * 2u + 1u)) & 1u;
+        if (keep && p0 + 16u * c + k < cnt) {
+          bits |= 1u << k;
+          // digit histograms of the kept positions (pass 0 sorts by byte 2, pass 2 by byte 0), four
+          // copies picked by lane: neighbouring lanes see the same common bytes at the same time
+          atomicAdd(&sub[0][(key >> 16) & 255u], 1u);
+          atomicAdd(&sub[1][(key >> 8) & 255u], 1u);
+          atomicAdd(&sub[2][key & 255u], 1u);
+        }
+      }
+      const uint32_t v = bits << (16u * (c & 1u));
+      f0 |= (c >> 1) == 0u ? v : 0u;
+      f1 |= (c >> 1) == 1u ? v : 0u;
+      f2 |= (c >> 1) == 2u ? v : 0u;
+      f3 |= (c >> 1) == 3u ? v : 0u;
+      cur = nxt;
+    }
+  }
+  SSTAMP(3);
+  // ordered compaction into B.  Exclusive scan of the per-thread counts; then the flag words and
+  // their running totals go to LDS (the counter table is dead by then) so that the list can be
+  // written with neighbouring lanes on neighbouring positions: coalesced stores.
+  const uint32_t mine = (uint32_t)(__popc(f0) + __popc(f1) + __popc(f2) + __popc(f3));
+  uint32_t incl = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t t = __shfl_up(incl, d);
+    if ((int)lane >= d) incl += t;
+  }
+  if (lane == 63) S.wsum[wave] = incl;
+  __syncthreads();  // also: every thread is done with the counter table
+  uint32_t woff = 0, ns = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < SORT_WAVES; w++) {
+    const uint32_t v = S.wsum[w];
+    woff += w < wave ? v : 0u;
+    ns += v;
+  }
+  uint32_t* fbits = reinterpret_cast<uint32_t*>(S.in);         // [4096] flag words
+  uint32_t* fpre = reinterpret_cast<uint32_t*>(S.in) + 4096;   // [4096] kept positions before each word
+  {
+    uint32_t o = woff + incl - mine;
+    fbits[4 * tid + 0] = f0;
+    fpre[4 * tid + 0] = o;
+    o += (uint32_t)__popc(f0);
+    fbits[4 * tid + 1] = f1;
+    fpre[4 * tid + 1] = o;
+    o += (uint32_t)__popc(f1);
+    fbits[4 * tid + 2] = f2;
+    fpre[4 * tid + 2] = o;
+    o += (uint32_t)__popc(f2);
+    fbits[4 * tid + 3] = f3;
+    fpre[4 * tid + 3] = o;
+  }
+  // fold the histogram copies
+  if (tid < 3 * 256) {
+    const uint32_t* hs = reinterpret_cast<const uint32_t*>(&S.whist[0][0][0]);
+    (&S.hist[0][0])[tid] = hs[tid] + hs[768 + tid] + hs[1536 + tid] + hs[2304 + tid];
+  }
+  __syncthreads();
+  for (uint32_t p = tid; p < cnt; p += SORT_THREADS) {
+    const uint32_t w = fbits[p >> 5];
+    if ((w >> (p & 31u)) & 1u) B[fpre[p >> 5] + (uint32_t)__popc(w & ((1u << (p & 31u)) - 1u))] = p;
+  }
+  __syncthreads();  // flag words read before the block is staged over them
+  SSTAMP(4);
+  if (tid == 0) A[ZES_BLK - 1] = ns;
+  if (ns == 0) return;  // uniform
   stage_block(S.in, src, T, (T + 15u) & ~15u);
-  if (tid < 256) S.hist[tid] = 0;
   __syncthreads();
-  if (cnt == 0) return;
-  for (uint32_t i = tid; i < T; i += SORT_THREADS) atomicAdd(&S.hist[S.in[i]], 1u);
-  __syncthreads();
+  SSTAMP(5);  // staged block and the survivor list in B visible to the whole workgroup
 
   uint32_t bsel = 0;
   for (int pass = 0; pass < 3; pass++) {
     const uint32_t off = 2u - (uint32_t)pass;  // least significant key byte first
     const uint32_t* from = (pass == 1) ? A : B;
     uint32_t* to = (pass == 1) ? B : A;
-    // exclusive scan of this pass's digit histogram: the pass sees positions [off, off+cnt),
-    // i.e. the block histogram minus `off` leading and `2-off` trailing bytes
+    // exclusive scan of this pass's digit histogram
     if (wave == 0) {
       uint32_t c[4];
       uint32_t sum = 0;
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        const uint32_t v = lane * 4 + k;
-        uint32_t h = S.hist[v];
-        for (uint32_t e = 0; e < off; e++) h -= (S.in[e] == v);
-        for (uint32_t e = off + cnt; e < T; e++) h -= (S.in[e] == v);
-        c[k] = h;
-        sum += h;
+        c[k] = S.hist[pass][lane * 4 + k];
+        sum += c[k];
       }
-      uint32_t incl = sum;
+      uint32_t in2 = sum;
 #pragma unroll
       for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = __shfl_up(incl, d);
-        if ((int)lane >= d) incl += t;
+        const uint32_t t = __shfl_up(in2, d);
+        if ((int)lane >= d) in2 += t;
       }
-      uint32_t run = incl - sum;
+      uint32_t run = in2 - sum;
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         S.base[bsel][lane * 4 + k] = run;
@@ -113,47 +264,68 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
       }
     }
     __syncthreads();
-    const uint32_t ntiles = (cnt + SORT_THREADS - 1) / SORT_THREADS;
+    // Tiles of 4096 elements: wave w takes elements [256 w, 256 w + 256) of the tile in four rounds of
+    // 64, so the three workgroup barriers and the cross-wave scan are paid once per 4096 elements.
+    const uint32_t ntiles = (ns + SORT_TILE - 1) / SORT_TILE;
     for (uint32_t t = 0; t < ntiles; t++) {
       uint16_t(*wh)[256] = S.whist[t & 1];
       // zero this tile's per-wave counters: 16 waves x 256 x u16 = 8 KiB = 1024 x 8 B
       reinterpret_cast<uint64_t*>(&wh[0][0])[tid] = 0ull;
-      const uint32_t i = t * SORT_THREADS + tid;
-      const bool valid = i < cnt;
-      uint32_t p = 0, d = 0;
-      if (valid) {
-        p = (pass == 0) ? i : from[i];
-        d = S.in[p + off];
-      }
-      // lanes of this wave holding the same digit (stable rank = lower lanes first)
-      uint64_t m = __ballot(valid);
+      const uint32_t i0 = t * SORT_TILE + wave * (SORT_TILE / SORT_WAVES) + lane;
+      uint32_t p[SORT_ROUNDS], d[SORT_ROUNDS], rk[SORT_ROUNDS];
 #pragma unroll
-      for (int b = 0; b < 8; b++) {
-        const bool bit = (d >> b) & 1u;
-        const uint64_t bal = __ballot(bit);
-        m &= bit ? bal : ~bal;
+      for (uint32_t r = 0; r < SORT_ROUNDS; r++) {
+        const uint32_t i = i0 + 64u * r;
+        p[r] = i < ns ? from[i] : 0u;
       }
-      const uint32_t rank = (uint32_t)__popcll(m & zes_lanemask_lt());
+#pragma unroll
+      for (uint32_t r = 0; r < SORT_ROUNDS; r++) d[r] = (i0 + 64u * r < ns) ? S.in[p[r] + off] : 0u;
       __syncthreads();  // (A) counters zeroed
-      if (valid && rank == 0) wh[wave][d] = (uint16_t)__popcll(m);
+#pragma unroll
+      for (uint32_t r = 0; r < SORT_ROUNDS; r++) {
+        const bool valid = i0 + 64u * r < ns;
+        // lanes of this wave holding the same digit (stable rank = lower lanes first)
+        uint64_t m = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+          const bool bit = (d[r] >> b) & 1u;
+          const uint64_t bal = __ballot(bit);
+          m &= bit ? bal : ~bal;
+        }
+        const uint32_t rank = (uint32_t)__popcll(m & zes_lanemask_lt());
+        // running count of this digit in the wave's earlier rounds: kept in the wave's own counter row
+        // (one writer per digit and round: the group's first lane)
+        uint32_t prev = 0;
+        if (valid && rank == 0) {
+          prev = wh[wave][d[r]];
+          wh[wave][d[r]] = (uint16_t)(prev + (uint32_t)__popcll(m));
+        }
+        prev = (uint32_t)__shfl((int)prev, valid ? (int)__builtin_ctzll(m) : 0);
+        rk[r] = prev + rank;
+      }
       __syncthreads();  // (B) counts visible
       if (tid < 256) {
+        uint32_t c[SORT_WAVES];
+#pragma unroll
+        for (int w = 0; w < SORT_WAVES; w++) c[w] = wh[w][tid];
         uint32_t o = 0;
 #pragma unroll
         for (int w = 0; w < SORT_WAVES; w++) {
-          const uint32_t c = wh[w][tid];
           wh[w][tid] = (uint16_t)o;  // offset of wave w inside this tile's run of digit tid
-          o += c;
+          o += c[w];
         }
         S.base[bsel ^ 1][tid] = S.base[bsel][tid] + o;
       }
       __syncthreads();  // (C) offsets visible
-      if (valid) to[S.base[bsel][d] + wh[wave][d] + rank] = p;
+#pragma unroll
+      for (uint32_t r = 0; r < SORT_ROUNDS; r++)
+        if (i0 + 64u * r < ns) to[S.base[bsel][d[r]] + wh[wave][d[r]] + rk[r]] = p[r];
       bsel ^= 1;
       // no barrier here: the next tile writes whist[other] and base[other-other] only after
       // its own barriers (A)/(B), which every thread reaches after this scatter
     }
     __syncthreads();
+    SSTAMP(6 + (pass == 2));
   }
 }
 
@@ -199,7 +371,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match(const uint8_t* __res
   const uint32_t avail = (uint32_t)(remain < (uint64_t)(T + ZES_MAXMATCH) ? remain : (uint64_t)(T + ZES_MAXMATCH));
   const uint32_t* idx = idx_a + (uint64_t)g * ZES_BLK;
   uint32_t* mo = match_out + (uint64_t)g * ZES_BLK;
-  const uint32_t cnt = T >= 3 ? T - 2 : 0;
+  const uint32_t cnt = idx[ZES_BLK - 1];  // positions k_lz_sort kept (the others share their key with nobody)
 
   // stage block + halo (zero padded), swizzled
   if ((((uintptr_t)src) & 15u) == 0) {

@@ -122,11 +122,16 @@ __device__ __forceinline__ static uint32_t lb_take(LaneBits& b, uint32_t k) {
 struct Lit8 {
   uint32_t lo, n, off;  // n == 0: fast path off for this block
 };
-__device__ __forceinline__ static bool four_lit8(uint32_t w, const Lit8& f) {
+// how many of the next four tokens (0..4, counted from the first) are 8-bit literals
+__device__ __forceinline__ static uint32_t lead_lit8(uint32_t w, const Lit8& f) {
   const uint32_t r = __brev(w);
   const bool a = ((r >> 24) - f.lo) < f.n, b = (((r >> 16) & 255u) - f.lo) < f.n, c = (((r >> 8) & 255u) - f.lo) < f.n,
              d = ((r & 255u) - f.lo) < f.n;
-  return a & b & c & d;
+  uint32_t n = d ? 4u : 3u;
+  n = c ? n : 2u;
+  n = b ? n : 1u;
+  n = a ? n : 0u;
+  return n;
 }
 
 // transfer table of a segment in registers: 64 entries x 8 bits.  Eight named words and explicit
@@ -354,7 +359,13 @@ __device__ __forceinline__ static uint32_t win_bits(uint32_t a0, uint32_t a1, ui
 // returns: 0 continue, C_EOB, C_FAIL (as code+1000 so 0 stays "continue")
 template <bool LDS>
 __device__ __forceinline__ static void seg_table(ParSmem& S, const BitSrc& src, uint32_t limit, uint32_t base, uint32_t stop,
-                                                 const Lit8& f8, SegTab& tab) {
+                                                 const Lit8& f8, SegTab& tab, unsigned long long* dp) {
+  // debug stamps (ZES_DEBUG_PHASES): slots 8..10 by the first wave of the workgroup, 12..14 by the last one
+#define TSTAMP(i)                                                                   \
+  do {                                                                              \
+    if (dp && (threadIdx.x == 0 || threadIdx.x == PAR_THREADS - 64))                \
+      dp[(threadIdx.x ? 12 : 8) + (i)] = (unsigned long long)clock64();             \
+  } while (0)
   // ---- (a) successors of the 64 window offsets ----
   uint32_t a0, a1, a2, a3, a4;
   {
@@ -389,6 +400,7 @@ __device__ __forceinline__ static void seg_table(ParSmem& S, const BitSrc& src, 
     tab_set(nx, o, v);  // v >= 1: a token has at least one bit
   }
 
+  TSTAMP(0);
   // ---- (b) full trajectories from the landing offsets, highest first ----
   SegTab lt = {0, 0, 0, 0, 0, 0, 0, 0};  // exit code of landing offset 64+i at entry i
   uint64_t Ldone = 0;
@@ -403,13 +415,14 @@ __device__ __forceinline__ static void seg_table(ParSmem& S, const BitSrc& src, 
     bool act = have && (base + 64u + L) < limit;
     // (the landing-window check only matters while a trajectory is still inside that window)
     while (__ballot(act)) {
-      if (f8.n) {  // uniform: up to eight 8-bit literals at once, past the landing window and inside the segment
+      // up to twelve 8-bit literals at once, past the landing window and inside the segment (skipped
+      // as a whole while every lane is still in its landing window: most trajectories end there)
+      if (f8.n && __ballot(act && (b.pos - base) >= 112u)) {
 #pragma unroll
-        for (int rep = 0; rep < 2; rep++) {
+        for (int rep = 0; rep < 3; rep++) {
           lb_refill_bf(b, src);
-          const bool fast = act && (b.pos - base) >= 112u && b.pos + 32u <= stop && b.pos + 32u <= limit &&
-                            four_lit8((uint32_t)b.bb, f8);
-          const uint32_t adv = fast ? 32u : 0u;
+          const bool fast = act && (b.pos - base) >= 112u && b.pos + 32u <= stop && b.pos + 32u <= limit;
+          const uint32_t adv = fast ? 8u * lead_lit8((uint32_t)b.bb, f8) : 0u;
           b.bb >>= adv;
           b.nb -= adv;
           b.pos += adv;
@@ -452,6 +465,7 @@ __device__ __forceinline__ static void seg_table(ParSmem& S, const BitSrc& src, 
     }
   }
 
+  TSTAMP(1);
   // ---- (c) table[o] from offset 63 down: successor inside the window -> its entry; landing ->
   //          the landing's code ----
   SegTab t = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -466,6 +480,8 @@ __device__ __forceinline__ static void seg_table(ParSmem& S, const BitSrc& src, 
     tab_set(t, (uint32_t)o, c);
   }
   tab = t;
+  TSTAMP(2);
+#undef TSTAMP
 }
 
 // Decodes tokens from bit `entry` while the token start is below `stop`.
@@ -526,23 +542,27 @@ __device__ __forceinline__ static void seg_run(ParSmem& S, const BitSrc& src, ui
   while (__ballot(act)) {
     if (f8.n) {  // uniform: four 8-bit literals at a time while they stay inside the segment
 #pragma unroll
-      for (int rep = 0; rep < 2; rep++) {
+      for (int rep = 0; rep < 3; rep++) {
         lb_refill<LDS>(b, src);
         const uint32_t w = (uint32_t)b.bb;
-        const bool fast = act && b.pos + 32u <= stop && b.pos + 32u <= limit && ob + 4u <= ZES_BLK && four_lit8(w, f8);
-        if (EMIT && fast) {
+        const bool fast = act && b.pos + 32u <= stop && b.pos + 32u <= limit && ob + 4u <= ZES_BLK;
+        const uint32_t nlit = fast ? lead_lit8(w, f8) : 0u;
+        if (EMIT && nlit) {
+          // symbols of all four candidates are looked up (clamped into the table), the stores are per byte:
+          // a byte past the literals belongs to a later token, possibly of the neighbouring lane
           const uint32_t r = __brev(w);
           const uint32_t k0 = f8.off - f8.lo;  // wraps when off < lo; the sums below are in range again
-          const uint32_t s0 = S.syms_l[k0 + (r >> 24)], s1 = S.syms_l[k0 + ((r >> 16) & 255u)],
-                         s2 = S.syms_l[k0 + ((r >> 8) & 255u)], s3 = S.syms_l[k0 + (r & 255u)];
+          const uint32_t i0 = k0 + (r >> 24), i1 = k0 + ((r >> 16) & 255u), i2 = k0 + ((r >> 8) & 255u), i3 = k0 + (r & 255u);
+          const uint32_t s0 = S.syms_l[i0], s1 = S.syms_l[nlit > 1u ? i1 : i0], s2 = S.syms_l[nlit > 2u ? i2 : i0],
+                         s3 = S.syms_l[nlit > 3u ? i3 : i0];
           uint8_t* o = S.out + out_off + ob;
           o[0] = (uint8_t)s0;
-          o[1] = (uint8_t)s1;
-          o[2] = (uint8_t)s2;
-          o[3] = (uint8_t)s3;
+          if (nlit > 1u) o[1] = (uint8_t)s1;
+          if (nlit > 2u) o[2] = (uint8_t)s2;
+          if (nlit > 3u) o[3] = (uint8_t)s3;
         }
-        const uint32_t adv = fast ? 32u : 0u;
-        ob += fast ? 4u : 0u;
+        const uint32_t adv = 8u * nlit;
+        ob += nlit;
         b.bb >>= adv;
         b.nb -= adv;
         b.pos += adv;
@@ -780,7 +800,7 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __
   __shared__ __align__(16) ParSmem S;
 #define STAMP(i)                                                     \
   do {                                                               \
-    if (dbg && threadIdx.x == 0) dbg[(size_t)blockIdx.x * 8 + (i)] = (unsigned long long)clock64(); \
+    if (dbg && threadIdx.x == 0) dbg[(size_t)blockIdx.x * 16 + (i)] = (unsigned long long)clock64(); \
   } while (0)
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   // buffer of this work item: the last entry whose first work item is <= blockIdx.x
@@ -848,7 +868,7 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __
     base = (uint32_t)(b_me64 < 0xFFFFFF00ull ? b_me64 : 0xFFFFFF00ull);
     stop = (uint32_t)((b_me64 + seglen) < 0xFFFFFF00ull ? (b_me64 + seglen) : 0xFFFFFF00ull);
     SegTab tab = {0, 0, 0, 0, 0, 0, 0, 0};
-    seg_table<true>(S, src, limit, base, stop, f8, tab);
+    seg_table<true>(S, src, limit, base, stop, f8, tab, dbg ? dbg + (size_t)blockIdx.x * 16 : nullptr);
     STAMP(2);
     {
       // composition over the 64 segments of this wave: lane j (< 48) carries input offset j
