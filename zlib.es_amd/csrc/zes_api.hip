@@ -247,9 +247,30 @@ int deflate_batch_core(const uint8_t* d_in, const uint64_t* in_off, const uint64
     Timed t("k_lz_match");  // match words go to idx_b (free after the sort)
     hipLaunchKernelGGL(k_lz_match, dim3(nblk), dim3(MATCH_THREADS), 0, g.stream, d_in, dbufs, dblks, idx_a, idx_b);
   }
+  if (sort_dbg) {
+    HIPCHK(hipMemsetAsync(g.dbg.p, 0, (size_t)nblk * 64, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    zes_parse_set_dbg((unsigned long long*)g.dbg.p);
+  }
   {
     Timed t("k_lz_parse");  // tokens go to idx_a (free after the match pass)
     hipLaunchKernelGGL(k_lz_parse, dim3(nblk), dim3(PARSE_THREADS), 0, g.stream, d_in, dbufs, dblks, idx_b, idx_a, (uint32_t*)g.hists.p);
+  }
+  if (sort_dbg) {  // average shader-clock cycles per phase of k_lz_parse
+    HIPCHK(hipStreamSynchronize(g.stream));
+    zes_parse_set_dbg(nullptr);
+    std::vector<unsigned long long> h((size_t)nblk * 8);
+    HIPCHK(hipMemcpy(h.data(), g.dbg.p, h.size() * 8, hipMemcpyDeviceToHost));
+    double acc[8] = {0};
+    uint32_t n = 0;
+    for (uint32_t i = 0; i < nblk; i++) {
+      if (!h[(size_t)i * 8 + 7]) continue;
+      n++;
+      for (int k = 1; k < 8; k++) acc[k] += (double)(h[(size_t)i * 8 + k] - h[(size_t)i * 8 + k - 1]);
+    }
+    if (n)
+      fprintf(stderr, "zes parse steps (avg cycles over %u blocks): A %.0f B %.0f C %.0f D1 %.0f D2 %.0f D3 %.0f out %.0f\n", n,
+              acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[5] / n, acc[6] / n, acc[7] / n);
   }
   {
     Timed t("k_huff");

@@ -76,6 +76,7 @@ void zes_sort_set_dbg(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBO
 #define SORT_OWN 128u  // consecutive positions owned by one thread in the filter phase
 #define SORT_ROUNDS 4u
 #define SORT_TILE (SORT_THREADS * SORT_ROUNDS)
+static_assert(SORT_ROUNDS == 4u, "the arrival wait names four registers");
 struct SortSmem {
   uint8_t in[ZES_BLK + 16];  // filter phase: the counter table; then the staged block
   uint32_t hist[3][256];     // digit histograms of the kept positions, one per pass
@@ -267,17 +268,22 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
     // Tiles of 4096 elements: wave w takes elements [256 w, 256 w + 256) of the tile in four rounds of
     // 64, so the three workgroup barriers and the cross-wave scan are paid once per 4096 elements.
     const uint32_t ntiles = (ns + SORT_TILE - 1) / SORT_TILE;
+    uint32_t pn[SORT_ROUNDS];
+#pragma unroll
+    for (uint32_t r = 0; r < SORT_ROUNDS; r++) pn[r] = from[min(wave * (SORT_TILE / SORT_WAVES) + lane + 64u * r, ns - 1u)];
     for (uint32_t t = 0; t < ntiles; t++) {
       uint16_t(*wh)[256] = S.whist[t & 1];
       // zero this tile's per-wave counters: 16 waves x 256 x u16 = 8 KiB = 1024 x 8 B
       reinterpret_cast<uint64_t*>(&wh[0][0])[tid] = 0ull;
       const uint32_t i0 = t * SORT_TILE + wave * (SORT_TILE / SORT_WAVES) + lane;
       uint32_t p[SORT_ROUNDS], d[SORT_ROUNDS], rk[SORT_ROUNDS];
+      // The tile's indices were requested before the previous tile's scatter (unconditional loads with
+      // clamped addresses).  One wait for all four here: a load or store under a branch makes the
+      // compiler wait for every outstanding memory operation, the scatter stores included, and those
+      // would then run one at a time.
 #pragma unroll
-      for (uint32_t r = 0; r < SORT_ROUNDS; r++) {
-        const uint32_t i = i0 + 64u * r;
-        p[r] = i < ns ? from[i] : 0u;
-      }
+      for (uint32_t r = 0; r < SORT_ROUNDS; r++) p[r] = pn[r];
+      asm volatile("" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]));
 #pragma unroll
       for (uint32_t r = 0; r < SORT_ROUNDS; r++) d[r] = (i0 + 64u * r < ns) ? S.in[p[r] + off] : 0u;
       __syncthreads();  // (A) counters zeroed
@@ -285,13 +291,18 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
       for (uint32_t r = 0; r < SORT_ROUNDS; r++) {
         const bool valid = i0 + 64u * r < ns;
         // lanes of this wave holding the same digit (stable rank = lower lanes first)
-        uint64_t m = __ballot(valid);
+        // per bit: lanes whose bit differs from mine drop out of the mask; written on 32-bit halves with
+        // the bit spread to a full word so that each half is one three-input logic op
+        const uint64_t m0 = __ballot(valid);
+        uint32_t mlo = (uint32_t)m0, mhi = (uint32_t)(m0 >> 32);
 #pragma unroll
         for (int b = 0; b < 8; b++) {
-          const bool bit = (d[r] >> b) & 1u;
-          const uint64_t bal = __ballot(bit);
-          m &= bit ? bal : ~bal;
+          const uint32_t nb = (uint32_t)((int32_t)(d[r] << (31 - b)) >> 31);  // 0 or ~0
+          const uint64_t bal = __ballot(nb != 0u);
+          mlo &= ~((uint32_t)bal ^ nb);
+          mhi &= ~((uint32_t)(bal >> 32) ^ nb);
         }
+        const uint64_t m = (uint64_t)mlo | ((uint64_t)mhi << 32);
         const uint32_t rank = (uint32_t)__popcll(m & zes_lanemask_lt());
         // running count of this digit in the wave's earlier rounds: kept in the wave's own counter row
         // (one writer per digit and round: the group's first lane)
@@ -318,8 +329,14 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
       }
       __syncthreads();  // (C) offsets visible
 #pragma unroll
-      for (uint32_t r = 0; r < SORT_ROUNDS; r++)
-        if (i0 + 64u * r < ns) to[S.base[bsel][d[r]] + wh[wave][d[r]] + rk[r]] = p[r];
+      for (uint32_t r = 0; r < SORT_ROUNDS; r++) pn[r] = from[min(i0 + SORT_TILE + 64u * r, ns - 1u)];  // next tile
+      // unconditional stores for the same reason (slot ZES_BLK-2 of either array is never used:
+      // ns <= ZES_BLK-2, and ns itself lives in slot ZES_BLK-1)
+#pragma unroll
+      for (uint32_t r = 0; r < SORT_ROUNDS; r++) {
+        const uint32_t dst = S.base[bsel][d[r]] + wh[wave][d[r]] + rk[r];
+        to[(i0 + 64u * r < ns) ? dst : ZES_BLK - 2u] = p[r];
+      }
       bsel ^= 1;
       // no barrier here: the next tile writes whist[other] and base[other-other] only after
       // its own barriers (A)/(B), which every thread reaches after this scatter
@@ -553,9 +570,16 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match(const uint8_t* __res
 //   D   per touched chunk, the visited lanes are found by binary hop decomposition (again
 //       doubling), counted, scanned, and the tokens and both histograms written in parallel.
 // ------------------------------------------------------------------------------------------
+__device__ unsigned long long* g_parse_dbg = nullptr;  // ZES_DEBUG_PHASES: cycle stamps [g][8]
+void zes_parse_set_dbg(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_parse_dbg), &p, sizeof p); }
+#define PSTAMP(i)                                                                                          \
+  do {                                                                                                     \
+    if (g_parse_dbg && threadIdx.x == 0) g_parse_dbg[(size_t)blockIdx.x * 8 + (i)] = (unsigned long long)clock64(); \
+  } while (0)
 #define PARSE_CHUNKS (ZES_BLK / 64)        // 2048
 #define PARSE_REGION 128                    // chunks per wave
 #define PARSE_NOENTRY 0xFFu
+#define PARSE_BATCH 8u                      // chunks whose global loads are issued together
 struct ParseSmem {
   union {
     uint8_t xmap[PARSE_CHUNKS][64];         // phase A-C
@@ -566,11 +590,18 @@ struct ParseSmem {
   } u;
   uint16_t rtab[PARSE_THREADS / 64][5 * 64];  // region transfer tables (entry offsets 0..319)
   uint8_t centry[PARSE_CHUNKS];
+  uint8_t cplain[PARSE_CHUNKS];              // 1: the chunk holds no match word at all (every hop is +1)
   uint32_t rentry[PARSE_THREADS / 64 + 1];
   uint32_t wsum[PARSE_THREADS / 64];
   uint32_t lh[288];
   uint32_t dh[32];
 };
+
+// All eight loaded words are needed "now": one wait for the whole batch here, instead of a full
+// vmcnt(0) wait (which also waits for the stores issued in between) at every later use under a branch.
+#define PARSE_ARRIVE8(a)                                                                                              \
+  asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]))
+static_assert(PARSE_BATCH == 8u, "PARSE_ARRIVE8 names eight registers");
 
 // exact landing offset past the chunk for entry lane e (slow path behind xmap code 255)
 __device__ static uint32_t parse_follow(const uint32_t* mi, uint32_t T, uint32_t chunk, uint32_t e) {
@@ -600,22 +631,43 @@ __global__ __launch_bounds__(PARSE_THREADS) void k_lz_parse(const uint8_t* __res
   if (tid < 32) S.dh[tid] = 0;
   for (uint32_t i = tid; i < PARSE_CHUNKS; i += PARSE_THREADS) S.centry[i] = PARSE_NOENTRY;
 
+  PSTAMP(0);
   // ---- A: exit map of every chunk ----
   const uint32_t c_lo = wave * PARSE_REGION, c_hi = min(nchunks, c_lo + PARSE_REGION);
-#pragma unroll 4
-  for (uint32_t c = c_lo; c < c_hi; c++) {
-    const uint32_t p = c * 64u + lane;
-    const uint32_t m = p < T ? mi[p] : 0u;
-    uint32_t v = lane + ((m & ZES_TOK_MATCH) ? zes_tok_len(m) : 1u);
+  // Batches of PARSE_BATCH chunks: all their match words are requested before the first is used (one
+  // memory latency per batch instead of per chunk).  A chunk without any match (nearly all of them on
+  // incompressible input) needs no pointer doubling: every lane leaves at offset 0.
+  for (uint32_t cb = c_lo; cb < c_hi; cb += PARSE_BATCH) {
+    uint32_t mw[PARSE_BATCH];
+    // (loads are unconditional with clamped addresses: a load under a branch makes the compiler wait
+    // for every outstanding memory operation, stores included, before the next one)
 #pragma unroll
-    for (int r = 0; r < 6; r++) {
-      const uint32_t nv = __shfl(v, (int)(v & 63u));
-      if (v < 64u) v = nv;
+    for (uint32_t k = 0; k < PARSE_BATCH; k++) {
+      const uint32_t p = (cb + k) * 64u + lane;
+      mw[k] = mi[min(p, T - 1u)];
     }
-    S.u.xmap[c][lane] = (uint8_t)min(v - 64u, 255u);
+    PARSE_ARRIVE8(mw);
+#pragma unroll
+    for (uint32_t k = 0; k < PARSE_BATCH; k++) {
+      const uint32_t c = cb + k;
+      if (c >= c_hi) break;
+      const uint32_t m = (c * 64u + lane < T) ? mw[k] : 0u;
+      const bool plain = __ballot(m & ZES_TOK_MATCH) == 0ull;
+      uint32_t v = lane + ((m & ZES_TOK_MATCH) ? zes_tok_len(m) : 1u);
+      if (!plain) {
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+          const uint32_t nv = __shfl(v, (int)(v & 63u));
+          if (v < 64u) v = nv;
+        }
+      }
+      S.u.xmap[c][lane] = plain ? (uint8_t)0 : (uint8_t)min(v - 64u, 255u);
+      if (lane == 0) S.cplain[c] = plain ? 1 : 0;
+    }
   }
   __syncthreads();
 
+  PSTAMP(1);
   // ---- B: fold the region backwards.  E_k[e] = offset past the region end reached from lane e
   //         of chunk c + k; a hop lands at most 4 chunks ahead (overshoot <= 257) ----
   if (wave < nregions) {
@@ -645,6 +697,7 @@ __global__ __launch_bounds__(PARSE_THREADS) void k_lz_parse(const uint8_t* __res
   }
   __syncthreads();
 
+  PSTAMP(2);
   // ---- C: chain the regions, then every wave walks its own region from its true entry ----
   if (tid == 0) {
     uint32_t e = 0;
@@ -667,48 +720,68 @@ __global__ __launch_bounds__(PARSE_THREADS) void k_lz_parse(const uint8_t* __res
   }
   __syncthreads();
 
+  PSTAMP(3);
   // ---- D1: visited lanes of every touched chunk ----
   unsigned long long mymask[2] = {0ull, 0ull};  // thread t owns chunks 2t, 2t+1 for the scan
-#pragma unroll 2
-  for (uint32_t c = c_lo; c < c_hi; c++) {
-    const uint32_t e = S.centry[c];
-    unsigned long long mk = 0ull;
-    if (e != PARSE_NOENTRY) {
+  for (uint32_t cb = c_lo; cb < c_hi; cb += PARSE_BATCH) {
+    uint32_t mw[PARSE_BATCH], en[PARSE_BATCH];
+#pragma unroll
+    for (uint32_t k = 0; k < PARSE_BATCH; k++) {  // match words only of touched chunks that hold a match
+      const uint32_t c = cb + k;
       const uint32_t p = c * 64u + lane;
-      const uint32_t m = p < T ? mi[p] : 0u;
-      uint32_t h[6], cnt = 1;
-      h[0] = lane + ((m & ZES_TOK_MATCH) ? zes_tok_len(m) : 1u);
-#pragma unroll
-      for (int r = 0; r < 5; r++) {  // h[r] = landing lane after 2^r hops (>= 64: left the chunk)
-        const uint32_t hv = __shfl(h[r], (int)(h[r] & 63u));
-        const uint32_t cv = __shfl(cnt, (int)(h[r] & 63u));
-        const bool in = h[r] < 64u;
-        h[r + 1] = in ? hv : h[r];
-        cnt = in ? cnt + cv : cnt;
-      }
-      {  // hops from h[5] on are not needed: 32+..; finish the count with one more round
-        const uint32_t cv = __shfl(cnt, (int)(h[5] & 63u));
-        if (h[5] < 64u) cnt += cv;
-      }
-      // lane i is visited iff i >= e and hopping (cnt[e] - cnt[i]) times from e lands on i
-      const uint32_t ce = __shfl(cnt, (int)e);
-      const bool cand = lane >= e && cnt <= ce;
-      const uint32_t k = cand ? ce - cnt : 0u;
-      uint32_t pos = e;
-#pragma unroll
-      for (int r = 0; r < 6; r++) {
-        const uint32_t nx = __shfl(h[r], (int)(pos & 63u));
-        if ((k >> r) & 1u) pos = nx;
-      }
-      mk = __ballot(cand && pos == lane && p < T);
+      en[k] = c < c_hi ? (uint32_t)S.centry[c] : PARSE_NOENTRY;
+      const bool need = en[k] != PARSE_NOENTRY && !S.cplain[min(c, PARSE_CHUNKS - 1u)] && p < T;
+      mw[k] = mi[need ? p : lane];  // unconditional: chunks that need no words read the block's first line
     }
-    // hand the mask to the thread that owns this chunk in the scan
-    if (lane == 0) S.u.d.mask[c] = mk;  // xmap of chunk c is dead: the walk of phase C is over
+    PARSE_ARRIVE8(mw);
+#pragma unroll
+    for (uint32_t k = 0; k < PARSE_BATCH; k++) {
+      const uint32_t c = cb + k;
+      if (c >= c_hi) break;
+      const uint32_t e = en[k];
+      unsigned long long mk = 0ull;
+      if (e != PARSE_NOENTRY && S.cplain[c]) {
+        // no match in the chunk: the chain visits every position from the entry lane on
+        const uint32_t left = T - c * 64u;  // > 0: the chunk exists
+        mk = (~0ull << e) & (left >= 64u ? ~0ull : ((1ull << left) - 1ull));
+      } else if (e != PARSE_NOENTRY) {
+        const uint32_t p = c * 64u + lane;
+        const uint32_t m = p < T ? mw[k] : 0u;
+        uint32_t h[6], cnt = 1;
+        h[0] = lane + ((m & ZES_TOK_MATCH) ? zes_tok_len(m) : 1u);
+#pragma unroll
+        for (int r = 0; r < 5; r++) {  // h[r] = landing lane after 2^r hops (>= 64: left the chunk)
+          const uint32_t hv = __shfl(h[r], (int)(h[r] & 63u));
+          const uint32_t cv = __shfl(cnt, (int)(h[r] & 63u));
+          const bool in = h[r] < 64u;
+          h[r + 1] = in ? hv : h[r];
+          cnt = in ? cnt + cv : cnt;
+        }
+        {  // hops from h[5] on are not needed: 32+..; finish the count with one more round
+          const uint32_t cv = __shfl(cnt, (int)(h[5] & 63u));
+          if (h[5] < 64u) cnt += cv;
+        }
+        // lane i is visited iff i >= e and hopping (cnt[e] - cnt[i]) times from e lands on i
+        const uint32_t ce = __shfl(cnt, (int)e);
+        const bool cand = lane >= e && cnt <= ce;
+        const uint32_t kk = cand ? ce - cnt : 0u;
+        uint32_t pos = e;
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+          const uint32_t nx = __shfl(h[r], (int)(pos & 63u));
+          if ((kk >> r) & 1u) pos = nx;
+        }
+        mk = __ballot(cand && pos == lane && p < T);
+      }
+      // hand the mask to the thread that owns this chunk in the scan
+      if (lane == 0) S.u.d.mask[c] = mk;  // xmap of chunk c is dead: the walk of phase C is over
+    }
   }
   __syncthreads();
   // NOTE: mask[] aliases xmap[]; chunk c's mask (8 B at c*8) overlaps xmap rows c/8 — all reads
   // of xmap finished at the barrier above phase D1 only for the walk; D1 itself does not read xmap.
 
+  PSTAMP(4);
   // ---- D2: token offsets = exclusive scan of the per-chunk counts ----
   uint32_t cnt2[2];
 #pragma unroll
@@ -738,27 +811,46 @@ __global__ __launch_bounds__(PARSE_THREADS) void k_lz_parse(const uint8_t* __res
   if (tid * 2 + 1 < PARSE_CHUNKS) S.u.d.cpre[tid * 2 + 1] = ex + cnt2[0];
   __syncthreads();
 
+  PSTAMP(5);
   // ---- D3: tokens + histograms ----
-  for (uint32_t c = c_lo; c < c_hi; c++) {
-    const unsigned long long mk = S.u.d.mask[c];
-    if (!mk) continue;
-    if ((mk >> lane) & 1ull) {
+  for (uint32_t cb = c_lo; cb < c_hi; cb += PARSE_BATCH) {
+    uint32_t mw[PARSE_BATCH], by[PARSE_BATCH];
+    unsigned long long mks[PARSE_BATCH];
+#pragma unroll
+    for (uint32_t k = 0; k < PARSE_BATCH; k++) {  // input bytes of visited positions; match words where the chunk has any
+      const uint32_t c = cb + k;
+      mks[k] = c < c_hi ? S.u.d.mask[c] : 0ull;
+      const bool vis = (mks[k] >> lane) & 1ull;  // implies p < T
       const uint32_t p = c * 64u + lane;
-      const uint32_t m = mi[p];
-      const uint32_t rank = (uint32_t)__popcll(mk & zes_lanemask_lt());
-      uint32_t tv;
-      if (m & ZES_TOK_MATCH) {
-        tv = m;
-        atomicAdd(&S.lh[257u + zes_len_code(zes_tok_len(m))], 1u);
-        atomicAdd(&S.dh[zes_dist_code(zes_tok_dist(m))], 1u);
-      } else {
-        tv = src[p];
-        atomicAdd(&S.lh[tv], 1u);
+      by[k] = src[vis ? p : min(lane, T - 1u)];  // unconditional loads (see phase A)
+      mw[k] = mi[(vis && !S.cplain[min(c, PARSE_CHUNKS - 1u)]) ? p : lane];
+    }
+    PARSE_ARRIVE8(by);
+    PARSE_ARRIVE8(mw);
+#pragma unroll
+    for (uint32_t k = 0; k < PARSE_BATCH; k++) {
+      const uint32_t c = cb + k;
+      const unsigned long long mk = mks[k];
+      if ((mk >> lane) & 1ull) {
+        const uint32_t m = S.cplain[c] ? 0u : mw[k];
+        const uint32_t rank = (uint32_t)__popcll(mk & zes_lanemask_lt());
+        uint32_t tv;
+        if (m & ZES_TOK_MATCH) {
+          tv = m;
+          atomicAdd(&S.lh[257u + zes_len_code(zes_tok_len(m))], 1u);
+          atomicAdd(&S.dh[zes_dist_code(zes_tok_dist(m))], 1u);
+        } else {
+          tv = by[k];
+#ifndef PARSE_EXPERIMENT_NO_HIST
+          atomicAdd(&S.lh[tv], 1u);
+#endif
+        }
+        to[S.u.d.cpre[c] + rank] = tv;
       }
-      to[S.u.d.cpre[c] + rank] = tv;
     }
   }
   __syncthreads();
+  PSTAMP(6);
   if (tid == 0) {
     S.lh[256] = 1;  // EOB (src/deflate.ts:58)
     blks[g].ntok = total;
@@ -767,6 +859,7 @@ __global__ __launch_bounds__(PARSE_THREADS) void k_lz_parse(const uint8_t* __res
   uint32_t* hg = hists + (uint64_t)g * 320;
   for (uint32_t i = tid; i < 288; i += PARSE_THREADS) hg[i] = S.lh[i];
   if (tid < 32) hg[288 + tid] = S.dh[tid];
+  PSTAMP(7);
 }
 
 // ------------------------------------------------------------------------------------------
