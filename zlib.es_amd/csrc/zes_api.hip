@@ -34,7 +34,7 @@ struct Ctx {
   int device = -1;
   hipStream_t stream = nullptr;
   // deflate scratch
-  DevBuf bufs, blks, idx_a, idx_b, hists, codes, hdrs, adler, res;
+  DevBuf bufs, blks, idx_a, idx_b, inv, hists, codes, hdrs, adler, res;
   // inflate scratch
   DevBuf surv, cand, cand_sorted, counters, cres, map, resume, dbg, ibufs;
   // staging for the host-pointer API
@@ -188,6 +188,7 @@ int deflate_batch_core(const uint8_t* d_in, const uint64_t* in_off, const uint64
   if ((rc = ensure(g.blks, sizeof(ZesBlk) * nblk))) return rc;
   if ((rc = ensure(g.idx_a, (size_t)nblk * ZES_BLK * 4))) return rc;
   if ((rc = ensure(g.idx_b, (size_t)nblk * ZES_BLK * 4))) return rc;
+  if ((rc = ensure(g.inv, (size_t)nblk * ZES_BLK * 8))) return rc;
   if ((rc = ensure(g.hists, (size_t)nblk * 320 * 4))) return rc;
   if ((rc = ensure(g.codes, (size_t)nblk * 320 * 4))) return rc;
   if ((rc = ensure(g.hdrs, (size_t)nblk * ZES_HDR_WORDS * 4))) return rc;
@@ -225,7 +226,7 @@ int deflate_batch_core(const uint8_t* d_in, const uint64_t* in_off, const uint64
   }
   {
     Timed t("k_lz_sort");
-    hipLaunchKernelGGL(k_lz_sort, dim3(nblk), dim3(SORT_THREADS), 0, g.stream, d_in, dbufs, dblks, idx_a, idx_b);
+    hipLaunchKernelGGL(k_lz_sort, dim3(nblk), dim3(SORT_THREADS), 0, g.stream, d_in, dbufs, dblks, idx_a, idx_b, (uint2*)g.inv.p);
   }
   if (sort_dbg) {  // average shader-clock cycles per step of k_lz_sort
     HIPCHK(hipStreamSynchronize(g.stream));
@@ -246,6 +247,34 @@ int deflate_batch_core(const uint8_t* d_in, const uint64_t* in_off, const uint64
   {
     Timed t("k_lz_match");  // match words go to idx_b (free after the sort)
     hipLaunchKernelGGL(k_lz_match, dim3(nblk), dim3(MATCH_THREADS), 0, g.stream, d_in, dbufs, dblks, idx_a, idx_b);
+  }
+  if (sort_dbg) {
+    HIPCHK(hipMemsetAsync(g.dbg.p, 0, (size_t)nblk * 64, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    zes_lazy_set_dbg((unsigned long long*)g.dbg.p);
+  }
+  {
+    Timed t("k_lz_match_lazy");  // the blocks k_lz_sort flagged (most positions kept); the others return at once
+    hipLaunchKernelGGL(k_lz_match_lazy, dim3(nblk), dim3(MATCH_THREADS), 0, g.stream, d_in, dbufs, dblks, idx_a,
+                       (const uint2*)g.inv.p, idx_b);
+  }
+  if (sort_dbg) {  // average shader-clock cycles per phase of k_lz_match_lazy
+    HIPCHK(hipStreamSynchronize(g.stream));
+    zes_lazy_set_dbg(nullptr);
+    std::vector<unsigned long long> h((size_t)nblk * 8);
+    HIPCHK(hipMemcpy(h.data(), g.dbg.p, h.size() * 8, hipMemcpyDeviceToHost));
+    double acc[8] = {0};
+    uint32_t n = 0;
+    for (uint32_t i = 0; i < nblk; i++) {
+      if (!h[(size_t)i * 8 + 4]) continue;
+      n++;
+      for (int k = 1; k < 5; k++) acc[k] += (double)(h[(size_t)i * 8 + k] - h[(size_t)i * 8 + k - 1]);
+      acc[5] += (double)h[(size_t)i * 8 + 5];
+      acc[6] += (double)h[(size_t)i * 8 + 6];
+    }
+    if (n)
+      fprintf(stderr, "zes lazy match steps (avg cycles over %u blocks): stage %.0f window chains %.0f entry chains %.0f true chain %.0f | first wave, window chains: %.0f loop rounds, %.0f with starts\n", n,
+              acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[5] / n, acc[6] / n);
   }
   if (sort_dbg) {
     HIPCHK(hipMemsetAsync(g.dbg.p, 0, (size_t)nblk * 64, g.stream));
@@ -611,7 +640,7 @@ int zes_shutdown(void) {
   std::lock_guard<std::mutex> lk(g_mu);
   if (!g.ready) return ZES_OK;
   hipStreamSynchronize(g.stream);
-  DevBuf* all[] = {&g.bufs, &g.blks, &g.idx_a, &g.idx_b, &g.hists, &g.codes, &g.hdrs, &g.adler, &g.res, &g.surv, &g.cand,
+  DevBuf* all[] = {&g.bufs, &g.blks, &g.idx_a, &g.idx_b, &g.inv, &g.hists, &g.codes, &g.hdrs, &g.adler, &g.res, &g.surv, &g.cand,
                    &g.cand_sorted, &g.counters, &g.cres, &g.map, &g.resume, &g.dbg, &g.ibufs, &g.st_in, &g.st_out};
   for (DevBuf* b : all) {
     if (b->p) hipFree(b->p);
@@ -832,13 +861,16 @@ int zes_stage_lz77_dev(const uint8_t* d_in, uint64_t n, uint64_t start, uint32_t
   if ((rc = ensure(g.blks, sizeof z))) return rc;
   if ((rc = ensure(g.idx_a, (size_t)ZES_BLK * 4))) return rc;
   if ((rc = ensure(g.idx_b, (size_t)ZES_BLK * 4))) return rc;
+  if ((rc = ensure(g.inv, (size_t)ZES_BLK * 8))) return rc;
   if ((rc = ensure(g.hists, 320 * 4))) return rc;
   HIPCHK(hipMemcpyAsync(g.bufs.p, &b, sizeof b, hipMemcpyHostToDevice, g.stream));
   HIPCHK(hipMemcpyAsync(g.blks.p, &z, sizeof z, hipMemcpyHostToDevice, g.stream));
   hipLaunchKernelGGL(k_lz_sort, dim3(1), dim3(SORT_THREADS), 0, g.stream, d_in, (const ZesBuf*)g.bufs.p, (const ZesBlk*)g.blks.p,
-                     (uint32_t*)g.idx_a.p, (uint32_t*)g.idx_b.p);
+                     (uint32_t*)g.idx_a.p, (uint32_t*)g.idx_b.p, (uint2*)g.inv.p);
   hipLaunchKernelGGL(k_lz_match, dim3(1), dim3(MATCH_THREADS), 0, g.stream, d_in, (const ZesBuf*)g.bufs.p,
                      (const ZesBlk*)g.blks.p, (const uint32_t*)g.idx_a.p, (uint32_t*)g.idx_b.p);
+  hipLaunchKernelGGL(k_lz_match_lazy, dim3(1), dim3(MATCH_THREADS), 0, g.stream, d_in, (const ZesBuf*)g.bufs.p,
+                     (const ZesBlk*)g.blks.p, (const uint32_t*)g.idx_a.p, (const uint2*)g.inv.p, (uint32_t*)g.idx_b.p);
   hipLaunchKernelGGL(k_lz_parse, dim3(1), dim3(PARSE_THREADS), 0, g.stream, d_in, (const ZesBuf*)g.bufs.p, (ZesBlk*)g.blks.p,
                      (const uint32_t*)g.idx_b.p, (uint32_t*)g.idx_a.p, (uint32_t*)g.hists.p);
   HIPCHK(hipGetLastError());

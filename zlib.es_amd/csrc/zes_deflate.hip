@@ -72,6 +72,7 @@ void zes_sort_set_dbg(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBO
     if (g_sort_dbg && threadIdx.x == 0) g_sort_dbg[(size_t)blockIdx.x * 8 + (i)] = (unsigned long long)clock64(); \
   } while (0)
 
+#define ZES_SORT_LAZY 0x80000000u  // flag beside ns in idx_a[g][ZES_BLK-1]
 #define SORT_HASH_BITS 19u
 #define SORT_OWN 128u  // consecutive positions owned by one thread in the filter phase
 #define SORT_ROUNDS 4u
@@ -100,7 +101,7 @@ __device__ __forceinline__ static uint4 sort_ld16(const uint8_t* __restrict__ sr
 
 __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restrict__ d_in, const ZesBuf* __restrict__ bufs,
                                                           const ZesBlk* __restrict__ blks, uint32_t* __restrict__ idx_a,
-                                                          uint32_t* __restrict__ idx_b) {
+                                                          uint32_t* __restrict__ idx_b, uint2* __restrict__ inv_all) {
   __shared__ __align__(16) SortSmem S;
   const uint32_t g = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const ZesBlk bk = blks[g];
@@ -231,8 +232,13 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
   }
   __syncthreads();  // flag words read before the block is staged over them
   SSTAMP(4);
-  if (tid == 0) A[ZES_BLK - 1] = ns;
+  // Blocks that keep most of their positions (text, periodic data) go to the lazy match finder, which
+  // evaluates positions along greedy chains and needs the sorted slot of a position: inv[p].
+  const bool lazy = inv_all != nullptr && ns * 2u >= cnt;
+  uint2* inv = inv_all ? inv_all + (uint64_t)g * ZES_BLK : nullptr;
+  if (tid == 0) A[ZES_BLK - 1] = ns | (lazy ? ZES_SORT_LAZY : 0u);
   if (ns == 0) return;  // uniform
+
   stage_block(S.in, src, T, (T + 15u) & ~15u);
   __syncthreads();
   SSTAMP(5);  // staged block and the survivor list in B visible to the whole workgroup
@@ -335,7 +341,8 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
 #pragma unroll
       for (uint32_t r = 0; r < SORT_ROUNDS; r++) {
         const uint32_t dst = S.base[bsel][d[r]] + wh[wave][d[r]] + rk[r];
-        to[(i0 + 64u * r < ns) ? dst : ZES_BLK - 2u] = p[r];
+        const bool valid = i0 + 64u * r < ns;
+        to[valid ? dst : ZES_BLK - 2u] = p[r];
       }
       bsel ^= 1;
       // no barrier here: the next tile writes whist[other] and base[other-other] only after
@@ -343,6 +350,55 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
     }
     __syncthreads();
     SSTAMP(6 + (pass == 2));
+  }
+  // For the lazy match finder: inv[p] = (sorted slot of p, nearest earlier position with the same key or
+  // none); positions the filter dropped get (none, none).  Scattering 8-byte entries straight to memory
+  // costs a whole memory transaction each, so the table is built in LDS in eight slices of 16384
+  // positions (the staged block is no longer needed once the same-key flags are taken) and each slice
+  // leaves with coalesced 16-byte stores; the sorted list is re-read per slice (it sits in the L2).
+  if (lazy) {
+    uint32_t* same = reinterpret_cast<uint32_t*>(&S.whist[0][0][0]);  // [4096] bit r: slot r holds the key of slot r-1
+    for (uint32_t wd = tid; wd < ZES_BLK / 32; wd += SORT_THREADS) same[wd] = 0;
+    __syncthreads();
+    for (uint32_t r0 = wave * 64u; r0 < ns; r0 += SORT_THREADS) {
+      const uint32_t r = r0 + lane;
+      bool sm = false;
+      if (r < ns && r != 0u) sm = ((lds_ld32u(S.in, A[r - 1u]) ^ lds_ld32u(S.in, A[r])) & 0xffffffu) == 0u;
+      const uint64_t m = __ballot(sm);
+      if (lane == 0) {
+        same[r0 >> 5] = (uint32_t)m;
+        same[(r0 >> 5) + 1u] = (uint32_t)(m >> 32);
+      }
+    }
+    __syncthreads();  // the block in S.in is dead from here on
+    uint2* stage = reinterpret_cast<uint2*>(S.in);  // [16384]
+    for (uint32_t b = 0; b < ZES_BLK / 16384u; b++) {
+      if (b * 16384u >= T) break;  // uniform
+      uint4* st4 = reinterpret_cast<uint4*>(S.in);
+      for (uint32_t i = tid; i < 8192u; i += SORT_THREADS) st4[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+      __syncthreads();
+      for (uint32_t rb = tid; rb < ns; rb += 8u * SORT_THREADS) {  // eight slots per thread and step: one memory latency for all
+        uint32_t pos[8], prv[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) {
+          const uint32_t r = min(rb + k * SORT_THREADS, ns - 1u);
+          pos[k] = A[r];
+          prv[k] = A[r ? r - 1u : 0u];
+        }
+        asm volatile("" : "+v"(pos[0]), "+v"(pos[1]), "+v"(pos[2]), "+v"(pos[3]), "+v"(pos[4]), "+v"(pos[5]), "+v"(pos[6]), "+v"(pos[7]));
+        asm volatile("" : "+v"(prv[0]), "+v"(prv[1]), "+v"(prv[2]), "+v"(prv[3]), "+v"(prv[4]), "+v"(prv[5]), "+v"(prv[6]), "+v"(prv[7]));
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) {
+          const uint32_t r = rb + k * SORT_THREADS;
+          if (r < ns && (pos[k] >> 14) == b)
+            stage[pos[k] & 16383u] = make_uint2(r, ((same[r >> 5] >> (r & 31u)) & 1u) ? prv[k] : ~0u);
+        }
+      }
+      __syncthreads();
+      uint4* o4 = reinterpret_cast<uint4*>(inv + b * 16384u);
+      for (uint32_t i = tid; i < 8192u; i += SORT_THREADS) o4[i] = st4[i];
+      __syncthreads();
+    }
   }
 }
 
@@ -388,6 +444,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match(const uint8_t* __res
   const uint32_t avail = (uint32_t)(remain < (uint64_t)(T + ZES_MAXMATCH) ? remain : (uint64_t)(T + ZES_MAXMATCH));
   const uint32_t* idx = idx_a + (uint64_t)g * ZES_BLK;
   uint32_t* mo = match_out + (uint64_t)g * ZES_BLK;
+  if (idx[ZES_BLK - 1] & ZES_SORT_LAZY) return;  // this block belongs to k_lz_match_lazy
   const uint32_t cnt = idx[ZES_BLK - 1];  // positions k_lz_sort kept (the others share their key with nobody)
 
   // stage block + halo (zero padded), swizzled
@@ -555,6 +612,375 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match(const uint8_t* __res
         mo[p] = ZES_TOK_MATCH | ((best - 3u) << 16) | (p - bestq - 1u);
       mode = 0u;
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_lz_match_lazy: match finder for blocks that keep most of their positions (text, periodic data).
+// The greedy parse only ever asks for the match at the positions of its chain p -> p + len | p + 1
+// (about one position in five on text, one in a hundred on long periodic matches), but which positions
+// those are is only known once the earlier ones are evaluated.  So:
+//   1  every 128-byte window gets the chain that starts at its first byte, evaluated position by
+//      position by one lane (1024 chains in flight); the positions it visits are kept as a bit mask
+//      V1 and the position where it leaves the window as xw[w]
+//   2  the chain that really enters a window starts wherever the previous window's chain left off:
+//      from each xw[u] a second chain is followed until it lands on a V1 position (greedy chains on
+//      text merge within a few tokens) or leaves the window; the outcome is e2[u]
+//   3  one wavefront walks the true chain from position 0 through these tables (a few LDS reads per
+//      window).  Where it arrives at a position nobody evaluated (periodic data: chains of maximal
+//      matches never merge) the position is evaluated on the spot, all 64 lanes sharing the
+//      candidates.
+// Afterwards every position of the true chain carries its exact match word; the others are zero
+// ("literal"), which k_lz_parse never looks at on the chain it resolves.
+// ------------------------------------------------------------------------------------------
+__device__ unsigned long long* g_lazy_dbg = nullptr;  // ZES_DEBUG_PHASES: cycle stamps [g][8]
+void zes_lazy_set_dbg(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lazy_dbg), &p, sizeof p); }
+#define LSTAMP(i)                                                                                        \
+  do {                                                                                                   \
+    if (g_lazy_dbg && threadIdx.x == 0) g_lazy_dbg[(size_t)blockIdx.x * 8 + (i)] = (unsigned long long)clock64(); \
+  } while (0)
+#define LAZY_WIN 128u
+#define LAZY_NWIN (ZES_BLK / LAZY_WIN)
+#define LAZY_NONE 0xFFFFFFFFu
+#ifndef LAZY_START_MIN
+#define LAZY_START_MIN 1u  // lanes that must be waiting before a batch of evaluations is started (measured: 1 best)
+#endif
+#ifndef LAZY_CMP_MIN
+#define LAZY_CMP_MIN 1u    // lanes that must be waiting before a batch of compares is run (measured: 1 best)
+#endif
+struct LazySmem {
+  uint32_t in[(MATCH_IN_DWORDS + 31) / 32 * 32];  // block + halo, swizzled like MatchSmem::in
+  uint32_t v1[ZES_BLK / 32];                      // positions on the window-start chains
+  uint16_t xw[LAZY_NWIN];                         // chain of window w leaves it at 128 w + xw[w]
+  uint16_t e2[LAZY_NWIN];                         // the chain entering at 128 u + xw[u] leaves that window at 128 u + e2[u]
+  uint32_t wq;                                    // next work item to hand out
+};
+
+// common prefix of the strings at q and p (q < p, first three bytes known equal), capped at maxl
+__device__ __forceinline__ static uint32_t lazy_lcp(const uint32_t* in, uint32_t q, uint32_t p, uint32_t maxl) {
+  uint32_t L = 3;
+  const uint32_t qo = q + 3u, po = p + 3u;
+  uint32_t qi = qo >> 2, pi = po >> 2;
+  const uint32_t qs = qo & 3u, ps = po & 3u;
+  uint32_t qlo = in[mswz(qi)], plo = in[mswz(pi)];
+  while (L < maxl) {
+    const uint32_t qm = in[mswz(qi + 1)], pm = in[mswz(pi + 1)];
+    const uint32_t qhi = in[mswz(qi + 2)], phi = in[mswz(pi + 2)];
+    const uint32_t x1 = __builtin_amdgcn_alignbyte(qm, qlo, qs) ^ __builtin_amdgcn_alignbyte(pm, plo, ps);
+    const uint32_t x2 = __builtin_amdgcn_alignbyte(qhi, qm, qs) ^ __builtin_amdgcn_alignbyte(phi, pm, ps);
+    const uint32_t f1 = ((uint32_t)__ffs((int)x1) - 1u) >> 3, f2 = ((uint32_t)__ffs((int)x2) - 1u) >> 3;
+    L += x1 ? f1 : (x2 ? 4u + f2 : 8u);
+    if (x1 | x2) break;
+    qi += 2;
+    pi += 2;
+    qlo = qhi;
+    plo = phi;
+  }
+  return min(L, maxl);
+}
+
+// Match at position p by the whole wavefront (p uniform): lane k takes candidate k of a round of 64.
+// Returns the match word (0 = literal).  Candidate order, early exits and tie rule of src/lz77.ts:49-95.
+__device__ static uint32_t lazy_wave_eval(const LazySmem& S, const uint32_t* __restrict__ idx, const uint2* __restrict__ inv, uint32_t p,
+                                          uint32_t T, uint32_t avail) {
+  const uint32_t lane = zes_lane();
+  const uint2 iv = inv[p];
+  if (iv.y == LAZY_NONE) return 0u;  // no earlier position with this key
+  const uint32_t r = iv.x;
+  const uint32_t keyp = m_ld32u(S.in, p) & 0xffffffu;
+  const uint32_t maxl = min(ZES_MAXMATCH, avail - p);
+  uint32_t best = 0, bestq = 0;
+  if (maxl == ZES_MAXMATCH) {
+    // Periodic data: the nearest candidate already matches at full length and ends the scan (:89-91).
+    // All lanes compare that one candidate, four bytes each (the halo covers p + 258).
+    const uint32_t q0 = iv.y;
+    if ((p - q0) <= ZES_WINDOW) {
+      const uint32_t x = m_ld32u(S.in, q0 + 4u * lane) ^ m_ld32u(S.in, p + 4u * lane);
+      const uint64_t full = __ballot(x == 0u);                                // dwords 0..63 = bytes 0..255
+      const uint32_t t = m_ld32u(S.in, q0 + 256u) ^ m_ld32u(S.in, p + 256u);  // bytes 256, 257
+      if (full == ~0ull && (t & 0xffffu) == 0u) {
+        if (p + ZES_MAXMATCH + 3u <= T) return ZES_TOK_MATCH | ((ZES_MAXMATCH - 3u) << 16) | (p - q0 - 1u);  // :95
+        return 0u;
+      }
+    }
+  }
+  for (uint32_t round = 0; round < 2u; round++) {  // at most 128 candidates (:66)
+    const uint32_t k = round * 64u + lane;
+    const int32_t slot = (int32_t)r - 1 - (int32_t)k;
+    const uint32_t q = idx[slot > 0 ? slot : 0];
+    const bool ok = slot >= 0 && (m_ld32u(S.in, q) & 0xffffffu) == keyp && (p - q) <= ZES_WINDOW;  // same key, inside the window (:49)
+    const uint64_t okm = __ballot(ok);
+    const uint32_t nrun = (~okm) ? (uint32_t)__builtin_ctzll(~okm) : 64u;  // candidates are one run of slots
+    const uint32_t L = lane < nrun ? lazy_lcp(S.in, q, p, maxl) : 0u;
+    // best length before candidate k is looked at = running maximum over the nearer candidates
+    uint32_t incl = L;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t t = (uint32_t)__shfl_up((int)incl, d);
+      if ((int)lane >= d) incl = max(incl, t);
+    }
+    uint32_t excl = (uint32_t)__shfl_up((int)incl, 1);
+    excl = max(lane ? excl : 0u, best);
+    // the scan stops in front of candidate k when the run is over, when a match of 8 is in hand after
+    // 16 candidates (:66-69), or right after a full-length match (:89-91)
+    const uint64_t stopm = __ballot(lane >= nrun || (k >= 16u && excl >= 8u) || excl >= ZES_MAXMATCH);
+    const uint32_t kstop = stopm ? (uint32_t)__builtin_ctzll(stopm) : 64u;
+    const uint32_t Lx = lane < kstop ? L : 0u;
+    uint32_t bm = Lx;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) bm = max(bm, (uint32_t)__shfl_xor((int)bm, d));
+    if (bm > best) {  // strictly longer only: the nearest candidate wins ties (:86-88)
+      const uint64_t who = __ballot(Lx == bm);
+      best = bm;
+      bestq = (uint32_t)__shfl((int)q, (int)__builtin_ctzll(who));
+    }
+    if (kstop < 64u) break;
+  }
+  if (best >= 3u && p + best + 3u <= T) return ZES_TOK_MATCH | ((best - 3u) << 16) | (p - bestq - 1u);  // :95
+  return 0u;
+}
+
+__global__ __launch_bounds__(MATCH_THREADS) void k_lz_match_lazy(const uint8_t* __restrict__ d_in, const ZesBuf* __restrict__ bufs,
+                                                                 const ZesBlk* __restrict__ blks, const uint32_t* __restrict__ idx_a,
+                                                                 const uint2* __restrict__ inv_all, uint32_t* __restrict__ match_out) {
+  __shared__ __align__(16) LazySmem S;
+  const uint32_t g = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t* idx = idx_a + (uint64_t)g * ZES_BLK;
+  if (!(idx[ZES_BLK - 1] & ZES_SORT_LAZY)) return;  // this block belongs to k_lz_match
+  const uint2* inv = inv_all + (uint64_t)g * ZES_BLK;
+  const ZesBlk bk = blks[g];
+  const ZesBuf bf = bufs[bk.buf];
+  const uint32_t T = bk.len;
+  const uint64_t S0 = (uint64_t)bk.blk * ZES_BLK;  // block start inside the buffer
+  const uint8_t* src = d_in + bf.in_off + S0;
+  const uint64_t remain = bf.n - S0;  // bytes from block start to input end
+  const uint32_t avail = (uint32_t)(remain < (uint64_t)(T + ZES_MAXMATCH) ? remain : (uint64_t)(T + ZES_MAXMATCH));
+  uint32_t* mo = match_out + (uint64_t)g * ZES_BLK;
+  const uint32_t cnt = T >= 3 ? T - 2 : 0;  // positions that have a 3-byte key
+  const uint32_t nwin = (T + LAZY_WIN - 1) / LAZY_WIN;
+
+  LSTAMP(0);
+  // stage block + halo (zero padded), swizzled; clear the result words and the tables
+  if ((((uintptr_t)src) & 15u) == 0) {
+    const uint4* g4 = reinterpret_cast<const uint4*>(src);
+    for (uint32_t i = tid; i < MATCH_IN_DWORDS / 4; i += MATCH_THREADS) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      const uint32_t b = i * 16u;
+      if (b + 16u <= avail) {
+        v = g4[i];
+      } else if (b < avail) {
+        uint32_t t[4] = {0, 0, 0, 0};
+        for (uint32_t k = 0; k < 16u && b + k < avail; k++) t[k >> 2] |= (uint32_t)src[b + k] << (8u * (k & 3u));
+        v = make_uint4(t[0], t[1], t[2], t[3]);
+      }
+      S.in[mswz(4 * i + 0)] = v.x;
+      S.in[mswz(4 * i + 1)] = v.y;
+      S.in[mswz(4 * i + 2)] = v.z;
+      S.in[mswz(4 * i + 3)] = v.w;
+    }
+  } else {
+    for (uint32_t i = tid; i < MATCH_IN_DWORDS; i += MATCH_THREADS) {
+      uint32_t t = 0;
+      for (uint32_t k = 0; k < 4u; k++)
+        if (4 * i + k < avail) t |= (uint32_t)src[4 * i + k] << (8u * k);
+      S.in[mswz(i)] = t;
+    }
+  }
+  {
+    uint4* mo4 = reinterpret_cast<uint4*>(mo);
+    const uint32_t n4 = (T + 3u) >> 2;
+    for (uint32_t i = tid; i < n4; i += MATCH_THREADS) mo4[i] = make_uint4(0, 0, 0, 0);
+  }
+  for (uint32_t i = tid; i < ZES_BLK / 32; i += MATCH_THREADS) S.v1[i] = 0;
+  if (tid == 0) S.wq = 0;
+  __syncthreads();
+
+  LSTAMP(1);
+  // ---- phases 1 and 2: one chain per lane, positions evaluated one after the other ----
+  for (uint32_t phase = 1; phase <= 2u; phase++) {
+    // lane state.  mode: 0 no chain, 5 chain standing at p, 6 p needs its match, 1 probing, 2 comparing, 3 match known
+    uint32_t mode = 0, item = 0, p = 0, wend = 0;
+    uint32_t best = 0, bestq = 0, check = 0, pprobe = 0, maxl = 0, keyp = 0, q = 0, cq = 0, cq2 = 0;
+    int32_t cslot = -1;
+    bool drained = false;  // no work items left (uniform)
+    uint32_t niter = 0, nstart = 0;
+    for (;;) {
+      niter++;
+      const uint64_t running = __ballot(mode == 1u || mode == 2u);
+      const uint64_t starting = __ballot(mode == 6u);
+      if (!running && !starting) {
+        if (!__ballot(mode != 0u) && drained) break;
+      }
+      // (D) start evaluations, batched (the global load stalls the whole wavefront).  One 8-byte load
+      // gives the sorted slot and the nearest candidate; a position without one is a literal at once.
+      if (starting && ((uint32_t)__popcll(starting) >= LAZY_START_MIN || !running)) {
+        nstart++;
+        const bool st = mode == 6u;
+        const uint2 iv = inv[st ? p : 0u];
+        const bool lit = iv.y == LAZY_NONE;
+        const int32_t sl = (int32_t)iv.x - 1;          // slot of the nearest candidate
+        const uint32_t c1 = idx[(st && !lit && sl > 1) ? sl - 1 : 0];  // the one after it, for the next round
+        if (st) {
+          cslot = lit ? -1 : sl;
+          cq = iv.y;
+          cq2 = c1;
+          best = 0;
+          bestq = 0;
+          check = 0;
+          maxl = min(ZES_MAXMATCH, avail - p);  // = min(258, n - p)
+          keyp = m_ld32u(S.in, p) & 0xffffffu;
+          mode = lit ? 3u : 1u;
+        }
+      }
+      // (E) compares, batched and run to completion (select code: see k_lz_match)
+      {
+        const uint32_t npend = (uint32_t)__popcll(__ballot(mode == 2u));
+        const uint32_t nprobe = (uint32_t)__popcll(__ballot(mode == 1u));
+        if (npend >= LAZY_CMP_MIN || (npend != 0u && nprobe == 0u)) {
+          bool cmp = mode == 2u;
+          uint32_t L = 3;
+          const uint32_t qo = q + 3u, po = p + 3u;
+          uint32_t qi = qo >> 2, pi = po >> 2;
+          const uint32_t qs = qo & 3u, ps = po & 3u;
+          uint32_t qlo = S.in[mswz(qi)], plo = S.in[mswz(pi)];
+          while (__ballot(cmp && L < maxl)) {  // 8 bytes per step
+            const uint32_t qm = S.in[mswz(qi + 1)], pm = S.in[mswz(pi + 1)];
+            const uint32_t qhi = S.in[mswz(qi + 2)], phi = S.in[mswz(pi + 2)];
+            const uint32_t x1 = __builtin_amdgcn_alignbyte(qm, qlo, qs) ^ __builtin_amdgcn_alignbyte(pm, plo, ps);
+            const uint32_t x2 = __builtin_amdgcn_alignbyte(qhi, qm, qs) ^ __builtin_amdgcn_alignbyte(phi, pm, ps);
+            const bool live = cmp && L < maxl;
+            const uint32_t f1 = ((uint32_t)__ffs((int)x1) - 1u) >> 3, f2 = ((uint32_t)__ffs((int)x2) - 1u) >> 3;
+            const uint32_t add = x1 ? f1 : (x2 ? 4u + f2 : 8u);
+            L += live ? add : 0u;
+            cmp = cmp && !(live && (x1 | x2));
+            qi += 2;
+            pi += 2;
+            qlo = qhi;
+            plo = phi;
+          }
+          const bool c2 = mode == 2u;
+          const uint32_t Lf = min(L, maxl);
+          const bool better = c2 && Lf > best;
+          best = better ? Lf : best;
+          bestq = better ? q : bestq;
+          if (__ballot(better)) {
+            const uint32_t pw = m_ld32u(S.in, p + (best >= 3u ? best - 3u : 0u));
+            pprobe = (better && best < maxl) ? pw : pprobe;
+          }
+          mode = c2 ? ((better && Lf >= ZES_MAXMATCH) ? 3u : 1u) : mode;
+        }
+      }
+      // (F) probe the next candidate: the slot before, while it holds the same key (select code)
+      if (__ballot(mode == 1u)) {
+        const bool pr = mode == 1u;
+        const uint32_t q2 = cq;
+        const bool same = cslot >= 0 && (m_ld32u(S.in, q2) & 0xffffffu) == keyp;
+        const bool stop0 = !same || check >= 128u || (best >= 8u && check >= 16u);  // src/lz77.ts:66-69
+        const bool far = (p - q2) > ZES_WINDOW;                                      // src/lz77.ts:49
+        const bool adv = pr && !stop0;
+        const bool cand = adv && !far;
+        // L > best needs bytes 0..best equal: one dword probe at best-3 rejects most candidates
+        const uint32_t pw = m_ld32u(S.in, q2 + (best >= 3u ? best - 3u : 0u));
+        const bool skip = (best >= maxl) || (best >= 3u && pw != pprobe);
+        q = adv ? q2 : q;
+        check += cand ? 1u : 0u;
+        const int32_t ns2 = adv ? cslot - 1 : cslot;
+        // two slots ahead is requested now: the load has two rounds to arrive
+        const uint32_t nq = idx[(pr && ns2 > 1) ? ns2 - 1 : 0];
+        cq = adv ? cq2 : cq;
+        cq2 = adv ? nq : cq2;
+        cslot = ns2;
+        mode = (pr && (stop0 || far)) ? 3u : ((cand && !skip) ? 2u : mode);
+      }
+      // (A) a finished evaluation moves its chain on
+      if (mode == 3u) {
+        const bool acc = best >= 3u && p + best + 3u <= T;  // src/lz77.ts:95
+        if (acc) mo[p] = ZES_TOK_MATCH | ((best - 3u) << 16) | (p - bestq - 1u);
+        p += acc ? best : 1u;
+        mode = 5u;
+      }
+      // (B) chain control: leave the window, merge, step over the keyless tail, or ask for a match
+      if (mode == 5u) {
+        const uint32_t w = (wend - 1u) / LAZY_WIN;  // the window being crossed
+        if (p >= wend) {
+          if (phase == 1u) S.xw[item] = (uint16_t)(p - item * LAZY_WIN);
+          else S.e2[item] = (uint16_t)(p - item * LAZY_WIN);
+          mode = 0u;
+        } else if (phase == 2u && ((S.v1[p >> 5] >> (p & 31u)) & 1u)) {
+          S.e2[item] = (uint16_t)(w * LAZY_WIN + S.xw[w] - item * LAZY_WIN);  // from here on it is window w's own chain
+          mode = 0u;
+        } else {
+          if (phase == 1u) atomicOr(&S.v1[p >> 5], 1u << (p & 31u));
+          if (p >= cnt) p += 1u;  // the block's last two bytes are always literals (src/lz77.ts:116-117)
+          else mode = 6u;
+        }
+      }
+      // (C) hand out work items to lanes without a chain
+      {
+        const uint64_t idle = __ballot(mode == 0u);
+        if (idle && !drained) {
+          uint32_t first = 0;
+          const uint32_t nidle = (uint32_t)__popcll(idle);
+          if (lane == 0) first = atomicAdd(&S.wq, nidle);
+          first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
+          if (first >= nwin) drained = true;
+          const uint32_t mine = first + (uint32_t)__popcll(idle & zes_lanemask_lt());
+          if (mode == 0u && mine < nwin) {
+            item = mine;
+            if (phase == 1u) {
+              p = item * LAZY_WIN;
+              wend = min(p + LAZY_WIN, T);
+              mode = 5u;
+            } else {
+              p = item * LAZY_WIN + S.xw[item];
+              if (p >= T) {
+                S.e2[item] = S.xw[item];  // the chain ends with the block
+              } else {
+                wend = min((p / LAZY_WIN + 1u) * LAZY_WIN, T);
+                mode = 5u;
+              }
+            }
+          }
+        }
+      }
+    }
+    if (g_lazy_dbg && tid == 0 && phase == 1u) {
+      g_lazy_dbg[(size_t)blockIdx.x * 8 + 5] = niter;
+      g_lazy_dbg[(size_t)blockIdx.x * 8 + 6] = nstart;
+    }
+    __syncthreads();
+    LSTAMP(1 + phase);
+    if (tid == 0) S.wq = 0;
+    __syncthreads();
+  }
+
+  // ---- phase 3: the true chain, by one wavefront ----
+  if (wave == 0) {
+    uint32_t p = 0;
+    while (p < cnt) {
+      const uint32_t w = p / LAZY_WIN;
+      uint32_t np = 0;
+      if ((S.v1[p >> 5] >> (p & 31u)) & 1u) {
+        np = w * LAZY_WIN + S.xw[w];  // on window w's own chain
+      } else {
+        bool found = false;
+        for (uint32_t d = 1; d <= 3u && d <= w; d++) {  // a hop is at most 258 bytes: the entry came from one of three windows
+          const uint32_t u = w - d;
+          if (u * LAZY_WIN + S.xw[u] == p) {
+            np = u * LAZY_WIN + S.e2[u];
+            found = true;
+            break;
+          }
+        }
+        if (!found) {  // nobody evaluated this position yet
+          const uint32_t m = lazy_wave_eval(S, idx, inv, p, T, avail);
+          if (m && lane == 0) mo[p] = m;
+          np = p + ((m & ZES_TOK_MATCH) ? zes_tok_len(m) : 1u);
+        }
+      }
+      p = np > p ? np : p + 1u;  // (np > p always; the guard only keeps a corrupted table from hanging the wavefront)
+    }
+    LSTAMP(4);
   }
 }
 
