@@ -266,15 +266,15 @@ int deflate_batch_core(const uint8_t* d_in, const uint64_t* in_off, const uint64
     double acc[8] = {0};
     uint32_t n = 0;
     for (uint32_t i = 0; i < nblk; i++) {
-      if (!h[(size_t)i * 8 + 4]) continue;
+      if (!h[(size_t)i * 8 + 5]) continue;
       n++;
-      for (int k = 1; k < 5; k++) acc[k] += (double)(h[(size_t)i * 8 + k] - h[(size_t)i * 8 + k - 1]);
-      acc[5] += (double)h[(size_t)i * 8 + 5];
+      for (int k = 1; k < 6; k++) acc[k] += (double)(h[(size_t)i * 8 + k] - h[(size_t)i * 8 + k - 1]);
       acc[6] += (double)h[(size_t)i * 8 + 6];
+      acc[7] += (double)h[(size_t)i * 8 + 7];
     }
     if (n)
-      fprintf(stderr, "zes lazy match steps (avg cycles over %u blocks): stage %.0f window chains %.0f entry chains %.0f true chain %.0f | first wave, window chains: %.0f loop rounds, %.0f with starts\n", n,
-              acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[5] / n, acc[6] / n);
+      fprintf(stderr, "zes lazy match steps (avg cycles over %u blocks): stage %.0f tail %.0f window chains %.0f entry chains %.0f true chain %.0f | first wave, window chains: %.0f loop rounds, %.0f with starts\n", n,
+              acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[5] / n, acc[6] / n, acc[7] / n);
   }
   if (sort_dbg) {
     HIPCHK(hipMemsetAsync(g.dbg.p, 0, (size_t)nblk * 64, g.stream));

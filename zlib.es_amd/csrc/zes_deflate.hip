@@ -642,6 +642,7 @@ void zes_lazy_set_dbg(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBO
 #define LAZY_WIN 128u
 #define LAZY_NWIN (ZES_BLK / LAZY_WIN)
 #define LAZY_NONE 0xFFFFFFFFu
+#define LAZY_TAIL 512u  // positions at the block end that are evaluated up front, one lane each
 #ifndef LAZY_START_MIN
 #define LAZY_START_MIN 1u  // lanes that must be waiting before a batch of evaluations is started (measured: 1 best)
 #endif
@@ -653,6 +654,7 @@ struct LazySmem {
   uint32_t v1[ZES_BLK / 32];                      // positions on the window-start chains
   uint16_t xw[LAZY_NWIN];                         // chain of window w leaves it at 128 w + xw[w]
   uint16_t e2[LAZY_NWIN];                         // the chain entering at 128 u + xw[u] leaves that window at 128 u + e2[u]
+  uint16_t tail[LAZY_TAIL];                       // hop (1 or match length) of the block's last LAZY_TAIL keyed positions
   uint32_t wq;                                    // next work item to hand out
 };
 
@@ -681,10 +683,9 @@ __device__ __forceinline__ static uint32_t lazy_lcp(const uint32_t* in, uint32_t
 
 // Match at position p by the whole wavefront (p uniform): lane k takes candidate k of a round of 64.
 // Returns the match word (0 = literal).  Candidate order, early exits and tie rule of src/lz77.ts:49-95.
-__device__ static uint32_t lazy_wave_eval(const LazySmem& S, const uint32_t* __restrict__ idx, const uint2* __restrict__ inv, uint32_t p,
-                                          uint32_t T, uint32_t avail) {
+__device__ static uint32_t lazy_wave_eval(const LazySmem& S, const uint32_t* __restrict__ idx, const uint2 iv, uint32_t p, uint32_t T,
+                                          uint32_t avail) {
   const uint32_t lane = zes_lane();
-  const uint2 iv = inv[p];
   if (iv.y == LAZY_NONE) return 0u;  // no earlier position with this key
   const uint32_t r = iv.x;
   const uint32_t keyp = m_ld32u(S.in, p) & 0xffffffu;
@@ -796,8 +797,13 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match_lazy(const uint8_t* 
   __syncthreads();
 
   LSTAMP(1);
+  // ---- phase 0: the last positions of the block, one lane each.  A match that would run into the
+  // block's last three bytes is dropped whole (src/lz77.ts:95), so on repetitive data every position
+  // of the tail pays a full-length compare and stays a literal: as a chain that is 128 of them in a row.
   // ---- phases 1 and 2: one chain per lane, positions evaluated one after the other ----
-  for (uint32_t phase = 1; phase <= 2u; phase++) {
+  const uint32_t tbase = cnt > LAZY_TAIL ? cnt - LAZY_TAIL : 0u;  // first pre-evaluated position
+  for (uint32_t phase = 0; phase <= 2u; phase++) {
+    const uint32_t nitems = phase == 0u ? cnt - tbase : nwin;
     // lane state.  mode: 0 no chain, 5 chain standing at p, 6 p needs its match, 1 probing, 2 comparing, 3 match known
     uint32_t mode = 0, item = 0, p = 0, wend = 0;
     uint32_t best = 0, bestq = 0, check = 0, pprobe = 0, maxl = 0, keyp = 0, q = 0, cq = 0, cq2 = 0;
@@ -896,6 +902,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match_lazy(const uint8_t* 
       if (mode == 3u) {
         const bool acc = best >= 3u && p + best + 3u <= T;  // src/lz77.ts:95
         if (acc) mo[p] = ZES_TOK_MATCH | ((best - 3u) << 16) | (p - bestq - 1u);
+        if (phase == 0u) S.tail[item] = (uint16_t)(acc ? best : 1u);
         p += acc ? best : 1u;
         mode = 5u;
       }
@@ -904,7 +911,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match_lazy(const uint8_t* 
         const uint32_t w = (wend - 1u) / LAZY_WIN;  // the window being crossed
         if (p >= wend) {
           if (phase == 1u) S.xw[item] = (uint16_t)(p - item * LAZY_WIN);
-          else S.e2[item] = (uint16_t)(p - item * LAZY_WIN);
+          if (phase == 2u) S.e2[item] = (uint16_t)(p - item * LAZY_WIN);
           mode = 0u;
         } else if (phase == 2u && ((S.v1[p >> 5] >> (p & 31u)) & 1u)) {
           S.e2[item] = (uint16_t)(w * LAZY_WIN + S.xw[w] - item * LAZY_WIN);  // from here on it is window w's own chain
@@ -912,6 +919,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match_lazy(const uint8_t* 
         } else {
           if (phase == 1u) atomicOr(&S.v1[p >> 5], 1u << (p & 31u));
           if (p >= cnt) p += 1u;  // the block's last two bytes are always literals (src/lz77.ts:116-117)
+          else if (phase != 0u && p >= tbase) p += S.tail[p - tbase];  // evaluated in phase 0
           else mode = 6u;
         }
       }
@@ -923,11 +931,15 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match_lazy(const uint8_t* 
           const uint32_t nidle = (uint32_t)__popcll(idle);
           if (lane == 0) first = atomicAdd(&S.wq, nidle);
           first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
-          if (first >= nwin) drained = true;
+          if (first >= nitems) drained = true;
           const uint32_t mine = first + (uint32_t)__popcll(idle & zes_lanemask_lt());
-          if (mode == 0u && mine < nwin) {
+          if (mode == 0u && mine < nitems) {
             item = mine;
-            if (phase == 1u) {
+            if (phase == 0u) {
+              p = tbase + item;
+              wend = p + 1u;
+              mode = 6u;
+            } else if (phase == 1u) {
               p = item * LAZY_WIN;
               wend = min(p + LAZY_WIN, T);
               mode = 5u;
@@ -945,11 +957,11 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match_lazy(const uint8_t* 
       }
     }
     if (g_lazy_dbg && tid == 0 && phase == 1u) {
-      g_lazy_dbg[(size_t)blockIdx.x * 8 + 5] = niter;
-      g_lazy_dbg[(size_t)blockIdx.x * 8 + 6] = nstart;
+      g_lazy_dbg[(size_t)blockIdx.x * 8 + 6] = niter;
+      g_lazy_dbg[(size_t)blockIdx.x * 8 + 7] = nstart;
     }
     __syncthreads();
-    LSTAMP(1 + phase);
+    LSTAMP(2 + phase);
     if (tid == 0) S.wq = 0;
     __syncthreads();
   }
@@ -957,6 +969,11 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match_lazy(const uint8_t* 
   // ---- phase 3: the true chain, by one wavefront ----
   if (wave == 0) {
     uint32_t p = 0;
+    // chains of maximal matches (periodic data) are evaluated here one position after the other: the
+    // table entry of p + 258 is requested while p is being looked at
+    uint32_t spec_p = LAZY_NONE;
+    uint2 spec_iv = make_uint2(0u, 0u);
+    uint32_t keep_p = 0, keep_m = 0, nkeep = 0;
     while (p < cnt) {
       const uint32_t w = p / LAZY_WIN;
       uint32_t np = 0;
@@ -972,15 +989,34 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match_lazy(const uint8_t* 
             break;
           }
         }
+        if (!found && p >= tbase) {
+          np = p + S.tail[p - tbase];  // evaluated in phase 0
+          found = true;
+        }
         if (!found) {  // nobody evaluated this position yet
-          const uint32_t m = lazy_wave_eval(S, idx, inv, p, T, avail);
-          if (m && lane == 0) mo[p] = m;
+          const uint2 iv = (p == spec_p) ? spec_iv : inv[p];
+          spec_p = min(p + ZES_MAXMATCH, cnt - 1u);
+          spec_iv = inv[spec_p];
+          const uint32_t m = lazy_wave_eval(S, idx, iv, p, T, avail);
+          // results are parked in registers, one per lane, and stored 64 at a time: a store followed by
+          // the next table load would make every evaluation wait for the store to complete
+          if (m) {
+            if (lane == nkeep) {
+              keep_p = p;
+              keep_m = m;
+            }
+            if (++nkeep == 64u) {
+              mo[keep_p] = keep_m;
+              nkeep = 0;
+            }
+          }
           np = p + ((m & ZES_TOK_MATCH) ? zes_tok_len(m) : 1u);
         }
       }
       p = np > p ? np : p + 1u;  // (np > p always; the guard only keeps a corrupted table from hanging the wavefront)
     }
-    LSTAMP(4);
+    if (lane < nkeep) mo[keep_p] = keep_m;
+    LSTAMP(5);
   }
 }
 
