@@ -78,6 +78,19 @@ int zes_inflate_dev(const uint8_t* d_in, uint64_t c, uint8_t* d_out, uint64_t ca
  * result the way the reference's growable Uint8WriteStream (src/utils/Uint8WriteStream.ts:1-25) does. */
 int zes_inflate_size(const uint8_t* in, uint64_t c, uint64_t* n, uint32_t flags);
 
+/* Raw DEFLATE, without the zlib wrapper, for callers that embed DEFLATE in another container.
+ * zes_deflate_raw*  replaces: `export function deflate(input)` of src/deflate.ts:14-39 (what src/zlib.ts:35 wraps):
+ *                   the same bytes as zes_deflate minus the 2-byte header and the 4-byte Adler-32 trailer.
+ * zes_inflate_raw*  replaces: `export function inflate(input, offset = 0)` of src/inflate.ts:16-40: decodes the raw
+ *                   stream that starts at byte `offset` of the c-byte buffer (bytes after the stream stay readable,
+ *                   exactly as for the reference, whose zlib wrapper calls this with offset 2, src/zlib.ts:21).
+ * Same statuses as the wrapped forms; there is no CM-nibble check on this path. */
+int zes_deflate_raw(const uint8_t* in, uint64_t n, uint8_t* out, uint64_t cap, uint64_t* out_len);
+int zes_deflate_raw_dev(const uint8_t* d_in, uint64_t n, uint8_t* d_out, uint64_t cap, uint64_t* out_len);
+int zes_inflate_raw(const uint8_t* in, uint64_t c, uint64_t offset, uint8_t* out, uint64_t cap, uint64_t* out_len, uint32_t flags);
+int zes_inflate_raw_dev(const uint8_t* d_in, uint64_t c, uint64_t offset, uint8_t* d_out, uint64_t cap, uint64_t* out_len,
+                        uint32_t flags);
+
 /* Adler-32 of a buffer (standard value as an unsigned 32-bit).
  * replaces: `calcAdler32` src/adler32.ts:1-10 (byte extraction at src/zlib.ts:37-40). */
 int zes_adler32(const uint8_t* in, uint64_t n, uint32_t* adler);

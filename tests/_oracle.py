@@ -39,6 +39,7 @@ def lib():
         L.zor_deflate.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, u64p]
         L.zor_inflate.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p), u64p]
         L.zor_inflate_raw.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p), u64p]
+        L.zor_deflate_raw.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, u64p]
         L.zor_lz77_block.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, u32p]
         L.zor_huff_lengths.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.zor_free.argtypes = [C.c_void_p]
@@ -86,6 +87,30 @@ def inflate(data):
     out = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(max(n.value, 1),))[: n.value].copy()
     lib().zor_free(p)
     return out
+
+
+def inflate_raw(data, offset=0):
+    a = _as_u8(data)
+    p = C.c_void_p()
+    n = C.c_uint64()
+    rc = lib().zor_inflate_raw(a.ctypes.data, a.size, offset, C.byref(p), C.byref(n))
+    if rc:
+        raise OracleError(rc)
+    out = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(max(n.value, 1),))[: n.value].copy()
+    lib().zor_free(p)
+    return out
+
+
+def deflate_raw(data):
+    a = _as_u8(data)
+    cap = C.c_uint64()
+    lib().zor_deflate_bound(a.size, C.byref(cap))
+    out = np.empty(cap.value, dtype=np.uint8)
+    n = C.c_uint64()
+    rc = lib().zor_deflate_raw(a.ctypes.data, a.size, out.ctypes.data, cap.value, C.byref(n))
+    if rc:
+        raise OracleError(rc)
+    return out[: n.value].copy()
 
 
 def lz77_block(data, start, length):

@@ -54,6 +54,11 @@ it('result is an exact-size Uint8Array', () => {
 it('Buffer input', () => assert.strictEqual(hex(zlibes.deflate(Buffer.from(RAW))), kat.small.RAW.deflate));
 // thrown messages (SURVEY §8b)
 function throwsMsg(f, msg) { assert.throws(f, (e) => e instanceof Error && e.message === msg); }
+// raw forms (src/deflate.ts:14, src/inflate.ts:16)
+it('deflateRaw == deflate without wrapper', () => assert.strictEqual(hex(zlibes.deflateRaw(RAW)), kat.small.RAW.deflate.slice(4, -8)));
+it('deflateRaw -> node zlib inflateRaw', () => assert.ok(nodeZlib.inflateRawSync(Buffer.from(zlibes.deflateRaw(RAW_BIN))).equals(Buffer.from(RAW_BIN))));
+it('inflateRaw(zlib stream, 2)', () => assert.deepStrictEqual(zlibes.inflateRaw(fromHex(kat.kat.DYNAMIC), 2), RAW));
+it('inflateRaw(raw)', () => assert.ok(Buffer.from(zlibes.inflateRaw(zlibes.deflateRaw(RAW_BIN))).equals(Buffer.from(RAW_BIN))));
 it('deflate(empty) throws', () => throwsMsg(() => zlibes.deflate(new Uint8Array(0)), 'Data is corrupted'));
 it('deflate(1 byte) throws', () => throwsMsg(() => zlibes.deflate(new Uint8Array(1)), 'Data is corrupted'));
 it('inflate(empty) throws', () => throwsMsg(() => zlibes.inflate(new Uint8Array(0)), 'Not compressed by deflate'));

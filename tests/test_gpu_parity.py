@@ -182,6 +182,26 @@ def test_inflate_batch_api(z, oracle, gpu):
     assert status[len(raws)] == -1 and status[len(raws) + 1] == -2
 
 
+def test_raw_deflate_and_offset_inflate_entry_points(z, oracle, gpu):
+    """src/deflate.ts:14 and src/inflate.ts:16: the raw forms the zlib wrapper of src/zlib.ts encloses."""
+    for kind, seed, n in (("itext", 71, 200000), ("xorshift", 72, 131073 + 5), ("lowent4k", 73, 300001), ("itext", 74, 2)):
+        a = z.gen(kind, seed, n)
+        raw = z.deflate_raw(a)
+        assert raw.tobytes() == oracle.deflate_raw(a).tobytes() == oracle.deflate(a)[2:-4].tobytes()
+        assert z.inflate_raw(raw).tobytes() == a.tobytes()
+        # embedded in a container: 7 foreign bytes in front, 9 behind (stay readable, like the zlib trailer)
+        boxed = np.concatenate([np.arange(7, dtype=np.uint8), raw, np.full(9, 0xEE, dtype=np.uint8)])
+        assert z.inflate_raw(boxed, 7).tobytes() == oracle.inflate_raw(boxed, 7).tobytes() == a.tobytes()
+    with pytest.raises(z.ZlibEsError, match="Data is corrupted"):
+        z.deflate_raw(np.zeros(1, dtype=np.uint8))
+    # the raw path has no CM-nibble check: garbage is reported by the decoder itself, as by the reference
+    junk = np.frombuffer(bytes([0x07, 0, 0, 0]), dtype=np.uint8)  # BFINAL=1, BTYPE=3
+    with pytest.raises(z.ZlibEsError, match="Not supported BTYPE : 3"):
+        z.inflate_raw(junk)
+    with pytest.raises(oracle.OracleError):
+        oracle.inflate_raw(junk)
+
+
 def test_deflate_capacity_is_checked(z, gpu):
     import torch
 

@@ -80,6 +80,10 @@ def lib():
         for name in ("zes_inflate", "zes_inflate_dev"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, u64p, C.c_uint32]
         L.zes_inflate_size.argtypes = [C.c_void_p, C.c_uint64, u64p, C.c_uint32]
+        for name in ("zes_deflate_raw", "zes_deflate_raw_dev"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, u64p]
+        for name in ("zes_inflate_raw", "zes_inflate_raw_dev"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, u64p, C.c_uint32]
         L.zes_adler32.argtypes = [C.c_void_p, C.c_uint64, u32p]
         L.zes_adler32_dev.argtypes = [C.c_void_p, C.c_uint64, u32p]
         L.zes_deflate_batch_dev.argtypes = [C.c_void_p, u64p, u64p, C.c_void_p, u64p, u64p, u64p, i32p, C.c_uint32]
@@ -165,6 +169,35 @@ def inflate(data, flags=0):
     if rc:
         _raise(rc)
     return out[: n.value].copy()
+
+
+def deflate_raw(data):
+    """Raw DEFLATE: ``deflate(input)`` of src/deflate.ts:14 (what the zlib wrapper of src/zlib.ts:25 encloses)."""
+    a = _as_u8(data)
+    cap = deflate_bound(a.size)
+    out = np.empty(cap, dtype=np.uint8)
+    n = C.c_uint64()
+    rc = lib().zes_deflate_raw(a.ctypes.data, a.size, out.ctypes.data, cap, C.byref(n))
+    if rc:
+        _raise(rc)
+    return out[: n.value].copy()
+
+
+def inflate_raw(data, offset=0, flags=0):
+    """Raw inflate from byte ``offset``: ``inflate(input, offset)`` of src/inflate.ts:16."""
+    a = _as_u8(data)
+    cap = max(a.size * 8, 1 << 16)
+    for _ in range(8):
+        out = np.empty(cap, dtype=np.uint8)
+        n = C.c_uint64()
+        rc = lib().zes_inflate_raw(a.ctypes.data, a.size, offset, out.ctypes.data, cap, C.byref(n), flags)
+        if rc == ZES_E_NOSPACE and n.value > cap:
+            cap = n.value
+            continue
+        if rc:
+            _raise(rc)
+        return out[: n.value].copy()
+    _raise(ZES_E_DEVICE)
 
 
 def adler32(data):

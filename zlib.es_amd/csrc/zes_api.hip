@@ -830,6 +830,104 @@ int zes_adler32_dev(const uint8_t* d_in, uint64_t n, uint32_t* adler_out) {
   return ZES_OK;
 }
 
+// ---- raw DEFLATE (src/deflate.ts:14, src/inflate.ts:16): thin forms over the wrapped pipeline ----
+// The raw stream is decoded as the body of a zlib stream whose two header bytes are supplied here; it is
+// copied device-to-device behind them so that the kernels keep their aligned dword view of the input.
+static int inflate_raw_staged(uint64_t n, uint8_t* d_out, uint64_t cap, uint64_t* out_len, uint32_t flags) {
+  HIPCHK(hipMemsetAsync(g.st_in.p, 0x78, 1, g.stream));
+  HIPCHK(hipMemsetAsync((uint8_t*)g.st_in.p + 1, 0x9C, 1, g.stream));
+  return inflate_one((const uint8_t*)g.st_in.p, 0, n + 2, d_out, 0, cap, out_len, flags, 0x78);
+}
+
+int zes_inflate_raw_dev(const uint8_t* d_in, uint64_t c, uint64_t offset, uint8_t* d_out, uint64_t cap, uint64_t* out_len,
+                        uint32_t flags) {
+  if (!out_len || (!d_in && c)) return ZES_E_ARG;
+  if ((((uintptr_t)d_out) & 15u)) return ZES_E_ARG;
+  std::lock_guard<std::mutex> lk(g_mu);
+  int rc = init_locked(-1);
+  if (rc) return rc;
+  const uint64_t n = offset < c ? c - offset : 0;
+  if ((rc = ensure(g.st_in, n + 2 + 64))) return rc;
+  if (n) HIPCHK(hipMemcpyAsync((uint8_t*)g.st_in.p + 2, d_in + offset, n, hipMemcpyDeviceToDevice, g.stream));
+  return inflate_raw_staged(n, d_out, cap, out_len, flags);
+}
+
+int zes_inflate_raw(const uint8_t* in, uint64_t c, uint64_t offset, uint8_t* out, uint64_t cap, uint64_t* out_len, uint32_t flags) {
+  if (!out_len || (!in && c)) return ZES_E_ARG;
+  *out_len = 0;
+  std::lock_guard<std::mutex> lk(g_mu);
+  int rc = init_locked(-1);
+  if (rc) return rc;
+  const uint64_t n = offset < c ? c - offset : 0;
+  if ((rc = ensure(g.st_in, n + 2 + 64))) return rc;
+  if (n) HIPCHK(hipMemcpyAsync((uint8_t*)g.st_in.p + 2, in + offset, n, hipMemcpyHostToDevice, g.stream));
+  // decode into pooled device memory: grow-and-retry like the reference's Uint8WriteStream
+  uint64_t dcap = std::max<uint64_t>(cap, std::max<uint64_t>(n * 4, 1 << 20));
+  for (int attempt = 0; attempt < 8; attempt++) {
+    if ((rc = ensure(g.st_out, dcap + 64))) return rc;
+    uint64_t m = 0;
+    rc = inflate_raw_staged(n, (uint8_t*)g.st_out.p, dcap, &m, flags);
+    if (rc == ZES_E_NOSPACE && m > dcap) {
+      dcap = m;
+      continue;
+    }
+    if (rc) return rc;
+    *out_len = m;
+    if (m > cap) return ZES_E_NOSPACE;
+    if (m) HIPCHK(hipMemcpyAsync(out, g.st_out.p, m, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return ZES_OK;
+  }
+  return ZES_E_DEVICE;
+}
+
+static int deflate_raw_common(const uint8_t* d_in, uint64_t n, uint64_t* raw_len) {
+  const uint64_t bound = deflate_bound(n);
+  int rc;
+  if ((rc = ensure(g.st_out, bound + 64))) return rc;
+  uint64_t zero = 0, dl = 0;
+  int32_t st = 0;
+  rc = deflate_batch_core(d_in, &zero, &n, (uint8_t*)g.st_out.p, &zero, &bound, &dl, &st, 1);
+  if (rc) return rc;
+  if (st) return st;
+  *raw_len = dl - 6;  // without 78 9C and the Adler-32 trailer (src/zlib.ts:28-46)
+  return ZES_OK;
+}
+
+int zes_deflate_raw_dev(const uint8_t* d_in, uint64_t n, uint8_t* d_out, uint64_t cap, uint64_t* out_len) {
+  if (!out_len || !d_out) return ZES_E_ARG;
+  *out_len = 0;
+  if (deflate_throws(n)) return ZES_E_CORRUPT;
+  std::lock_guard<std::mutex> lk(g_mu);
+  int rc = init_locked(-1);
+  if (rc) return rc;
+  uint64_t rl = 0;
+  if ((rc = deflate_raw_common(d_in, n, &rl))) return rc;
+  *out_len = rl;
+  if (rl > cap) return ZES_E_NOSPACE;
+  HIPCHK(hipMemcpyAsync(d_out, (const uint8_t*)g.st_out.p + 2, rl, hipMemcpyDeviceToDevice, g.stream));
+  HIPCHK(hipStreamSynchronize(g.stream));
+  return ZES_OK;
+}
+
+int zes_deflate_raw(const uint8_t* in, uint64_t n, uint8_t* out, uint64_t cap, uint64_t* out_len) {
+  if (!out_len || (!in && n) || !out) return ZES_E_ARG;
+  *out_len = 0;
+  if (deflate_throws(n)) return ZES_E_CORRUPT;
+  std::lock_guard<std::mutex> lk(g_mu);
+  int rc = init_locked(-1);
+  if (rc) return rc;
+  if ((rc = ensure(g.st_in, n + 64))) return rc;
+  HIPCHK(hipMemcpyAsync(g.st_in.p, in, n, hipMemcpyHostToDevice, g.stream));
+  uint64_t rl = 0;
+  if ((rc = deflate_raw_common((const uint8_t*)g.st_in.p, n, &rl))) return rc;
+  *out_len = rl;
+  if (rl > cap) return ZES_E_NOSPACE;
+  HIPCHK(hipMemcpyAsync(out, (const uint8_t*)g.st_out.p + 2, rl, hipMemcpyDeviceToHost, g.stream));
+  HIPCHK(hipStreamSynchronize(g.stream));
+  return ZES_OK;
+}
+
 int zes_adler32(const uint8_t* in, uint64_t n, uint32_t* adler_out) {
   if (!adler_out || (!in && n)) return ZES_E_ARG;
   {

@@ -99,6 +99,58 @@ napi_value Inflate(napi_env env, napi_callback_info info) {
   return ta;
 }
 
+// deflateRaw(input): the raw stream of the reference's src/deflate.ts:14 (no zlib wrapper)
+napi_value DeflateRaw(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr);
+  const uint8_t* in = nullptr;
+  size_t n = 0;
+  if (argc < 1 || !get_bytes(env, argv[0], &in, &n)) {
+    napi_throw_type_error(env, nullptr, "deflateRaw(input): input must be a Uint8Array");
+    return nullptr;
+  }
+  uint64_t cap = 0, out_len = 0;
+  zes_deflate_bound(n, &cap);
+  uint8_t* tmp = static_cast<uint8_t*>(malloc(cap));
+  if (!tmp) return throw_status(env, ZES_E_ARG);
+  const int rc = zes_deflate_raw(in, n, tmp, cap, &out_len);
+  napi_value res = rc ? throw_status(env, rc) : make_u8(env, tmp, out_len);
+  free(tmp);
+  return res;
+}
+
+// inflateRaw(input, offset = 0): the reference's src/inflate.ts:16 (what src/zlib.ts:21 calls with offset 2)
+napi_value InflateRaw(napi_env env, napi_callback_info info) {
+  size_t argc = 2;
+  napi_value argv[2];
+  napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr);
+  const uint8_t* in = nullptr;
+  size_t c = 0;
+  if (argc < 1 || !get_bytes(env, argv[0], &in, &c)) {
+    napi_throw_type_error(env, nullptr, "inflateRaw(input, offset): input must be a Uint8Array");
+    return nullptr;
+  }
+  uint32_t offset = 0;
+  if (argc >= 2) napi_get_value_uint32(env, argv[1], &offset);
+  // grow-and-retry like the reference's Uint8WriteStream (src/utils/Uint8WriteStream.ts:13-21)
+  uint64_t cap = c * 4 + 65536, out_len = 0;
+  for (int attempt = 0; attempt < 8; attempt++) {
+    uint8_t* tmp = static_cast<uint8_t*>(malloc(cap));
+    if (!tmp) return throw_status(env, ZES_E_ARG);
+    const int rc = zes_inflate_raw(in, c, offset, tmp, cap, &out_len, ZES_F_DEFAULT);
+    if (rc == ZES_E_NOSPACE && out_len > cap) {
+      free(tmp);
+      cap = out_len;
+      continue;
+    }
+    napi_value res = rc ? throw_status(env, rc) : make_u8(env, tmp, out_len);
+    free(tmp);
+    return res;
+  }
+  return throw_status(env, ZES_E_DEVICE);
+}
+
 napi_value Adler32(napi_env env, napi_callback_info info) {
   size_t argc = 1;
   napi_value argv[1];
@@ -134,6 +186,8 @@ napi_value ModuleInit(napi_env env, napi_value exports) {
   napi_property_descriptor props[] = {
       {"deflate", nullptr, Deflate, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"inflate", nullptr, Inflate, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"deflateRaw", nullptr, DeflateRaw, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"inflateRaw", nullptr, InflateRaw, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"adler32", nullptr, Adler32, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"init", nullptr, Init, nullptr, nullptr, nullptr, napi_default, nullptr},
   };

@@ -21,6 +21,19 @@ function deflate(input) {
   return addon.deflate(input);
 }
 
+/**
+ * The raw forms the wrapper above encloses, for callers that keep DEFLATE inside another container:
+ * `deflateRaw` is the reference's internal `deflate(input)` (src/deflate.ts:14), `inflateRaw` its
+ * `inflate(input, offset = 0)` (src/inflate.ts:16) — not exported by the reference's package entry.
+ */
+function deflateRaw(input) {
+  return addon.deflateRaw(input);
+}
+
+function inflateRaw(input, offset) {
+  return addon.inflateRaw(input, offset);
+}
+
 /** Extra (not in the reference API): Adler-32 of a buffer, computed on the GPU. */
 function adler32(input) {
   return addon.adler32(input);
@@ -33,5 +46,7 @@ function init(device) {
 
 exports.inflate = inflate;
 exports.deflate = deflate;
+exports.deflateRaw = deflateRaw;
+exports.inflateRaw = inflateRaw;
 exports.adler32 = adler32;
 exports.init = init;

@@ -19,6 +19,19 @@ export function deflate(input: Uint8Array): Uint8Array {
   return addon.deflate(input);
 }
 
+/**
+ * The raw forms the wrapper above encloses, for callers that keep DEFLATE inside another container:
+ * `deflateRaw` is the reference's internal `deflate(input)` (src/deflate.ts:14), `inflateRaw` its
+ * `inflate(input, offset = 0)` (src/inflate.ts:16) — not exported by the reference's package entry.
+ */
+export function deflateRaw(input: Uint8Array): Uint8Array {
+  return addon.deflateRaw(input);
+}
+
+export function inflateRaw(input: Uint8Array, offset: number = 0): Uint8Array {
+  return addon.inflateRaw(input, offset);
+}
+
 /** Extra (not in the reference API): Adler-32 of a buffer, computed on the GPU. */
 export function adler32(input: Uint8Array): number {
   return addon.adler32(input);
