@@ -321,6 +321,28 @@ def test_inflate_false_candidate_inside_a_block_stays_block_parallel(z, oracle, 
     assert launches.get("k_inf_block_par") == 2  # the remapped pass ran: the false candidate was really there
 
 
+def test_inflate_mostly_8bit_codes_with_other_tokens_mixed_in(z, oracle, gpu):
+    """The block decoder's fast paths for 8-bit literal codes must hand over to the
+    generic construction when a segment holds more other tokens than its list takes, and must agree
+    with it when matches and shorter codes are sprinkled in."""
+    import torch
+
+    rnd = z.gen("xorshift", 81, 600000).copy()
+    a = rnd.copy()
+    a[::7] = 0                                   # one byte value gets a short code: many non-8-bit tokens per segment
+    b = rnd.copy()
+    for k in range(40, len(b) - 200, 997):       # copies of earlier data: matches between long literal runs
+        b[k:k + 37] = b[k - 31:k + 6]
+    c = rnd.copy()
+    c[300000:] = z.gen("itext", 82, 300000)      # a block of each kind, and one that changes in the middle
+    for data in (a, b, c):
+        comp = dev(oracle.deflate(data), gpu)
+        out = torch.empty(len(data), dtype=torch.uint8, device=gpu)
+        back = z.inflate_tensor(comp, out)
+        assert back.numel() == len(data) and (back.cpu().numpy() == data).all()
+        assert z.last_inflate_tier() == 1
+
+
 # ---------------------------------------------------------------------------------------------
 # BASELINE.json sizes: 64 MiB, pinned by sha256 of the reference's own output + round trip
 # ---------------------------------------------------------------------------------------------

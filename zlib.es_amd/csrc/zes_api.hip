@@ -449,7 +449,7 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
   if (dbg) {  // average shader-clock cycles per phase of k_inf_block_par
     std::vector<unsigned long long> h((size_t)work * 16);
     HIPCHK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
-    double acc[8] = {0}, t0[3] = {0}, t15[3] = {0};
+    double acc[8] = {0}, t0[3] = {0}, t15[3] = {0}, fb_lanes = 0, fb_waves = 0;
     uint32_t cntd = 0;
     for (uint32_t i = 0; i < work; i++) {
       const unsigned long long* r = &h[(size_t)i * 16];
@@ -460,11 +460,14 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
         t0[k] += (double)(r[8 + k] - r[1]);
         t15[k] += (double)(r[12 + k] - r[1]);
       }
+      fb_lanes += (double)r[11];
+      fb_waves += (double)r[15];
     }
     fprintf(stderr, "zes phases (avg cycles over %u blocks): hdr %.0f tables %.0f compose %.0f count %.0f emit %.0f resolve %.0f flush %.0f\n",
             cntd, acc[1] / cntd, acc[2] / cntd, acc[3] / cntd, acc[4] / cntd, acc[5] / cntd, acc[6] / cntd, acc[7] / cntd);
     fprintf(stderr, "zes table steps, cycles since the header: first wave window %.0f landing %.0f fill %.0f | last wave %.0f %.0f %.0f\n",
             t0[0] / cntd, t0[1] / cntd, t0[2] / cntd, t15[0] / cntd, t15[1] / cntd, t15[2] / cntd);
+    fprintf(stderr, "zes 8-bit table path: %.2f lanes in %.2f waves per block fell back to the generic construction\n", fb_lanes / cntd, fb_waves / cntd);
   }
   if (getenv("ZES_DEBUG")) {
     for (uint32_t i = 0, shown_b = 0; i < nbuf && shown_b < 4; i++) {

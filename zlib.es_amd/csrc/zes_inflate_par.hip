@@ -357,9 +357,164 @@ __device__ __forceinline__ static uint32_t win_bits(uint32_t a0, uint32_t a1, ui
 
 // one step of a predicated trajectory: lanes with act decode one token at b.pos (count-free)
 // returns: 0 continue, C_EOB, C_FAIL (as code+1000 so 0 stays "continue")
+// ------------------------------------------------------------------------------------------
+// Transfer table of a segment when nearly every literal has an 8-bit code (incompressible data).
+// There the eight bit phases never merge, and the generic construction below decodes the segment
+// eight times, token by token.  Instead:
+//  (A) one regular pass over the segment's dwords tests every bit position for "an 8-bit literal
+//      code starts here" — four positions of one phase per SWAR range test on the bit-reversed
+//      dword — and keeps the few positions that fail (other code lengths, matches, end of block:
+//      about nine per segment on random data) in a 32-entry list in registers;
+//  (B) a trajectory then runs along its phase straight to the next listed position (or to the
+//      segment end), takes that one token the generic way, and goes on; every entry offset it
+//      passes gets its exit code, so eight trajectories (plus one per listed position inside the
+//      entry zone) settle all 48 entries.
+// Returns false for a lane that must use the generic construction (list overflow, data end near).
+// ------------------------------------------------------------------------------------------
+#define F8_MAXSEG 1800u  // longest segment (bits) the 11-bit list entries and the scan loop are sized for
+#define F8_LIST 32u
+struct F8List {
+  // thirty-two u16 positions relative to the segment base, four per word, 0xFFFF = empty (named fields: see SegTab)
+  uint64_t q0, q1, q2, q3, q4, q5, q6, q7;
+};
+// store a group of four positions as word k of the list
+__device__ __forceinline__ static void f8_flush(F8List& l, uint32_t k, uint64_t grp) {
+  l.q0 = (k == 0u) ? grp : l.q0;
+  l.q1 = (k == 1u) ? grp : l.q1;
+  l.q2 = (k == 2u) ? grp : l.q2;
+  l.q3 = (k == 3u) ? grp : l.q3;
+  l.q4 = (k == 4u) ? grp : l.q4;
+  l.q5 = (k == 5u) ? grp : l.q5;
+  l.q6 = (k == 6u) ? grp : l.q6;
+  l.q7 = (k == 7u) ? grp : l.q7;
+}
+// smallest listed position q >= x on x's bit phase (0xFFFF if none)
+__device__ __forceinline__ static uint32_t f8_next(const F8List& l, uint64_t tail, uint32_t x) {
+  uint32_t nx = 0xFFFFu;
+#define F8_ONE(q)                                                  \
+  {                                                                \
+    const uint32_t qq = (q);                                       \
+    const bool hit = (((qq - x) & 7u) == 0u) && qq >= x && qq < nx; \
+    nx = hit ? qq : nx;                                            \
+  }
+#define F8_FOUR(r)                                                                                       \
+  F8_ONE((uint32_t)(r) & 0xFFFFu) F8_ONE(((uint32_t)(r)) >> 16) F8_ONE((uint32_t)((r) >> 32) & 0xFFFFu) \
+  F8_ONE((uint32_t)((r) >> 48))
+  F8_FOUR(l.q0) F8_FOUR(l.q1) F8_FOUR(l.q2) F8_FOUR(l.q3) F8_FOUR(l.q4) F8_FOUR(l.q5) F8_FOUR(l.q6) F8_FOUR(l.q7) F8_FOUR(tail)
+#undef F8_FOUR
+#undef F8_ONE
+  return nx;
+}
+
+__device__ __forceinline__ static bool seg_table_f8(ParSmem& S, const BitSrc& src, uint32_t limit, uint32_t base, uint32_t stop,
+                                                    const Lit8& f8, SegTab& tab) {
+  const uint32_t sl = stop - base;
+  bool ok = sl >= 64u && sl <= F8_MAXSEG && stop + 128u <= limit;  // every bit the scan looks at is data
+  // ---- (A) positions where no 8-bit literal code starts ----
+  // per byte of the bit-reversed dword: t = byte - lo (mod 256); the byte is a literal code iff t < n.
+  // With m = 256 - n <= 128: t >= n  <=>  bit7(t) and bit7((t & 0x7f) + m)   (no carries between bytes)
+  const uint32_t H = 0x80808080u;
+  const uint32_t LO = f8.lo * 0x01010101u, M = (256u - f8.n) * 0x01010101u;
+  const uint32_t LOm = LO & ~H, nLO = ~LO;
+  F8List li = {~0ull, ~0ull, ~0ull, ~0ull, ~0ull, ~0ull, ~0ull, ~0ull};
+  uint64_t grp = ~0ull;  // the last up to four positions, newest in the low 16 bits; goes to the list when full
+  uint32_t nl = 0;
+  const uint32_t d0 = base >> 5, bo = base & 31u;
+  const uint32_t nd = (sl + 48u + 62u) >> 5;  // dwords that cover [base, stop + 48) for any alignment (uniform)
+  uint32_t lo = src_ldw<true>(src, d0);
+#pragma unroll 1
+  for (uint32_t j = 0; j < nd; j++) {
+    const uint32_t hi = src_ldw<true>(src, d0 + j + 1u);
+    uint32_t bad = 0;  // bit b: no 8-bit literal code starts at bit 32 j + b
+#pragma unroll
+    for (uint32_t phi = 0; phi < 8u; phi++) {
+      const uint32_t x = __brev(__builtin_amdgcn_alignbit(hi, lo, phi));  // top byte = the token at bit 32 j + phi
+      const uint32_t t = ((x | H) - LOm) ^ ((x ^ nLO) & H);
+      const uint32_t inv = t & ((t & ~H) + M) & H;  // bit 31 - 8k: token k of this phase
+      bad |= (__brev(inv) << phi);                   // -> bit phi + 8k
+    }
+    while (__ballot(bad != 0u)) {  // about a quarter of the lanes have one per dword on random data
+      const bool hv = bad != 0u;
+      const uint32_t bpos = hv ? (uint32_t)__builtin_ctz(bad) : 0u;
+      bad &= bad - 1u;
+      const uint32_t rel = 32u * j + bpos - bo;  // wraps for positions in front of the segment
+      const bool take = hv && rel < sl + 48u;
+      grp = take ? ((grp << 16) | rel) : grp;
+      nl += take ? 1u : 0u;
+      const bool full = take && (nl & 3u) == 0u;
+      if (__ballot(full)) {
+        if (full && nl <= F8_LIST) f8_flush(li, (nl >> 2) - 1u, grp);
+        grp = full ? ~0ull : grp;
+      }
+    }
+    lo = hi;
+  }
+  ok = ok && nl <= F8_LIST;
+  // ---- (B) trajectories ----
+  SegTab t = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t pend = (1ull << 48) - 1ull;
+  while (__ballot(ok && pend != 0ull)) {
+    const bool run = ok && pend != 0ull;
+    uint32_t x = run ? (uint32_t)__builtin_ctzll(pend) : 0u;
+    uint64_t vis = 0;
+    uint32_t code = C_FAIL;
+    bool act = run;
+    while (__ballot(act)) {
+      const uint32_t nx = f8_next(li, grp, x);
+      if (act && x < 48u) {  // entry offsets this stretch of the trajectory passes: x, x+8, ... up to the listed position
+        const uint32_t top = min(nx + 1u, 48u);
+        vis |= (0x0101010101010101ull << x) & ((1ull << top) - 1ull);
+      }
+      const bool through = act && nx >= sl;  // nothing listed before the segment ends: 8-bit literals all the way
+      if (through) {
+        code = ((sl - x + 7u) & ~7u) - (sl - x);  // first token start at or past the end, minus the end
+        act = false;
+      }
+      if (__ballot(act)) {  // one token the generic way, at the listed position
+        LaneBits b;
+        lb_seek<true>(b, src, base + (act ? nx : 0u));
+        uint32_t adv;
+        bool eob, bad;
+        len_step(S, src, b, act, adv, eob, bad);
+        x = act ? (b.pos - base) + adv : x;  // (len_step leaves b behind a match's length part, adv = the rest)
+        if (act && eob) {
+          code = C_EOB;
+          act = false;
+        }
+        if (act && bad) {
+          code = C_FAIL;
+          act = false;
+        }
+        if (act && x >= sl) {
+          code = x - sl;
+          act = false;
+        }
+      }
+    }
+    pend &= run ? ~vis : ~0ull;
+    while (__ballot(run && vis != 0ull)) {
+      const bool w = run && vis != 0ull;
+      const uint32_t e = w ? (uint32_t)__builtin_ctzll(vis) : 0u;
+      vis &= vis - 1ull;
+      if (w) tab_set(t, e, code);
+    }
+  }
+  tab = t;
+  return ok;
+}
+
 template <bool LDS>
 __device__ __forceinline__ static void seg_table(ParSmem& S, const BitSrc& src, uint32_t limit, uint32_t base, uint32_t stop,
                                                  const Lit8& f8, SegTab& tab, unsigned long long* dp) {
+  if (LDS && f8.n) {  // uniform: most literals have 8-bit codes
+    const bool done = seg_table_f8(S, src, limit, base, stop, f8, tab);
+    const uint64_t redo = __ballot(!done);
+    if (dp && redo && zes_lane() == 0) {  // ZES_DEBUG_PHASES: lanes / waves that fell back
+      atomicAdd(&dp[11], (unsigned long long)__popcll(redo));
+      atomicAdd(&dp[15], 1ull);
+    }
+    if (!redo) return;  // a wave with a lane that could not use it redoes the segment tables the generic way
+  }
   // debug stamps (ZES_DEBUG_PHASES): slots 8..10 by the first wave of the workgroup, 12..14 by the last one
 #define TSTAMP(i)                                                                   \
   do {                                                                              \
