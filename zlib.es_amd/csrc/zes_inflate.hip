@@ -123,6 +123,10 @@ __global__ __launch_bounds__(INF_SCAN_THREADS) void k_inf_scan(const uint8_t* __
       const uint64_t hi = w1 >> i;
       const uint32_t ncl = (uint32_t)((lo >> 13) & 15u) + 4u;
       const uint64_t clb = ((lo >> 17) | (hi << 47)) & ((1ull << (3u * ncl)) - 1ull);  // ncl x 3 bits, up to 57
+      // The reference sends exactly as many code-length-code lengths as reach its last used symbol
+      // (src/deflate.ts:143-148), so the last one is never zero.  T1 only has to find reference-made
+      // blocks: a stream from an encoder that pads this list is still decoded, by T2.
+      if (((clb >> (3u * ncl - 3u)) & 7ull) == 0ull) continue;
       const uint32_t c_lo = (uint32_t)clb, c_hi = (uint32_t)(clb >> 32);
       const uint32_t kraft = (uint32_t)s_kraft[c_lo & 4095u] + s_kraft[(c_lo >> 12) & 4095u] +
                              s_kraft[((c_lo >> 24) | (c_hi << 8)) & 4095u] + s_kraft[(c_hi >> 4) & 4095u] +

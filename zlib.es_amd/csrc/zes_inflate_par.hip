@@ -506,7 +506,9 @@ __device__ __forceinline__ static bool seg_table_f8(ParSmem& S, const BitSrc& sr
 template <bool LDS>
 __device__ __forceinline__ static void seg_table(ParSmem& S, const BitSrc& src, uint32_t limit, uint32_t base, uint32_t stop,
                                                  const Lit8& f8, SegTab& tab, unsigned long long* dp) {
-  if (LDS && f8.n) {  // uniform: most literals have 8-bit codes
+  // uniform: most literals have 8-bit codes, and the segments are long enough for literal runs to matter
+  // (a block of long matches has 64-bit segments that are nearly all listed positions)
+  if (LDS && f8.n && !__ballot(stop - base < 256u)) {
     const bool done = seg_table_f8(S, src, limit, base, stop, f8, tab);
     const uint64_t redo = __ballot(!done);
     if (dp && redo && zes_lane() == 0) {  // ZES_DEBUG_PHASES: lanes / waves that fell back
