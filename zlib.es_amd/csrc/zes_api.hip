@@ -423,7 +423,7 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
   HIPCHK(hipMemcpyAsync(g.ibufs.p, hb, sizeof(ZesInfBuf) * (nbuf + 1), hipMemcpyHostToDevice, g.stream));
   unsigned long long* dbg = nullptr;
   if (getenv("ZES_DEBUG_PHASES")) {
-    if ((rc = ensure(g.dbg, (size_t)work * 128))) return rc;
+    if ((rc = ensure(g.dbg, (size_t)work * 192))) return rc;
     HIPCHK(hipMemsetAsync(g.dbg.p, 0, (size_t)work * 64, g.stream));
     dbg = (unsigned long long*)g.dbg.p;
   }
@@ -447,12 +447,12 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
   HIPCHK(hipStreamSynchronize(g.stream));
   std::vector<ZesRes> r1(hres, hres + nbuf);
   if (dbg) {  // average shader-clock cycles per phase of k_inf_block_par
-    std::vector<unsigned long long> h((size_t)work * 16);
+    std::vector<unsigned long long> h((size_t)work * 24);
     HIPCHK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
-    double acc[8] = {0}, t0[3] = {0}, t15[3] = {0}, fb_lanes = 0, fb_waves = 0;
+    double acc[8] = {0}, t0[3] = {0}, t15[3] = {0}, fb_lanes = 0, fb_waves = 0, hs[5] = {0};
     uint32_t cntd = 0;
     for (uint32_t i = 0; i < work; i++) {
-      const unsigned long long* r = &h[(size_t)i * 16];
+      const unsigned long long* r = &h[(size_t)i * 24];
       if (!r[7]) continue;
       cntd++;
       for (int k = 1; k < 8; k++) acc[k] += (double)(r[k] - r[k - 1]);
@@ -460,6 +460,8 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
         t0[k] += (double)(r[8 + k] - r[1]);
         t15[k] += (double)(r[12 + k] - r[1]);
       }
+      hs[0] += (double)(r[16] - r[0]);
+      for (int k = 1; k < 5; k++) hs[k] += (double)(r[16 + k] - r[15 + k]);
       fb_lanes += (double)r[11];
       fb_waves += (double)r[15];
     }
@@ -467,6 +469,8 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
             cntd, acc[1] / cntd, acc[2] / cntd, acc[3] / cntd, acc[4] / cntd, acc[5] / cntd, acc[6] / cntd, acc[7] / cntd);
     fprintf(stderr, "zes table steps, cycles since the header: first wave window %.0f landing %.0f fill %.0f | last wave %.0f %.0f %.0f\n",
             t0[0] / cntd, t0[1] / cntd, t0[2] / cntd, t15[0] / cntd, t15[1] / cntd, t15[2] / cntd);
+    fprintf(stderr, "zes header steps (avg cycles): staging %.0f fixed fields + code-length code %.0f code lengths %.0f lit/len tables %.0f distance tables %.0f\n",
+            hs[0] / cntd, hs[1] / cntd, hs[2] / cntd, hs[3] / cntd, hs[4] / cntd);
     fprintf(stderr, "zes 8-bit table path: %.2f lanes in %.2f waves per block fell back to the generic construction\n", fb_lanes / cntd, fb_waves / cntd);
   }
   if (getenv("ZES_DEBUG")) {

@@ -843,12 +843,29 @@ __device__ __forceinline__ static bool par_build(ParSmem& S, uint32_t base, uint
     offs[lane] = (uint16_t)o2;
     cnt[lane] = (uint16_t)cc;
   }
+  uint32_t run[16];  // symbols of each length seen in the chunks before this one (uniform)
+#pragma unroll
+  for (int k = 0; k < 16; k++) run[k] = 0;
   for (uint32_t s0 = 0; s0 < nsym; s0 += 64) {
     const uint32_t s = s0 + lane;
     const uint32_t l = s < nsym ? lens[s] : 0u;
+    // rank of s among the symbols of its length = those in earlier chunks + lower lanes of this chunk with
+    // the same length (four ballots match the 4-bit length)
+    uint64_t same = ~0ull;
+#pragma unroll
+    for (int bt = 0; bt < 4; bt++) {
+      const bool bit = (l >> bt) & 1u;
+      const uint64_t bal = __ballot(bit);
+      same &= bit ? bal : ~bal;
+    }
+    uint32_t before = 0;
+#pragma unroll
+    for (int k = 1; k < 16; k++) {
+      before = ((int)l == k) ? run[k] : before;
+      run[k] += (uint32_t)__popcll(__ballot(l == (uint32_t)k));
+    }
     if (l) {
-      uint32_t rank = 0;
-      for (uint32_t j = 0; j < s; j++) rank += (lens[j] == l);
+      const uint32_t rank = before + (uint32_t)__popcll(same & zes_lanemask_lt());
       uint32_t f = 0, o2 = 0;
 #pragma unroll
       for (int k = 1; k < 16; k++)
@@ -874,10 +891,16 @@ __device__ __forceinline__ static bool par_build(ParSmem& S, uint32_t base, uint
   return true;
 }
 
+// ZES_DEBUG_PHASES: header-step stamps go to slots 16..21 of the block's row (pointer set by the kernel)
+#define HSTAMP(i)                                                          \
+  do {                                                                     \
+    if (hdbg && zes_lane() == 0) hdbg[16 + (i)] = (unsigned long long)clock64(); \
+  } while (0)
 // dynamic header by wave 0 (uniform): returns false on anything T2/T3 should look at
 template <bool LDS>
-__device__ __forceinline__ static bool par_header(ParSmem& S, const BitSrc& src, uint32_t limit, uint32_t start) {
+__device__ __forceinline__ static bool par_header(ParSmem& S, const BitSrc& src, uint32_t limit, uint32_t start, unsigned long long* hdbg) {
   const uint32_t lane = zes_lane();
+  HSTAMP(0);
   LaneBits b;
   lb_seek<LDS>(b, src, start);
   lb_refill<LDS>(b, src);
@@ -911,37 +934,53 @@ __device__ __forceinline__ static bool par_header(ParSmem& S, const BitSrc& src,
   }
   if (kraft > 128u) return false;
   for (uint32_t i = lane; i < 352; i += 64) S.lens[i] = 0;
+  HSTAMP(1);
   const uint32_t total = HLIT + HDIST;
+  // The code-length symbols, 64 bit positions at a time: lane j decodes the symbol that would start at
+  // bit j of the window (one table lookup for all 64), then the real chain is followed through the
+  // lanes' results with lane reads — one LDS latency per window instead of one per symbol.
   uint32_t prev = 0;
+  uint32_t wbase = b.pos & ~31u, off = b.pos & 31u;  // window start (dword aligned), offset of the next symbol in it
   for (uint32_t k = 0; k < total;) {
-    lb_refill<LDS>(b, src);
-    const uint32_t e = S.cl_lut[(uint32_t)b.bb & 127u];
+    const uint32_t d = wbase >> 5;
+    const uint32_t w0 = src_ldw<LDS>(src, d), w1 = src_ldw<LDS>(src, d + 1), w2 = src_ldw<LDS>(src, d + 2);
+    const uint64_t lo64 = (uint64_t)w0 | ((uint64_t)w1 << 32), hi64 = (uint64_t)w1 | ((uint64_t)w2 << 32);
+    const uint32_t bits = lane < 32u ? (uint32_t)(lo64 >> lane) : (uint32_t)(hi64 >> (lane - 32u));  // >= 32 bits from bit `lane` on
+    const uint32_t e = S.cl_lut[bits & 127u];
     const uint32_t l = e >> 5, sy = e & 31u;
-    if (!l) return false;
-    lb_take(b, l);
-    uint32_t rep = 1, val = sy;
-    if (sy == 16) {
-      if (k == 0) return false;
-      rep = 3 + lb_take(b, 2);
-      val = prev;
-    } else if (sy == 17) {
-      rep = 3 + lb_take(b, 3);
-      val = 0;
-    } else if (sy == 18) {
-      rep = 11 + lb_take(b, 7);
-      val = 0;
+    const uint32_t xb = sy == 16u ? 2u : sy == 17u ? 3u : sy == 18u ? 7u : 0u;
+    const uint32_t xv = (bits >> l) & ((1u << xb) - 1u);
+    const uint32_t rep = sy == 16u ? 3u + xv : sy == 17u ? 3u + xv : sy == 18u ? 11u + xv : 1u;
+    // packed per lane: [6:0] offset of the following symbol (up to 77), [14:7] repeat count, [19:15] symbol, [20] valid
+    const uint32_t pk = (lane + l + xb) | (rep << 7) | (sy << 15) | ((l != 0u) << 20);
+    uint32_t bad = 0;  // errors are collected and looked at once per window: no branches inside the chain
+    while (off < 64u && k < total) {
+      const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)pk, (int)off);
+      const uint32_t s1 = (v >> 15) & 31u, r1 = (v >> 7) & 255u;
+      const uint32_t val = (s1 == 16u) ? prev : (s1 >= 17u ? 0u : s1);
+      const bool fits = k + r1 <= total;
+      bad |= (((v >> 20) & 1u) ^ 1u) | (uint32_t)(s1 == 16u && k == 0u) | (uint32_t)!fits;
+      if (val && lane < r1 && fits) {
+        const uint32_t idx = k + lane;
+        S.lens[idx < HLIT ? idx : 288 + (idx - HLIT)] = (uint8_t)val;
+      }
+      prev = val;
+      k += r1;
+      off = v & 127u;
     }
-    if (k + rep > total) return false;
-    if (val && lane < rep) {
-      const uint32_t idx = k + lane;
-      S.lens[idx < HLIT ? idx : 288 + (idx - HLIT)] = (uint8_t)val;
+    if (bad) return false;
+    if (off >= 64u) {
+      wbase += 64u;
+      off -= 64u;
     }
-    prev = val;
-    k += rep;
   }
+  b.pos = wbase + off;
+  HSTAMP(2);
   if (b.pos > limit) return false;
   if (!par_build(S, 0, 288, PL_ROOT, false, S.lut_l, S.syms_l, S.first_l, S.cnt_l, S.offs_l)) return false;
+  HSTAMP(3);
   if (!par_build(S, 288, 32, PD_ROOT, true, S.lut_d, S.syms_d, S.first_d, S.cnt_d, S.offs_d)) return false;
+  HSTAMP(4);
   if (lane == 0) {
     S.hdr_end = b.pos;
     S.bfinal = bfinal;
@@ -957,7 +996,7 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __
   __shared__ __align__(16) ParSmem S;
 #define STAMP(i)                                                     \
   do {                                                               \
-    if (dbg && threadIdx.x == 0) dbg[(size_t)blockIdx.x * 16 + (i)] = (unsigned long long)clock64(); \
+    if (dbg && threadIdx.x == 0) dbg[(size_t)blockIdx.x * 24 + (i)] = (unsigned long long)clock64(); \
   } while (0)
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   // buffer of this work item: the last entry whose first work item is <= blockIdx.x
@@ -1007,7 +1046,7 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __
     }
     __syncthreads();
     if (wave == 0 && use_lds) {
-      const bool ok = par_header<true>(S, src, limit, start);
+      const bool ok = par_header<true>(S, src, limit, start, dbg ? dbg + (size_t)blockIdx.x * 24 : nullptr);
       if (!ok && lane == 0) S.status = 1;
     }
     __syncthreads();
@@ -1025,7 +1064,7 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __
     base = (uint32_t)(b_me64 < 0xFFFFFF00ull ? b_me64 : 0xFFFFFF00ull);
     stop = (uint32_t)((b_me64 + seglen) < 0xFFFFFF00ull ? (b_me64 + seglen) : 0xFFFFFF00ull);
     SegTab tab = {0, 0, 0, 0, 0, 0, 0, 0};
-    seg_table<true>(S, src, limit, base, stop, f8, tab, dbg ? dbg + (size_t)blockIdx.x * 16 : nullptr);
+    seg_table<true>(S, src, limit, base, stop, f8, tab, dbg ? dbg + (size_t)blockIdx.x * 24 : nullptr);
     STAMP(2);
     {
       // composition over the 64 segments of this wave: lane j (< 48) carries input offset j
