@@ -1303,9 +1303,7 @@ __global__ __launch_bounds__(PARSE_THREADS) void k_lz_parse(const uint8_t* __res
           atomicAdd(&S.dh[zes_dist_code(zes_tok_dist(m))], 1u);
         } else {
           tv = by[k];
-#ifndef PARSE_EXPERIMENT_NO_HIST
           atomicAdd(&S.lh[tv], 1u);
-#endif
         }
         to[S.u.d.cpre[c] + rank] = tv;
       }
@@ -1779,7 +1777,10 @@ __global__ __launch_bounds__(EMIT_THREADS) void k_emit(uint8_t* __restrict__ d_o
   const uint64_t blk_last_dw = (bk.bit_off + bk.bits - 1) >> 5;
   const bool is_final = (bk.blk + 1 == bf.nblk);
   const uint32_t nhdr_items = 1 + ((bk.hdr_bits + 31u) >> 5);  // block bits + header words
-  const uint32_t nitems = nhdr_items + bk.ntok + 1;            // + EOB
+  // item space: the first tile holds only the header items, token i is item EMIT_TILE + i, so that a
+  // thread's four tokens are one aligned 16-byte load (issued unconditionally: no wait under a branch)
+  const uint32_t nitems = EMIT_TILE + bk.ntok + 1;             // + EOB
+  static_assert(1 + ZES_HDR_WORDS <= EMIT_TILE, "header items fit the first tile");
   uint64_t cur_bit = bk.bit_off;                               // uniform
   __syncthreads();
 
@@ -1788,12 +1789,21 @@ __global__ __launch_bounds__(EMIT_THREADS) void k_emit(uint8_t* __restrict__ d_o
     uint64_t val[EMIT_ITEMS];
     uint32_t nb[EMIT_ITEMS];
     uint32_t mysum = 0;
+    uint32_t tv4[EMIT_ITEMS];
+    {
+      const uint32_t ti0 = (t0 >= EMIT_TILE ? t0 - EMIT_TILE : 0u) + tid * EMIT_ITEMS;  // first token of this thread
+      const uint4 q = *reinterpret_cast<const uint4*>(tk + min(ti0, ZES_BLK - EMIT_ITEMS));
+      tv4[0] = q.x;
+      tv4[1] = q.y;
+      tv4[2] = q.z;
+      tv4[3] = q.w;
+    }
 #pragma unroll
     for (int k = 0; k < EMIT_ITEMS; k++) {
       const uint32_t it = t0 + tid * EMIT_ITEMS + k;
       uint64_t v = 0;
       uint32_t b = 0;
-      if (it < nitems) {
+      if (it < EMIT_TILE) {
         if (it == 0) {  // BFINAL + BTYPE=2 (src/deflate.ts:21-28)
           v = (is_final ? 1u : 0u) | (2u << 1);
           b = 3;
@@ -1801,12 +1811,14 @@ __global__ __launch_bounds__(EMIT_THREADS) void k_emit(uint8_t* __restrict__ d_o
           const uint32_t wi = it - 1;
           v = hd[wi];
           b = min(32u, bk.hdr_bits - wi * 32u);
-        } else if (it == nitems - 1) {  // EOB (src/deflate.ts:222-226)
+        }
+      } else if (it < nitems) {
+        if (it == nitems - 1) {  // EOB (src/deflate.ts:222-226)
           const uint32_t c = S.codes[256];
           v = c & 0xffffu;
           b = c >> 16;
         } else {
-          const uint32_t tv = tk[it - nhdr_items];
+          const uint32_t tv = tv4[k];
           if (tv & ZES_TOK_MATCH) {  // src/deflate.ts:187-211
             const uint32_t len = zes_tok_len(tv), dist = zes_tok_dist(tv);
             const uint32_t lc = zes_len_code(len), dc = zes_dist_code(dist);
