@@ -188,7 +188,7 @@ int deflate_batch_core(const uint8_t* d_in, const uint64_t* in_off, const uint64
   if ((rc = ensure(g.blks, sizeof(ZesBlk) * nblk))) return rc;
   if ((rc = ensure(g.idx_a, (size_t)nblk * ZES_BLK * 4))) return rc;
   if ((rc = ensure(g.idx_b, (size_t)nblk * ZES_BLK * 4))) return rc;
-  if ((rc = ensure(g.inv, (size_t)nblk * ZES_BLK * 8))) return rc;
+  if ((rc = ensure(g.inv, (size_t)nblk * ZES_BLK * 4))) return rc;
   if ((rc = ensure(g.hists, (size_t)nblk * 320 * 4))) return rc;
   if ((rc = ensure(g.codes, (size_t)nblk * 320 * 4))) return rc;
   if ((rc = ensure(g.hdrs, (size_t)nblk * ZES_HDR_WORDS * 4))) return rc;
@@ -226,7 +226,7 @@ int deflate_batch_core(const uint8_t* d_in, const uint64_t* in_off, const uint64
   }
   {
     Timed t("k_lz_sort");
-    hipLaunchKernelGGL(k_lz_sort, dim3(nblk), dim3(SORT_THREADS), 0, g.stream, d_in, dbufs, dblks, idx_a, idx_b, (uint2*)g.inv.p);
+    hipLaunchKernelGGL(k_lz_sort, dim3(nblk), dim3(SORT_THREADS), 0, g.stream, d_in, dbufs, dblks, idx_a, idx_b, (uint32_t*)g.inv.p);
   }
   if (sort_dbg) {  // average shader-clock cycles per step of k_lz_sort
     HIPCHK(hipStreamSynchronize(g.stream));
@@ -256,7 +256,7 @@ int deflate_batch_core(const uint8_t* d_in, const uint64_t* in_off, const uint64
   {
     Timed t("k_lz_match_lazy");  // the blocks k_lz_sort flagged (most positions kept); the others return at once
     hipLaunchKernelGGL(k_lz_match_lazy, dim3(nblk), dim3(MATCH_THREADS), 0, g.stream, d_in, dbufs, dblks, idx_a,
-                       (const uint2*)g.inv.p, idx_b);
+                       (const uint32_t*)g.inv.p, idx_b);
   }
   if (sort_dbg) {  // average shader-clock cycles per phase of k_lz_match_lazy
     HIPCHK(hipStreamSynchronize(g.stream));
@@ -966,16 +966,16 @@ int zes_stage_lz77_dev(const uint8_t* d_in, uint64_t n, uint64_t start, uint32_t
   if ((rc = ensure(g.blks, sizeof z))) return rc;
   if ((rc = ensure(g.idx_a, (size_t)ZES_BLK * 4))) return rc;
   if ((rc = ensure(g.idx_b, (size_t)ZES_BLK * 4))) return rc;
-  if ((rc = ensure(g.inv, (size_t)ZES_BLK * 8))) return rc;
+  if ((rc = ensure(g.inv, (size_t)ZES_BLK * 4))) return rc;
   if ((rc = ensure(g.hists, 320 * 4))) return rc;
   HIPCHK(hipMemcpyAsync(g.bufs.p, &b, sizeof b, hipMemcpyHostToDevice, g.stream));
   HIPCHK(hipMemcpyAsync(g.blks.p, &z, sizeof z, hipMemcpyHostToDevice, g.stream));
   hipLaunchKernelGGL(k_lz_sort, dim3(1), dim3(SORT_THREADS), 0, g.stream, d_in, (const ZesBuf*)g.bufs.p, (const ZesBlk*)g.blks.p,
-                     (uint32_t*)g.idx_a.p, (uint32_t*)g.idx_b.p, (uint2*)g.inv.p);
+                     (uint32_t*)g.idx_a.p, (uint32_t*)g.idx_b.p, (uint32_t*)g.inv.p);
   hipLaunchKernelGGL(k_lz_match, dim3(1), dim3(MATCH_THREADS), 0, g.stream, d_in, (const ZesBuf*)g.bufs.p,
                      (const ZesBlk*)g.blks.p, (const uint32_t*)g.idx_a.p, (uint32_t*)g.idx_b.p);
   hipLaunchKernelGGL(k_lz_match_lazy, dim3(1), dim3(MATCH_THREADS), 0, g.stream, d_in, (const ZesBuf*)g.bufs.p,
-                     (const ZesBlk*)g.blks.p, (const uint32_t*)g.idx_a.p, (const uint2*)g.inv.p, (uint32_t*)g.idx_b.p);
+                     (const ZesBlk*)g.blks.p, (const uint32_t*)g.idx_a.p, (const uint32_t*)g.inv.p, (uint32_t*)g.idx_b.p);
   hipLaunchKernelGGL(k_lz_parse, dim3(1), dim3(PARSE_THREADS), 0, g.stream, d_in, (const ZesBuf*)g.bufs.p, (ZesBlk*)g.blks.p,
                      (const uint32_t*)g.idx_b.p, (uint32_t*)g.idx_a.p, (uint32_t*)g.hists.p);
   HIPCHK(hipGetLastError());

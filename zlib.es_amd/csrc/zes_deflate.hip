@@ -73,6 +73,7 @@ void zes_sort_set_dbg(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBO
   } while (0)
 
 #define ZES_SORT_LAZY 0x80000000u  // flag beside ns in idx_a[g][ZES_BLK-1]
+#define ZES_INV_NONE 0xFFFFFFFFu   // inv entry of a position without a candidate
 #define SORT_HASH_BITS 19u
 #define SORT_OWN 128u  // consecutive positions owned by one thread in the filter phase
 #define SORT_ROUNDS 4u
@@ -101,7 +102,7 @@ __device__ __forceinline__ static uint4 sort_ld16(const uint8_t* __restrict__ sr
 
 __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restrict__ d_in, const ZesBuf* __restrict__ bufs,
                                                           const ZesBlk* __restrict__ blks, uint32_t* __restrict__ idx_a,
-                                                          uint32_t* __restrict__ idx_b, uint2* __restrict__ inv_all) {
+                                                          uint32_t* __restrict__ idx_b, uint32_t* __restrict__ inv_all) {
   __shared__ __align__(16) SortSmem S;
   const uint32_t g = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const ZesBlk bk = blks[g];
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
   // Blocks that keep most of their positions (text, periodic data) go to the lazy match finder, which
   // evaluates positions along greedy chains and needs the sorted slot of a position: inv[p].
   const bool lazy = inv_all != nullptr && ns * 2u >= cnt;
-  uint2* inv = inv_all ? inv_all + (uint64_t)g * ZES_BLK : nullptr;
+  uint32_t* inv = inv_all ? inv_all + (uint64_t)g * ZES_BLK : nullptr;
   if (tid == 0) A[ZES_BLK - 1] = ns | (lazy ? ZES_SORT_LAZY : 0u);
   if (ns == 0) return;  // uniform
 
@@ -351,9 +352,10 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
     __syncthreads();
     SSTAMP(6 + (pass == 2));
   }
-  // For the lazy match finder: inv[p] = (sorted slot of p, nearest earlier position with the same key or
-  // none); positions the filter dropped get (none, none).  Scattering 8-byte entries straight to memory
-  // costs a whole memory transaction each, so the table is built in LDS in eight slices of 16384
+  // For the lazy match finder: inv[p] = sorted slot of p (17 bits) | distance - 1 to the nearest earlier
+  // position with the same key (15 bits), or ZES_INV_NONE when there is none inside the 32768-byte window
+  // (then no candidate is: src/lz77.ts:49) or the filter dropped p.  Scattering the entries straight to
+  // memory costs a whole memory transaction each, so the table is built in LDS in four slices of 32768
   // positions (the staged block is no longer needed once the same-key flags are taken) and each slice
   // leaves with coalesced 16-byte stores; the sorted list is re-read per slice (it sits in the L2).
   if (lazy) {
@@ -371,9 +373,9 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
       }
     }
     __syncthreads();  // the block in S.in is dead from here on
-    uint2* stage = reinterpret_cast<uint2*>(S.in);  // [16384]
-    for (uint32_t b = 0; b < ZES_BLK / 16384u; b++) {
-      if (b * 16384u >= T) break;  // uniform
+    uint32_t* stage = reinterpret_cast<uint32_t*>(S.in);  // [32768]
+    for (uint32_t b = 0; b < ZES_BLK / 32768u; b++) {
+      if (b * 32768u >= T) break;  // uniform
       uint4* st4 = reinterpret_cast<uint4*>(S.in);
       for (uint32_t i = tid; i < 8192u; i += SORT_THREADS) st4[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
       __syncthreads();
@@ -390,12 +392,15 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
 #pragma unroll
         for (uint32_t k = 0; k < 8; k++) {
           const uint32_t r = rb + k * SORT_THREADS;
-          if (r < ns && (pos[k] >> 14) == b)
-            stage[pos[k] & 16383u] = make_uint2(r, ((same[r >> 5] >> (r & 31u)) & 1u) ? prv[k] : ~0u);
+          if (r < ns && (pos[k] >> 15) == b) {
+            const uint32_t delta = pos[k] - prv[k];  // > 0: equal keys are in ascending position order
+            const bool has = ((same[r >> 5] >> (r & 31u)) & 1u) && delta <= ZES_WINDOW;
+            stage[pos[k] & 32767u] = has ? (r | ((delta - 1u) << 17)) : ZES_INV_NONE;
+          }
         }
       }
       __syncthreads();
-      uint4* o4 = reinterpret_cast<uint4*>(inv + b * 16384u);
+      uint4* o4 = reinterpret_cast<uint4*>(inv + b * 32768u);
       for (uint32_t i = tid; i < 8192u; i += SORT_THREADS) o4[i] = st4[i];
       __syncthreads();
     }
@@ -683,19 +688,19 @@ __device__ __forceinline__ static uint32_t lazy_lcp(const uint32_t* in, uint32_t
 
 // Match at position p by the whole wavefront (p uniform): lane k takes candidate k of a round of 64.
 // Returns the match word (0 = literal).  Candidate order, early exits and tie rule of src/lz77.ts:49-95.
-__device__ static uint32_t lazy_wave_eval(const LazySmem& S, const uint32_t* __restrict__ idx, const uint2 iv, uint32_t p, uint32_t T,
+__device__ static uint32_t lazy_wave_eval(const LazySmem& S, const uint32_t* __restrict__ idx, const uint32_t iv, uint32_t p, uint32_t T,
                                           uint32_t avail) {
   const uint32_t lane = zes_lane();
-  if (iv.y == LAZY_NONE) return 0u;  // no earlier position with this key
-  const uint32_t r = iv.x;
+  if (iv == ZES_INV_NONE) return 0u;  // no earlier position with this key inside the window
+  const uint32_t r = iv & 0x1FFFFu;
   const uint32_t keyp = m_ld32u(S.in, p) & 0xffffffu;
   const uint32_t maxl = min(ZES_MAXMATCH, avail - p);
   uint32_t best = 0, bestq = 0;
   if (maxl == ZES_MAXMATCH) {
     // Periodic data: the nearest candidate already matches at full length and ends the scan (:89-91).
     // All lanes compare that one candidate, four bytes each (the halo covers p + 258).
-    const uint32_t q0 = iv.y;
-    if ((p - q0) <= ZES_WINDOW) {
+    const uint32_t q0 = p - ((iv >> 17) + 1u);
+    {
       const uint32_t x = m_ld32u(S.in, q0 + 4u * lane) ^ m_ld32u(S.in, p + 4u * lane);
       const uint64_t full = __ballot(x == 0u);                                // dwords 0..63 = bytes 0..255
       const uint32_t t = m_ld32u(S.in, q0 + 256u) ^ m_ld32u(S.in, p + 256u);  // bytes 256, 257
@@ -743,12 +748,12 @@ __device__ static uint32_t lazy_wave_eval(const LazySmem& S, const uint32_t* __r
 
 __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match_lazy(const uint8_t* __restrict__ d_in, const ZesBuf* __restrict__ bufs,
                                                                  const ZesBlk* __restrict__ blks, const uint32_t* __restrict__ idx_a,
-                                                                 const uint2* __restrict__ inv_all, uint32_t* __restrict__ match_out) {
+                                                                 const uint32_t* __restrict__ inv_all, uint32_t* __restrict__ match_out) {
   __shared__ __align__(16) LazySmem S;
   const uint32_t g = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint32_t* idx = idx_a + (uint64_t)g * ZES_BLK;
   if (!(idx[ZES_BLK - 1] & ZES_SORT_LAZY)) return;  // this block belongs to k_lz_match
-  const uint2* inv = inv_all + (uint64_t)g * ZES_BLK;
+  const uint32_t* inv = inv_all + (uint64_t)g * ZES_BLK;
   const ZesBlk bk = blks[g];
   const ZesBuf bf = bufs[bk.buf];
   const uint32_t T = bk.len;
@@ -817,18 +822,18 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match_lazy(const uint8_t* 
       if (!running && !starting) {
         if (!__ballot(mode != 0u) && drained) break;
       }
-      // (D) start evaluations, batched (the global load stalls the whole wavefront).  One 8-byte load
+      // (D) start evaluations, batched (the global load stalls the whole wavefront).  One 4-byte load
       // gives the sorted slot and the nearest candidate; a position without one is a literal at once.
       if (starting && ((uint32_t)__popcll(starting) >= LAZY_START_MIN || !running)) {
         nstart++;
         const bool st = mode == 6u;
-        const uint2 iv = inv[st ? p : 0u];
-        const bool lit = iv.y == LAZY_NONE;
-        const int32_t sl = (int32_t)iv.x - 1;          // slot of the nearest candidate
+        const uint32_t iv = inv[st ? p : 0u];
+        const bool lit = iv == ZES_INV_NONE;
+        const int32_t sl = (int32_t)(iv & 0x1FFFFu) - 1;  // slot of the nearest candidate
         const uint32_t c1 = idx[(st && !lit && sl > 1) ? sl - 1 : 0];  // the one after it, for the next round
         if (st) {
           cslot = lit ? -1 : sl;
-          cq = iv.y;
+          cq = p - ((iv >> 17) + 1u);
           cq2 = c1;
           best = 0;
           bestq = 0;
@@ -972,7 +977,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match_lazy(const uint8_t* 
     // chains of maximal matches (periodic data) are evaluated here one position after the other: the
     // table entry of p + 258 is requested while p is being looked at
     uint32_t spec_p = LAZY_NONE;
-    uint2 spec_iv = make_uint2(0u, 0u);
+    uint32_t spec_iv = 0u;
     uint32_t keep_p = 0, keep_m = 0, nkeep = 0;
     while (p < cnt) {
       const uint32_t w = p / LAZY_WIN;
@@ -994,7 +999,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match_lazy(const uint8_t* 
           found = true;
         }
         if (!found) {  // nobody evaluated this position yet
-          const uint2 iv = (p == spec_p) ? spec_iv : inv[p];
+          const uint32_t iv = (p == spec_p) ? spec_iv : inv[p];
           spec_p = min(p + ZES_MAXMATCH, cnt - 1u);
           spec_iv = inv[spec_p];
           const uint32_t m = lazy_wave_eval(S, idx, iv, p, T, avail);
