@@ -1143,12 +1143,18 @@ __global__ __launch_bounds__(PARSE_THREADS) void k_lz_parse(const uint8_t* __res
     uint32_t E1 = lane, E2 = 64u + lane, E3 = 128u + lane, E4 = 192u + lane, E5 = 256u + lane;
     for (int k = (int)nch - 1; k >= 0; k--) {
       const uint32_t c = c_lo + (uint32_t)k;
-      uint32_t ov = S.u.xmap[c][lane];
-      if (ov == 255u) ov = parse_follow(mi, T, c, lane);
-      const uint32_t d = ov >> 6, sl = ov & 63u;
-      const uint32_t a1 = __shfl(E1, (int)sl), a2 = __shfl(E2, (int)sl), a3 = __shfl(E3, (int)sl), a4 = __shfl(E4, (int)sl),
-                     a5 = __shfl(E5, (int)sl);
-      const uint32_t E0 = d == 0 ? a1 : d == 1 ? a2 : d == 2 ? a3 : d == 3 ? a4 : a5;
+      uint32_t E0;
+      if (S.cplain[c]) {
+        // no match in the chunk: every lane leaves it at offset 0 of the next chunk
+        E0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)E1);
+      } else {
+        uint32_t ov = S.u.xmap[c][lane];
+        if (ov == 255u) ov = parse_follow(mi, T, c, lane);
+        const uint32_t d = ov >> 6, sl = ov & 63u;
+        const uint32_t a1 = __shfl(E1, (int)sl), a2 = __shfl(E2, (int)sl), a3 = __shfl(E3, (int)sl), a4 = __shfl(E4, (int)sl),
+                       a5 = __shfl(E5, (int)sl);
+        E0 = d == 0 ? a1 : d == 1 ? a2 : d == 2 ? a3 : d == 3 ? a4 : a5;
+      }
       E5 = E4;
       E4 = E3;
       E3 = E2;
