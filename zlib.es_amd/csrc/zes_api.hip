@@ -301,10 +301,31 @@ int deflate_batch_core(const uint8_t* d_in, const uint64_t* in_off, const uint64
       fprintf(stderr, "zes parse steps (avg cycles over %u blocks): A %.0f B %.0f C %.0f D1 %.0f D2 %.0f D3 %.0f out %.0f\n", n,
               acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[5] / n, acc[6] / n, acc[7] / n);
   }
+  if (sort_dbg) {
+    HIPCHK(hipMemsetAsync(g.dbg.p, 0, (size_t)nblk * 64, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    zes_huff_set_dbg((unsigned long long*)g.dbg.p);
+  }
   {
     Timed t("k_huff");
     hipLaunchKernelGGL(k_huff, dim3(nblk), dim3(HUFF_THREADS_HOST), 0, g.stream, dblks, (const uint32_t*)g.hists.p,
                        (uint32_t*)g.codes.p, (uint32_t*)g.hdrs.p);
+  }
+  if (sort_dbg) {  // average shader-clock cycles per step of k_huff
+    HIPCHK(hipStreamSynchronize(g.stream));
+    zes_huff_set_dbg(nullptr);
+    std::vector<unsigned long long> h((size_t)nblk * 8);
+    HIPCHK(hipMemcpy(h.data(), g.dbg.p, h.size() * 8, hipMemcpyDeviceToHost));
+    double acc[8] = {0};
+    uint32_t n = 0;
+    for (uint32_t i = 0; i < nblk; i++) {
+      if (!h[(size_t)i * 8 + 7]) continue;
+      n++;
+      for (int k = 1; k < 8; k++) acc[k] += (double)(h[(size_t)i * 8 + k] - h[(size_t)i * 8 + k - 1]);
+    }
+    if (n)
+      fprintf(stderr, "zes huff steps (avg cycles over %u blocks): lit/len lengths %.0f distance lengths %.0f codes %.0f run-length coding %.0f its code %.0f header bits %.0f totals+out %.0f\n", n,
+              acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[5] / n, acc[6] / n, acc[7] / n);
   }
   {
     Timed t("k_layout");

@@ -1340,6 +1340,12 @@ __global__ __launch_bounds__(PARSE_THREADS) void k_lz_parse(const uint8_t* __res
 // every item's slot is a binary-search rank; a code length is the number of levels whose
 // selected prefix still contains the leaf (the selected items of a level are a prefix of it).
 // ------------------------------------------------------------------------------------------
+__device__ unsigned long long* g_huff_dbg = nullptr;  // ZES_DEBUG_PHASES: cycle stamps [g][8]
+void zes_huff_set_dbg(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_huff_dbg), &p, sizeof p); }
+#define USTAMP(i)                                                                                        \
+  do {                                                                                                   \
+    if (g_huff_dbg && threadIdx.x == 0) g_huff_dbg[(size_t)blockIdx.x * 8 + (i)] = (unsigned long long)clock64(); \
+  } while (0)
 #define HUFF_THREADS 256
 #define PM_MAXN 288
 struct HuffSmem {
@@ -1361,6 +1367,12 @@ struct HuffSmem {
   uint32_t hdr_bits;
   uint32_t total_bits;
   uint32_t n_nonzero;
+  uint32_t ccount[16], cfirst[16], crun[16];     // canonical codes: symbols per length, first code, symbols seen so far
+  uint16_t cwave[HUFF_THREADS / 64][16];         // canonical codes: symbols of each length per wave of the current pass
+  uint8_t cl[320];                               // lit/len lengths followed by the distance lengths (src/deflate.ts:81-97)
+  uint16_t run_tok[320];                         // run-length coding: tokens before the run that starts at this index
+  uint32_t wsum[HUFF_THREADS / 64];
+  unsigned long long starts[5];                  // run-length coding: bit i = a run starts at index i
 };
 
 __device__ static inline uint32_t lower_bound_u32(const uint32_t* a, uint32_t n, uint32_t v) {  // #{a[i] < v}
@@ -1456,26 +1468,64 @@ __device__ static void pm_lengths(HuffSmem& S, const uint32_t* hist, uint32_t ns
   __syncthreads();
 }
 
-// canonical codes (src/huffman.ts:117-151), stored bit-reversed for LSB-first packing
-__device__ static void canon_codes(const uint8_t* lens, uint32_t nsym, uint16_t* codes) {
-  const uint32_t tid = threadIdx.x;
-  for (uint32_t s = tid; s < nsym; s += HUFF_THREADS) {
-    const uint32_t l = lens[s];
+// canonical codes (src/huffman.ts:117-151), stored bit-reversed for LSB-first packing.  The code of a
+// symbol is the first code of its length plus its rank among the symbols of that length: counts per
+// length by LDS atomics, ranks from ballots (lower lanes) plus per-wave counts (earlier waves and passes).
+__device__ static void canon_codes(HuffSmem& S, const uint8_t* lens, uint32_t nsym, uint16_t* codes) {
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  if (tid < 16) {
+    S.ccount[tid] = 0;
+    S.crun[tid] = 0;
+  }
+  __syncthreads();
+  for (uint32_t s = tid; s < nsym; s += HUFF_THREADS)
+    if (lens[s]) atomicAdd(&S.ccount[lens[s]], 1u);
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t code = 0;
+    for (uint32_t l = 1; l < 16; l++) {
+      S.cfirst[l] = code;
+      code = (code + S.ccount[l]) << 1;
+    }
+  }
+  for (uint32_t s0 = 0; s0 < nsym; s0 += HUFF_THREADS) {  // uniform trip count
+    const uint32_t s = s0 + tid;
+    const uint32_t l = s < nsym ? lens[s] : 0u;
+    uint64_t same = ~0ull;
+#pragma unroll
+    for (int bt = 0; bt < 4; bt++) {
+      const bool bit = (l >> bt) & 1u;
+      const uint64_t bal = __ballot(bit);
+      same &= bit ? bal : ~bal;
+    }
+    const uint32_t below = (uint32_t)__popcll(same & zes_lanemask_lt());
+    if (lane < 16) S.cwave[wave][lane] = 0;
+    __syncthreads();  // cfirst / crun of the previous pass visible, cwave cleared
+    if (l && below == 0) S.cwave[wave][l] = (uint16_t)__popcll(same);
+    __syncthreads();
     uint32_t code = 0;
     if (l) {
-      // first code of length l = sum over shorter lengths of count << (l - len); plus rank inside l
-      for (uint32_t j = 0; j < nsym; j++) {
-        const uint32_t lj = lens[j];
-        if (lj && lj < l) code += 1u << (l - lj);
-        else if (lj == l && j < s) code += 1u;
-      }
-      code = __brev(code) >> (32u - l);
+      uint32_t rank = S.crun[l] + below;
+      for (uint32_t w = 0; w < wave; w++) rank += S.cwave[w][l];
+      code = __brev(S.cfirst[l] + rank) >> (32u - l);
     }
-    codes[s] = (uint16_t)code;
+    if (s < nsym) codes[s] = (uint16_t)code;
+    __syncthreads();
+    if (tid < 16) {
+      uint32_t add = 0;
+      for (uint32_t w = 0; w < HUFF_THREADS / 64; w++) add += S.cwave[w][tid];
+      S.crun[tid] += add;
+    }
   }
   __syncthreads();
 }
 
+// LSB-first bits at a known offset of S.hdr (zeroed beforehand), from any thread
+__device__ static inline void hdr_or(HuffSmem& S, uint32_t bitpos, uint32_t value, uint32_t nbits) {
+  const uint32_t w = bitpos >> 5, sh = bitpos & 31u;
+  atomicOr(&S.hdr[w], value << sh);
+  if (sh + nbits > 32u) atomicOr(&S.hdr[w + 1], value >> (32u - sh));
+}
 __device__ static inline void hdr_put(HuffSmem& S, uint32_t& bitpos, uint32_t value, uint32_t nbits) {
   // single-thread LSB-first append into S.hdr (zeroed beforehand)
   const uint32_t w = bitpos >> 5, sh = bitpos & 31u;
@@ -1494,82 +1544,173 @@ __global__ __launch_bounds__(HUFF_THREADS) void k_huff(ZesBlk* __restrict__ blks
   if (tid == 0) S.total_bits = 0;
   __syncthreads();
 
+  USTAMP(0);
   pm_lengths(S, S.hist, 286, 15, S.lens);             // src/deflate.ts:78
+  USTAMP(1);
   pm_lengths(S, S.hist + 288, 30, 15, S.lens + 288);  // src/deflate.ts:79
-  canon_codes(S.lens, 286, S.codes);
-  canon_codes(S.lens + 288, 30, S.codes + 288);
+  USTAMP(2);
+  canon_codes(S, S.lens, 286, S.codes);
+  canon_codes(S, S.lens + 288, 30, S.codes + 288);
+  USTAMP(3);
 
-  // code-length sequence + RLE (src/deflate.ts:81-139), serial: <= 316 entries
+  // code-length sequence + run-length coding (src/deflate.ts:81-139), one thread per run
+  const uint32_t lane = tid & 63u, wave = tid >> 6;
   if (tid == 0) {
-    int lmax = 256, dmax = 0;
-    for (int i = 257; i < 286; i++)
-      if (S.hist[i]) lmax = i;
-    for (int i = 0; i < 30; i++)
-      if (S.hist[288 + i]) dmax = i;
-    const int HLIT = lmax + 1, HDIST = dmax + 1, ncl = HLIT + HDIST;
-    uint32_t nrl = 0;
-    auto CL = [&](int i) -> int { return i < HLIT ? S.lens[i] : S.lens[288 + i - HLIT]; };
-    for (int i = 0; i < ncl; i++) {
-      const int cl = CL(i);
-      int rep = 1;
-      while (i + 1 < ncl && cl == CL(i + 1)) {
-        rep++;
-        i++;
-        if (cl == 0) {
-          if (138 <= rep) break;
-        } else {
-          if (6 <= rep) break;
-        }
-      }
-      if (4 <= rep) {
-        if (cl == 0) {
-          S.rl_sym[nrl] = (11 <= rep) ? 18 : 17;
-        } else {
-          S.rl_sym[nrl] = (uint8_t)cl;
-          S.rl_val[nrl] = 1;
-          nrl++;
-          rep--;
-          S.rl_sym[nrl] = 16;
-        }
-        S.rl_val[nrl] = (uint8_t)rep;
-        nrl++;
-      } else {
-        for (int j = 0; j < rep; j++) {
-          S.rl_sym[nrl] = (uint8_t)cl;
-          S.rl_val[nrl] = 1;
-          nrl++;
-        }
-      }
-    }
-    S.nrl = nrl;
-    for (int i = 0; i < 32; i++) S.hist[i] = 0;  // reuse as the code-length-code histogram
-    for (uint32_t i = 0; i < nrl; i++) S.hist[S.rl_sym[i]]++;
-    // header fields that do not depend on the CL code
-    S.hdr_bits = ((uint32_t)(HLIT - 257)) | ((uint32_t)(HDIST - 1) << 5);
+    S.a_k[0] = 256;  // highest used lit/len symbol (the end-of-block code is always used)
+    S.a_k[1] = 0;    // highest used distance symbol
+    S.nrl = 0;
   }
   __syncthreads();
+  if (tid < 29 && S.hist[257 + tid]) atomicMax(&S.a_k[0], 257u + tid);
+  if (tid < 30 && S.hist[288 + tid]) atomicMax(&S.a_k[1], tid);
+  __syncthreads();
+  const uint32_t HLIT = S.a_k[0] + 1u, HDIST = S.a_k[1] + 1u, ncl = HLIT + HDIST;  // <= 316
+  for (uint32_t i = tid; i < ncl; i += HUFF_THREADS) S.cl[i] = i < HLIT ? S.lens[i] : S.lens[288 + i - HLIT];
+  if (tid < 32) S.hist[tid] = 0;  // reused as the histogram of the run-length symbols
+  __syncthreads();
+  // a run = maximal stretch of equal lengths (it may cross the lit/len | distance border); the reference
+  // cuts it into chunks of at most 138 (zeros) or 6 (other lengths): a chunk of 4 or more becomes one
+  // repeat token (zeros) or the length plus a "repeat previous" token, a shorter one plain lengths
+  // run starts as bit masks (320 indices = five 64-bit words, index ncl counts as a start)
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    const uint32_t i = tid + q * HUFF_THREADS;
+    const bool st = i < 320u && (i >= ncl || i == 0 || S.cl[i] != S.cl[i - 1]);
+    const uint64_t m = __ballot(st);
+    if (lane == 0 && (i >> 6) < 5u) S.starts[i >> 6] = m;
+  }
+  __syncthreads();
+  uint32_t mytok[2] = {0, 0}, myn[2] = {0, 0};
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    const uint32_t i = tid + q * HUFF_THREADS;
+    if (i < ncl && (i == 0 || S.cl[i] != S.cl[i - 1])) {
+      const uint32_t v = S.cl[i];
+      // next start after i: first set bit above i in the masks
+      uint32_t nxt = ncl;
+      {
+        uint32_t wd = (i + 1u) >> 6;
+        uint64_t mm = wd < 5u ? (S.starts[wd] & (~0ull << ((i + 1u) & 63u))) : 0ull;
+        while (wd < 5u && mm == 0ull) {
+          wd++;
+          mm = wd < 5u ? S.starts[wd] : 0ull;
+        }
+        if (wd < 5u) nxt = min(ncl, wd * 64u + (uint32_t)__builtin_ctzll(mm));
+      }
+      const uint32_t n = nxt - i;
+      const uint32_t cap = v ? 6u : 138u, per = v ? 2u : 1u;
+      const uint32_t m = n % cap;
+      myn[q] = n;
+      mytok[q] = (n / cap) * per + (m >= 4u ? per : m);
+    }
+  }
+  // exclusive scan of the token counts in index order (thread t holds indices t and t + 256)
+  uint32_t pre[2];
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    uint32_t incl = mytok[q];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t t = __shfl_up(incl, d);
+      if ((int)lane >= d) incl += t;
+    }
+    if (lane == 63) S.wsum[wave] = incl;
+    __syncthreads();
+    uint32_t base = S.nrl;  // tokens of the first 256 indices (0 in the first round)
+    for (uint32_t w = 0; w < wave; w++) base += S.wsum[w];
+    pre[q] = base + incl - mytok[q];
+    __syncthreads();
+    if (tid == HUFF_THREADS - 1) S.nrl = pre[q] + mytok[q];
+    __syncthreads();
+  }
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    if (myn[q]) {
+      const uint32_t v = S.cl[tid + q * HUFF_THREADS];
+      const uint32_t cap = v ? 6u : 138u;
+      uint32_t pos = pre[q], rem = myn[q];
+      while (rem) {
+        const uint32_t r = min(rem, cap);
+        if (r >= 4u) {
+          if (v == 0) {
+            S.rl_sym[pos] = (r >= 11u) ? 18 : 17;
+            S.rl_val[pos] = (uint8_t)r;
+            pos++;
+          } else {
+            S.rl_sym[pos] = (uint8_t)v;
+            S.rl_val[pos] = 1;
+            pos++;
+            S.rl_sym[pos] = 16;
+            S.rl_val[pos] = (uint8_t)(r - 1u);
+            pos++;
+          }
+        } else {
+          for (uint32_t j = 0; j < r; j++) {
+            S.rl_sym[pos] = (uint8_t)v;
+            S.rl_val[pos] = 1;
+            pos++;
+          }
+        }
+        rem -= r;
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t nrl = S.nrl;
+  for (uint32_t i = tid; i < nrl; i += HUFF_THREADS) atomicAdd(&S.hist[S.rl_sym[i]], 1u);
+  __syncthreads();
+  USTAMP(4);
   pm_lengths(S, S.hist, 19, 7, S.clens);  // src/deflate.ts:141
-  canon_codes(S.clens, 19, S.ccodes);
+  canon_codes(S, S.clens, 19, S.ccodes);
+  USTAMP(5);
 
-  if (tid == 0) {
-    const uint32_t hl_hd = S.hdr_bits;
-    uint32_t HCLEN = 0;
-    for (uint32_t i = 0; i < 19; i++)
-      if (S.clens[kClOrder[i]]) HCLEN = i + 1;  // src/deflate.ts:143-148
-    uint32_t bp = 0;
-    hdr_put(S, bp, hl_hd, 10);                                                     // HLIT, HDIST
-    hdr_put(S, bp, (HCLEN - 4u) & 15u, 4);                                         // HCLEN
-    for (uint32_t i = 0; i < HCLEN; i++) hdr_put(S, bp, S.clens[kClOrder[i]], 3);  // src/deflate.ts:158-165
-    for (uint32_t i = 0; i < S.nrl; i++) {                                         // src/deflate.ts:167-181
-      const uint32_t v = S.rl_sym[i];
-      hdr_put(S, bp, S.ccodes[v], S.clens[v]);
-      if (v == 18) hdr_put(S, bp, S.rl_val[i] - 11u, 7);
-      else if (v == 17) hdr_put(S, bp, S.rl_val[i] - 3u, 3);
-      else if (v == 16) hdr_put(S, bp, S.rl_val[i] - 3u, 2);
+  // header bits (src/deflate.ts:143-181): fixed fields, the code-length code, then the coded run-length tokens,
+  // each token ORed in at its bit offset (exclusive scan of the token bit counts)
+  if (tid == 0) S.a_k[2] = 4;  // HCLEN: 1 + last index in transmission order whose symbol is used
+  __syncthreads();
+  if (tid < 19 && S.clens[kClOrder[tid]]) atomicMax(&S.a_k[2], tid + 1u);
+  __syncthreads();
+  const uint32_t HCLEN = S.a_k[2];
+  if (tid == 0) atomicOr(&S.hdr[0], (HLIT - 257u) | ((HDIST - 1u) << 5) | (((HCLEN - 4u) & 15u) << 10));
+  if (tid < HCLEN) {
+    uint32_t bp = 14u + 3u * tid;
+    hdr_or(S, bp, S.clens[kClOrder[tid]], 3);  // src/deflate.ts:158-165
+  }
+  uint32_t tv[2] = {0, 0}, tb[2] = {0, 0};
+#pragma unroll
+  for (int q = 0; q < 2; q++) {  // thread t holds tokens 2t and 2t + 1
+    const uint32_t i = 2u * tid + (uint32_t)q;
+    if (i < nrl) {
+      const uint32_t sy = S.rl_sym[i], cl = S.clens[sy];
+      const uint32_t xb = sy == 18u ? 7u : sy == 17u ? 3u : sy == 16u ? 2u : 0u;
+      const uint32_t xv = sy == 18u ? S.rl_val[i] - 11u : (sy == 17u || sy == 16u) ? S.rl_val[i] - 3u : 0u;
+      tv[q] = (uint32_t)S.ccodes[sy] | (xv << cl);
+      tb[q] = cl + xb;
     }
-    S.hdr_bits = bp;
+  }
+  {
+    const uint32_t mine = tb[0] + tb[1];
+    uint32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t t = __shfl_up(incl, d);
+      if ((int)lane >= d) incl += t;
+    }
+    if (lane == 63) S.wsum[wave] = incl;
+    __syncthreads();
+    uint32_t base = 14u + 3u * HCLEN, total = 0;
+    for (uint32_t w = 0; w < HUFF_THREADS / 64; w++) {
+      if (w < wave) base += S.wsum[w];
+      total += S.wsum[w];
+    }
+    uint32_t bp = base + incl - mine;
+    if (tb[0]) hdr_or(S, bp, tv[0], tb[0]);
+    bp += tb[0];
+    if (tb[1]) hdr_or(S, bp, tv[1], tb[1]);
+    if (tid == 0) S.hdr_bits = 14u + 3u * HCLEN + total;
   }
   __syncthreads();
+  USTAMP(6);
   // block bit count straight from the histograms
   uint32_t part = 0;
   for (uint32_t s = tid; s < 286; s += HUFF_THREADS) {
@@ -1587,6 +1728,7 @@ __global__ __launch_bounds__(HUFF_THREADS) void k_huff(ZesBlk* __restrict__ blks
   for (uint32_t i = tid; i < 320; i += HUFF_THREADS) cg[i] = (uint32_t)S.codes[i] | ((uint32_t)S.lens[i] << 16);
   uint32_t* hd = hdr_out + (uint64_t)g * ZES_HDR_WORDS;
   for (uint32_t i = tid; i < ZES_HDR_WORDS; i += HUFF_THREADS) hd[i] = S.hdr[i];
+  USTAMP(7);
 }
 
 // stage-level entry for tests: lengths only

@@ -46,6 +46,7 @@ __global__ void k_inf_exact(const uint8_t*, uint64_t, uint64_t, uint8_t*, uint64
 void zes_sort_set_dbg(unsigned long long*);
 void zes_parse_set_dbg(unsigned long long*);
 void zes_lazy_set_dbg(unsigned long long*);
+void zes_huff_set_dbg(unsigned long long*);
 __global__ void k_lz_sort(const uint8_t*, const ZesBuf*, const ZesBlk*, uint32_t*, uint32_t*, uint32_t*);
 __global__ void k_lz_match_lazy(const uint8_t*, const ZesBuf*, const ZesBlk*, const uint32_t*, const uint32_t*, uint32_t*);
 __global__ void k_lz_match(const uint8_t*, const ZesBuf*, const ZesBlk*, const uint32_t*, uint32_t*);
