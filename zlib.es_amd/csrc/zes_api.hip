@@ -44,6 +44,7 @@ struct Ctx {
   // profiling
   bool profiling = false;
   std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending;
+  std::vector<hipEvent_t> event_pool;
   std::vector<std::pair<std::string, KTime>> last_times;
   std::vector<std::string> name_pool;
   int last_tier = 0;
@@ -63,6 +64,9 @@ std::mutex g_mu;
       return ZES_E_DEVICE;                                                                     \
     }                                                                                          \
   } while (0)
+
+// pinned staging: [0, PIN_UP) read-back area, [PIN_UP, pinned_cap) upload area for the buffer table
+constexpr size_t PIN_UP = 256 << 10;
 
 int ensure(DevBuf& b, size_t bytes) {
   if (bytes <= b.cap) return ZES_OK;
@@ -96,14 +100,26 @@ int init_locked(int device) {
 }
 
 // ---- kernel timing (HIP events on the library's stream) ----
+// events are pooled: creating and destroying a pair per launch costs more than recording them
+hipEvent_t take_event() {
+  if (!g.event_pool.empty()) {
+    hipEvent_t e = g.event_pool.back();
+    g.event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
 struct Timed {
   hipEvent_t a = nullptr, b = nullptr;
   const char* name;
   explicit Timed(const char* n) : name(n) {
     if (g.profiling) {
-      hipEventCreate(&a);
-      hipEventCreate(&b);
-      hipEventRecord(a, g.stream);
+      a = take_event();
+      b = take_event();
+      (void)hipEventRecord(a, g.stream);
     }
   }
   ~Timed() {
@@ -125,8 +141,8 @@ void collect_times() {
     if (!acc.count(p.first)) order.push_back(p.first);
     acc[p.first].ms += ms;
     acc[p.first].launches++;
-    hipEventDestroy(p.second.first);
-    hipEventDestroy(p.second.second);
+    g.event_pool.push_back(p.second.first);
+    g.event_pool.push_back(p.second.second);
   }
   g.pending.clear();
   g.last_times.clear();
@@ -143,7 +159,7 @@ int deflate_batch_core(const uint8_t* d_in, const uint64_t* in_off, const uint64
                        const uint64_t* out_off, const uint64_t* out_cap, uint64_t* out_len, int32_t* status,
                        uint32_t count) {
   std::vector<ZesBuf> hb;
-  std::vector<ZesBlk> hk;
+  uint64_t nblk_total = 0;
   std::vector<uint32_t> live;
   hb.reserve(count);
   for (uint32_t i = 0; i < count; i++) {
@@ -167,22 +183,15 @@ int deflate_batch_core(const uint8_t* d_in, const uint64_t* in_off, const uint64
     b.n = in_len[i];
     b.out_off = out_off[i];
     b.cap = out_cap[i];
-    b.first_blk = (uint32_t)hk.size();
+    b.first_blk = (uint32_t)nblk_total;
     b.nblk = (uint32_t)((in_len[i] + ZES_BLK - 1) / ZES_BLK);
-    for (uint32_t k = 0; k < b.nblk; k++) {
-      ZesBlk z;
-      memset(&z, 0, sizeof z);
-      z.buf = (uint32_t)hb.size();
-      z.blk = k;
-      const uint64_t s = (uint64_t)k * ZES_BLK;
-      z.len = (uint32_t)std::min<uint64_t>(ZES_BLK, in_len[i] - s);
-      hk.push_back(z);
-    }
+    nblk_total += b.nblk;
     hb.push_back(b);
     live.push_back(i);
   }
   if (hb.empty()) return ZES_OK;
-  const uint32_t nbuf = (uint32_t)hb.size(), nblk = (uint32_t)hk.size();
+  if (nblk_total >= (1ull << 31)) return ZES_E_ARG;
+  const uint32_t nbuf = (uint32_t)hb.size(), nblk = (uint32_t)nblk_total;
   int rc;
   if ((rc = ensure(g.bufs, sizeof(ZesBuf) * nbuf))) return rc;
   if ((rc = ensure(g.blks, sizeof(ZesBlk) * nblk))) return rc;
@@ -194,18 +203,25 @@ int deflate_batch_core(const uint8_t* d_in, const uint64_t* in_off, const uint64
   if ((rc = ensure(g.hdrs, (size_t)nblk * ZES_HDR_WORDS * 4))) return rc;
   if ((rc = ensure(g.adler, (size_t)nbuf * 16))) return rc;
   if ((rc = ensure(g.res, sizeof(ZesRes) * nbuf))) return rc;
-  HIPCHK(hipMemcpyAsync(g.bufs.p, hb.data(), sizeof(ZesBuf) * nbuf, hipMemcpyHostToDevice, g.stream));
-  HIPCHK(hipMemcpyAsync(g.blks.p, hk.data(), sizeof(ZesBlk) * nblk, hipMemcpyHostToDevice, g.stream));
-  // the H2D sources are host vectors: make sure the copies are done before they go out of scope
-  // (pageable memcpyAsync is staged synchronously by the runtime, the sync below covers the rest)
+  // the buffer table goes up through pinned memory (a one-buffer call passes its entry as a kernel
+  // argument instead); the block records and the cleared Adler accumulators are made on the device
   ZesBuf* dbufs = (ZesBuf*)g.bufs.p;
   ZesBlk* dblks = (ZesBlk*)g.blks.p;
   uint32_t* idx_a = (uint32_t*)g.idx_a.p;
   uint32_t* idx_b = (uint32_t*)g.idx_b.p;
   unsigned long long* adler = (unsigned long long*)g.adler.p;
+  if (nbuf > 1) {
+    if (sizeof(ZesBuf) * nbuf <= g.pinned_cap - PIN_UP) {
+      memcpy((uint8_t*)g.pinned + PIN_UP, hb.data(), sizeof(ZesBuf) * nbuf);
+      HIPCHK(hipMemcpyAsync(g.bufs.p, (uint8_t*)g.pinned + PIN_UP, sizeof(ZesBuf) * nbuf, hipMemcpyHostToDevice, g.stream));
+    } else {
+      HIPCHK(hipMemcpy(g.bufs.p, hb.data(), sizeof(ZesBuf) * nbuf, hipMemcpyHostToDevice));
+    }
+  }
   {
-    Timed t("k_zero");
-    hipLaunchKernelGGL(k_zero_u64, dim3((nbuf * 2 + 255) / 256), dim3(256), 0, g.stream, adler, nbuf * 2);
+    Timed t("k_make_blks");
+    const uint32_t nthr = std::max(nblk, 2u * nbuf);
+    hipLaunchKernelGGL(k_make_blks, dim3((nthr + 255) / 256), dim3(256), 0, g.stream, hb[0], nbuf, dbufs, dblks, nblk, adler);
   }
   {
     Timed t("k_adler");
@@ -361,8 +377,6 @@ int read_res(ZesRes* out) {
   return ZES_OK;
 }
 
-// pinned staging: [0, PIN_UP) read-back area, [PIN_UP, pinned_cap) upload area for the buffer table
-constexpr size_t PIN_UP = 256 << 10;
 constexpr uint32_t INF_GROUP = 4096;  // buffers per T1 group (table and read-backs fit the pinned area)
 
 struct InfJob {
@@ -377,7 +391,7 @@ bool t1_eligible(const InfJob& j, uint32_t flags) { return !(flags & ZES_F_NO_FA
 // T1 over a group of buffers: every launch covers all of them (scan, verify, sort, one decode work
 // item per candidate block, chain check), two host synchronisations for the whole group.  Jobs the
 // tier settles get tier = 1; the others are left for the per-buffer tiers.
-int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const uint32_t* ids, uint32_t nbuf) {
+int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const uint32_t* ids, uint32_t nbuf, bool check_first) {
   int rc;
   ZesInfBuf* hb = (ZesInfBuf*)((uint8_t*)g.pinned + PIN_UP);
   uint64_t chunks = 0, cands = 0, total_c = 0;
@@ -400,8 +414,12 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
   memset(&hb[nbuf], 0, sizeof(ZesInfBuf));
   hb[nbuf].first_chunk = (uint32_t)chunks;
   hb[nbuf].cand_base = (uint32_t)cands;
+  if (nbuf == 1) {  // see the single-synchronisation path below
+    hb[1].work_first = ZES_WORK_AUTO;
+    hb[1].cand_cap = (uint32_t)std::min<uint64_t>(hb[0].cand_cap, hb[0].cap / ZES_BLK + 65);
+  }
   const uint32_t surv_cap = (uint32_t)std::min<uint64_t>(total_c / 4 + 1024ull * nbuf, 1ull << 30);
-  const size_t cnt_bytes = 16 + (size_t)nbuf * 4;  // counters[4] followed by cnt[nbuf]
+  const size_t cnt_bytes = 16 + (size_t)nbuf * 4 + (((size_t)nbuf + 3) & ~(size_t)3);  // counters[4], cnt[nbuf], first bytes [nbuf]
   if ((rc = ensure(g.ibufs, sizeof(ZesInfBuf) * (nbuf + 1)))) return rc;
   if ((rc = ensure(g.surv, (size_t)surv_cap * 8))) return rc;
   if ((rc = ensure(g.cand, (size_t)cands * 4))) return rc;
@@ -413,12 +431,18 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
   const ZesInfBuf* dbufs = (const ZesInfBuf*)g.ibufs.p;
   uint32_t* counters = (uint32_t*)g.counters.p;
   uint32_t* cnt = counters + 4;
-  HIPCHK(hipMemcpyAsync(g.ibufs.p, hb, sizeof(ZesInfBuf) * (nbuf + 1), hipMemcpyHostToDevice, g.stream));
-  HIPCHK(hipMemsetAsync(g.counters.p, 0, cnt_bytes, g.stream));
+  uint8_t* dfirst = (uint8_t*)(cnt + nbuf);
+  if (nbuf == 1) {  // table and cleared counters straight from kernel arguments
+    hipLaunchKernelGGL(k_inf_set_table1, dim3(1), dim3(64), 0, g.stream, hb[0], hb[1], (ZesInfBuf*)g.ibufs.p, counters,
+                       (uint32_t)(cnt_bytes / 4));
+  } else {
+    HIPCHK(hipMemcpyAsync(g.ibufs.p, hb, sizeof(ZesInfBuf) * (nbuf + 1), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipMemsetAsync(g.counters.p, 0, cnt_bytes, g.stream));
+  }
   {
     Timed t("k_inf_scan");
     hipLaunchKernelGGL(k_inf_scan, dim3((uint32_t)chunks), dim3(INF_SCAN_THREADS), 0, g.stream, d_in, dbufs, nbuf,
-                       (unsigned long long*)g.surv.p, surv_cap, counters);
+                       (unsigned long long*)g.surv.p, surv_cap, counters, dfirst);
   }
   {
     // persistent lanes pulling survivors from a counter: the grid only has to be large enough to fill the chip
@@ -427,25 +451,44 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
     hipLaunchKernelGGL(k_inf_verify, dim3(nwg), dim3(64), 0, g.stream, d_in, dbufs, (const unsigned long long*)g.surv.p, surv_cap,
                        counters, (uint32_t*)g.cand.p, cnt);
   }
+  // One buffer: nothing has to come back before the decode is launched.  The grid is sized for the most
+  // blocks the caller's capacity can hold (plus room for false candidates); the kernels take the real
+  // candidate count from device memory (table sentinel ZES_WORK_AUTO) and the host reads counters and
+  // result together — one synchronisation per call.  Several buffers: the counts come back first.
+  const bool one = nbuf == 1;
   uint32_t* hc = (uint32_t*)g.pinned;
-  HIPCHK(hipMemcpyAsync(hc, g.counters.p, cnt_bytes, hipMemcpyDeviceToHost, g.stream));
-  HIPCHK(hipStreamSynchronize(g.stream));  // the table upload has completed too: hb may be rewritten
-  const uint32_t nsurv = hc[0];
-  if (nsurv == 0 || nsurv > surv_cap) return ZES_OK;  // nothing that looks like this format (or a poisoned count)
-  std::vector<uint32_t> ncand(nbuf);
+  ZesRes* hres = (ZesRes*)((uint8_t*)g.pinned + 128 * 1024);
   uint64_t work = 0;
-  for (uint32_t i = 0; i < nbuf; i++) {
-    ncand[i] = hc[4 + i];
-    hb[i].work_first = (uint32_t)work;
-    if (ncand[i] > 0 && ncand[i] <= hb[i].cand_cap) work += ncand[i];
+  std::vector<uint32_t> ncand(nbuf);
+  if (!one) {
+    HIPCHK(hipMemcpyAsync(hc, g.counters.p, cnt_bytes, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));  // the table upload has completed too: hb may be rewritten
+    if (check_first) {  // CM nibble of the first byte (src/zlib.ts:13-16): the scan kernel sent it along
+      const uint8_t* hfirst = (const uint8_t*)(hc + 4 + nbuf);
+      for (uint32_t i = 0; i < nbuf; i++)
+        if ((hfirst[i] & 15u) != 8u) {
+          jobs[ids[i]].status = ZES_E_NOT_DEFLATE;
+          jobs[ids[i]].tier = -1;
+          hc[4 + i] = 0;  // no candidates are looked at
+        }
+    }
+    const uint32_t nsurv0 = hc[0];
+    if (nsurv0 == 0 || nsurv0 > surv_cap) return ZES_OK;  // nothing that looks like this format (or a poisoned count)
+    for (uint32_t i = 0; i < nbuf; i++) {
+      ncand[i] = hc[4 + i];
+      hb[i].work_first = (uint32_t)work;
+      if (ncand[i] > 0 && ncand[i] <= hb[i].cand_cap) work += ncand[i];
+    }
+    hb[nbuf].work_first = (uint32_t)work;
+    if (work == 0) return ZES_OK;
+    HIPCHK(hipMemcpyAsync(g.ibufs.p, hb, sizeof(ZesInfBuf) * (nbuf + 1), hipMemcpyHostToDevice, g.stream));
+  } else {
+    work = hb[1].cand_cap;  // the launch bound written into the sentinel above
   }
-  hb[nbuf].work_first = (uint32_t)work;
-  if (work == 0) return ZES_OK;
-  HIPCHK(hipMemcpyAsync(g.ibufs.p, hb, sizeof(ZesInfBuf) * (nbuf + 1), hipMemcpyHostToDevice, g.stream));
   unsigned long long* dbg = nullptr;
   if (getenv("ZES_DEBUG_PHASES")) {
     if ((rc = ensure(g.dbg, (size_t)work * 192))) return rc;
-    HIPCHK(hipMemsetAsync(g.dbg.p, 0, (size_t)work * 64, g.stream));
+    HIPCHK(hipMemsetAsync(g.dbg.p, 0, (size_t)work * 192, g.stream));
     dbg = (unsigned long long*)g.dbg.p;
   }
   {
@@ -463,9 +506,22 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
     hipLaunchKernelGGL(k_inf_chain, dim3(nbuf), dim3(256), 0, g.stream, dbufs, (const uint32_t*)cnt, (const uint32_t*)g.cand_sorted.p,
                        (const ZesCandRes*)g.cres.p, (const uint32_t*)nullptr, (uint32_t*)g.map.p, (ZesRes*)g.res.p);
   }
-  ZesRes* hres = (ZesRes*)g.pinned;
+  if (one) HIPCHK(hipMemcpyAsync(hc, g.counters.p, cnt_bytes, hipMemcpyDeviceToHost, g.stream));
   HIPCHK(hipMemcpyAsync(hres, g.res.p, sizeof(ZesRes) * nbuf, hipMemcpyDeviceToHost, g.stream));
   HIPCHK(hipStreamSynchronize(g.stream));
+  const uint32_t nsurv = hc[0];
+  if (one) {
+    if (check_first && (((const uint8_t*)(hc + 5))[0] & 15u) != 8u) {  // src/zlib.ts:13-16
+      jobs[ids[0]].status = ZES_E_NOT_DEFLATE;
+      jobs[ids[0]].tier = -1;
+      return ZES_OK;
+    }
+    ncand[0] = hc[4];
+    // nothing that looks like this format, a poisoned count, or more candidates than were launched
+    if (nsurv == 0 || nsurv > surv_cap || ncand[0] == 0 || ncand[0] > hb[0].cand_cap || ncand[0] > work) return ZES_OK;
+    hb[0].work_first = 0;
+    work = ncand[0];
+  }
   std::vector<ZesRes> r1(hres, hres + nbuf);
   if (dbg) {  // average shader-clock cycles per phase of k_inf_block_par
     std::vector<unsigned long long> h((size_t)work * 24);
@@ -597,27 +653,47 @@ int inflate_jobs(const uint8_t* d_in, uint8_t* d_out, std::vector<InfJob>& jobs,
   g.last_tier = 0;
   std::vector<uint32_t> ids;
   std::vector<uint32_t> todo;
+  std::vector<uint32_t> small;  // buffers T1 does not take and whose first byte is still on the device
   for (uint32_t i = 0; i < jobs.size(); i++) {
     InfJob& j = jobs[i];
     j.out_len = 0;
     j.tier = 0;
     if (j.status) continue;
-    if (j.c == 0 || (firsts[i] & 15u) != 8u) {  // src/zlib.ts:13-16
+    if (j.c == 0 || (firsts && (firsts[i] & 15u) != 8u)) {  // src/zlib.ts:13-16
       j.status = ZES_E_NOT_DEFLATE;
       j.tier = -1;
       continue;
     }
     todo.push_back(i);
     if (t1_eligible(j, flags)) ids.push_back(i);
+    else if (!firsts) small.push_back(i);
   }
   int rc;
+  // first bytes nobody supplied: T1 gets them back with its counters; the buffers T1 does not take are
+  // gathered here (device kernel + one read-back per group)
+  for (size_t g0 = 0; g0 < small.size(); g0 += INF_GROUP) {
+    const uint32_t nb = (uint32_t)std::min<size_t>(INF_GROUP, small.size() - g0);
+    if ((rc = ensure(g.ibufs, (size_t)INF_GROUP * 8 + INF_GROUP))) return rc;
+    uint64_t* ho = (uint64_t*)((uint8_t*)g.pinned + PIN_UP);
+    for (uint32_t k = 0; k < nb; k++) ho[k] = jobs[small[g0 + k]].in_off;
+    uint8_t* dfirst = (uint8_t*)g.ibufs.p + (size_t)INF_GROUP * 8;
+    HIPCHK(hipMemcpyAsync(g.ibufs.p, ho, (size_t)nb * 8, hipMemcpyHostToDevice, g.stream));
+    hipLaunchKernelGGL(k_inf_first_bytes, dim3((nb + 255) / 256), dim3(256), 0, g.stream, d_in, (const uint64_t*)g.ibufs.p, dfirst, nb);
+    HIPCHK(hipMemcpyAsync(g.pinned, dfirst, nb, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    for (uint32_t k = 0; k < nb; k++)
+      if ((((const uint8_t*)g.pinned)[k] & 15u) != 8u) {
+        jobs[small[g0 + k]].status = ZES_E_NOT_DEFLATE;
+        jobs[small[g0 + k]].tier = -1;
+      }
+  }
   for (size_t g0 = 0; g0 < ids.size(); g0 += INF_GROUP) {
     const uint32_t nb = (uint32_t)std::min<size_t>(INF_GROUP, ids.size() - g0);
-    if ((rc = inflate_t1_group(d_in, d_out, jobs.data(), ids.data() + g0, nb))) return rc;
+    if ((rc = inflate_t1_group(d_in, d_out, jobs.data(), ids.data() + g0, nb, firsts == nullptr))) return rc;
   }
   int worst = 0;
   for (uint32_t i : todo) {
-    if (jobs[i].tier == 0 && (rc = inflate_slow(d_in, d_out, jobs[i]))) return rc;
+    if (jobs[i].tier == 0 && jobs[i].status == ZES_OK && (rc = inflate_slow(d_in, d_out, jobs[i]))) return rc;
     worst = std::max(worst, jobs[i].tier);
   }
   collect_times();
@@ -628,10 +704,11 @@ int inflate_jobs(const uint8_t* d_in, uint8_t* d_out, std::vector<InfJob>& jobs,
 // One buffer at d_in+in_off (16-byte aligned), result at d_out+out_off (16-byte aligned).
 // Returns the reference-equivalent status; *out_len = bytes produced (or needed on NOSPACE).
 int inflate_one(const uint8_t* d_in, uint64_t in_off, uint64_t c, uint8_t* d_out, uint64_t out_off, uint64_t cap,
-                uint64_t* out_len, uint32_t flags, uint8_t first_byte) {
+                uint64_t* out_len, uint32_t flags, int first_byte /* -1: still on the device */) {
   std::vector<InfJob> jobs(1);
   jobs[0] = InfJob{in_off, c, out_off, cap, 0, ZES_OK, 0};
-  int rc = inflate_jobs(d_in, d_out, jobs, &first_byte, flags);
+  const uint8_t fb = (uint8_t)first_byte;
+  int rc = inflate_jobs(d_in, d_out, jobs, first_byte < 0 ? nullptr : &fb, flags);
   if (rc) return rc;
   *out_len = jobs[0].out_len;
   return jobs[0].status;
@@ -747,13 +824,7 @@ int zes_inflate_dev(const uint8_t* d_in, uint64_t c, uint8_t* d_out, uint64_t ca
   std::lock_guard<std::mutex> lk(g_mu);
   int rc = init_locked(-1);
   if (rc) return rc;
-  uint8_t first = 0;
-  if (c) {
-    HIPCHK(hipMemcpyAsync(g.pinned, d_in, 1, hipMemcpyDeviceToHost, g.stream));
-    HIPCHK(hipStreamSynchronize(g.stream));
-    first = *(const uint8_t*)g.pinned;
-  }
-  return inflate_one(d_in, 0, c, d_out, 0, cap, out_len, flags, first);
+  return inflate_one(d_in, 0, c, d_out, 0, cap, out_len, flags, -1);
 }
 
 int zes_inflate_batch_dev(const uint8_t* d_in, const uint64_t* in_off, const uint64_t* in_len, uint8_t* d_out,
@@ -764,27 +835,10 @@ int zes_inflate_batch_dev(const uint8_t* d_in, const uint64_t* in_off, const uin
   std::lock_guard<std::mutex> lk(g_mu);
   int rc = init_locked(-1);
   if (rc) return rc;
-  // first bytes of the buffers (CM nibble check, src/zlib.ts:13), gathered on the device in groups
-  std::vector<uint8_t> firsts(count, 0);
-  if ((rc = ensure(g.ibufs, (size_t)INF_GROUP * 8 + INF_GROUP))) return rc;
-  for (uint32_t g0 = 0; g0 < count; g0 += INF_GROUP) {
-    const uint32_t g1 = std::min(count, g0 + INF_GROUP);
-    uint64_t* ho = (uint64_t*)((uint8_t*)g.pinned + PIN_UP);
-    for (uint32_t i = g0; i < g1; i++) {
-      status[i] = ((in_off[i] & 15u) || (out_off[i] & 15u)) ? ZES_E_ARG : ZES_OK;
-      ho[i - g0] = in_len[i] ? in_off[i] : 0;  // an empty buffer reads byte 0 of the arena; its result is ignored
-    }
-    uint8_t* dfirst = (uint8_t*)g.ibufs.p + (size_t)INF_GROUP * 8;
-    HIPCHK(hipMemcpyAsync(g.ibufs.p, ho, (size_t)(g1 - g0) * 8, hipMemcpyHostToDevice, g.stream));
-    hipLaunchKernelGGL(k_inf_first_bytes, dim3((g1 - g0 + 255) / 256), dim3(256), 0, g.stream, d_in, (const uint64_t*)g.ibufs.p, dfirst,
-                       g1 - g0);
-    HIPCHK(hipMemcpyAsync(g.pinned, dfirst, g1 - g0, hipMemcpyDeviceToHost, g.stream));
-    HIPCHK(hipStreamSynchronize(g.stream));
-    for (uint32_t i = g0; i < g1; i++) firsts[i] = in_len[i] ? ((const uint8_t*)g.pinned)[i - g0] : 0;
-  }
+  for (uint32_t i = 0; i < count; i++) status[i] = ((in_off[i] & 15u) || (out_off[i] & 15u)) ? ZES_E_ARG : ZES_OK;
   std::vector<InfJob> jobs(count);
   for (uint32_t i = 0; i < count; i++) jobs[i] = InfJob{in_off[i], in_len[i], out_off[i], out_cap[i], 0, status[i], 0};
-  rc = inflate_jobs(d_in, d_out, jobs, firsts.data(), flags);
+  rc = inflate_jobs(d_in, d_out, jobs, nullptr, flags);  // the first bytes (CM nibble, src/zlib.ts:13) are read on the way
   if (rc) return rc;
   for (uint32_t i = 0; i < count; i++) {
     status[i] = jobs[i].status;

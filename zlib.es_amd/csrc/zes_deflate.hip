@@ -1743,6 +1743,34 @@ __global__ __launch_bounds__(HUFF_THREADS) void k_huff_lengths_only(const uint32
 }
 
 // ------------------------------------------------------------------------------------------
+// k_make_blks: the per-block records from the buffer table (a one-buffer call passes its buffer as a
+// kernel argument: nothing is uploaded), and the Adler-32 accumulators cleared.
+// ------------------------------------------------------------------------------------------
+__global__ void k_make_blks(ZesBuf b0, uint32_t nbuf, ZesBuf* __restrict__ bufs, ZesBlk* __restrict__ blks, uint32_t nblk,
+                            unsigned long long* __restrict__ adler) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (nbuf == 1u && i == 0) bufs[0] = b0;
+  if (i < 2u * nbuf) adler[i] = 0ull;
+  if (i >= nblk) return;
+  uint32_t lo = 0, hi = nbuf;  // the last buffer whose first block is <= i
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if ((nbuf == 1u ? b0.first_blk : bufs[mid].first_blk) <= i) lo = mid; else hi = mid;
+  }
+  const uint64_t n = nbuf == 1u ? b0.n : bufs[lo].n;
+  const uint32_t fb = nbuf == 1u ? b0.first_blk : bufs[lo].first_blk;
+  ZesBlk z;
+  z.buf = lo;
+  z.blk = i - fb;
+  z.len = (uint32_t)min((uint64_t)ZES_BLK, n - (uint64_t)z.blk * ZES_BLK);
+  z.ntok = 0;
+  z.hdr_bits = 0;
+  z.bits = 0;
+  z.bit_off = 0;
+  blks[i] = z;
+}
+
+// ------------------------------------------------------------------------------------------
 // k_adler: each workgroup reduces one 64 KiB chunk to (A, B) and adds its closed-form share
 //  to two u64 accumulators per buffer: acc[0] += A, acc[1] += B + A * bytesAfter.
 // ------------------------------------------------------------------------------------------

@@ -42,6 +42,17 @@ __device__ static inline uint64_t g_load64_le(const uint8_t* p, uint64_t byte, u
 // ------------------------------------------------------------------------------------------
 #define SCAN_BYTES INF_SCAN_BYTES  // bytes of the stream per workgroup
 #define SCAN_LIST 4096u             // survivors a workgroup can stage (expected: ~0.2 % of 65536 positions)
+// One-buffer calls: the two-entry buffer table and the zeroed counters come from kernel arguments (a
+// host-to-device copy plus a memset cost two trips through the copy engine).
+__global__ void k_inf_set_table1(ZesInfBuf b0, ZesInfBuf sentinel, ZesInfBuf* __restrict__ bufs, uint32_t* __restrict__ counters,
+                                 uint32_t nwords) {
+  if (threadIdx.x == 0) {
+    bufs[0] = b0;
+    bufs[1] = sentinel;
+  }
+  if (counters && threadIdx.x < nwords) counters[threadIdx.x] = 0;
+}
+
 // first byte of every buffer of a batch (CM nibble check on the host, src/zlib.ts:13)
 __global__ void k_inf_first_bytes(const uint8_t* __restrict__ d_in, const uint64_t* __restrict__ offs, uint8_t* __restrict__ out,
                                   uint32_t n) {
@@ -61,7 +72,8 @@ __device__ __forceinline__ static uint32_t buf_of_chunk(const ZesInfBuf* bufs, u
 
 __global__ __launch_bounds__(INF_SCAN_THREADS) void k_inf_scan(const uint8_t* __restrict__ d_in, const ZesInfBuf* __restrict__ bufs,
                                                                uint32_t nbuf, unsigned long long* __restrict__ surv,
-                                                               uint32_t surv_cap, uint32_t* __restrict__ counters) {
+                                                               uint32_t surv_cap, uint32_t* __restrict__ counters,
+                                                               uint8_t* __restrict__ first_bytes) {
   // Each thread owns 32 consecutive bit positions at a time.  The fixed-field tests (BTYPE = 2,
   // HLIT <= 29, HDIST <= 29) run on all 32 positions at once as shifted word logic; only the
   // surviving positions (about one in five) pay for the Kraft sum of the code-length code.
@@ -103,6 +115,8 @@ __global__ __launch_bounds__(INF_SCAN_THREADS) void k_inf_scan(const uint8_t* __
     }
   }
   __syncthreads();
+  // the buffer's first byte rides back with the counters (CM nibble check on the host, src/zlib.ts:13)
+  if (tid == 0 && b0 == 0) first_bytes[bi] = (uint8_t)(s[0] & 0xffu);
   const uint64_t end_bits = c * 8;
 #pragma unroll 1
   for (uint32_t k = 0; k < SCAN_BYTES / 4 / INF_SCAN_THREADS; k++) {
@@ -779,7 +793,9 @@ __global__ __launch_bounds__(256) void k_inf_chain(const ZesInfBuf* __restrict__
   const uint32_t tid = threadIdx.x;
   const ZesInfBuf bf = bufs[blockIdx.x];
   const uint32_t ncand = min(cnt[blockIdx.x], bf.cand_cap);
-  const uint32_t nwork = bufs[blockIdx.x + 1].work_first - bf.work_first;
+  uint32_t nwork = bufs[blockIdx.x + 1].work_first - bf.work_first;
+  const bool autow = bufs[gridDim.x].work_first == ZES_WORK_AUTO;  // one buffer: see k_inf_block_par
+  if (autow) nwork = min(ncand, bufs[gridDim.x].cand_cap);
   const uint32_t* cand = cand_all + bf.cand_base;
   const ZesCandRes* cres = cres_all + bf.cand_base;
   const uint32_t* map_in = map_in_all ? map_in_all + bf.cand_base : nullptr;
@@ -795,6 +811,7 @@ __global__ __launch_bounds__(256) void k_inf_chain(const ZesInfBuf* __restrict__
   }
   __syncthreads();
   if (ncand == 0 || cand[0] != 0) return;
+  if (autow && ncand > nwork) return;  // more candidates than work items were launched: the host falls back
   // Fast check, all work items in parallel: item k is ok, non-final items give exactly one slot
   // and end where item k+1 starts, the first final item closes the chain.
   uint32_t first_final = 0xFFFFFFFFu;

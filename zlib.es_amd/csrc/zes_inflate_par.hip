@@ -1010,8 +1010,12 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __
     bi = lo;
   }
   const uint32_t w = blockIdx.x - bufs[bi].work_first;              // work item inside the buffer = output slot
-  const uint32_t nwork = bufs[bi + 1].work_first - bufs[bi].work_first;
   const uint32_t ncand = min(cnt[bi], bufs[bi].cand_cap);
+  uint32_t nwork = bufs[bi + 1].work_first - bufs[bi].work_first;
+  if (bufs[nbuf].work_first == ZES_WORK_AUTO) {  // one buffer, launched before the host saw the candidate count
+    nwork = min(ncand, bufs[nbuf].cand_cap);
+    if (blockIdx.x >= nwork) return;
+  }
   const uint32_t* cand = cand_all + bufs[bi].cand_base;
   const uint32_t* map = map_all ? map_all + bufs[bi].cand_base : nullptr;
   ZesCandRes* cres = cres_all + bufs[bi].cand_base;

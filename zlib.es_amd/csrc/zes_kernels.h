@@ -24,6 +24,10 @@ struct ZesInfBuf {
   uint32_t work_first;   // k_inf_block_par: first work item of this buffer
 };
 
+// work_first of the table's sentinel entry in one-buffer calls: the decode kernels take the number of work
+// items from the candidate counter on the device (the sentinel's cand_cap holds the launch bound)
+#define ZES_WORK_AUTO 0xFFFFFFFFu
+
 struct ZesCandRes {
   uint64_t end_bit;   // absolute bit just past the block's EOB
   uint32_t out_len;
@@ -33,7 +37,8 @@ struct ZesCandRes {
 #ifdef __HIPCC__
 // inflate direction (zes_inflate.hip)
 __global__ void k_inf_first_bytes(const uint8_t*, const uint64_t*, uint8_t*, uint32_t);
-__global__ void k_inf_scan(const uint8_t*, const ZesInfBuf*, uint32_t, unsigned long long*, uint32_t, uint32_t*);
+__global__ void k_inf_scan(const uint8_t*, const ZesInfBuf*, uint32_t, unsigned long long*, uint32_t, uint32_t*, uint8_t*);
+__global__ void k_inf_set_table1(ZesInfBuf, ZesInfBuf, ZesInfBuf*, uint32_t*, uint32_t);
 __global__ void k_inf_verify(const uint8_t*, const ZesInfBuf*, const unsigned long long*, uint32_t, uint32_t*, uint32_t*, uint32_t*);
 __global__ void k_inf_ranksort(const ZesInfBuf*, const uint32_t*, const uint32_t*, uint32_t*);
 __global__ void k_inf_decode(const uint8_t*, uint64_t, uint64_t, uint8_t*, uint64_t, uint64_t, const uint32_t*, const uint32_t*,
@@ -47,6 +52,7 @@ void zes_sort_set_dbg(unsigned long long*);
 void zes_parse_set_dbg(unsigned long long*);
 void zes_lazy_set_dbg(unsigned long long*);
 void zes_huff_set_dbg(unsigned long long*);
+__global__ void k_make_blks(ZesBuf, uint32_t, ZesBuf*, ZesBlk*, uint32_t, unsigned long long*);
 __global__ void k_lz_sort(const uint8_t*, const ZesBuf*, const ZesBlk*, uint32_t*, uint32_t*, uint32_t*);
 __global__ void k_lz_match_lazy(const uint8_t*, const ZesBuf*, const ZesBlk*, const uint32_t*, const uint32_t*, uint32_t*);
 __global__ void k_lz_match(const uint8_t*, const ZesBuf*, const ZesBlk*, const uint32_t*, uint32_t*);
