@@ -1924,7 +1924,7 @@ __global__ __launch_bounds__(256) void k_layout(uint8_t* __restrict__ d_out, con
 // whole dwords.  Only the first and last dword of a block (shared with its neighbours) use
 // global atomics.
 // ------------------------------------------------------------------------------------------
-#define EMIT_ITEMS 4  // tokens per thread per tile
+#define EMIT_ITEMS 8  // tokens per thread per tile (a multiple of 4: 16-byte loads)
 #define EMIT_TILE (EMIT_THREADS * EMIT_ITEMS)
 #define EMIT_STAGE_WORDS (EMIT_TILE * 48 / 32 + 8)
 struct EmitSmem {
@@ -1973,11 +1973,15 @@ __global__ __launch_bounds__(EMIT_THREADS) void k_emit(uint8_t* __restrict__ d_o
     uint32_t tv4[EMIT_ITEMS];
     {
       const uint32_t ti0 = (t0 >= EMIT_TILE ? t0 - EMIT_TILE : 0u) + tid * EMIT_ITEMS;  // first token of this thread
-      const uint4 q = *reinterpret_cast<const uint4*>(tk + min(ti0, ZES_BLK - EMIT_ITEMS));
-      tv4[0] = q.x;
-      tv4[1] = q.y;
-      tv4[2] = q.z;
-      tv4[3] = q.w;
+      const uint4* qp = reinterpret_cast<const uint4*>(tk + min(ti0, ZES_BLK - EMIT_ITEMS));
+#pragma unroll
+      for (int k4 = 0; k4 < EMIT_ITEMS / 4; k4++) {
+        const uint4 q = qp[k4];
+        tv4[4 * k4 + 0] = q.x;
+        tv4[4 * k4 + 1] = q.y;
+        tv4[4 * k4 + 2] = q.z;
+        tv4[4 * k4 + 3] = q.w;
+      }
     }
 #pragma unroll
     for (int k = 0; k < EMIT_ITEMS; k++) {

@@ -41,6 +41,7 @@ __device__ static inline uint64_t g_load64_le(const uint8_t* p, uint64_t byte, u
 // bits look like BTYPE=2 with HLIT<=29, HDIST<=29 and whose code-length code is Kraft-complete.
 // ------------------------------------------------------------------------------------------
 #define SCAN_BYTES INF_SCAN_BYTES  // bytes of the stream per workgroup
+#define RANK_LDS 8192u  // candidates k_inf_ranksort keeps in LDS
 #define SCAN_LIST 4096u             // survivors a workgroup can stage (expected: ~0.2 % of 65536 positions)
 // One-buffer calls: the two-entry buffer table and the zeroed counters come from kernel arguments (a
 // host-to-device copy plus a memset cost two trips through the copy engine).
@@ -345,15 +346,30 @@ __global__ __launch_bounds__(64) void k_inf_verify(const uint8_t* __restrict__ d
 // rank sort of each buffer's candidate list (a few to a few thousand entries); one workgroup per buffer
 __global__ __launch_bounds__(256) void k_inf_ranksort(const ZesInfBuf* __restrict__ bufs, const uint32_t* __restrict__ cnt,
                                                       const uint32_t* __restrict__ cand, uint32_t* __restrict__ out) {
+  __shared__ uint32_t s_c[RANK_LDS];  // the list itself when it fits (it does: one entry per block of the stream)
   const ZesInfBuf bf = bufs[blockIdx.x];
   const uint32_t n = min(cnt[blockIdx.x], bf.cand_cap);
   const uint32_t* in = cand + bf.cand_base;
   uint32_t* o = out + bf.cand_base;
+  const bool lds = n <= RANK_LDS;
+  if (lds) {
+    for (uint32_t i = threadIdx.x; i < n; i += 256) s_c[i] = in[i];
+    __syncthreads();
+  }
+  const uint32_t* src = lds ? s_c : in;
   for (uint32_t i = threadIdx.x; i < n; i += 256) {
-    const uint32_t v = in[i];
+    const uint32_t v = src[i];
     uint32_t r = 0;
-    for (uint32_t j = 0; j < n; j++) {
-      const uint32_t u = in[j];
+    uint32_t j = 0;
+    for (; j + 16u <= n; j += 16u) {  // sixteen independent reads per step: the loop is bound by LDS latency
+      uint32_t u[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) u[k] = src[j + k];
+#pragma unroll
+      for (int k = 0; k < 16; k++) r += (u[k] < v) || (u[k] == v && j + k < i);
+    }
+    for (; j < n; j++) {
+      const uint32_t u = src[j];
       r += (u < v) || (u == v && j < i);
     }
     o[r] = v;
