@@ -198,7 +198,7 @@ __global__ __launch_bounds__(64) void k_inf_verify(const uint8_t* __restrict__ d
   const uint32_t chunk = min(1024u, max(64u, ((ns / (2u * gridDim.x)) + 63u) & ~63u));
   uint32_t wnext = 0, wend = 0;
   uint64_t bb = 0;
-  uint32_t pos = 0, pos0 = 0, nb = 0;
+  uint32_t pos = 0, pos0 = 0, nb = 0, nw = 0, nwi = 0;
   uint32_t HLIT = 0, total = 0, k = 0, kl = 0, kd = 0, nd = 0, dmaxlen = 0, prev = 0;
   bool has_eob = false;
   constexpr uint64_t M0 = 0x0049249249249249ull;  // bit 0 of each of the 19 three-bit fields
@@ -248,6 +248,8 @@ __global__ __launch_bounds__(64) void k_inf_verify(const uint8_t* __restrict__ d
           const uint64_t w = (uint64_t)in32[min(di, lastdw)] | ((uint64_t)in32[min(di + 1, lastdw)] << 32);
           bb = w >> sh;
           nb = 64u - sh;
+          nwi = di + 2u;  // the dword behind the bit buffer is kept loaded: a refill never waits for memory,
+          nw = in32[min(nwi, lastdw)];  // which matters for the few lanes that decode a real header (~300 symbols)
         }
         // lengths from transmission order into symbol order (3 bits per symbol)
         uint64_t sl = 0;
@@ -289,8 +291,10 @@ __global__ __launch_bounds__(64) void k_inf_verify(const uint8_t* __restrict__ d
     if (have) {
       bool ok = pos + 14u <= limit;
       if (nb <= 32u) {
-        bb |= (uint64_t)in32[min((pos + nb) >> 5, lastdw)] << nb;
+        bb |= (uint64_t)nw << nb;
         nb += 32u;
+        nwi++;
+        nw = in32[min(nwi, lastdw)];
       }
       const uint32_t ix = __brev((uint32_t)bb) >> 25;
       const uint32_t ent = lut8[((ix >> 2) * 64u + lane) * 4u + (ix & 3u)];
