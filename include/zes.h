@@ -46,6 +46,8 @@ typedef enum zes_status {
 /* flags for zes_inflate*: */
 #define ZES_F_DEFAULT 0u
 #define ZES_F_NO_FASTPATH 1u   /* force the general (serial, any-stream) decoder: testing aid */
+#define ZES_F_LOOSE_CANDIDATES 2u /* block-start search without the reference's run-length-coding rules: more false
+                                  * candidates reach the block decoder (testing aid for that path; same results) */
 
 /* Exact reference message for a status (engine-defined codes get a descriptive string). */
 const char* zes_strerror(int status);

@@ -36,6 +36,7 @@ ZES_E_NOSPACE = -16
 ZES_E_DEVICE = -17
 ZES_E_ARG = -18
 ZES_F_NO_FASTPATH = 1
+ZES_F_LOOSE_CANDIDATES = 2
 
 GEN_KINDS = {"xorshift": 0, "lowent4k": 1, "itext": 2}
 

@@ -36,7 +36,7 @@ struct Ctx {
   // deflate scratch
   DevBuf bufs, blks, idx_a, idx_b, inv, hists, codes, hdrs, adler, res;
   // inflate scratch
-  DevBuf surv, cand, cand_sorted, counters, cres, map, resume, dbg, ibufs;
+  DevBuf surv, cand, cand_sorted, counters, cres, map, resume, dbg, ibufs, ibufs2, mvlist, scratch;
   // staging for the host-pointer API
   DevBuf st_in, st_out;
   void* pinned = nullptr;  // small pinned area for read-backs
@@ -391,7 +391,7 @@ bool t1_eligible(const InfJob& j, uint32_t flags) { return !(flags & ZES_F_NO_FA
 // T1 over a group of buffers: every launch covers all of them (scan, verify, sort, one decode work
 // item per candidate block, chain check), two host synchronisations for the whole group.  Jobs the
 // tier settles get tier = 1; the others are left for the per-buffer tiers.
-int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const uint32_t* ids, uint32_t nbuf, bool check_first) {
+int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const uint32_t* ids, uint32_t nbuf, bool check_first, uint32_t flags) {
   int rc;
   ZesInfBuf* hb = (ZesInfBuf*)((uint8_t*)g.pinned + PIN_UP);
   uint64_t chunks = 0, cands = 0, total_c = 0;
@@ -449,7 +449,7 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
     Timed t("k_inf_verify");
     const uint32_t nwg = (uint32_t)std::min<uint64_t>(total_c / 2048 + 1, 8192);
     hipLaunchKernelGGL(k_inf_verify, dim3(nwg), dim3(64), 0, g.stream, d_in, dbufs, (const unsigned long long*)g.surv.p, surv_cap,
-                       counters, (uint32_t*)g.cand.p, cnt);
+                       counters, (uint32_t*)g.cand.p, cnt, (flags & ZES_F_LOOSE_CANDIDATES) ? 1u : 0u);
   }
   // One buffer: nothing has to come back before the decode is launched.  The grid is sized for the most
   // blocks the caller's capacity can hold (plus room for false candidates); the kernels take the real
@@ -499,7 +499,7 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
   {
     Timed t("k_inf_block_par");
     hipLaunchKernelGGL(k_inf_block_par, dim3((uint32_t)work), dim3(PAR_THREADS), 0, g.stream, d_in, d_out, dbufs, nbuf,
-                       (const uint32_t*)cnt, (const uint32_t*)g.cand_sorted.p, (const uint32_t*)nullptr, (ZesCandRes*)g.cres.p, dbg);
+                       (const uint32_t*)cnt, (const uint32_t*)g.cand_sorted.p, (const uint32_t*)nullptr, (ZesCandRes*)g.cres.p, dbg, (const uint32_t*)nullptr);
   }
   {
     Timed t("k_inf_chain");
@@ -573,34 +573,79 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
       }
     }
   }
-  // buffers whose candidate list holds false positives between the blocks: the chain kernel left
-  // the true chain in map[]; decode those chains again with every block in its own slot
-  uint64_t work2 = 0;
+  // Buffers whose candidate list holds false positives between the blocks: every true block decoded fine, but
+  // the blocks behind a false candidate sit one (or more) slots too far right.  The chain kernel left the true
+  // chain in map[] (true block k = candidate map[k]) and has checked it block by block, so the blocks only
+  // have to move: through a scratch copy, because sources and destinations overlap.  A block whose slot was cut
+  // off by the caller's capacity (typically the last one) is decoded again, straight into its own slot.
   for (uint32_t i = 0; i < nbuf; i++) {
-    hb[i].work_first = (uint32_t)work2;
-    if (r1[i].status == 2) work2 += r1[i].aux;
-  }
-  hb[nbuf].work_first = (uint32_t)work2;
-  std::vector<ZesRes> r2;
-  if (work2) {
-    HIPCHK(hipMemcpyAsync(g.ibufs.p, hb, sizeof(ZesInfBuf) * (nbuf + 1), hipMemcpyHostToDevice, g.stream));
-    {
-      Timed t("k_inf_block_par");
-      hipLaunchKernelGGL(k_inf_block_par, dim3((uint32_t)work2), dim3(PAR_THREADS), 0, g.stream, d_in, d_out, dbufs, nbuf,
-                         (const uint32_t*)cnt, (const uint32_t*)g.cand_sorted.p, (const uint32_t*)g.map.p, (ZesCandRes*)g.cres.p,
-                         (unsigned long long*)nullptr);
-    }
-    {
-      Timed t("k_inf_chain");
-      hipLaunchKernelGGL(k_inf_chain, dim3(nbuf), dim3(256), 0, g.stream, dbufs, (const uint32_t*)cnt, (const uint32_t*)g.cand_sorted.p,
-                         (const ZesCandRes*)g.cres.p, (const uint32_t*)g.map.p, (uint32_t*)g.map.p, (ZesRes*)g.res.p);
-    }
-    HIPCHK(hipMemcpyAsync(hres, g.res.p, sizeof(ZesRes) * nbuf, hipMemcpyDeviceToHost, g.stream));
+    if (r1[i].status != 2) continue;
+    const uint32_t K = r1[i].aux;
+    InfJob& j = jobs[ids[i]];
+    std::vector<uint32_t> hmap(K);
+    HIPCHK(hipMemcpyAsync(hmap.data(), (const uint32_t*)g.map.p + hb[i].cand_base, (size_t)K * 4, hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
-    r2.assign(hres, hres + nbuf);
+    std::vector<uint32_t> mv_src, mv_dst, redo;
+    for (uint32_t k = 0; k < K; k++) {
+      if (hmap[k] == k) continue;
+      if ((uint64_t)(hmap[k] + 1u) * ZES_BLK <= j.cap) {
+        mv_src.push_back(hmap[k]);
+        mv_dst.push_back(k);
+      } else {
+        redo.push_back(k);
+      }
+    }
+    const uint32_t nmv = (uint32_t)mv_src.size(), nre = (uint32_t)redo.size();
+    if ((rc = ensure(g.mvlist, (size_t)(3 * nmv + nre + 4) * 4))) return rc;
+    uint32_t* dl = (uint32_t*)g.mvlist.p;  // [src slots][dst slots][0..nmv)[redo]
+    if (nmv) {
+      if ((rc = ensure(g.scratch, (size_t)nmv * ZES_BLK))) return rc;
+      std::vector<uint32_t> up(3 * (size_t)nmv);
+      for (uint32_t q = 0; q < nmv; q++) {
+        up[q] = mv_src[q];
+        up[nmv + q] = mv_dst[q];
+        up[2 * (size_t)nmv + q] = q;
+      }
+      HIPCHK(hipMemcpy(dl, up.data(), up.size() * 4, hipMemcpyHostToDevice));
+      Timed t("k_inf_move_slots");
+      uint8_t* outb = d_out + j.out_off;
+      hipLaunchKernelGGL(k_inf_move_slots, dim3(nmv * 32u), dim3(256), 0, g.stream, (uint8_t*)g.scratch.p, (const uint8_t*)outb,
+                         (const uint32_t*)(dl + 2 * (size_t)nmv), (const uint32_t*)dl, nmv);
+      hipLaunchKernelGGL(k_inf_move_slots, dim3(nmv * 32u), dim3(256), 0, g.stream, outb, (const uint8_t*)g.scratch.p,
+                         (const uint32_t*)(dl + nmv), (const uint32_t*)(dl + 2 * (size_t)nmv), nmv);
+    }
+    bool ok = true;
+    if (nre) {
+      HIPCHK(hipMemcpy(dl + 3 * (size_t)nmv, redo.data(), (size_t)nre * 4, hipMemcpyHostToDevice));
+      // a two-entry table for this buffer alone: work item -> slot through redo[], K work items in all
+      ZesInfBuf* one = (ZesInfBuf*)((uint8_t*)g.pinned + PIN_UP) + nbuf + 2;
+      one[0] = hb[i];
+      one[0].work_first = 0;
+      one[1] = hb[i];
+      one[1].work_first = K;
+      if ((rc = ensure(g.ibufs2, sizeof(ZesInfBuf) * 2))) return rc;
+      HIPCHK(hipMemcpyAsync(g.ibufs2.p, one, sizeof(ZesInfBuf) * 2, hipMemcpyHostToDevice, g.stream));
+      {
+        Timed t("k_inf_block_par");
+        // cnt / candidates / map / results are indexed from this buffer's region: the table's cand_base does that
+        hipLaunchKernelGGL(k_inf_block_par, dim3(nre), dim3(PAR_THREADS), 0, g.stream, d_in, d_out, (const ZesInfBuf*)g.ibufs2.p, 1u,
+                           (const uint32_t*)cnt + i, (const uint32_t*)g.cand_sorted.p, (const uint32_t*)g.map.p,
+                           (ZesCandRes*)g.cres.p, (unsigned long long*)nullptr, (const uint32_t*)(dl + 3 * (size_t)nmv));
+      }
+      std::vector<ZesCandRes> hcr(nre);
+      for (uint32_t q = 0; q < nre; q++)
+        HIPCHK(hipMemcpyAsync(&hcr[q], (const ZesCandRes*)g.cres.p + hb[i].cand_base + redo[q], sizeof(ZesCandRes), hipMemcpyDeviceToHost,
+                              g.stream));
+      HIPCHK(hipStreamSynchronize(g.stream));
+      for (uint32_t q = 0; q < nre; q++) {
+        const bool last = redo[q] + 1u == K;
+        ok = ok && (hcr[q].flags & 1u) && (last ? hcr[q].out_len <= ZES_BLK : hcr[q].out_len == ZES_BLK);
+      }
+    }
+    r1[i].status = ok ? 0 : 1;  // out_len already holds the chain's total
   }
   for (uint32_t i = 0; i < nbuf; i++) {
-    const ZesRes& r = (r1[i].status == 2 && work2) ? r2[i] : r1[i];
+    const ZesRes& r = r1[i];
     if (r.status != 0) continue;
     InfJob& j = jobs[ids[i]];
     j.tier = 1;
@@ -689,7 +734,7 @@ int inflate_jobs(const uint8_t* d_in, uint8_t* d_out, std::vector<InfJob>& jobs,
   }
   for (size_t g0 = 0; g0 < ids.size(); g0 += INF_GROUP) {
     const uint32_t nb = (uint32_t)std::min<size_t>(INF_GROUP, ids.size() - g0);
-    if ((rc = inflate_t1_group(d_in, d_out, jobs.data(), ids.data() + g0, nb, firsts == nullptr))) return rc;
+    if ((rc = inflate_t1_group(d_in, d_out, jobs.data(), ids.data() + g0, nb, firsts == nullptr, flags))) return rc;
   }
   int worst = 0;
   for (uint32_t i : todo) {
@@ -746,7 +791,7 @@ int zes_shutdown(void) {
   if (!g.ready) return ZES_OK;
   hipStreamSynchronize(g.stream);
   DevBuf* all[] = {&g.bufs, &g.blks, &g.idx_a, &g.idx_b, &g.inv, &g.hists, &g.codes, &g.hdrs, &g.adler, &g.res, &g.surv, &g.cand,
-                   &g.cand_sorted, &g.counters, &g.cres, &g.map, &g.resume, &g.dbg, &g.ibufs, &g.st_in, &g.st_out};
+                   &g.cand_sorted, &g.counters, &g.cres, &g.map, &g.resume, &g.dbg, &g.ibufs, &g.ibufs2, &g.mvlist, &g.scratch, &g.st_in, &g.st_out};
   for (DevBuf* b : all) {
     if (b->p) hipFree(b->p);
     b->p = nullptr;

@@ -43,6 +43,18 @@ __device__ static inline uint64_t g_load64_le(const uint8_t* p, uint64_t byte, u
 #define SCAN_BYTES INF_SCAN_BYTES  // bytes of the stream per workgroup
 #define RANK_LDS 8192u  // candidates k_inf_ranksort keeps in LDS
 #define SCAN_LIST 4096u             // survivors a workgroup can stage (expected: ~0.2 % of 65536 positions)
+// Copies whole 128 KiB slots: item i moves slot src_slot[i] of src to slot dst_slot[i] of dst (32 workgroups
+// per item, 16 bytes per lane and step).  Used to close the gaps false candidates leave in the output.
+__global__ __launch_bounds__(256) void k_inf_move_slots(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src,
+                                                        const uint32_t* __restrict__ dst_slot, const uint32_t* __restrict__ src_slot,
+                                                        uint32_t nitems) {
+  const uint32_t item = blockIdx.x >> 5, part = blockIdx.x & 31u;
+  if (item >= nitems) return;
+  const uint4* s4 = reinterpret_cast<const uint4*>(src + (uint64_t)src_slot[item] * ZES_BLK) + part * 256u;
+  uint4* d4 = reinterpret_cast<uint4*>(dst + (uint64_t)dst_slot[item] * ZES_BLK) + part * 256u;
+  d4[threadIdx.x] = s4[threadIdx.x];
+}
+
 // One-buffer calls: the two-entry buffer table and the zeroed counters come from kernel arguments (a
 // host-to-device copy plus a memset cost two trips through the copy engine).
 __global__ void k_inf_set_table1(ZesInfBuf b0, ZesInfBuf sentinel, ZesInfBuf* __restrict__ bufs, uint32_t* __restrict__ counters,
@@ -173,7 +185,7 @@ __global__ __launch_bounds__(INF_SCAN_THREADS) void k_inf_scan(const uint8_t* __
 __global__ __launch_bounds__(64) void k_inf_verify(const uint8_t* __restrict__ d_in, const ZesInfBuf* __restrict__ bufs,
                                                    const unsigned long long* __restrict__ surv, uint32_t surv_cap,
                                                    uint32_t* __restrict__ counters, uint32_t* __restrict__ cand,
-                                                   uint32_t* __restrict__ cnt) {
+                                                   uint32_t* __restrict__ cnt, uint32_t loose) {
   // Persistent lanes: most survivors are rejected within ~15 code-length symbols (their codes
   // over-subscribe at once), a few need all ~300, so a lane that is done pulls the next survivor
   // from a shared counter (counters[2]) instead of idling until the wave's slowest lane ends.
@@ -199,7 +211,7 @@ __global__ __launch_bounds__(64) void k_inf_verify(const uint8_t* __restrict__ d
   uint32_t wnext = 0, wend = 0;
   uint64_t bb = 0;
   uint32_t pos = 0, pos0 = 0, nb = 0, nw = 0, nwi = 0;
-  uint32_t HLIT = 0, total = 0, k = 0, kl = 0, kd = 0, nd = 0, dmaxlen = 0, prev = 0;
+  uint32_t HLIT = 0, total = 0, k = 0, kl = 0, kd = 0, nd = 0, dmaxlen = 0, prev = 0, psym = 31;
   bool has_eob = false;
   constexpr uint64_t M0 = 0x0049249249249249ull;  // bit 0 of each of the 19 three-bit fields
 
@@ -282,6 +294,7 @@ __global__ __launch_bounds__(64) void k_inf_verify(const uint8_t* __restrict__ d
           }
         }
         k = kl = kd = nd = dmaxlen = prev = 0;
+        psym = 31;  // no previous symbol
         has_eob = false;
         have = fill == 128u;  // anything else cannot come from the scan kernel; dropped, not decoded
       }
@@ -314,6 +327,21 @@ __global__ __launch_bounds__(64) void k_inf_verify(const uint8_t* __restrict__ d
       const uint32_t xv = ((uint32_t)(bb >> len)) & ((1u << xb) - 1u);
       if (sy == 16 || sy == 17) rep = 3 + xv;
       if (sy == 18) rep = 11 + xv;
+      // T1 looks for blocks the reference wrote, and its run-length coding of the code lengths
+      // (src/deflate.ts:100-139) never produces these (another encoder's stream that does is decoded by T2):
+      //  - "repeat previous" (16) directly after anything but a plain non-zero length, or with count 6: a run
+      //    is cut into chunks of at most 6, the chunk's first length is written out, 16 repeats the other 3..5
+      //  - a zero run (17) of 3: three zeros are written as three plain zeros
+      //  - 17 closes its zero run (it codes the remainder 4..10), so a non-zero plain length follows;
+      //    plain zeros (a remainder below 4) close their run as well, so no 17/18 follows them
+      if (!loose) {  // (ZES_F_LOOSE_CANDIDATES switches the rules off to exercise the false-candidate path)
+        const bool plain_nz = psym >= 1u && psym <= 15u;
+        ok = ok && !(sy == 16u && (!plain_nz || xv == 3u));
+        ok = ok && !(sy == 17u && xv == 0u);
+        ok = ok && !(psym == 17u && !(sy >= 1u && sy <= 15u));
+        ok = ok && !(psym == 0u && (sy == 17u || sy == 18u));
+      }
+      psym = sy;
       const uint32_t adv = len + xb;
       bb >>= adv;
       nb -= adv;

@@ -992,7 +992,7 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __
                                                                const ZesInfBuf* __restrict__ bufs, uint32_t nbuf,
                                                                const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ cand_all,
                                                                const uint32_t* __restrict__ map_all, ZesCandRes* __restrict__ cres_all,
-                                                               unsigned long long* __restrict__ dbg) {
+                                                               unsigned long long* __restrict__ dbg, const uint32_t* __restrict__ redo) {
   __shared__ __align__(16) ParSmem S;
 #define STAMP(i)                                                     \
   do {                                                               \
@@ -1009,7 +1009,8 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __
     }
     bi = lo;
   }
-  const uint32_t w = blockIdx.x - bufs[bi].work_first;              // work item inside the buffer = output slot
+  // work item inside the buffer = output slot (a one-buffer launch may name the slots to decode again: redo[])
+  const uint32_t w = redo ? redo[blockIdx.x] : blockIdx.x - bufs[bi].work_first;
   const uint32_t ncand = min(cnt[bi], bufs[bi].cand_cap);
   uint32_t nwork = bufs[bi + 1].work_first - bufs[bi].work_first;
   if (bufs[nbuf].work_first == ZES_WORK_AUTO) {  // one buffer, launched before the host saw the candidate count

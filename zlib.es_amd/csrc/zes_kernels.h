@@ -39,12 +39,13 @@ struct ZesCandRes {
 __global__ void k_inf_first_bytes(const uint8_t*, const uint64_t*, uint8_t*, uint32_t);
 __global__ void k_inf_scan(const uint8_t*, const ZesInfBuf*, uint32_t, unsigned long long*, uint32_t, uint32_t*, uint8_t*);
 __global__ void k_inf_set_table1(ZesInfBuf, ZesInfBuf, ZesInfBuf*, uint32_t*, uint32_t);
-__global__ void k_inf_verify(const uint8_t*, const ZesInfBuf*, const unsigned long long*, uint32_t, uint32_t*, uint32_t*, uint32_t*);
+__global__ void k_inf_verify(const uint8_t*, const ZesInfBuf*, const unsigned long long*, uint32_t, uint32_t*, uint32_t*, uint32_t*, uint32_t);
 __global__ void k_inf_ranksort(const ZesInfBuf*, const uint32_t*, const uint32_t*, uint32_t*);
 __global__ void k_inf_decode(const uint8_t*, uint64_t, uint64_t, uint8_t*, uint64_t, uint64_t, const uint32_t*, const uint32_t*,
                              uint32_t, ZesCandRes*, ZesRes*, uint64_t*, int);
 __global__ void k_inf_block_par(const uint8_t*, uint8_t*, const ZesInfBuf*, uint32_t, const uint32_t*, const uint32_t*, const uint32_t*,
-                                ZesCandRes*, unsigned long long*);
+                                ZesCandRes*, unsigned long long*, const uint32_t*);
+__global__ void k_inf_move_slots(uint8_t*, const uint8_t*, const uint32_t*, const uint32_t*, uint32_t);
 __global__ void k_inf_chain(const ZesInfBuf*, const uint32_t*, const uint32_t*, const ZesCandRes*, const uint32_t*, uint32_t*, ZesRes*);
 __global__ void k_inf_exact(const uint8_t*, uint64_t, uint64_t, uint8_t*, uint64_t, uint64_t, const uint64_t*, ZesRes*);
 // deflate direction (zes_deflate.hip)
