@@ -85,6 +85,7 @@ struct SortSmem {
   uint32_t base[2][256];     // running output offset per digit (double-buffered across tiles)
   uint16_t whist[2][SORT_WAVES][256];
   uint32_t wsum[SORT_WAVES];
+  uint32_t nsat;             // filter: positions that found their key already counted twice
 };
 static_assert((1u << SORT_HASH_BITS) * 2u / 8u <= ZES_BLK, "counter table must fit the block area");
 static_assert(SORT_OWN * SORT_THREADS == ZES_BLK, "one thread per 128 positions");
@@ -124,12 +125,16 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
     uint4* t4 = reinterpret_cast<uint4*>(S.in);
     for (uint32_t i = tid; i < ZES_BLK / 16; i += SORT_THREADS) t4[i] = make_uint4(0, 0, 0, 0);
     for (uint32_t i = tid; i < 4 * 3 * 256; i += SORT_THREADS) reinterpret_cast<uint32_t*>(&S.whist[0][0][0])[i] = 0;
+    if (tid == 0) S.nsat = 0;
   }
   __syncthreads();
   SSTAMP(1);
   const bool aligned = (((uintptr_t)src) & 15u) == 0;
   const uint32_t p0 = tid * SORT_OWN;  // this thread's positions: [p0, p0 + 128) below cnt
   // pass 1: count every key (saturating at two: bit 0 = seen, bit 1 = seen again)
+  uint32_t samp[SORT_OWN / 16];  // hash of the first key of each 16-position chunk: the survivor rate is sampled on these
+#pragma unroll
+  for (uint32_t c = 0; c < SORT_OWN / 16; c++) samp[c] = ~0u;
   if (p0 < cnt) {
     uint4 cur = sort_ld16(src, aligned, p0, T);
 #pragma unroll 1
@@ -143,7 +148,13 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
         const uint32_t sh = (h & 15u) * 2u;
         // a plain read first: keys that repeat often (text, periodic data) are saturated early and
         // would otherwise hammer one word with same-address atomics
-        if (p0 + 16u * c + k < cnt && !((tbl[h >> 4] >> sh) & 2u)) {
+        const bool inr = p0 + 16u * c + k < cnt;
+        const bool sat = (tbl[h >> 4] >> sh) & 2u;
+        if (k == 0 && inr) {
+#pragma unroll
+          for (uint32_t cc = 0; cc < SORT_OWN / 16; cc++) samp[cc] = (cc == c) ? h : samp[cc];
+        }
+        if (inr && !sat) {
           const uint32_t old = atomicOr(&tbl[h >> 4], 1u << sh);
           if (((old >> sh) & 3u) == 1u) atomicOr(&tbl[h >> 4], 2u << sh);
         }
@@ -153,6 +164,25 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
   }
   __syncthreads();
   SSTAMP(2);
+  // Sample: one position in sixteen.  When three quarters of them are kept, nearly everything would be
+  // (text, periodic data): the second filter pass and the compaction are skipped and all positions are
+  // sorted (a position with a unique key simply has no neighbour of its key).
+  {
+    uint32_t kept = 0, tried = 0;
+#pragma unroll
+    for (uint32_t c = 0; c < SORT_OWN / 16; c++) {
+      const uint32_t h = samp[c];
+      if (h != ~0u) {
+        tried++;
+        kept += (tbl[h >> 4] >> ((h & 15u) * 2u + 1u)) & 1u;
+      }
+    }
+    atomicAdd(&S.nsat, kept | (tried << 16));
+  }
+  __syncthreads();
+  const bool dense = (S.nsat & 0xFFFFu) * 4u >= (S.nsat >> 16) * 3u;
+  uint32_t ns = cnt;
+  if (!dense) {
   // pass 2: keep the positions whose counter reached two; 128 flags per thread
   uint32_t f0 = 0, f1 = 0, f2 = 0, f3 = 0;
   uint32_t(*sub)[256] = reinterpret_cast<uint32_t(*)[256]>(&S.whist[0][0][0]) + 3u * (lane & 3u);  // 4 x 3 x 256 u32 = 12 KiB
@@ -198,7 +228,8 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
   }
   if (lane == 63) S.wsum[wave] = incl;
   __syncthreads();  // also: every thread is done with the counter table
-  uint32_t woff = 0, ns = 0;
+  uint32_t woff = 0;
+  ns = 0;
 #pragma unroll
   for (uint32_t w = 0; w < SORT_WAVES; w++) {
     const uint32_t v = S.wsum[w];
@@ -231,7 +262,8 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
     const uint32_t w = fbits[p >> 5];
     if ((w >> (p & 31u)) & 1u) B[fpre[p >> 5] + (uint32_t)__popc(w & ((1u << (p & 31u)) - 1u))] = p;
   }
-  __syncthreads();  // flag words read before the block is staged over them
+  }  // !dense
+  __syncthreads();  // flag words (or, dense, the counter table) read before the block is staged over them
   SSTAMP(4);
   // Blocks that keep most of their positions (text, periodic data) go to the lazy match finder, which
   // evaluates positions along greedy chains and needs the sorted slot of a position: inv[p].
@@ -242,6 +274,25 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
 
   stage_block(S.in, src, T, (T + 15u) & ~15u);
   __syncthreads();
+  if (dense) {
+    // digit histograms of all positions: the block's byte histogram (four copies by lane) minus the few
+    // bytes a pass does not see (pass k sorts by the byte at offset 2 - k of positions 0 .. cnt-1)
+    uint32_t(*hc)[256] = reinterpret_cast<uint32_t(*)[256]>(&S.whist[0][0][0]);  // zeroed at the start, [4] used
+    for (uint32_t i = tid; i < T; i += SORT_THREADS) atomicAdd(&hc[lane & 3u][S.in[i]], 1u);
+    __syncthreads();
+    if (tid < 256) {
+      const uint32_t H = hc[0][tid] + hc[1][tid] + hc[2][tid] + hc[3][tid];
+#pragma unroll
+      for (uint32_t ps = 0; ps < 3; ps++) {
+        const uint32_t off = 2u - ps;
+        uint32_t h = H;
+        for (uint32_t e = 0; e < off; e++) h -= (S.in[e] == tid);
+        for (uint32_t e = off + cnt; e < T; e++) h -= (S.in[e] == tid);
+        S.hist[ps][tid] = h;
+      }
+    }
+    __syncthreads();
+  }
   SSTAMP(5);  // staged block and the survivor list in B visible to the whole workgroup
 
   uint32_t bsel = 0;
@@ -289,7 +340,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
       // compiler wait for every outstanding memory operation, the scatter stores included, and those
       // would then run one at a time.
 #pragma unroll
-      for (uint32_t r = 0; r < SORT_ROUNDS; r++) p[r] = pn[r];
+      for (uint32_t r = 0; r < SORT_ROUNDS; r++) p[r] = (dense && pass == 0) ? min(i0 + 64u * r, ns - 1u) : pn[r];  // dense: the list is 0, 1, 2, ...
       asm volatile("" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]));
 #pragma unroll
       for (uint32_t r = 0; r < SORT_ROUNDS; r++) d[r] = (i0 + 64u * r < ns) ? S.in[p[r] + off] : 0u;
