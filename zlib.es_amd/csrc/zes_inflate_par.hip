@@ -1229,22 +1229,59 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __
     // with per-wave watermarks was measured slower: text distances stagger the ranges.) ----
     if (wave == 0) {
       uint16_t* ml = S.mlist;
-      for (uint32_t wb = 0; wb < total; wb += 2048) {
-        const uint32_t wi = (wb >> 5) + lane;
-        uint32_t bits = (wi < ZES_BLK / 32) ? S.bitmap[wi] : 0u;
-        const uint32_t cntb = (uint32_t)__popc(bits);
-        uint32_t inc2 = cntb;
+      // Matches are listed per window of the image.  A block with few matches (incompressible data:
+      // ~250) takes 8 KiB windows, four bitmap words per lane: the per-window scan is the whole cost there.
+      uint32_t nmatch = 0;
+      for (uint32_t i = lane; i < ZES_BLK / 32; i += 64) nmatch += (uint32_t)__popc(S.bitmap[i]);
 #pragma unroll
-        for (int dlt = 1; dlt < 64; dlt <<= 1) {
-          const uint32_t t = __shfl_up(inc2, dlt);
-          if ((int)lane >= dlt) inc2 += t;
-        }
-        const uint32_t nwin = __shfl(inc2, 63);
-        uint32_t slot = inc2 - cntb;
-        while (bits) {
-          const uint32_t t = (uint32_t)__builtin_ctz(bits);
-          bits &= bits - 1u;
-          ml[slot++] = (uint16_t)((lane << 5) + t);
+      for (int d = 32; d >= 1; d >>= 1) nmatch += __shfl_xor(nmatch, d);
+      const uint32_t wwords = nmatch <= 512u ? 4u : 1u;  // bitmap words per lane and window (uniform); 512 <= the list's 704
+      const uint32_t wbytes = wwords * 2048u;
+      for (uint32_t wb = 0; wb < total; wb += wbytes) {
+        uint32_t nwin;
+        if (wwords == 1u) {  // uniform
+          const uint32_t wi = (wb >> 5) + lane;
+          uint32_t bits = (wi < ZES_BLK / 32) ? S.bitmap[wi] : 0u;
+          const uint32_t cntb = (uint32_t)__popc(bits);
+          uint32_t inc2 = cntb;
+#pragma unroll
+          for (int dlt = 1; dlt < 64; dlt <<= 1) {
+            const uint32_t t = __shfl_up(inc2, dlt);
+            if ((int)lane >= dlt) inc2 += t;
+          }
+          nwin = __shfl(inc2, 63);
+          uint32_t slot = inc2 - cntb;
+          while (bits) {
+            const uint32_t t = (uint32_t)__builtin_ctz(bits);
+            bits &= bits - 1u;
+            ml[slot++] = (uint16_t)((lane << 5) + t);
+          }
+        } else {
+          uint32_t wbits[4];
+          uint32_t cntb = 0;
+#pragma unroll
+          for (uint32_t q = 0; q < 4; q++) {
+            const uint32_t wi = (wb >> 5) + lane * 4u + q;
+            wbits[q] = (wi < ZES_BLK / 32) ? S.bitmap[wi] : 0u;
+            cntb += (uint32_t)__popc(wbits[q]);
+          }
+          uint32_t inc2 = cntb;
+#pragma unroll
+          for (int dlt = 1; dlt < 64; dlt <<= 1) {
+            const uint32_t t = __shfl_up(inc2, dlt);
+            if ((int)lane >= dlt) inc2 += t;
+          }
+          nwin = __shfl(inc2, 63);
+          uint32_t slot = inc2 - cntb;
+#pragma unroll
+          for (uint32_t q = 0; q < 4; q++) {
+            uint32_t bits = wbits[q];
+            while (bits) {
+              const uint32_t t = (uint32_t)__builtin_ctz(bits);
+              bits &= bits - 1u;
+              ml[slot++] = (uint16_t)(((lane * 4u + q) << 5) + t);
+            }
+          }
         }
         for (uint32_t k = 0; k < nwin; k += 64) {
           const uint32_t i = k + lane;
