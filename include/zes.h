@@ -79,6 +79,9 @@ int zes_inflate_dev(const uint8_t* d_in, uint64_t c, uint8_t* d_out, uint64_t ca
 /* Size-only pass (decodes, writes nothing to the caller): lets a binding allocate the exact
  * result the way the reference's growable Uint8WriteStream (src/utils/Uint8WriteStream.ts:1-25) does. */
 int zes_inflate_size(const uint8_t* in, uint64_t c, uint64_t* n, uint32_t flags);
+/* Copies out what the zes_inflate_size call right before it decoded (it stays in the library's device buffer),
+ * so that size-then-allocate bindings decode and cross PCIe once.  Any other call in between drops it (ZES_E_ARG). */
+int zes_inflate_fetch(uint8_t* out, uint64_t cap, uint64_t* out_len);
 
 /* Raw DEFLATE, without the zlib wrapper, for callers that embed DEFLATE in another container.
  * zes_deflate_raw*  replaces: `export function deflate(input)` of src/deflate.ts:14-39 (what src/zlib.ts:35 wraps):

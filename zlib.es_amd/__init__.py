@@ -81,6 +81,7 @@ def lib():
         for name in ("zes_inflate", "zes_inflate_dev"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, u64p, C.c_uint32]
         L.zes_inflate_size.argtypes = [C.c_void_p, C.c_uint64, u64p, C.c_uint32]
+        L.zes_inflate_fetch.argtypes = [C.c_void_p, C.c_uint64, u64p]
         for name in ("zes_deflate_raw", "zes_deflate_raw_dev"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, u64p]
         for name in ("zes_inflate_raw", "zes_inflate_raw_dev"):
@@ -154,7 +155,7 @@ def deflate(data):
     rc = lib().zes_deflate(a.ctypes.data, a.size, out.ctypes.data, cap, C.byref(n))
     if rc:
         _raise(rc)
-    return out[: n.value].copy()
+    return out[: n.value].copy() if n.value < (1 << 20) else out[: n.value]  # large results: a view, not a second copy
 
 
 def inflate(data, flags=0):
@@ -166,10 +167,10 @@ def inflate(data, flags=0):
         _raise(rc)
     out = np.empty(max(need.value, 1), dtype=np.uint8)
     n = C.c_uint64()
-    rc = lib().zes_inflate(a.ctypes.data, a.size, out.ctypes.data, need.value, C.byref(n), flags)
+    rc = lib().zes_inflate_fetch(out.ctypes.data, need.value, C.byref(n))  # the size call left the bytes on the device
     if rc:
         _raise(rc)
-    return out[: n.value].copy()
+    return out[: n.value]
 
 
 def deflate_raw(data):

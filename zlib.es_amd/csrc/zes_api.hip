@@ -45,6 +45,8 @@ struct Ctx {
   bool profiling = false;
   std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending;
   std::vector<hipEvent_t> event_pool;
+  uint64_t kept_len = 0;     // zes_inflate_size left this many decoded bytes in st_out for zes_inflate_fetch
+  bool kept_valid = false;
   std::vector<std::pair<std::string, KTime>> last_times;
   std::vector<std::string> name_pool;
   int last_tier = 0;
@@ -847,6 +849,7 @@ int zes_deflate(const uint8_t* in, uint64_t n, uint8_t* out, uint64_t cap, uint6
     std::lock_guard<std::mutex> lk(g_mu);
     int rc = init_locked(-1);
     if (rc) return rc;
+    g.kept_valid = false;
     if ((rc = ensure(g.st_in, n + 64))) return rc;
     if ((rc = ensure(g.st_out, bound + 64))) return rc;
     HIPCHK(hipMemcpyAsync(g.st_in.p, in, n, hipMemcpyHostToDevice, g.stream));
@@ -900,6 +903,7 @@ static int inflate_host(const uint8_t* in, uint64_t c, uint8_t* out, uint64_t ca
   std::lock_guard<std::mutex> lk(g_mu);
   int rc = init_locked(-1);
   if (rc) return rc;
+  g.kept_valid = false;
   if ((rc = ensure(g.st_in, c + 64))) return rc;
   if (c) HIPCHK(hipMemcpyAsync(g.st_in.p, in, c, hipMemcpyHostToDevice, g.stream));
   // decode into pooled device memory: grow-and-retry like the reference's Uint8WriteStream
@@ -910,15 +914,15 @@ static int inflate_host(const uint8_t* in, uint64_t c, uint8_t* out, uint64_t ca
     rc = inflate_one((const uint8_t*)g.st_in.p, 0, c, (uint8_t*)g.st_out.p, 0, dcap, &n, flags, c ? in[0] : 0);
     if (rc == ZES_E_NOSPACE && n > dcap) {
       dcap = n;
-      if (size_only) {
-        *out_len = n;
-        return ZES_OK;
-      }
       continue;
     }
     if (rc) return rc;
     *out_len = n;
-    if (size_only) return ZES_OK;
+    if (size_only) {  // the decoded bytes stay on the device for zes_inflate_fetch
+      g.kept_len = n;
+      g.kept_valid = true;
+      return ZES_OK;
+    }
     if (n > cap) return ZES_E_NOSPACE;
     if (n) HIPCHK(hipMemcpyAsync(out, g.st_out.p, n, hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
@@ -932,6 +936,19 @@ int zes_inflate(const uint8_t* in, uint64_t c, uint8_t* out, uint64_t cap, uint6
 }
 int zes_inflate_size(const uint8_t* in, uint64_t c, uint64_t* n, uint32_t flags) {
   return inflate_host(in, c, nullptr, 0, n, flags, true);
+}
+
+int zes_inflate_fetch(uint8_t* out, uint64_t cap, uint64_t* out_len) {
+  if (!out_len) return ZES_E_ARG;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g.ready || !g.kept_valid) return ZES_E_ARG;  // nothing kept: zes_inflate_size must be the call right before
+  *out_len = g.kept_len;
+  if (g.kept_len > cap) return ZES_E_NOSPACE;
+  if (g.kept_len && !out) return ZES_E_ARG;
+  if (g.kept_len) HIPCHK(hipMemcpyAsync(out, g.st_out.p, g.kept_len, hipMemcpyDeviceToHost, g.stream));
+  HIPCHK(hipStreamSynchronize(g.stream));
+  g.kept_valid = false;
+  return ZES_OK;
 }
 
 int zes_adler32_dev(const uint8_t* d_in, uint64_t n, uint32_t* adler_out) {
@@ -986,6 +1003,7 @@ int zes_inflate_raw(const uint8_t* in, uint64_t c, uint64_t offset, uint8_t* out
   int rc = init_locked(-1);
   if (rc) return rc;
   const uint64_t n = offset < c ? c - offset : 0;
+  g.kept_valid = false;
   if ((rc = ensure(g.st_in, n + 2 + 64))) return rc;
   if (n) HIPCHK(hipMemcpyAsync((uint8_t*)g.st_in.p + 2, in + offset, n, hipMemcpyHostToDevice, g.stream));
   // decode into pooled device memory: grow-and-retry like the reference's Uint8WriteStream
@@ -1011,6 +1029,7 @@ int zes_inflate_raw(const uint8_t* in, uint64_t c, uint64_t offset, uint8_t* out
 static int deflate_raw_common(const uint8_t* d_in, uint64_t n, uint64_t* raw_len) {
   const uint64_t bound = deflate_bound(n);
   int rc;
+  g.kept_valid = false;
   if ((rc = ensure(g.st_out, bound + 64))) return rc;
   uint64_t zero = 0, dl = 0;
   int32_t st = 0;

@@ -84,7 +84,7 @@ napi_value Inflate(napi_env env, napi_callback_info info) {
     napi_throw_type_error(env, nullptr, "inflate(input): input must be a Uint8Array");
     return nullptr;
   }
-  // size first (the reference grows a Uint8WriteStream instead, src/inflate.ts:17), then decode
+  // size first (the reference grows a Uint8WriteStream instead, src/inflate.ts:17), then fetch
   // straight into the result's ArrayBuffer
   uint64_t need = 0, out_len = 0;
   int rc = zes_inflate_size(in, c, &need, ZES_F_DEFAULT);
@@ -93,7 +93,8 @@ napi_value Inflate(napi_env env, napi_callback_info info) {
   napi_value ab, ta;
   if (napi_create_arraybuffer(env, need, &dst, &ab) != napi_ok) return nullptr;
   uint8_t dummy = 0;
-  rc = zes_inflate(in, c, need ? static_cast<uint8_t*>(dst) : &dummy, need, &out_len, ZES_F_DEFAULT);
+  // the size call left the decoded bytes in the library's device buffer: one decode, one trip over PCIe
+  rc = zes_inflate_fetch(need ? static_cast<uint8_t*>(dst) : &dummy, need, &out_len);
   if (rc) return throw_status(env, rc);
   if (napi_create_typedarray(env, napi_uint8_array, out_len, ab, 0, &ta) != napi_ok) return nullptr;
   return ta;
