@@ -126,7 +126,7 @@ struct Timed {
   }
   ~Timed() {
     if (g.profiling) {
-      hipEventRecord(b, g.stream);
+      (void)hipEventRecord(b, g.stream);
       g.pending.push_back({name, {a, b}});
     }
   }
@@ -138,8 +138,8 @@ void collect_times() {
   std::vector<std::string> order;
   for (auto& p : g.pending) {
     float ms = 0;
-    hipEventSynchronize(p.second.second);
-    hipEventElapsedTime(&ms, p.second.first, p.second.second);
+    (void)hipEventSynchronize(p.second.second);
+    (void)hipEventElapsedTime(&ms, p.second.first, p.second.second);
     if (!acc.count(p.first)) order.push_back(p.first);
     acc[p.first].ms += ms;
     acc[p.first].launches++;
@@ -791,17 +791,19 @@ int zes_init(int device) {
 int zes_shutdown(void) {
   std::lock_guard<std::mutex> lk(g_mu);
   if (!g.ready) return ZES_OK;
-  hipStreamSynchronize(g.stream);
+  (void)hipStreamSynchronize(g.stream);
   DevBuf* all[] = {&g.bufs, &g.blks, &g.idx_a, &g.idx_b, &g.inv, &g.hists, &g.codes, &g.hdrs, &g.adler, &g.res, &g.surv, &g.cand,
                    &g.cand_sorted, &g.counters, &g.cres, &g.map, &g.resume, &g.dbg, &g.ibufs, &g.ibufs2, &g.mvlist, &g.scratch, &g.st_in, &g.st_out};
   for (DevBuf* b : all) {
-    if (b->p) hipFree(b->p);
+    if (b->p) (void)hipFree(b->p);
     b->p = nullptr;
     b->cap = 0;
   }
-  if (g.pinned) hipHostFree(g.pinned);
+  if (g.pinned) (void)hipHostFree(g.pinned);
   g.pinned = nullptr;
-  hipStreamDestroy(g.stream);
+  for (hipEvent_t e : g.event_pool) (void)hipEventDestroy(e);
+  g.event_pool.clear();
+  (void)hipStreamDestroy(g.stream);
   g.stream = nullptr;
   g.ready = false;
   return ZES_OK;

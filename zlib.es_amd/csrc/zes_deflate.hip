@@ -1417,7 +1417,6 @@ struct HuffSmem {
   uint32_t hdr[ZES_HDR_WORDS];
   uint32_t hdr_bits;
   uint32_t total_bits;
-  uint32_t n_nonzero;
   uint32_t ccount[16], cfirst[16], crun[16];     // canonical codes: symbols per length, first code, symbols seen so far
   uint16_t cwave[HUFF_THREADS / 64][16];         // canonical codes: symbols of each length per wave of the current pass
   uint8_t cl[320];                               // lit/len lengths followed by the distance lengths (src/deflate.ts:81-97)
@@ -1576,13 +1575,6 @@ __device__ static inline void hdr_or(HuffSmem& S, uint32_t bitpos, uint32_t valu
   const uint32_t w = bitpos >> 5, sh = bitpos & 31u;
   atomicOr(&S.hdr[w], value << sh);
   if (sh + nbits > 32u) atomicOr(&S.hdr[w + 1], value >> (32u - sh));
-}
-__device__ static inline void hdr_put(HuffSmem& S, uint32_t& bitpos, uint32_t value, uint32_t nbits) {
-  // single-thread LSB-first append into S.hdr (zeroed beforehand)
-  const uint32_t w = bitpos >> 5, sh = bitpos & 31u;
-  S.hdr[w] |= value << sh;
-  if (sh + nbits > 32u) S.hdr[w + 1] |= value >> (32u - sh);
-  bitpos += nbits;
 }
 
 __global__ __launch_bounds__(HUFF_THREADS) void k_huff(ZesBlk* __restrict__ blks, const uint32_t* __restrict__ hists,
