@@ -407,7 +407,13 @@ __device__ __forceinline__ static uint32_t f8_next(const F8List& l, uint64_t tai
 }
 
 __device__ __forceinline__ static bool seg_table_f8(ParSmem& S, const BitSrc& src, uint32_t limit, uint32_t base, uint32_t stop,
-                                                    const Lit8& f8, SegTab& tab) {
+                                                    const Lit8& f8, SegTab& tab, unsigned long long* dp) {
+  // debug stamps (ZES_DEBUG_PHASES): slots 8..10 by the first wave of the workgroup, 12..14 by the last one
+#define T8STAMP(i)                                                                  \
+  do {                                                                              \
+    if (dp && (threadIdx.x == 0 || threadIdx.x == PAR_THREADS - 64))                \
+      dp[(threadIdx.x ? 12 : 8) + (i)] = (unsigned long long)clock64();             \
+  } while (0)
   const uint32_t sl = stop - base;
   bool ok = sl >= 64u && sl <= F8_MAXSEG && stop + 128u <= limit;  // every bit the scan looks at is data
   // ---- (A) positions where no 8-bit literal code starts ----
@@ -422,22 +428,37 @@ __device__ __forceinline__ static bool seg_table_f8(ParSmem& S, const BitSrc& sr
   const uint32_t d0 = base >> 5, bo = base & 31u;
   const uint32_t nd = (sl + 48u + 62u) >> 5;  // dwords that cover [base, stop + 48) for any alignment (uniform)
   uint32_t lo = src_ldw<true>(src, d0);
+  // four dwords per step: the listing loop below runs as often as the busiest lane has positions to list,
+  // so it is entered once per 128 bit positions, not once per 32
 #pragma unroll 1
-  for (uint32_t j = 0; j < nd; j++) {
-    const uint32_t hi = src_ldw<true>(src, d0 + j + 1u);
-    uint32_t bad = 0;  // bit b: no 8-bit literal code starts at bit 32 j + b
+  for (uint32_t j0 = 0; j0 < nd; j0 += 4u) {
+    uint32_t bad[4];
 #pragma unroll
-    for (uint32_t phi = 0; phi < 8u; phi++) {
-      const uint32_t x = __brev(__builtin_amdgcn_alignbit(hi, lo, phi));  // top byte = the token at bit 32 j + phi
-      const uint32_t t = ((x | H) - LOm) ^ ((x ^ nLO) & H);
-      const uint32_t inv = t & ((t & ~H) + M) & H;  // bit 31 - 8k: token k of this phase
-      bad |= (__brev(inv) << phi);                   // -> bit phi + 8k
+    for (uint32_t jj = 0; jj < 4u; jj++) {
+      const uint32_t hi = src_ldw<true>(src, d0 + j0 + jj + 1u);
+      uint32_t bd = 0;  // bit b: no 8-bit literal code starts at bit 32 (j0 + jj) + b
+#pragma unroll
+      for (uint32_t phi = 0; phi < 8u; phi++) {
+        const uint32_t x = __brev(__builtin_amdgcn_alignbit(hi, lo, phi));  // top byte = the token at bit 32 j + phi
+        const uint32_t t = ((x | H) - LOm) ^ ((x ^ nLO) & H);
+        const uint32_t inv = t & ((t & ~H) + M) & H;  // bit 31 - 8k: token k of this phase
+        bd |= (__brev(inv) << phi);                    // -> bit phi + 8k
+      }
+      bad[jj] = (j0 + jj < nd) ? bd : 0u;
+      lo = hi;
     }
-    while (__ballot(bad != 0u)) {  // about a quarter of the lanes have one per dword on random data
-      const bool hv = bad != 0u;
-      const uint32_t bpos = hv ? (uint32_t)__builtin_ctz(bad) : 0u;
-      bad &= bad - 1u;
-      const uint32_t rel = 32u * j + bpos - bo;  // wraps for positions in front of the segment
+    while (__ballot((bad[0] | bad[1] | bad[2] | bad[3]) != 0u)) {
+      // lowest listed position first (ascending order inside a lane is not needed by f8_next, but cheap to keep)
+      const uint32_t q = bad[0] ? 0u : bad[1] ? 1u : bad[2] ? 2u : 3u;
+      const uint32_t bq = bad[0] ? bad[0] : bad[1] ? bad[1] : bad[2] ? bad[2] : bad[3];
+      const bool hv = bq != 0u;
+      const uint32_t bpos = hv ? (uint32_t)__builtin_ctz(bq) : 0u;
+      const uint32_t cl = bq & (bq - 1u);  // that bit cleared
+      bad[0] = (q == 0u) ? cl : bad[0];
+      bad[1] = (q == 1u && hv) ? cl : bad[1];
+      bad[2] = (q == 2u && hv) ? cl : bad[2];
+      bad[3] = (q == 3u && hv) ? cl : bad[3];
+      const uint32_t rel = 32u * (j0 + q) + bpos - bo;  // wraps for positions in front of the segment
       const bool take = hv && rel < sl + 48u;
       grp = take ? ((grp << 16) | rel) : grp;
       nl += take ? 1u : 0u;
@@ -447,9 +468,9 @@ __device__ __forceinline__ static bool seg_table_f8(ParSmem& S, const BitSrc& sr
         grp = full ? ~0ull : grp;
       }
     }
-    lo = hi;
   }
   ok = ok && nl <= F8_LIST;
+  T8STAMP(0);
   // ---- (B) trajectories ----
   SegTab t = {0, 0, 0, 0, 0, 0, 0, 0};
   uint64_t pend = (1ull << 48) - 1ull;
@@ -500,6 +521,9 @@ __device__ __forceinline__ static bool seg_table_f8(ParSmem& S, const BitSrc& sr
     }
   }
   tab = t;
+  T8STAMP(1);
+  T8STAMP(2);
+#undef T8STAMP
   return ok;
 }
 
@@ -509,7 +533,7 @@ __device__ __forceinline__ static void seg_table(ParSmem& S, const BitSrc& src, 
   // uniform: most literals have 8-bit codes, and the segments are long enough for literal runs to matter
   // (a block of long matches has 64-bit segments that are nearly all listed positions)
   if (LDS && f8.n && !__ballot(stop - base < 256u)) {
-    const bool done = seg_table_f8(S, src, limit, base, stop, f8, tab);
+    const bool done = seg_table_f8(S, src, limit, base, stop, f8, tab, dp);
     const uint64_t redo = __ballot(!done);
     if (dp && redo && zes_lane() == 0) {  // ZES_DEBUG_PHASES: lanes / waves that fell back
       atomicAdd(&dp[11], (unsigned long long)__popcll(redo));
