@@ -127,8 +127,9 @@ int zes_stage_huff_lengths_dev(const uint32_t* h_hist, uint32_t nsym, uint32_t m
  * stream: name/ms pairs for bench.py's roofline leg.  Returns the number of entries. */
 typedef struct zes_ktime { const char* name; float ms; uint32_t launches; } zes_ktime;
 int zes_last_kernel_times(zes_ktime* out, int cap);
-/* Which decoder produced the last zes_inflate*() result: 1 block-parallel, 2 sequential wavefront,
- * 3 exact single-lane restatement; 0 if the call failed before decoding. */
+/* Which decoder produced the last zes_inflate*() result: 1 block-parallel (reference-made streams),
+ * 2 segment-parallel (any valid stream), 3 sequential wavefront, 4 exact single-lane restatement
+ * (DESIGN.md §4); 0 if the call failed before decoding. */
 int zes_last_inflate_tier(void);
 int zes_set_profiling(int on);
 

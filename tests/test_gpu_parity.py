@@ -269,8 +269,55 @@ def test_reference_made_streams_take_the_block_parallel_tier(z, oracle, gpu):
     raw = open(os.path.join(GOLDEN, "ref_data", "compressed.bin"), "rb").read()
     z.inflate(raw)  # foreign stream with cross-block history
     assert z.last_inflate_tier() == 2
+    z.inflate(raw, z.ZES_F_NO_FASTPATH)
+    assert z.last_inflate_tier() == 3
     z.inflate(bytes.fromhex(golden("kat.json")["kat"]["FIXED"]))
-    assert z.last_inflate_tier() in (2, 3)
+    assert z.last_inflate_tier() in (3, 4)
+
+
+def _foreign_cases(z):
+    """Streams of another encoder (CPython's zlib module): history across blocks, stored and fixed blocks,
+    sync-flush markers, blocks far longer than 131072 bytes.  -> (name, stream, plain, expected tier or None)"""
+    import zlib as pz
+
+    text = z.gen("itext", 61, 6 << 20).tobytes()
+    rnd = z.gen("xorshift", 62, 3 << 20).tobytes()
+    low = z.gen("lowent4k", 63, 24 << 20).tobytes()
+    cases = [("text level 6", pz.compress(text, 6), text, 2), ("text level 1", pz.compress(text, 1), text, 2),
+             ("text level 9", pz.compress(text, 9), text, 2),
+             ("stored blocks", pz.compress(rnd, 6), rnd, None),  # no dynamic block to cut at: serial tier
+             ("long blocks", pz.compress(low, 6), low, None)]
+    co = pz.compressobj(6)
+    parts, plain = [], []
+    for i in range(40):  # dynamic / stored / empty stored (sync flush) / history reset (full flush), interleaved
+        chunk = (text[i * 150000:(i + 1) * 150000], rnd[i * 70001:(i + 1) * 70001], text[i * 333:i * 333 + 1500])[i % 3]
+        plain.append(chunk)
+        parts.append(co.compress(chunk))
+        parts.append(co.flush(pz.Z_FULL_FLUSH if i % 7 == 3 else pz.Z_SYNC_FLUSH if i % 2 else pz.Z_NO_FLUSH))
+    parts.append(co.flush())
+    cases.append(("mixed block types", b"".join(parts), b"".join(plain), 2))
+    co = pz.compressobj(6, pz.DEFLATED, 15, 8, pz.Z_FIXED)
+    fixed = co.compress(text[:1 << 20]) + co.flush()
+    cases.append(("fixed blocks only", fixed, text[:1 << 20], None))
+    return cases
+
+
+def test_inflate_foreign_streams_in_parallel_segments(z, gpu):
+    import torch
+
+    for name, comp, plain, tier in _foreign_cases(z):
+        out = z.inflate(comp)
+        assert bytes(out) == plain, name
+        if tier is not None:
+            assert z.last_inflate_tier() == tier, (name, z.last_inflate_tier())
+        # the device entry point, at an exact-size and at a too-small capacity
+        d = dev(np.frombuffer(comp, dtype=np.uint8), gpu)
+        o = torch.empty(len(plain), dtype=torch.uint8, device=gpu)
+        back = z.inflate_tensor(d, o)
+        assert back.numel() == len(plain) and bytes(back.cpu().numpy()) == plain, name
+        with pytest.raises(z.ZlibEsError, match="need %d bytes" % len(plain)):
+            z.inflate_tensor(d, torch.empty(len(plain) - 1, dtype=torch.uint8, device=gpu))
+        assert bytes(z.inflate(comp, z.ZES_F_NO_FASTPATH)) == plain, name
 
 
 def test_inflate_reports_needed_size(z, oracle, gpu):

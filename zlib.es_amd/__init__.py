@@ -279,7 +279,7 @@ def inflate_batch_tensor(d_in, in_off, in_len, d_out, out_off, out_cap, flags=0)
 
 
 def last_inflate_tier():
-    """1 block-parallel, 2 sequential wavefront, 3 exact restatement."""
+    """1 block-parallel, 2 segment-parallel (any stream), 3 sequential wavefront, 4 exact restatement."""
     return int(lib().zes_last_inflate_tier())
 
 

@@ -36,7 +36,7 @@ struct Ctx {
   // deflate scratch
   DevBuf bufs, blks, idx_a, idx_b, inv, hists, codes, hdrs, adler, res;
   // inflate scratch
-  DevBuf surv, cand, cand_sorted, counters, cres, map, resume, dbg, ibufs, ibufs2, mvlist, scratch;
+  DevBuf surv, cand, cand_sorted, counters, cres, map, resume, dbg, ibufs, ibufs2, mvlist, scratch, sres, maps, seglist, segprefix, wins;
   // staging for the host-pointer API
   DevBuf st_in, st_out;
   void* pinned = nullptr;  // small pinned area for read-backs
@@ -657,38 +657,140 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
   return ZES_OK;
 }
 
-// T2 then T3 for one buffer the block-parallel tier did not settle.
+// T2 for one buffer the block-parallel tier did not settle: segment-parallel decode of any valid stream
+// (blocks of every type, 32 KiB history across blocks).  Leaves j.tier at 0 when the stream is not a clean
+// chain of blocks; the serial tiers then reproduce the reference's result.
+constexpr uint64_t SEG_MIN_C = 32768;  // shorter streams go straight to the serial wavefront
+int inflate_segments(const uint8_t* d_in, uint8_t* d_out, InfJob& j) {
+  int rc;
+  ZesInfBuf* hb = (ZesInfBuf*)((uint8_t*)g.pinned + PIN_UP);
+  memset(hb, 0, sizeof(ZesInfBuf) * 2);
+  hb[0].in_off = j.in_off;
+  hb[0].c = j.c;
+  hb[0].out_off = j.out_off;
+  hb[0].cap = j.cap;
+  hb[0].cand_cap = (uint32_t)(j.c / 64 + 64);
+  const uint32_t chunks = (uint32_t)((j.c + INF_SCAN_BYTES - 1) / INF_SCAN_BYTES);
+  hb[1].first_chunk = chunks;
+  hb[1].cand_base = hb[0].cand_cap;
+  const uint32_t cand_cap = hb[0].cand_cap;
+  const uint32_t surv_cap = (uint32_t)std::min<uint64_t>(j.c / 4 + 1024ull, 1ull << 30);
+  const size_t cnt_bytes = 16 + 4 + 4;
+  if ((rc = ensure(g.ibufs, sizeof(ZesInfBuf) * 2))) return rc;
+  if ((rc = ensure(g.surv, (size_t)surv_cap * 8))) return rc;
+  if ((rc = ensure(g.cand, (size_t)cand_cap * 4))) return rc;
+  if ((rc = ensure(g.cand_sorted, (size_t)cand_cap * 4))) return rc;
+  if ((rc = ensure(g.counters, cnt_bytes))) return rc;
+  if ((rc = ensure(g.res, sizeof(ZesRes)))) return rc;
+  const ZesInfBuf* dbufs = (const ZesInfBuf*)g.ibufs.p;
+  uint32_t* counters = (uint32_t*)g.counters.p;
+  uint32_t* cnt = counters + 4;
+  hipLaunchKernelGGL(k_inf_set_table1, dim3(1), dim3(64), 0, g.stream, hb[0], hb[1], (ZesInfBuf*)g.ibufs.p, counters,
+                     (uint32_t)(cnt_bytes / 4));
+  {
+    Timed t("k_inf_scan");
+    hipLaunchKernelGGL(k_inf_scan, dim3(chunks), dim3(INF_SCAN_THREADS), 0, g.stream, d_in, dbufs, 1u, (unsigned long long*)g.surv.p,
+                       surv_cap, counters, (uint8_t*)(cnt + 1));
+  }
+  {
+    // foreign encoders do not follow the reference's run-length rules for code lengths: loose candidates
+    Timed t("k_inf_verify");
+    const uint32_t nwg = (uint32_t)std::min<uint64_t>(j.c / 2048 + 1, 8192);
+    hipLaunchKernelGGL(k_inf_verify, dim3(nwg), dim3(64), 0, g.stream, d_in, dbufs, (const unsigned long long*)g.surv.p, surv_cap,
+                       counters, (uint32_t*)g.cand.p, cnt, 1u);
+  }
+  {
+    Timed t("k_inf_ranksort");
+    hipLaunchKernelGGL(k_inf_ranksort, dim3(1), dim3(256), 0, g.stream, dbufs, (const uint32_t*)cnt, (const uint32_t*)g.cand.p,
+                       (uint32_t*)g.cand_sorted.p);
+  }
+  uint32_t* hc = (uint32_t*)g.pinned;
+  HIPCHK(hipMemcpyAsync(hc, g.counters.p, cnt_bytes, hipMemcpyDeviceToHost, g.stream));
+  HIPCHK(hipStreamSynchronize(g.stream));
+  const uint32_t nsurv = hc[0], ncand = hc[4];
+  if (nsurv > surv_cap || ncand > cand_cap || ncand < 2) return ZES_OK;  // nothing to cut the stream with
+  const uint32_t nwork = ncand + 1;
+  if ((rc = ensure(g.sres, sizeof(ZesSegRes) * nwork))) return rc;
+  if ((rc = ensure(g.maps, (size_t)nwork * ZES_WINDOW * 2))) return rc;
+  if ((rc = ensure(g.seglist, (size_t)nwork * 4))) return rc;
+  if ((rc = ensure(g.segprefix, (size_t)nwork * 8))) return rc;
+  {
+    Timed t("k_inf_seg_scan");
+    hipLaunchKernelGGL(k_inf_seg_scan, dim3(nwork), dim3(64), 0, g.stream, d_in, j.in_off, j.c, (const uint32_t*)g.cand_sorted.p, ncand,
+                       (ZesSegRes*)g.sres.p, (uint32_t*)g.maps.p);
+  }
+  {
+    Timed t("k_inf_seg_chain");
+    hipLaunchKernelGGL(k_inf_seg_chain, dim3(1), dim3(256), 0, g.stream, (const ZesSegRes*)g.sres.p, nwork, (uint32_t*)g.seglist.p,
+                       (uint64_t*)g.segprefix.p, (ZesRes*)g.res.p);
+  }
+  ZesRes hr;
+  if ((rc = read_res(&hr))) return rc;
+  if (getenv("ZES_DEBUG"))
+    fprintf(stderr, "zes T2: c=%llu candidates=%u chain status=%d segments=%u out_len=%llu\n", (unsigned long long)j.c, ncand, hr.status,
+            hr.aux, (unsigned long long)hr.out_len);
+  if (hr.status != 0 || hr.aux == 0) return ZES_OK;
+  const uint32_t nseg = hr.aux;
+  if (hr.out_len > j.cap) {  // the caller learns the size without the second decode
+    j.tier = 2;
+    j.out_len = hr.out_len;
+    j.status = ZES_E_NOSPACE;
+    return ZES_OK;
+  }
+  if ((rc = ensure(g.wins, (size_t)nseg * ZES_WINDOW))) return rc;
+  uint32_t* fail = counters + 3;
+  HIPCHK(hipMemsetAsync(fail, 0, 4, g.stream));
+  if (nseg > 1) {
+    Timed t("k_inf_seg_windows");
+    hipLaunchKernelGGL(k_inf_seg_windows, dim3(1), dim3(1024), 0, g.stream, (const uint32_t*)g.maps.p, (const uint32_t*)g.seglist.p, nseg,
+                       (uint8_t*)g.wins.p);
+  }
+  {
+    Timed t("k_inf_seg_decode");
+    hipLaunchKernelGGL(k_inf_seg_decode, dim3(nseg), dim3(64), 0, g.stream, d_in, j.in_off, j.c, d_out, j.out_off, j.cap,
+                       (const uint32_t*)g.cand_sorted.p, (const ZesSegRes*)g.sres.p, (const uint32_t*)g.seglist.p,
+                       (const uint64_t*)g.segprefix.p, (const uint8_t*)g.wins.p, fail);
+  }
+  HIPCHK(hipMemcpyAsync(hc, fail, 4, hipMemcpyDeviceToHost, g.stream));
+  HIPCHK(hipStreamSynchronize(g.stream));
+  if (hc[0] != 0) return ZES_OK;  // a match behind the first byte of the stream: the serial tiers decide
+  j.tier = 2;
+  j.out_len = hr.out_len;
+  j.status = ZES_OK;
+  return ZES_OK;
+}
+
+// T3 then T4 for one buffer the parallel tiers did not settle.
 int inflate_slow(const uint8_t* d_in, uint8_t* d_out, InfJob& j) {
   int rc;
   if ((rc = ensure(g.res, sizeof(ZesRes)))) return rc;
   if ((rc = ensure(g.resume, 16))) return rc;
   ZesRes hr;
   bool have_resume = false;
-  // T2: one wavefront, any valid stream
+  // T3: one wavefront, any valid stream
   if (j.c >= 3) {
     {
       Timed t("k_inf_decode_seq");
-      hipLaunchKernelGGL(k_inf_decode, dim3(1), dim3(64), 0, g.stream, d_in, j.in_off, j.c, d_out, j.out_off, j.cap,
-                         (const uint32_t*)nullptr, (const uint32_t*)nullptr, 1u, (ZesCandRes*)nullptr, (ZesRes*)g.res.p,
-                         (uint64_t*)g.resume.p, 1);
+      hipLaunchKernelGGL(k_inf_decode, dim3(1), dim3(64), 0, g.stream, d_in, j.in_off, j.c, d_out, j.out_off, j.cap, (ZesRes*)g.res.p,
+                         (uint64_t*)g.resume.p);
     }
     if ((rc = read_res(&hr))) return rc;
     if (hr.status == 0) {
-      j.tier = 2;
+      j.tier = 3;
       j.out_len = hr.out_len;
       j.status = hr.out_len > j.cap ? ZES_E_NOSPACE : ZES_OK;
       return ZES_OK;
     }
     have_resume = true;
   }
-  // T3: exact restatement from the failing block on
+  // T4: exact restatement from the failing block on
   {
     Timed t("k_inf_exact");
     hipLaunchKernelGGL(k_inf_exact, dim3(1), dim3(64), 0, g.stream, d_in, j.in_off, j.c, d_out, j.out_off, j.cap,
                        have_resume ? (const uint64_t*)g.resume.p : (const uint64_t*)nullptr, (ZesRes*)g.res.p);
   }
   if ((rc = read_res(&hr))) return rc;
-  j.tier = 3;
+  j.tier = 4;
   j.out_len = hr.out_len;
   j.status = hr.status;
   return ZES_OK;
@@ -740,6 +842,9 @@ int inflate_jobs(const uint8_t* d_in, uint8_t* d_out, std::vector<InfJob>& jobs,
   }
   int worst = 0;
   for (uint32_t i : todo) {
+    if (jobs[i].tier == 0 && jobs[i].status == ZES_OK && !(flags & ZES_F_NO_FASTPATH) && jobs[i].c >= SEG_MIN_C && jobs[i].c < (1ull << 29) &&
+        (rc = inflate_segments(d_in, d_out, jobs[i])))
+      return rc;
     if (jobs[i].tier == 0 && jobs[i].status == ZES_OK && (rc = inflate_slow(d_in, d_out, jobs[i]))) return rc;
     worst = std::max(worst, jobs[i].tier);
   }
@@ -793,7 +898,8 @@ int zes_shutdown(void) {
   if (!g.ready) return ZES_OK;
   (void)hipStreamSynchronize(g.stream);
   DevBuf* all[] = {&g.bufs, &g.blks, &g.idx_a, &g.idx_b, &g.inv, &g.hists, &g.codes, &g.hdrs, &g.adler, &g.res, &g.surv, &g.cand,
-                   &g.cand_sorted, &g.counters, &g.cres, &g.map, &g.resume, &g.dbg, &g.ibufs, &g.ibufs2, &g.mvlist, &g.scratch, &g.st_in, &g.st_out};
+                   &g.cand_sorted, &g.counters, &g.cres, &g.map, &g.resume, &g.dbg, &g.ibufs, &g.ibufs2, &g.mvlist, &g.scratch, &g.st_in, &g.st_out,
+                   &g.sres, &g.maps, &g.seglist, &g.segprefix, &g.wins};
   for (DevBuf* b : all) {
     if (b->p) (void)hipFree(b->p);
     b->p = nullptr;

@@ -1,18 +1,25 @@
 // zes_inflate.hip — gfx950 kernels of the decompress direction.
 //
-// Three tiers, each falling back to the next on anything unusual:
+// Four tiers, each falling back to the next on anything unusual:
 //
 //  T1  block-parallel: reference-made streams are chains of BTYPE=2 blocks that each inflate
 //      to exactly 131072 bytes without looking behind their own start.
 //        k_inf_scan      every bit position is tested for "could start a clean dynamic block"
 //        k_inf_verify    survivors get their whole header decoded and Kraft-checked
 //        k_inf_ranksort  candidate positions in ascending order
-//        k_inf_decode    one wavefront per candidate block, 64 KiB LDS ring, lane-parallel copies
+//        k_inf_block_par one workgroup per candidate block (zes_inflate_par.hip)
 //        k_inf_chain     walks end-bit -> next start from bit 16; accepts only a gap-free chain
-//  T2  k_inf_decode in sequential mode: one wavefront walks all blocks (stored / fixed / dynamic,
-//      32 KiB history across blocks) — any *valid* stream.
-//  T3  k_inf_exact: single-lane state-for-state restatement of the reference reader and block
-//      decoders (src/inflate.ts, src/utils/BitReadStream.ts), resumed at the block where T2 gave
+//  T2  segment-parallel, any valid stream (stored / fixed / dynamic blocks, 32 KiB history across
+//      blocks): the candidate block starts cut the stream into segments, one wavefront each.
+//        k_inf_seg_scan    decodes a segment with its unknown 32 KiB history as marker symbols
+//                          (16-bit ring): gives its end bit, its length and the last 32 Ki
+//                          symbols as a map "literal | index into the previous window"
+//        k_inf_seg_chain   follows the segments from bit 16 to the final block; output offsets
+//        k_inf_seg_windows resolves the window behind every segment, in order
+//        k_inf_seg_decode  decodes each segment again, now with its window, into its place
+//  T3  k_inf_decode: one wavefront walks all blocks of the stream in order.
+//  T4  k_inf_exact: single-lane state-for-state restatement of the reference reader and block
+//      decoders (src/inflate.ts, src/utils/BitReadStream.ts), resumed at the block where T3 gave
 //      up — reproduces the reference's result on malformed streams (which error, or which bytes).
 #include "zes_common.h"
 #include "zes_kernels.h"
@@ -416,9 +423,10 @@ __global__ __launch_bounds__(256) void k_inf_ranksort(const ZesInfBuf* __restric
 #define RING 65536u
 #define FLUSH 16384u
 #define INWIN 1024u
+#define RING16 33280u  // marker ring (16-bit symbols): window + longest match + slack; not a power of two
 
 struct InfSmem {
-  uint8_t ring[RING];
+  uint8_t ring[RING16 * 2];  // byte mode uses the first RING bytes
   uint16_t lut_l[1u << LROOT];
   uint16_t lut_d[1u << DROOT];
   uint16_t syms_l[288];
@@ -442,8 +450,10 @@ struct WaveDec {
   uint64_t cap;   // bytes that may be stored at out
   uint64_t o;     // bytes produced so far
   uint64_t flushed;
-  uint64_t hist0; // oldest output offset a match may reach
-  uint64_t omax;  // give up once more than this many bytes were produced (slot size in T1)
+  uint64_t ostart; // value of o at the start (0..15: out is the 16-byte aligned base below the first byte)
+  uint64_t avail;  // history bytes in front of ostart a match may reach (preloaded into the ring)
+  uint64_t omax;   // give up once o passes this
+  uint32_t oi;     // marker mode: ring index of output position o
 };
 
 enum { WD_OK = 0, WD_ANOMALY = 1, WD_NEEDS_HISTORY = 2 };
@@ -500,11 +510,11 @@ __device__ __forceinline__ static void wd_flush_range(InfSmem& S, WaveDec& d, ui
   const uint32_t lane = zes_lane();
   for (uint64_t off = from + (uint64_t)lane * 16; off < to; off += 64 * 16) {
     const uint32_t r = (uint32_t)(off & (RING - 1));
-    if (off + 16 <= to && off + 16 <= d.cap) {
+    if (off + 16 <= to && off + 16 <= d.cap && off >= d.ostart) {
       *reinterpret_cast<uint4*>(d.out + off) = *reinterpret_cast<const uint4*>(&S.ring[r]);
-    } else {
+    } else {  // a group shared with the neighbouring segment, or cut by the capacity: own bytes only
       for (uint32_t j = 0; j < 16; j++)
-        if (off + j < to && off + j < d.cap) d.out[off + j] = S.ring[(r + j) & (RING - 1)];
+        if (off + j < to && off + j < d.cap && off + j >= d.ostart) d.out[off + j] = S.ring[(r + j) & (RING - 1)];
     }
   }
 }
@@ -607,15 +617,25 @@ __device__ __forceinline__ static int wd_sym(WaveDec& d, const uint16_t* lut, ui
 }
 
 // Decodes the symbols of one fixed/dynamic block whose tables are built.  Uniform control flow.
+// MARK: 16-bit symbols in the marker ring (values >= 256 stand for bytes of the unknown window in
+// front of the segment), nothing is stored and every distance is allowed.
+template <bool MARK>
 __device__ __forceinline__ static int wd_symbols(InfSmem& S, WaveDec& d, uint32_t droot_used) {
   const uint32_t lane = zes_lane();
   const uint64_t limit = d.nbytes * 8;
+  uint16_t* r16 = reinterpret_cast<uint16_t*>(S.ring);
   for (;;) {
     wd_refill(S, d);
     const int s = wd_sym(d, S.lut_l, LROOT, S.syms_l, S.first_l, S.cnt_l, S.offs_l);
     if (s < 0) return WD_ANOMALY;
     if (d.pos > limit) return WD_ANOMALY;
     if (s < 256) {
+      if (MARK) {
+        if (lane == 0) r16[d.oi] = (uint16_t)s;
+        d.oi = d.oi + 1u == RING16 ? 0u : d.oi + 1u;
+        d.o++;
+        continue;
+      }
       if (lane == 0) S.ring[d.o & (RING - 1)] = (uint8_t)s;
       d.o++;
       if (d.o > d.omax) return WD_ANOMALY;
@@ -633,11 +653,26 @@ __device__ __forceinline__ static int wd_symbols(InfSmem& S, WaveDec& d, uint32_
     wd_refill(S, d);
     const uint32_t dist = kDistBase[ds] + wd_take(d, kDistXbits[ds]);
     if (d.pos > limit) return WD_ANOMALY;
-    if ((uint64_t)dist > d.o - d.hist0) return WD_NEEDS_HISTORY;  // T1: behind the block start; T2: behind the output start
-    if (d.o + len > d.omax) return WD_ANOMALY;
-    // lane-parallel copy; overlapping matches read i % dist so every source byte already exists
-    const uint64_t srcb = d.o - dist;
+    // lane-parallel copy; overlapping matches read i % dist so every source symbol already exists
     const uint32_t recip = (dist < len) ? (1048576u / dist + 1u) : 0u;
+    if (MARK) {
+      const uint32_t si = d.oi >= dist ? d.oi - dist : d.oi + RING16 - dist;
+      for (uint32_t i = lane; i < len; i += 64) {
+        uint32_t k = i;
+        if (recip) k = i - ((i * recip) >> 20) * dist;
+        uint32_t a = si + k, b = d.oi + i;
+        if (a >= RING16) a -= RING16;
+        if (b >= RING16) b -= RING16;
+        r16[b] = r16[a];
+      }
+      d.oi += len;
+      if (d.oi >= RING16) d.oi -= RING16;
+      d.o += len;
+      continue;
+    }
+    if ((uint64_t)dist > d.o - d.ostart + d.avail) return WD_NEEDS_HISTORY;  // behind the first output byte of the stream
+    if (d.o + len > d.omax) return WD_ANOMALY;
+    const uint64_t srcb = d.o - dist;
     for (uint32_t i = lane; i < len; i += 64) {
       uint32_t k = i;
       if (recip) k = i - ((i * recip) >> 20) * dist;
@@ -650,13 +685,13 @@ __device__ __forceinline__ static int wd_symbols(InfSmem& S, WaveDec& d, uint32_
 }
 
 // One block starting at d.pos (bit position of BFINAL).  *bfinal receives the flag.
-__device__ __forceinline__ static int wd_block(InfSmem& S, WaveDec& d, uint32_t* bfinal, bool dynamic_only) {
+template <bool MARK>
+__device__ __forceinline__ static int wd_block(InfSmem& S, WaveDec& d, uint32_t* bfinal) {
   const uint32_t lane = zes_lane();
   wd_refill(S, d);
   *bfinal = wd_take(d, 1);
   const uint32_t btype = wd_take(d, 2);
   if (btype == 3) return WD_ANOMALY;
-  if (btype != 2 && dynamic_only) return WD_ANOMALY;
   if (btype == 0) {  // stored (src/inflate.ts:42-55)
     uint64_t bit = (d.pos + 7) & ~7ull;
     if (bit + 32 > d.nbytes * 8) return WD_ANOMALY;
@@ -668,6 +703,23 @@ __device__ __forceinline__ static int wd_block(InfSmem& S, WaveDec& d, uint32_t*
     if (LEN + NLEN != 65535u) return WD_ANOMALY;
     const uint64_t src = d.pos >> 3;
     if (src + LEN > d.nbytes) return WD_ANOMALY;
+    if (MARK) {
+      uint16_t* r16 = reinterpret_cast<uint16_t*>(S.ring);
+      for (uint32_t done = 0; done < LEN;) {
+        const uint32_t n = min(LEN - done, FLUSH);
+        for (uint32_t i = lane; i < n; i += 64) {
+          uint32_t b = d.oi + i;
+          if (b >= RING16) b -= RING16;
+          r16[b] = d.in[src + done + i];
+        }
+        d.oi += n;
+        if (d.oi >= RING16) d.oi -= RING16;
+        d.o += n;
+        done += n;
+      }
+      wd_seek(S, d, (src + LEN) * 8);
+      return WD_OK;
+    }
     if (d.o + LEN > d.omax) return WD_ANOMALY;
     for (uint32_t done = 0; done < LEN;) {
       const uint32_t room = (uint32_t)(FLUSH - ((d.o - d.flushed) % FLUSH));
@@ -747,82 +799,297 @@ __device__ __forceinline__ static int wd_block(InfSmem& S, WaveDec& d, uint32_t*
   }
   if (!wd_build(S, 0, 288, LROOT, S.lut_l, S.syms_l, S.first_l, S.cnt_l, S.offs_l)) return WD_ANOMALY;
   if (!wd_build(S, 288, 32, droot, S.lut_d, S.syms_d, S.first_d, S.cnt_d, S.offs_d)) return WD_ANOMALY;
-  return wd_symbols(S, d, droot);
+  return wd_symbols<MARK>(S, d, droot);
 }
 
 
-// mode 0 (T1): work item w decodes the block at cand[map ? map[w] : w] into slot w.
-// mode 1 (T2): a single wavefront decodes the whole stream from bit 16.
+// T3: a single wavefront decodes the whole stream from bit 16.
 __global__ __launch_bounds__(64) void k_inf_decode(const uint8_t* __restrict__ d_in, uint64_t in_off, uint64_t c,
                                                    uint8_t* __restrict__ d_out, uint64_t out_off, uint64_t cap,
-                                                   const uint32_t* __restrict__ cand, const uint32_t* __restrict__ map,
-                                                   uint32_t nwork, ZesCandRes* __restrict__ cres, ZesRes* __restrict__ res,
-                                                   uint64_t* __restrict__ resume, int mode) {
+                                                   ZesRes* __restrict__ res, uint64_t* __restrict__ resume) {
   __shared__ __align__(16) InfSmem S;
-  const uint32_t w = blockIdx.x, lane = threadIdx.x;
-  if (w >= nwork) return;
+  const uint32_t lane = threadIdx.x;
   WaveDec d;
   d.in = d_in + in_off;
   d.nbytes = c;
   d.win = ~0ull;
   d.o = 0;
   d.flushed = 0;
-  if (mode == 0) {
-    const uint32_t ci = map ? map[w] : w;
-    const uint64_t slot_off = (uint64_t)w * ZES_BLK;
-    d.out = d_out + out_off + slot_off;
-    d.cap = cap > slot_off ? min(cap - slot_off, (uint64_t)ZES_BLK) : 0;
-    d.hist0 = 0;
-    d.omax = ZES_BLK;
-    wd_seek(S, d, (uint64_t)cand[ci] + 16);
-    uint32_t bfinal = 0;
-    // hist0 = 0 with o starting at 0: a distance reaching before the block start shows up as
-    // dist > o; report it as "needs history" rather than an anomaly
-    const int rc = wd_block(S, d, &bfinal, true);
-    if (rc == WD_OK) wd_flush_range(S, d, d.flushed, d.o);
+  d.out = d_out + out_off;
+  d.cap = cap;
+  d.ostart = 0;
+  d.avail = 0;
+  d.omax = ~0ull >> 1;
+  d.oi = 0;
+  wd_seek(S, d, 16);
+  uint32_t bfinal = 0;
+  int rc = WD_OK;
+  uint64_t blk_bit = 16, blk_out = 0;
+  while (!bfinal) {
+    blk_bit = d.pos;
+    blk_out = d.o;
+    rc = wd_block<false>(S, d, &bfinal);
+    if (rc != WD_OK) break;
+    if (!bfinal && d.pos >= d.nbytes * 8) {  // stream exhausted without a final block: T4 decides
+      rc = WD_ANOMALY;  // resume T4 at the start of the block just decoded so its reader state is exact
+      break;
+    }
+  }
+  if (rc == WD_OK) {
+    wd_flush_range(S, d, d.flushed, d.o);
     if (lane == 0) {
-      ZesCandRes r;
-      r.end_bit = d.pos;
-      r.out_len = (uint32_t)d.o;
-      r.flags = (rc == WD_OK ? 1u : 0u) | (bfinal ? 2u : 0u) | (rc != WD_OK ? 4u : 0u);
-      cres[w] = r;
+      res->out_len = d.o;
+      res->status = 0;
+      res->aux = 3;  // tier
     }
   } else {
-    d.out = d_out + out_off;
-    d.cap = cap;
-    d.hist0 = 0;
-    d.omax = ~0ull >> 1;
-    wd_seek(S, d, 16);
-    uint32_t bfinal = 0;
-    int rc = WD_OK;
-    uint64_t blk_bit = 16, blk_out = 0;
-    while (!bfinal) {
-      blk_bit = d.pos;
-      blk_out = d.o;
-      rc = wd_block(S, d, &bfinal, false);
-      if (rc != WD_OK) break;
-      if (!bfinal && d.pos >= d.nbytes * 8) {  // stream exhausted without a final block: T3 decides
-        rc = WD_ANOMALY;  // resume T3 at the start of the block just decoded so its reader state is exact
+    // hand the failing block to the exact decoder: everything before it is valid output
+    wd_flush_range(S, d, d.flushed, blk_out);
+    if (lane == 0) {
+      resume[0] = blk_bit;
+      resume[1] = blk_out;
+      res->status = 1;  // continue with T4
+      res->out_len = blk_out;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// T2, segment-parallel decode of any valid stream.  Work item 0 starts at bit 16, work item
+// w > 0 at candidate w-1 (sorted).  A segment runs block after block (any BTYPE) until it lands
+// exactly on a candidate position, passes a final block, or fails; false candidates make
+// segments nobody chains to.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ static uint32_t seg_ring_idx(uint32_t oi, uint32_t i) {  // ring index of position o - 32768 + i
+  uint32_t a = oi + (RING16 - ZES_WINDOW) + i;
+  if (a >= RING16) a -= RING16;
+  if (a >= RING16) a -= RING16;
+  return a;
+}
+
+__global__ __launch_bounds__(64) void k_inf_seg_scan(const uint8_t* __restrict__ d_in, uint64_t in_off, uint64_t c,
+                                                     const uint32_t* __restrict__ cand, uint32_t ncand,
+                                                     ZesSegRes* __restrict__ sres, uint32_t* __restrict__ maps) {
+  __shared__ __align__(16) InfSmem S;
+  const uint32_t w = blockIdx.x, lane = threadIdx.x;
+  ZesSegRes r;
+  r.end_bit = 0;
+  r.out_len = 0;
+  r.flags = 0;
+  r.next = 0;
+  uint64_t start = 16;
+  if (w > 0) {
+    const uint32_t c0 = cand[w - 1];
+    if (c0 == 0) {  // the stream start is work item 0 already
+      if (lane == 0) sres[w] = r;
+      return;
+    }
+    start = (uint64_t)c0 + 16;
+  }
+  WaveDec d;
+  d.in = d_in + in_off;
+  d.nbytes = c;
+  d.win = ~0ull;
+  d.o = 0;
+  d.flushed = 0;
+  d.out = nullptr;
+  d.cap = 0;
+  d.ostart = 0;
+  d.avail = 0;
+  d.omax = ~0ull >> 1;
+  d.oi = ZES_WINDOW;
+  uint16_t* r16 = reinterpret_cast<uint16_t*>(S.ring);
+  for (uint32_t i = lane; i < ZES_WINDOW; i += 64) r16[i] = (uint16_t)(256u + i);  // window byte i of the previous segment
+  wd_seek(S, d, start);
+  uint32_t bfinal = 0;
+  int rc;
+  for (;;) {
+    rc = wd_block<true>(S, d, &bfinal);
+    if (rc != WD_OK || bfinal) break;
+    if (d.pos >= d.nbytes * 8) {
+      rc = WD_ANOMALY;
+      break;
+    }
+    // does the next block start on a candidate?  (uniform binary search)
+    const uint64_t want = d.pos - 16;
+    uint32_t lo = 0, hi = ncand;
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if ((uint64_t)cand[mid] < want) lo = mid + 1; else hi = mid;
+    }
+    if (lo < ncand && (uint64_t)cand[lo] == want) {
+      r.next = lo + 1;
+      break;
+    }
+  }
+  if (rc != WD_OK) {
+    if (lane == 0) sres[w] = r;
+    return;
+  }
+  // the last 32 Ki symbols of the output so far (for a short segment they start inside the previous window)
+  uint32_t* mp = maps + (size_t)w * (ZES_WINDOW / 2);
+  for (uint32_t i2 = lane; i2 < ZES_WINDOW / 2; i2 += 64) {
+    const uint32_t lo16 = r16[seg_ring_idx(d.oi, 2 * i2)], hi16 = r16[seg_ring_idx(d.oi, 2 * i2 + 1)];
+    mp[i2] = lo16 | (hi16 << 16);
+  }
+  r.end_bit = d.pos;
+  r.out_len = d.o;
+  r.flags = 1u | (bfinal ? 2u : 0u);
+  if (lane == 0) sres[w] = r;
+}
+
+// One workgroup per stream: the chain of segments from work item 0 to the final block.
+// res->status 0: seg[0..aux) / prefix[] hold the chain, out_len the total; 1: not a clean chain.
+#define SEGCHAIN_LDS 8192u
+__global__ __launch_bounds__(256) void k_inf_seg_chain(const ZesSegRes* __restrict__ sres, uint32_t nwork, uint32_t* __restrict__ seg,
+                                                       uint64_t* __restrict__ prefix, ZesRes* __restrict__ res) {
+  __shared__ uint32_t s_nf[SEGCHAIN_LDS];  // next | flags << 30
+  __shared__ unsigned long long s_part[256];
+  __shared__ uint32_t s_nseg;
+  const uint32_t tid = threadIdx.x;
+  const bool lds = nwork <= SEGCHAIN_LDS;
+  if (lds)
+    for (uint32_t i = tid; i < nwork; i += 256) s_nf[i] = (sres[i].next & 0x3FFFFFFFu) | (sres[i].flags << 30);
+  if (tid == 0) {
+    s_nseg = 0;
+    res->status = 1;
+    res->out_len = 0;
+    res->aux = 0;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t w = 0, k = 0;
+    for (;;) {
+      const uint32_t nf = lds ? s_nf[w] : ((sres[w].next & 0x3FFFFFFFu) | (sres[w].flags << 30));
+      if (!(nf >> 30 & 1u) || k >= nwork) {
+        k = 0;
+        break;
+      }
+      seg[k++] = w;
+      if (nf >> 31) break;  // final block inside this segment
+      w = nf & 0x3FFFFFFFu;
+      if (w == 0 || w >= nwork) {
+        k = 0;
         break;
       }
     }
-    if (rc == WD_OK) {
-      wd_flush_range(S, d, d.flushed, d.o);
-      if (lane == 0) {
-        res->out_len = d.o;
-        res->status = 0;
-        res->aux = 2;  // tier
-      }
-    } else {
-      // hand the failing block to the exact decoder: everything before it is valid output
-      wd_flush_range(S, d, d.flushed, blk_out);
-      if (lane == 0) {
-        resume[0] = blk_bit;
-        resume[1] = blk_out;
-        res->status = 1;  // continue with T3
-        res->out_len = blk_out;
-      }
+    s_nseg = k;
+  }
+  __syncthreads();
+  const uint32_t nseg = s_nseg;
+  if (nseg == 0) return;
+  // output offsets: chunked sums, scan of the chunk totals, chunked prefixes
+  const uint32_t per = (nseg + 255u) / 256u;
+  const uint32_t k0 = min(nseg, tid * per), k1 = min(nseg, k0 + per);
+  unsigned long long sum = 0;
+  for (uint32_t k = k0; k < k1; k++) sum += sres[seg[k]].out_len;
+  s_part[tid] = sum;
+  __syncthreads();
+  if (tid == 0) {
+    unsigned long long run = 0;
+    for (uint32_t t = 0; t < 256; t++) {
+      const unsigned long long v = s_part[t];
+      s_part[t] = run;
+      run += v;
     }
+    res->out_len = run;
+    res->aux = nseg;
+    res->status = 0;
+  }
+  __syncthreads();
+  unsigned long long run = s_part[tid];
+  for (uint32_t k = k0; k < k1; k++) {
+    prefix[k] = run;
+    run += sres[seg[k]].out_len;
+  }
+}
+
+// The 32 KiB window behind each chain segment, in order: wins[k] = the bytes in front of segment k+1.
+// One workgroup; every step rewrites the window through the segment's map.
+__global__ __launch_bounds__(1024) void k_inf_seg_windows(const uint32_t* __restrict__ maps, const uint32_t* __restrict__ seg,
+                                                          uint32_t nseg, uint8_t* __restrict__ wins) {
+  __shared__ __align__(16) uint8_t W[2][ZES_WINDOW];
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t i = tid; i < ZES_WINDOW / 4; i += 1024) reinterpret_cast<uint32_t*>(W[0])[i] = 0;
+  if (nseg < 2) return;
+  uint4 cur[4], nxt[4];
+  {
+    const uint4* m = reinterpret_cast<const uint4*>(maps + (size_t)seg[0] * (ZES_WINDOW / 2));
+#pragma unroll
+    for (int j = 0; j < 4; j++) cur[j] = m[j * 1024 + tid];
+  }
+  for (uint32_t k = 0; k + 1 < nseg; k++) {
+    __syncthreads();
+    const uint8_t* Wo = W[k & 1];
+    uint8_t* Wn = W[(k & 1) ^ 1];
+    if (k + 2 < nseg) {
+      const uint4* m = reinterpret_cast<const uint4*>(maps + (size_t)seg[k + 1] * (ZES_WINDOW / 2));
+#pragma unroll
+      for (int j = 0; j < 4; j++) nxt[j] = m[j * 1024 + tid];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint32_t wsrc[4] = {cur[j].x, cur[j].y, cur[j].z, cur[j].w};
+      uint32_t o2[2] = {0, 0};
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const uint32_t v = (wsrc[q >> 1] >> ((q & 1) * 16)) & 0xFFFFu;
+        const uint32_t b = v < 256u ? v : (uint32_t)Wo[(v - 256u) & (ZES_WINDOW - 1)];
+        o2[q >> 2] |= b << ((q & 3) * 8);
+      }
+      const uint32_t e = (j * 1024 + tid) * 8;
+      *reinterpret_cast<uint2*>(&Wn[e]) = make_uint2(o2[0], o2[1]);
+      *reinterpret_cast<uint2*>(&wins[(size_t)k * ZES_WINDOW + e]) = make_uint2(o2[0], o2[1]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) cur[j] = nxt[j];
+  }
+}
+
+// Chain segment k again, this time with its window and into its place.
+__global__ __launch_bounds__(64) void k_inf_seg_decode(const uint8_t* __restrict__ d_in, uint64_t in_off, uint64_t c,
+                                                       uint8_t* __restrict__ d_out, uint64_t out_off, uint64_t cap,
+                                                       const uint32_t* __restrict__ cand, const ZesSegRes* __restrict__ sres,
+                                                       const uint32_t* __restrict__ seg, const uint64_t* __restrict__ prefix,
+                                                       const uint8_t* __restrict__ wins, uint32_t* __restrict__ fail) {
+  __shared__ __align__(16) InfSmem S;
+  const uint32_t k = blockIdx.x, lane = threadIdx.x;
+  const uint32_t w = seg[k];
+  const ZesSegRes r = sres[w];
+  const uint64_t pre = prefix[k];
+  const uint64_t base = pre & ~15ull;
+  WaveDec d;
+  d.in = d_in + in_off;
+  d.nbytes = c;
+  d.win = ~0ull;
+  d.out = d_out + out_off + base;
+  d.cap = cap > base ? cap - base : 0;
+  d.ostart = pre & 15u;
+  d.o = d.ostart;
+  d.flushed = 0;
+  d.avail = min(pre, (uint64_t)ZES_WINDOW);
+  d.omax = d.ostart + r.out_len;
+  d.oi = 0;
+  if (k > 0) {  // window bytes in front of the segment: positions ostart - 32768 .. ostart - 1
+    const uint32_t* wv = reinterpret_cast<const uint32_t*>(wins + (size_t)(k - 1) * ZES_WINDOW);
+    for (uint32_t i = lane; i < ZES_WINDOW / 4; i += 64) {
+      const uint32_t v = wv[i];
+      const uint32_t p = (uint32_t)d.ostart + ZES_WINDOW + 4u * i;  // == position mod 65536
+#pragma unroll
+      for (uint32_t q = 0; q < 4; q++) S.ring[(p + q) & (RING - 1)] = (uint8_t)(v >> (8 * q));
+    }
+  }
+  wd_seek(S, d, w ? (uint64_t)cand[w - 1] + 16 : 16);
+  uint32_t bfinal = 0;
+  int rc;
+  for (;;) {
+    rc = wd_block<false>(S, d, &bfinal);
+    if (rc != WD_OK || bfinal || d.pos >= r.end_bit) break;
+  }
+  if (rc == WD_OK && d.pos == r.end_bit && d.o - d.ostart == r.out_len) {
+    wd_flush_range(S, d, d.flushed, d.o);
+  } else if (lane == 0) {
+    atomicOr(fail, 1u);
   }
 }
 
