@@ -422,12 +422,16 @@ __global__ __launch_bounds__(256) void k_inf_ranksort(const ZesInfBuf* __restric
 #define DROOT 10u
 #define RING 65536u
 #define FLUSH 16384u
-#define INWIN 1024u
 #define RING16 33280u  // marker ring (16-bit symbols): window + longest match + slack; not a power of two
 
+// One wavefront decodes serially; all decoder state is wave-uniform and kept in scalar registers
+// (every value that comes out of LDS goes through readfirstlane), so the per-token work is a few
+// scalar instructions around one or two LDS table reads.  The compressed input sits in two vector
+// registers (lane l = dword l of a 64-dword window and of the next one) and is picked with
+// readlane; a window is re-loaded every 2048 bits, one window ahead of its use.
 struct InfSmem {
   uint8_t ring[RING16 * 2];  // byte mode uses the first RING bytes
-  uint16_t lut_l[1u << LROOT];
+  uint16_t lut_l[1u << LROOT];  // symbol | code length << 9 (0 = longer than the root, or no code)
   uint16_t lut_d[1u << DROOT];
   uint16_t syms_l[288];
   uint16_t syms_d[32];
@@ -435,73 +439,78 @@ struct InfSmem {
   uint16_t cnt_l[16], cnt_d[16], offs_l[16], offs_d[16];
   uint8_t lens[352];  // [0,288) lit/len, [288,320) dist
   uint8_t cl_lut[128];
-  uint8_t inbuf[INWIN + 32];
 };
 
 struct WaveDec {
   // uniform state (identical in all 64 lanes)
-  const uint8_t* in;  // buffer base (16-byte aligned)
+  const uint32_t* in32;  // buffer base (16-byte aligned)
   uint64_t nbytes;
-  uint64_t pos;   // absolute bit position of bit 0 of bb
-  uint64_t bb;
-  uint32_t nb;    // valid bits in bb; (pos + nb) % 8 == 0
-  uint64_t win;   // byte offset held at inbuf[0]; ~0 = nothing loaded
-  uint8_t* out;   // where output byte 0 goes
-  uint64_t cap;   // bytes that may be stored at out
-  uint64_t o;     // bytes produced so far
+  uint64_t bb;     // bit buffer, next bit at bit 0
+  uint32_t nb;     // valid bits in bb
+  uint64_t idx;    // next input dword to enter bb; absolute bit position of bb's bit 0 = 32 * idx - nb
+  uint8_t* out;    // where output byte 0 goes
+  uint64_t cap;    // bytes that may be stored at out
+  uint64_t o;      // bytes produced so far
   uint64_t flushed;
   uint64_t ostart; // value of o at the start (0..15: out is the 16-byte aligned base below the first byte)
   uint64_t avail;  // history bytes in front of ostart a match may reach (preloaded into the ring)
   uint64_t omax;   // give up once o passes this
   uint32_t oi;     // marker mode: ring index of output position o
+  // per lane
+  uint32_t vcur, vnxt;  // input dwords (idx & ~63) + lane (end-of-stream zeros applied) and + 64 + lane (as loaded)
 };
 
 enum { WD_OK = 0, WD_ANOMALY = 1, WD_NEEDS_HISTORY = 2 };
 
-__device__ __forceinline__ static void wd_load_window(InfSmem& S, WaveDec& d, uint64_t byte) {
-  const uint32_t lane = zes_lane();
-  d.win = byte & ~15ull;
-  // 64 lanes x 16 B + 32 B tail
-  for (uint32_t k = lane; k < (INWIN + 32) / 16; k += 64) {
-    const uint64_t off = d.win + (uint64_t)k * 16;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (off + 16 <= d.nbytes) {
-      v = *reinterpret_cast<const uint4*>(d.in + off);
-    } else if (off < d.nbytes) {
-      uint8_t t[16];
-      for (int j = 0; j < 16; j++) t[j] = (off + j < d.nbytes) ? d.in[off + j] : (uint8_t)0;
-      v = *reinterpret_cast<uint4*>(t);
-    }
-    *reinterpret_cast<uint4*>(&S.inbuf[k * 16]) = v;
+#define WD_SGPR(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+// Placed right behind every lane-dependent branch or loop of the decoder: keeps the join of that branch a block
+// of its own.  Without it the join is often folded into a block where the uniform reader state merges (loop
+// header, end of an if), the uniformity analysis then calls that state divergent and the whole decoder runs
+// on the vector unit.  (Checked with opt -passes='print<uniformity>' on the device IR.)
+#define WD_JOIN() asm volatile("")
+
+__device__ __forceinline__ static uint32_t wd_fetch_raw(const WaveDec& d, uint64_t dw) {
+  // branch-free on purpose: a divergent branch here joins where the uniform reader state merges, and the
+  // compiler then keeps that state in vector registers
+  return d.in32[dw * 4 < d.nbytes ? dw : 0];  // the last dword may reach past nbytes inside its own aligned word: masked later
+}
+__device__ __forceinline__ static uint32_t wd_fetch_fix(const WaveDec& d, uint32_t raw, uint64_t dw) {  // zero beyond the end of the stream
+  const uint64_t byte = dw * 4;
+  const uint32_t keep = byte + 4 > d.nbytes ? (1u << (8u * ((uint32_t)(d.nbytes - byte) & 3u))) - 1u : 0xFFFFFFFFu;
+  return byte < d.nbytes ? raw & keep : 0u;
+}
+__device__ __forceinline__ static uint64_t wd_pos(const WaveDec& d) { return d.idx * 32 - d.nb; }
+
+__device__ __forceinline__ static void wd_seek(WaveDec& d, uint64_t bit) {
+  const uint64_t dw = bit >> 5;
+  const uint64_t base = dw & ~63ull;
+  d.vcur = wd_fetch_fix(d, wd_fetch_raw(d, base + zes_lane()), base + zes_lane());
+  d.vnxt = wd_fetch_raw(d, base + 64 + zes_lane());
+  const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)d.vcur, (int)(dw & 63u));
+  d.bb = (uint64_t)(w >> (bit & 31u));
+  d.nb = 32u - (uint32_t)(bit & 31u);
+  d.idx = dw + 1;
+  if ((d.idx & 63u) == 0) {
+    d.vcur = wd_fetch_fix(d, d.vnxt, d.idx + zes_lane());
+    d.vnxt = wd_fetch_raw(d, d.idx + 64 + zes_lane());
   }
 }
-
-__device__ __forceinline__ static uint32_t wd_ld32(InfSmem& S, WaveDec& d, uint64_t byte) {
-  if (byte < d.win || byte + 8 > d.win + INWIN + 32) wd_load_window(S, d, byte);
-  const uint32_t off = (uint32_t)(byte - d.win);
-  const uint32_t* w = reinterpret_cast<const uint32_t*>(S.inbuf);
-  const uint32_t i = off >> 2;
-  return __builtin_amdgcn_alignbyte(w[i + 1], w[i], off & 3u);
-}
-
-__device__ __forceinline__ static void wd_seek(InfSmem& S, WaveDec& d, uint64_t bit) {
-  d.pos = bit;
-  const uint32_t w = wd_ld32(S, d, bit >> 3);
-  d.bb = (uint64_t)(w >> (bit & 7));
-  d.nb = 32u - (uint32_t)(bit & 7);
-}
-__device__ __forceinline__ static void wd_refill(InfSmem& S, WaveDec& d) {  // guarantees nb >= 33
+__device__ __forceinline__ static void wd_refill(WaveDec& d) {  // guarantees nb >= 33
   if (d.nb <= 32u) {
-    const uint32_t w = wd_ld32(S, d, (d.pos + d.nb) >> 3);
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)d.vcur, (int)((uint32_t)d.idx & 63u));
     d.bb |= (uint64_t)w << d.nb;
     d.nb += 32u;
+    d.idx++;
+    if (((uint32_t)d.idx & 63u) == 0) {  // the load issued one window ago is waited for here
+      d.vcur = wd_fetch_fix(d, d.vnxt, d.idx + zes_lane());
+      d.vnxt = wd_fetch_raw(d, d.idx + 64 + zes_lane());
+    }
   }
 }
 __device__ __forceinline__ static uint32_t wd_take(WaveDec& d, uint32_t k) {  // k <= 16, after wd_refill
   const uint32_t v = (uint32_t)d.bb & ((1u << k) - 1u);
   d.bb >>= k;
   d.nb -= k;
-  d.pos += k;
   return v;
 }
 
@@ -517,6 +526,7 @@ __device__ __forceinline__ static void wd_flush_range(InfSmem& S, WaveDec& d, ui
         if (off + j < to && off + j < d.cap && off + j >= d.ostart) d.out[off + j] = S.ring[(r + j) & (RING - 1)];
     }
   }
+  WD_JOIN();
 }
 __device__ __forceinline__ static void wd_maybe_flush(InfSmem& S, WaveDec& d) {
   while (d.o - d.flushed >= FLUSH) {
@@ -527,12 +537,12 @@ __device__ __forceinline__ static void wd_maybe_flush(InfSmem& S, WaveDec& d) {
 
 // canonical tables + root LUT for one alphabet; lens in S.lens[base .. base+nsym).
 // Returns false when the length set is over-subscribed.
-__device__ __forceinline__ static bool wd_build(InfSmem& S, uint32_t base, uint32_t nsym, uint32_t root, uint16_t* lut, uint16_t* syms,
-                                uint32_t* first, uint16_t* cnt, uint16_t* offs) {
+__device__ __noinline__ static bool wd_build(InfSmem& S, uint32_t base, uint32_t nsym, uint32_t root, uint16_t* lut, uint16_t* syms,
+                                             uint32_t* first, uint16_t* cnt, uint16_t* offs) {
   const uint32_t lane = zes_lane();
   const uint8_t* lens = S.lens + base;
   for (uint32_t i = lane; i < (1u << root); i += 64) lut[i] = 0;
-  // counts per length (uniform loop: nsym <= 288 broadcast reads)
+  // counts per length
   uint32_t c[16];
 #pragma unroll
   for (int l = 0; l < 16; l++) c[l] = 0;
@@ -543,11 +553,12 @@ __device__ __forceinline__ static bool wd_build(InfSmem& S, uint32_t base, uint3
     for (int k = 1; k < 16; k++) c[k] += (uint32_t)__popcll(__ballot(l == (uint32_t)k));
   }
   uint32_t code = 0, off = 0, kraft = 0;
-  uint32_t fst[16], ofs[16];
+  uint32_t fst[16], ofs[16], run[16];
 #pragma unroll
   for (int l = 1; l < 16; l++) {
     fst[l] = code;
     ofs[l] = off;
+    run[l] = 0;
     code = (code + c[l]) << 1;
     off += c[l];
     kraft += c[l] << (15 - l);
@@ -566,20 +577,22 @@ __device__ __forceinline__ static bool wd_build(InfSmem& S, uint32_t base, uint3
     offs[lane] = (uint16_t)o2;
     cnt[lane] = (uint16_t)cc;
   }
-  // per symbol: rank inside its length, canonical code, LUT fill / sorted-symbol slot
+  // per symbol: rank inside its length (ballots, symbols ascending), canonical code, LUT fill / sorted-symbol slot
   for (uint32_t s0 = 0; s0 < nsym; s0 += 64) {
     const uint32_t s = s0 + lane;
     const uint32_t l = s < nsym ? lens[s] : 0u;
-    if (l) {
-      uint32_t rank = 0;
-      for (uint32_t j = 0; j < s; j++) rank += (lens[j] == l);
-      uint32_t f = 0, o2 = 0;
+    uint32_t rank = 0, f = 0, o2 = 0;
 #pragma unroll
-      for (int k = 1; k < 16; k++)
-        if ((int)l == k) {
-          f = fst[k];
-          o2 = ofs[k];
-        }
+    for (int k = 1; k < 16; k++) {
+      const uint64_t m = __ballot(l == (uint32_t)k);
+      if ((int)l == k) {
+        rank = run[k] + (uint32_t)__popcll(m & zes_lanemask_lt());
+        f = fst[k];
+        o2 = ofs[k];
+      }
+      run[k] += (uint32_t)__popcll(m);
+    }
+    if (l) {
       syms[o2 + rank] = (uint16_t)s;
       if (l <= root) {
         const uint32_t rev = __brev(f + rank) >> (32u - l);
@@ -593,27 +606,48 @@ __device__ __forceinline__ static bool wd_build(InfSmem& S, uint32_t base, uint3
 // symbol decode: root LUT, then canonical walk for codes longer than root (reference
 // src/inflate.ts:238-252 extends one bit at a time the same way).  Returns -1 if no code matches.
 __device__ __forceinline__ static int wd_sym(WaveDec& d, const uint16_t* lut, uint32_t root, const uint16_t* syms,
-                                    const uint32_t* first, const uint16_t* cnt, const uint16_t* offs) {
-  const uint32_t e = lut[(uint32_t)d.bb & ((1u << root) - 1u)];
+                                             const uint32_t* first, const uint16_t* cnt, const uint16_t* offs) {
+  const uint32_t e = WD_SGPR(lut[(uint32_t)d.bb & ((1u << root) - 1u)]);
   const uint32_t l = e >> 9;
   if (l) {
     d.bb >>= l;
     d.nb -= l;
-    d.pos += l;
     return (int)(e & 511u);
   }
   uint32_t code = __brev((uint32_t)d.bb & ((1u << root) - 1u)) >> (32u - root);
   for (uint32_t len = root + 1; len <= 15u; len++) {
     code = (code << 1) | (uint32_t)((d.bb >> (len - 1)) & 1u);
-    const uint32_t rel = code - first[len];
-    if (code >= first[len] && rel < cnt[len]) {
+    const uint32_t fl = WD_SGPR(first[len]), cl = WD_SGPR(cnt[len]);
+    const uint32_t rel = code - fl;
+    if (code >= fl && rel < cl) {
       d.bb >>= len;
       d.nb -= len;
-      d.pos += len;
-      return (int)syms[offs[len] + rel];
+      return (int)WD_SGPR(syms[WD_SGPR(offs[len]) + rel]);
     }
   }
   return -1;
+}
+
+// base value and extra-bit count of length code lc (0..28) and distance code dc (0..29) in closed form
+// (the values of src/const.ts:9-35)
+__device__ __forceinline__ static void wd_len_code(uint32_t lc, uint32_t* base, uint32_t* xb) {
+  const uint32_t e = lc < 8u ? 0u : (lc - 4u) >> 2;
+  *base = lc < 8u ? 3u + lc : lc == 28u ? 258u : 3u + ((4u + (lc & 3u)) << e);
+  *xb = lc == 28u ? 0u : e;
+}
+__device__ __forceinline__ static void wd_dist_code(uint32_t dc, uint32_t* base, uint32_t* xb) {
+  const uint32_t e = dc < 4u ? 0u : (dc - 2u) >> 1;
+  *base = dc < 4u ? 1u + dc : 1u + ((2u + (dc & 1u)) << e);
+  *xb = e;
+}
+
+// i mod dist for i < 512, dist < 512 (overlapping matches): float reciprocal plus one correction either way
+__device__ __forceinline__ static uint32_t wd_mod(uint32_t i, uint32_t dist, float rcp) {
+  const uint32_t q = (uint32_t)((float)i * rcp);
+  int r = (int)i - (int)(q * dist);
+  if (r < 0) r += (int)dist;
+  if (r >= (int)dist) r -= (int)dist;
+  return (uint32_t)r;
 }
 
 // Decodes the symbols of one fixed/dynamic block whose tables are built.  Uniform control flow.
@@ -625,46 +659,50 @@ __device__ __forceinline__ static int wd_symbols(InfSmem& S, WaveDec& d, uint32_
   const uint64_t limit = d.nbytes * 8;
   uint16_t* r16 = reinterpret_cast<uint16_t*>(S.ring);
   for (;;) {
-    wd_refill(S, d);
+    wd_refill(d);
     const int s = wd_sym(d, S.lut_l, LROOT, S.syms_l, S.first_l, S.cnt_l, S.offs_l);
     if (s < 0) return WD_ANOMALY;
-    if (d.pos > limit) return WD_ANOMALY;
     if (s < 256) {
       if (MARK) {
         if (lane == 0) r16[d.oi] = (uint16_t)s;
+        WD_JOIN();
         d.oi = d.oi + 1u == RING16 ? 0u : d.oi + 1u;
         d.o++;
-        continue;
+      } else {
+        if (lane == 0) S.ring[d.o & (RING - 1)] = (uint8_t)s;
+        WD_JOIN();
+        d.o++;
+        if (d.o > d.omax) return WD_ANOMALY;
+        wd_maybe_flush(S, d);
       }
-      if (lane == 0) S.ring[d.o & (RING - 1)] = (uint8_t)s;
-      d.o++;
-      if (d.o > d.omax) return WD_ANOMALY;
-      wd_maybe_flush(S, d);
+      if (wd_pos(d) > limit) return WD_ANOMALY;
       continue;
     }
-    if (s == 256) return WD_OK;
+    if (s == 256) return wd_pos(d) > limit ? WD_ANOMALY : WD_OK;
     const uint32_t lc = (uint32_t)s - 257u;
     if (lc >= 29u) return WD_ANOMALY;
-    wd_refill(S, d);
-    const uint32_t len = kLenBase[lc] + wd_take(d, kLenXbits[lc]);
-    wd_refill(S, d);
+    uint32_t lbase, lxb, dbase, dxb;
+    wd_len_code(lc, &lbase, &lxb);
+    const uint32_t len = lbase + wd_take(d, lxb);  // code (<= 15) + extra (<= 5) bits fit one refill
+    wd_refill(d);
     const int ds = wd_sym(d, S.lut_d, droot_used, S.syms_d, S.first_d, S.cnt_d, S.offs_d);
     if (ds < 0 || ds >= 30) return WD_ANOMALY;
-    wd_refill(S, d);
-    const uint32_t dist = kDistBase[ds] + wd_take(d, kDistXbits[ds]);
-    if (d.pos > limit) return WD_ANOMALY;
+    wd_dist_code((uint32_t)ds, &dbase, &dxb);
+    const uint32_t dist = dbase + wd_take(d, dxb);  // <= 15 + 13 bits
+    if (wd_pos(d) > limit) return WD_ANOMALY;
     // lane-parallel copy; overlapping matches read i % dist so every source symbol already exists
-    const uint32_t recip = (dist < len) ? (1048576u / dist + 1u) : 0u;
+    const bool overlap = dist < len;
+    const float rcp = overlap ? 1.0f / (float)dist : 0.0f;
     if (MARK) {
       const uint32_t si = d.oi >= dist ? d.oi - dist : d.oi + RING16 - dist;
       for (uint32_t i = lane; i < len; i += 64) {
-        uint32_t k = i;
-        if (recip) k = i - ((i * recip) >> 20) * dist;
+        const uint32_t k = overlap ? wd_mod(i, dist, rcp) : i;
         uint32_t a = si + k, b = d.oi + i;
         if (a >= RING16) a -= RING16;
         if (b >= RING16) b -= RING16;
         r16[b] = r16[a];
       }
+      WD_JOIN();
       d.oi += len;
       if (d.oi >= RING16) d.oi -= RING16;
       d.o += len;
@@ -672,37 +710,38 @@ __device__ __forceinline__ static int wd_symbols(InfSmem& S, WaveDec& d, uint32_
     }
     if ((uint64_t)dist > d.o - d.ostart + d.avail) return WD_NEEDS_HISTORY;  // behind the first output byte of the stream
     if (d.o + len > d.omax) return WD_ANOMALY;
-    const uint64_t srcb = d.o - dist;
+    const uint32_t srcb = (uint32_t)(d.o - dist), dstb = (uint32_t)d.o;
     for (uint32_t i = lane; i < len; i += 64) {
-      uint32_t k = i;
-      if (recip) k = i - ((i * recip) >> 20) * dist;
+      const uint32_t k = overlap ? wd_mod(i, dist, rcp) : i;
       const uint8_t v = S.ring[(srcb + k) & (RING - 1)];
-      S.ring[(d.o + i) & (RING - 1)] = v;
+      S.ring[(dstb + i) & (RING - 1)] = v;
     }
+    WD_JOIN();
     d.o += len;
     wd_maybe_flush(S, d);
   }
 }
 
-// One block starting at d.pos (bit position of BFINAL).  *bfinal receives the flag.
+// One block starting at the reader's position (BFINAL bit).  *bfinal receives the flag.
 template <bool MARK>
 __device__ __forceinline__ static int wd_block(InfSmem& S, WaveDec& d, uint32_t* bfinal) {
   const uint32_t lane = zes_lane();
-  wd_refill(S, d);
+  wd_refill(d);
   *bfinal = wd_take(d, 1);
   const uint32_t btype = wd_take(d, 2);
   if (btype == 3) return WD_ANOMALY;
   if (btype == 0) {  // stored (src/inflate.ts:42-55)
-    uint64_t bit = (d.pos + 7) & ~7ull;
+    const uint64_t bit = (wd_pos(d) + 7) & ~7ull;
     if (bit + 32 > d.nbytes * 8) return WD_ANOMALY;
-    wd_seek(S, d, bit);
-    wd_refill(S, d);
+    wd_seek(d, bit);
+    wd_refill(d);
     const uint32_t LEN = wd_take(d, 16);
-    wd_refill(S, d);
+    wd_refill(d);
     const uint32_t NLEN = wd_take(d, 16);
     if (LEN + NLEN != 65535u) return WD_ANOMALY;
-    const uint64_t src = d.pos >> 3;
+    const uint64_t src = wd_pos(d) >> 3;
     if (src + LEN > d.nbytes) return WD_ANOMALY;
+    const uint8_t* in8 = reinterpret_cast<const uint8_t*>(d.in32);
     if (MARK) {
       uint16_t* r16 = reinterpret_cast<uint16_t*>(S.ring);
       for (uint32_t done = 0; done < LEN;) {
@@ -710,45 +749,50 @@ __device__ __forceinline__ static int wd_block(InfSmem& S, WaveDec& d, uint32_t*
         for (uint32_t i = lane; i < n; i += 64) {
           uint32_t b = d.oi + i;
           if (b >= RING16) b -= RING16;
-          r16[b] = d.in[src + done + i];
+          r16[b] = in8[src + done + i];
         }
+        WD_JOIN();
         d.oi += n;
         if (d.oi >= RING16) d.oi -= RING16;
         d.o += n;
         done += n;
       }
-      wd_seek(S, d, (src + LEN) * 8);
+      wd_seek(d, (src + LEN) * 8);
       return WD_OK;
     }
     if (d.o + LEN > d.omax) return WD_ANOMALY;
     for (uint32_t done = 0; done < LEN;) {
       const uint32_t room = (uint32_t)(FLUSH - ((d.o - d.flushed) % FLUSH));
       const uint32_t n = min(LEN - done, room);
-      for (uint32_t i = lane; i < n; i += 64) S.ring[(d.o + i) & (RING - 1)] = d.in[src + done + i];
+      for (uint32_t i = lane; i < n; i += 64) S.ring[(d.o + i) & (RING - 1)] = in8[src + done + i];
+      WD_JOIN();
       d.o += n;
       done += n;
       wd_maybe_flush(S, d);
     }
-    wd_seek(S, d, (src + LEN) * 8);
+    wd_seek(d, (src + LEN) * 8);
     return WD_OK;
   }
   uint32_t droot = DROOT;
   if (btype == 1) {  // fixed (src/huffman.ts:41-53; distance = 5 bits MSB-first, src/inflate.ts:107)
     for (uint32_t i = lane; i < 288; i += 64) S.lens[i] = (uint8_t)(i <= 143 ? 8 : i <= 255 ? 9 : i <= 279 ? 7 : 8);
+    WD_JOIN();
     if (lane < 32) S.lens[288 + lane] = 5;
+    WD_JOIN();
   } else {  // dynamic header (src/inflate.ts:120-204)
-    wd_refill(S, d);
+    wd_refill(d);
     const uint32_t HLIT = wd_take(d, 5) + 257u;
     const uint32_t HDIST = wd_take(d, 5) + 1u;
     const uint32_t HCLEN = wd_take(d, 4) + 4u;
     uint32_t mycl = 0;  // lane s holds the length of code-length symbol s
     for (uint32_t k = 0; k < HCLEN; k++) {
-      wd_refill(S, d);
+      wd_refill(d);
       const uint32_t v = wd_take(d, 3);
-      if (lane == kClOrder[k]) mycl = v;
+      mycl = lane == kClOrder[k] ? v : mycl;
     }
     // 7-bit LUT of the code-length code
     for (uint32_t i = lane; i < 128; i += 64) S.cl_lut[i] = 0;
+    WD_JOIN();
     uint32_t kraft = 0;
     {
       uint32_t code = 0;
@@ -759,6 +803,7 @@ __device__ __forceinline__ static int wd_block(InfSmem& S, WaveDec& d, uint32_t*
           const uint32_t rev = __brev(code + rank) >> (32u - l);
           for (uint32_t e = rev; e < 128; e += 1u << l) S.cl_lut[e] = (uint8_t)(lane | (l << 5));
         }
+        WD_JOIN();
         const uint32_t n = (uint32_t)__popcll(m);
         kraft += n << (7 - l);
         code = (code + n) << 1;
@@ -766,11 +811,12 @@ __device__ __forceinline__ static int wd_block(InfSmem& S, WaveDec& d, uint32_t*
     }
     if (kraft > 128u) return WD_ANOMALY;
     for (uint32_t i = lane; i < 352; i += 64) S.lens[i] = 0;
+    WD_JOIN();
     const uint32_t total = HLIT + HDIST;
     uint32_t prev = 0;
     for (uint32_t k = 0; k < total;) {
-      wd_refill(S, d);
-      const uint32_t e = S.cl_lut[(uint32_t)d.bb & 127u];
+      wd_refill(d);
+      const uint32_t e = WD_SGPR(S.cl_lut[(uint32_t)d.bb & 127u]);
       const uint32_t l = e >> 5, sy = e & 31u;
       if (!l) return WD_ANOMALY;
       wd_take(d, l);
@@ -786,19 +832,21 @@ __device__ __forceinline__ static int wd_block(InfSmem& S, WaveDec& d, uint32_t*
         rep = 11 + wd_take(d, 7);
         val = 0;
       }
-      if (k + rep > total) return WD_ANOMALY;  // the reference spills into the distance table: T3
+      if (k + rep > total) return WD_ANOMALY;  // the reference spills into the distance table: T4
       if (val && lane < rep) {
         const uint32_t idx = k + lane;
         S.lens[idx < HLIT ? idx : 288 + (idx - HLIT)] = (uint8_t)val;
       }
+      WD_JOIN();
       // the reference keeps `codelen` across 17/18 as 0 (src/inflate.ts:172-183)
       prev = val;
       k += rep;
     }
-    if (d.pos > d.nbytes * 8) return WD_ANOMALY;
+    if (wd_pos(d) > d.nbytes * 8) return WD_ANOMALY;
   }
-  if (!wd_build(S, 0, 288, LROOT, S.lut_l, S.syms_l, S.first_l, S.cnt_l, S.offs_l)) return WD_ANOMALY;
-  if (!wd_build(S, 288, 32, droot, S.lut_d, S.syms_d, S.first_d, S.cnt_d, S.offs_d)) return WD_ANOMALY;
+  // (a call returns in a vector register: back to scalar, or everything behind the branch counts as divergent)
+  if (!WD_SGPR(wd_build(S, 0, 288, LROOT, S.lut_l, S.syms_l, S.first_l, S.cnt_l, S.offs_l))) return WD_ANOMALY;
+  if (!WD_SGPR(wd_build(S, 288, 32, droot, S.lut_d, S.syms_d, S.first_d, S.cnt_d, S.offs_d))) return WD_ANOMALY;
   return wd_symbols<MARK>(S, d, droot);
 }
 
@@ -810,9 +858,8 @@ __global__ __launch_bounds__(64) void k_inf_decode(const uint8_t* __restrict__ d
   __shared__ __align__(16) InfSmem S;
   const uint32_t lane = threadIdx.x;
   WaveDec d;
-  d.in = d_in + in_off;
+  d.in32 = reinterpret_cast<const uint32_t*>(d_in + in_off);
   d.nbytes = c;
-  d.win = ~0ull;
   d.o = 0;
   d.flushed = 0;
   d.out = d_out + out_off;
@@ -821,16 +868,16 @@ __global__ __launch_bounds__(64) void k_inf_decode(const uint8_t* __restrict__ d
   d.avail = 0;
   d.omax = ~0ull >> 1;
   d.oi = 0;
-  wd_seek(S, d, 16);
+  wd_seek(d, 16);
   uint32_t bfinal = 0;
   int rc = WD_OK;
   uint64_t blk_bit = 16, blk_out = 0;
   while (!bfinal) {
-    blk_bit = d.pos;
+    blk_bit = wd_pos(d);
     blk_out = d.o;
     rc = wd_block<false>(S, d, &bfinal);
     if (rc != WD_OK) break;
-    if (!bfinal && d.pos >= d.nbytes * 8) {  // stream exhausted without a final block: T4 decides
+    if (!bfinal && wd_pos(d) >= d.nbytes * 8) {  // stream exhausted without a final block: T4 decides
       rc = WD_ANOMALY;  // resume T4 at the start of the block just decoded so its reader state is exact
       break;
     }
@@ -887,9 +934,8 @@ __global__ __launch_bounds__(64) void k_inf_seg_scan(const uint8_t* __restrict__
     start = (uint64_t)c0 + 16;
   }
   WaveDec d;
-  d.in = d_in + in_off;
+  d.in32 = reinterpret_cast<const uint32_t*>(d_in + in_off);
   d.nbytes = c;
-  d.win = ~0ull;
   d.o = 0;
   d.flushed = 0;
   d.out = nullptr;
@@ -900,18 +946,18 @@ __global__ __launch_bounds__(64) void k_inf_seg_scan(const uint8_t* __restrict__
   d.oi = ZES_WINDOW;
   uint16_t* r16 = reinterpret_cast<uint16_t*>(S.ring);
   for (uint32_t i = lane; i < ZES_WINDOW; i += 64) r16[i] = (uint16_t)(256u + i);  // window byte i of the previous segment
-  wd_seek(S, d, start);
+  wd_seek(d, start);
   uint32_t bfinal = 0;
   int rc;
   for (;;) {
     rc = wd_block<true>(S, d, &bfinal);
     if (rc != WD_OK || bfinal) break;
-    if (d.pos >= d.nbytes * 8) {
+    if (wd_pos(d) >= d.nbytes * 8) {
       rc = WD_ANOMALY;
       break;
     }
     // does the next block start on a candidate?  (uniform binary search)
-    const uint64_t want = d.pos - 16;
+    const uint64_t want = wd_pos(d) - 16;
     uint32_t lo = 0, hi = ncand;
     while (lo < hi) {
       const uint32_t mid = (lo + hi) >> 1;
@@ -932,7 +978,7 @@ __global__ __launch_bounds__(64) void k_inf_seg_scan(const uint8_t* __restrict__
     const uint32_t lo16 = r16[seg_ring_idx(d.oi, 2 * i2)], hi16 = r16[seg_ring_idx(d.oi, 2 * i2 + 1)];
     mp[i2] = lo16 | (hi16 << 16);
   }
-  r.end_bit = d.pos;
+  r.end_bit = wd_pos(d);
   r.out_len = d.o;
   r.flags = 1u | (bfinal ? 2u : 0u);
   if (lane == 0) sres[w] = r;
@@ -1059,9 +1105,8 @@ __global__ __launch_bounds__(64) void k_inf_seg_decode(const uint8_t* __restrict
   const uint64_t pre = prefix[k];
   const uint64_t base = pre & ~15ull;
   WaveDec d;
-  d.in = d_in + in_off;
+  d.in32 = reinterpret_cast<const uint32_t*>(d_in + in_off);
   d.nbytes = c;
-  d.win = ~0ull;
   d.out = d_out + out_off + base;
   d.cap = cap > base ? cap - base : 0;
   d.ostart = pre & 15u;
@@ -1079,14 +1124,14 @@ __global__ __launch_bounds__(64) void k_inf_seg_decode(const uint8_t* __restrict
       for (uint32_t q = 0; q < 4; q++) S.ring[(p + q) & (RING - 1)] = (uint8_t)(v >> (8 * q));
     }
   }
-  wd_seek(S, d, w ? (uint64_t)cand[w - 1] + 16 : 16);
+  wd_seek(d, w ? (uint64_t)cand[w - 1] + 16 : 16);
   uint32_t bfinal = 0;
   int rc;
   for (;;) {
     rc = wd_block<false>(S, d, &bfinal);
-    if (rc != WD_OK || bfinal || d.pos >= r.end_bit) break;
+    if (rc != WD_OK || bfinal || wd_pos(d) >= r.end_bit) break;
   }
-  if (rc == WD_OK && d.pos == r.end_bit && d.o - d.ostart == r.out_len) {
+  if (rc == WD_OK && wd_pos(d) == r.end_bit && d.o - d.ostart == r.out_len) {
     wd_flush_range(S, d, d.flushed, d.o);
   } else if (lane == 0) {
     atomicOr(fail, 1u);
