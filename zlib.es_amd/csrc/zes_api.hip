@@ -769,12 +769,26 @@ int inflate_slow(const uint8_t* d_in, uint8_t* d_out, InfJob& j) {
   bool have_resume = false;
   // T3: one wavefront, any valid stream
   if (j.c >= 3) {
+#ifdef WD_PROFILE
+    if ((rc = ensure(g.dbg, 64))) return rc;
+    HIPCHK(hipMemsetAsync(g.dbg.p, 0, 64, g.stream));
+    zes_wd_set_dbg((unsigned long long*)g.dbg.p);
+#endif
     {
       Timed t("k_inf_decode_seq");
       hipLaunchKernelGGL(k_inf_decode, dim3(1), dim3(64), 0, g.stream, d_in, j.in_off, j.c, d_out, j.out_off, j.cap, (ZesRes*)g.res.p,
                          (uint64_t*)g.resume.p);
     }
     if ((rc = read_res(&hr))) return rc;
+#ifdef WD_PROFILE
+    {
+      unsigned long long h[8];
+      HIPCHK(hipMemcpy(h, g.dbg.p, 64, hipMemcpyDeviceToHost));
+      const double n = (double)std::max<unsigned long long>(h[5], 1);
+      fprintf(stderr, "zes wave decoder: %llu tokens, cycles per token: lit/len entry %.1f, literal path %.1f, distance entry %.1f, copy %.1f, flush test %.1f; kernel %.1f\n",
+              h[5], h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[6] / n);
+    }
+#endif
     if (hr.status == 0) {
       j.tier = 3;
       j.out_len = hr.out_len;

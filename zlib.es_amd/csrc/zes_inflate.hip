@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256) void k_inf_ranksort(const ZesInfBuf* __restric
 // wave decoder
 // ------------------------------------------------------------------------------------------
 #define LROOT 11u
-#define DROOT 10u
+#define DROOT 9u
 #define RING 65536u
 #define FLUSH 16384u
 #define RING16 33280u  // marker ring (16-bit symbols): window + longest match + slack; not a power of two
@@ -431,8 +431,8 @@ __global__ __launch_bounds__(256) void k_inf_ranksort(const ZesInfBuf* __restric
 // readlane; a window is re-loaded every 2048 bits, one window ahead of its use.
 struct InfSmem {
   uint8_t ring[RING16 * 2];  // byte mode uses the first RING bytes
-  uint16_t lut_l[1u << LROOT];  // symbol | code length << 9 (0 = longer than the root, or no code)
-  uint16_t lut_d[1u << DROOT];
+  uint32_t lut_l[1u << LROOT];  // wd_entry() words; 0 = code longer than the root, or no code
+  uint32_t lut_d[1u << DROOT];
   uint16_t syms_l[288];
   uint16_t syms_d[32];
   uint32_t first_l[16], first_d[16];
@@ -453,9 +453,12 @@ struct WaveDec {
   uint64_t o;      // bytes produced so far
   uint64_t flushed;
   uint64_t ostart; // value of o at the start (0..15: out is the 16-byte aligned base below the first byte)
-  uint64_t avail;  // history bytes in front of ostart a match may reach (preloaded into the ring)
-  uint64_t omax;   // give up once o passes this
+  uint32_t reach;  // how far back a match may go: min(32768, bytes produced + history preloaded into the ring)
+  uint32_t unfl;   // o - flushed
   uint32_t oi;     // marker mode: ring index of output position o
+#ifdef WD_PROFILE
+  uint64_t pt[6];  // cycles: lit/len entry, literal path, distance entry, copy, flush test; pt[5] tokens
+#endif
   // per lane
   uint32_t vcur, vnxt;  // input dwords (idx & ~63) + lane (end-of-stream zeros applied) and + 64 + lane (as loaded)
 };
@@ -463,6 +466,15 @@ struct WaveDec {
 enum { WD_OK = 0, WD_ANOMALY = 1, WD_NEEDS_HISTORY = 2 };
 
 #define WD_SGPR(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+#ifdef WD_PROFILE
+__device__ unsigned long long* g_wd_dbg = nullptr;
+void zes_wd_set_dbg(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wd_dbg), &p, sizeof p); }
+#define WDT(var) const uint64_t var = (uint64_t)__builtin_readcyclecounter()
+#define WDACC(i, a, b) d.pt[i] += (b) - (a)
+#else
+#define WDT(var)
+#define WDACC(i, a, b)
+#endif
 // Placed right behind every lane-dependent branch or loop of the decoder: keeps the join of that branch a block
 // of its own.  Without it the join is often folded into a block where the uniform reader state merges (loop
 // header, end of an if), the uniformity analysis then calls that state divergent and the whole decoder runs
@@ -495,8 +507,9 @@ __device__ __forceinline__ static void wd_seek(WaveDec& d, uint64_t bit) {
     d.vnxt = wd_fetch_raw(d, d.idx + 64 + zes_lane());
   }
 }
-__device__ __forceinline__ static void wd_refill(WaveDec& d) {  // guarantees nb >= 33
-  if (d.nb <= 32u) {
+__device__ __forceinline__ static bool wd_refill(WaveDec& d) {  // guarantees nb >= 33; true if a dword was taken in
+  const bool take = d.nb <= 32u;
+  if (take) {
     const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)d.vcur, (int)((uint32_t)d.idx & 63u));
     d.bb |= (uint64_t)w << d.nb;
     d.nb += 32u;
@@ -506,6 +519,7 @@ __device__ __forceinline__ static void wd_refill(WaveDec& d) {  // guarantees nb
       d.vnxt = wd_fetch_raw(d, d.idx + 64 + zes_lane());
     }
   }
+  return take;
 }
 __device__ __forceinline__ static uint32_t wd_take(WaveDec& d, uint32_t k) {  // k <= 16, after wd_refill
   const uint32_t v = (uint32_t)d.bb & ((1u << k) - 1u);
@@ -528,19 +542,62 @@ __device__ __forceinline__ static void wd_flush_range(InfSmem& S, WaveDec& d, ui
   }
   WD_JOIN();
 }
-__device__ __forceinline__ static void wd_maybe_flush(InfSmem& S, WaveDec& d) {
-  while (d.o - d.flushed >= FLUSH) {
+__device__ __forceinline__ static void wd_produced(InfSmem& S, WaveDec& d, uint32_t n) {  // n bytes were put into the ring
+  d.o += n;
+  d.reach = min(d.reach + n, ZES_WINDOW);
+  d.unfl += n;
+  while (d.unfl >= FLUSH) {
     wd_flush_range(S, d, d.flushed, d.flushed + FLUSH);
     d.flushed += FLUSH;
+    d.unfl -= FLUSH;
   }
+}
+
+// base value and extra-bit count of length code lc (0..28) and distance code dc (0..29) in closed form
+// (the values of src/const.ts:9-35)
+__device__ __forceinline__ static void wd_len_code(uint32_t lc, uint32_t* base, uint32_t* xb) {
+  const uint32_t e = lc < 8u ? 0u : (lc - 4u) >> 2;
+  *base = lc < 8u ? 3u + lc : lc == 28u ? 258u : 3u + ((4u + (lc & 3u)) << e);
+  *xb = lc == 28u ? 0u : e;
+}
+__device__ __forceinline__ static void wd_dist_code(uint32_t dc, uint32_t* base, uint32_t* xb) {
+  const uint32_t e = dc < 4u ? 0u : (dc - 2u) >> 1;
+  *base = dc < 4u ? 1u + dc : 1u + ((2u + (dc & 1u)) << e);
+  *xb = e;
+}
+
+// Table entry of symbol s with code length l: everything the symbol loop needs in one word.
+//   [4:0]  bits to take in all (code + extra bits)      [8:5] code length
+//   [10:9] kind: 0 literal, 1 length / distance, 2 end of block, 3 a symbol that must not occur (286, 287, 30, 31)
+//   [31:16] literal byte, or base value of the length / distance
+#define WE_LIT 0u
+#define WE_BASE 1u
+#define WE_EOB 2u
+#define WE_BAD 3u
+__device__ __forceinline__ static uint32_t wd_entry(uint32_t s, uint32_t l, bool dist) {
+  uint32_t kind, val = s, xb = 0;
+  if (dist) {
+    kind = s < 30u ? WE_BASE : WE_BAD;
+    wd_dist_code(s < 30u ? s : 0u, &val, &xb);
+  } else if (s < 256u) {
+    kind = WE_LIT;
+  } else if (s == 256u) {
+    kind = WE_EOB;
+  } else {
+    kind = s < 286u ? WE_BASE : WE_BAD;
+    wd_len_code(s < 286u ? s - 257u : 0u, &val, &xb);
+  }
+  if (kind != WE_BASE) xb = 0;
+  return (l + xb) | (l << 5) | (kind << 9) | (val << 16);
 }
 
 // canonical tables + root LUT for one alphabet; lens in S.lens[base .. base+nsym).
 // Returns false when the length set is over-subscribed.
-__device__ __noinline__ static bool wd_build(InfSmem& S, uint32_t base, uint32_t nsym, uint32_t root, uint16_t* lut, uint16_t* syms,
+__device__ __noinline__ static bool wd_build(InfSmem& S, uint32_t base, uint32_t nsym, uint32_t root, uint32_t* lut, uint16_t* syms,
                                              uint32_t* first, uint16_t* cnt, uint16_t* offs) {
   const uint32_t lane = zes_lane();
   const uint8_t* lens = S.lens + base;
+  const bool dist = base != 0;
   for (uint32_t i = lane; i < (1u << root); i += 64) lut[i] = 0;
   // counts per length
   uint32_t c[16];
@@ -596,52 +653,29 @@ __device__ __noinline__ static bool wd_build(InfSmem& S, uint32_t base, uint32_t
       syms[o2 + rank] = (uint16_t)s;
       if (l <= root) {
         const uint32_t rev = __brev(f + rank) >> (32u - l);
-        for (uint32_t e = rev; e < (1u << root); e += 1u << l) lut[e] = (uint16_t)(s | (l << 9));
+        const uint32_t ent = wd_entry(s, l, dist);
+        for (uint32_t e = rev; e < (1u << root); e += 1u << l) lut[e] = ent;
       }
     }
   }
   return true;
 }
 
-// symbol decode: root LUT, then canonical walk for codes longer than root (reference
-// src/inflate.ts:238-252 extends one bit at a time the same way).  Returns -1 if no code matches.
-__device__ __forceinline__ static int wd_sym(WaveDec& d, const uint16_t* lut, uint32_t root, const uint16_t* syms,
-                                             const uint32_t* first, const uint16_t* cnt, const uint16_t* offs) {
-  const uint32_t e = WD_SGPR(lut[(uint32_t)d.bb & ((1u << root) - 1u)]);
-  const uint32_t l = e >> 9;
-  if (l) {
-    d.bb >>= l;
-    d.nb -= l;
-    return (int)(e & 511u);
-  }
-  uint32_t code = __brev((uint32_t)d.bb & ((1u << root) - 1u)) >> (32u - root);
+// Entry of the next symbol when its code is longer than the root table: canonical walk (reference
+// src/inflate.ts:238-252 extends one bit at a time the same way).  Returns 0 if no code matches.
+__device__ __noinline__ static uint32_t wd_long(uint64_t bb, uint32_t root, const uint16_t* syms, const uint32_t* first, const uint16_t* cnt,
+                                                const uint16_t* offs, bool dist) {
+  uint32_t code = __brev((uint32_t)bb & ((1u << root) - 1u)) >> (32u - root);
   for (uint32_t len = root + 1; len <= 15u; len++) {
-    code = (code << 1) | (uint32_t)((d.bb >> (len - 1)) & 1u);
-    const uint32_t fl = WD_SGPR(first[len]), cl = WD_SGPR(cnt[len]);
+    code = (code << 1) | (uint32_t)((bb >> (len - 1)) & 1u);
+    const uint32_t fl = first[len], cl = cnt[len];
     const uint32_t rel = code - fl;
-    if (code >= fl && rel < cl) {
-      d.bb >>= len;
-      d.nb -= len;
-      return (int)WD_SGPR(syms[WD_SGPR(offs[len]) + rel]);
-    }
+    if (code >= fl && rel < cl) return wd_entry(syms[offs[len] + rel], len, dist);
   }
-  return -1;
+  return 0;
 }
 
-// base value and extra-bit count of length code lc (0..28) and distance code dc (0..29) in closed form
-// (the values of src/const.ts:9-35)
-__device__ __forceinline__ static void wd_len_code(uint32_t lc, uint32_t* base, uint32_t* xb) {
-  const uint32_t e = lc < 8u ? 0u : (lc - 4u) >> 2;
-  *base = lc < 8u ? 3u + lc : lc == 28u ? 258u : 3u + ((4u + (lc & 3u)) << e);
-  *xb = lc == 28u ? 0u : e;
-}
-__device__ __forceinline__ static void wd_dist_code(uint32_t dc, uint32_t* base, uint32_t* xb) {
-  const uint32_t e = dc < 4u ? 0u : (dc - 2u) >> 1;
-  *base = dc < 4u ? 1u + dc : 1u + ((2u + (dc & 1u)) << e);
-  *xb = e;
-}
-
-// i mod dist for i < 512, dist < 512 (overlapping matches): float reciprocal plus one correction either way
+// i mod dist for i < 512, dist < 512 (overlapping matches): approximate float reciprocal plus one correction either way
 __device__ __forceinline__ static uint32_t wd_mod(uint32_t i, uint32_t dist, float rcp) {
   const uint32_t q = (uint32_t)((float)i * rcp);
   int r = (int)i - (int)(q * dist);
@@ -654,71 +688,115 @@ __device__ __forceinline__ static uint32_t wd_mod(uint32_t i, uint32_t dist, flo
 // MARK: 16-bit symbols in the marker ring (values >= 256 stand for bytes of the unknown window in
 // front of the segment), nothing is stored and every distance is allowed.
 template <bool MARK>
-__device__ __forceinline__ static int wd_symbols(InfSmem& S, WaveDec& d, uint32_t droot_used) {
+__device__ __forceinline__ static int wd_symbols(InfSmem& S, WaveDec& d) {
   const uint32_t lane = zes_lane();
   const uint64_t limit = d.nbytes * 8;
+  // every token refills first, so the reader can run at most 64 bits + one dword ahead of a valid position;
+  // the exact test against the end of the data is made at the end of the block
+  const uint64_t idx_lim = d.nbytes / 4 + 3;
   uint16_t* r16 = reinterpret_cast<uint16_t*>(S.ring);
   for (;;) {
-    wd_refill(d);
-    const int s = wd_sym(d, S.lut_l, LROOT, S.syms_l, S.first_l, S.cnt_l, S.offs_l);
-    if (s < 0) return WD_ANOMALY;
-    if (s < 256) {
+    WDT(t0);
+    if (wd_refill(d) && d.idx > idx_lim) return WD_ANOMALY;
+    uint32_t e = WD_SGPR(S.lut_l[(uint32_t)d.bb & ((1u << LROOT) - 1u)]);
+    if ((e & 31u) == 0) {
+      e = WD_SGPR(wd_long(d.bb, LROOT, S.syms_l, S.first_l, S.cnt_l, S.offs_l, false));
+      if (e == 0) return WD_ANOMALY;
+    }
+    const uint32_t kind = (e >> 9) & 3u, tot = e & 31u, cl = (e >> 5) & 15u;
+    WDT(t1);
+    WDACC(0, t0, t1);
+#ifdef WD_PROFILE
+    d.pt[5]++;
+#endif
+    if (kind == WE_LIT) {
+      d.bb >>= tot;
+      d.nb -= tot;
       if (MARK) {
-        if (lane == 0) r16[d.oi] = (uint16_t)s;
+        if (lane == 0) r16[d.oi] = (uint16_t)(e >> 16);
         WD_JOIN();
         d.oi = d.oi + 1u == RING16 ? 0u : d.oi + 1u;
         d.o++;
       } else {
-        if (lane == 0) S.ring[d.o & (RING - 1)] = (uint8_t)s;
+        if (lane == 0) S.ring[d.o & (RING - 1)] = (uint8_t)(e >> 16);
         WD_JOIN();
-        d.o++;
-        if (d.o > d.omax) return WD_ANOMALY;
-        wd_maybe_flush(S, d);
+        wd_produced(S, d, 1);
       }
-      if (wd_pos(d) > limit) return WD_ANOMALY;
+      WDT(t2);
+      WDACC(1, t1, t2);
       continue;
     }
-    if (s == 256) return wd_pos(d) > limit ? WD_ANOMALY : WD_OK;
-    const uint32_t lc = (uint32_t)s - 257u;
-    if (lc >= 29u) return WD_ANOMALY;
-    uint32_t lbase, lxb, dbase, dxb;
-    wd_len_code(lc, &lbase, &lxb);
-    const uint32_t len = lbase + wd_take(d, lxb);  // code (<= 15) + extra (<= 5) bits fit one refill
-    wd_refill(d);
-    const int ds = wd_sym(d, S.lut_d, droot_used, S.syms_d, S.first_d, S.cnt_d, S.offs_d);
-    if (ds < 0 || ds >= 30) return WD_ANOMALY;
-    wd_dist_code((uint32_t)ds, &dbase, &dxb);
-    const uint32_t dist = dbase + wd_take(d, dxb);  // <= 15 + 13 bits
-    if (wd_pos(d) > limit) return WD_ANOMALY;
+    if (kind != WE_BASE) {
+      d.bb >>= tot;
+      d.nb -= tot;
+      return kind == WE_EOB && wd_pos(d) <= limit ? WD_OK : WD_ANOMALY;
+    }
+    const uint32_t len = (e >> 16) + (((uint32_t)(d.bb >> cl)) & ((1u << (tot - cl)) - 1u));  // code (<= 15) + extra (<= 5) bits fit one refill
+    d.bb >>= tot;
+    d.nb -= tot;
+    if (wd_refill(d) && d.idx > idx_lim) return WD_ANOMALY;  // (both refills: either one may be the only one that ever takes a dword)
+    uint32_t e2 = WD_SGPR(S.lut_d[(uint32_t)d.bb & ((1u << DROOT) - 1u)]);
+    if ((e2 & 31u) == 0) {
+      e2 = WD_SGPR(wd_long(d.bb, DROOT, S.syms_d, S.first_d, S.cnt_d, S.offs_d, true));
+      if (e2 == 0) return WD_ANOMALY;
+    }
+    if (((e2 >> 9) & 3u) != WE_BASE) return WD_ANOMALY;
+    const uint32_t tot2 = e2 & 31u, cl2 = (e2 >> 5) & 15u;
+    const uint32_t dist = (e2 >> 16) + (((uint32_t)(d.bb >> cl2)) & ((1u << (tot2 - cl2)) - 1u));  // <= 15 + 13 bits
+    d.bb >>= tot2;
+    d.nb -= tot2;
+    WDT(t3);
+    WDACC(2, t1, t3);
     // lane-parallel copy; overlapping matches read i % dist so every source symbol already exists
     const bool overlap = dist < len;
-    const float rcp = overlap ? 1.0f / (float)dist : 0.0f;
     if (MARK) {
       const uint32_t si = d.oi >= dist ? d.oi - dist : d.oi + RING16 - dist;
-      for (uint32_t i = lane; i < len; i += 64) {
-        const uint32_t k = overlap ? wd_mod(i, dist, rcp) : i;
-        uint32_t a = si + k, b = d.oi + i;
-        if (a >= RING16) a -= RING16;
-        if (b >= RING16) b -= RING16;
-        r16[b] = r16[a];
+      if (!overlap) {  // the common case, kept lean: the wave executes about one instruction per five cycles
+        for (uint32_t i0 = 0; i0 < len; i0 += 64) {
+          const uint32_t i = i0 + lane;
+          uint32_t a = si + i, b = d.oi + i;
+          if (a >= RING16) a -= RING16;
+          if (b >= RING16) b -= RING16;
+          if (i < len) r16[b] = r16[a];
+          WD_JOIN();
+        }
+      } else {
+        const float rcp = __builtin_amdgcn_rcpf((float)dist);
+        for (uint32_t i0 = 0; i0 < len; i0 += 64) {
+          const uint32_t i = i0 + lane;
+          uint32_t a = si + wd_mod(i, dist, rcp), b = d.oi + i;
+          if (a >= RING16) a -= RING16;
+          if (b >= RING16) b -= RING16;
+          if (i < len) r16[b] = r16[a];
+          WD_JOIN();
+        }
       }
-      WD_JOIN();
       d.oi += len;
       if (d.oi >= RING16) d.oi -= RING16;
       d.o += len;
       continue;
     }
-    if ((uint64_t)dist > d.o - d.ostart + d.avail) return WD_NEEDS_HISTORY;  // behind the first output byte of the stream
-    if (d.o + len > d.omax) return WD_ANOMALY;
+    if (dist > d.reach) return WD_NEEDS_HISTORY;  // behind the first output byte of the stream
     const uint32_t srcb = (uint32_t)(d.o - dist), dstb = (uint32_t)d.o;
-    for (uint32_t i = lane; i < len; i += 64) {
-      const uint32_t k = overlap ? wd_mod(i, dist, rcp) : i;
-      const uint8_t v = S.ring[(srcb + k) & (RING - 1)];
-      S.ring[(dstb + i) & (RING - 1)] = v;
+    if (!overlap) {
+      for (uint32_t i0 = 0; i0 < len; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        if (i < len) S.ring[(dstb + i) & (RING - 1)] = S.ring[(srcb + i) & (RING - 1)];
+        WD_JOIN();
+      }
+    } else {
+      const float rcp = __builtin_amdgcn_rcpf((float)dist);
+      for (uint32_t i0 = 0; i0 < len; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        if (i < len) S.ring[(dstb + i) & (RING - 1)] = S.ring[(srcb + wd_mod(i, dist, rcp)) & (RING - 1)];
+        WD_JOIN();
+      }
     }
-    WD_JOIN();
-    d.o += len;
-    wd_maybe_flush(S, d);
+    WDT(t4);
+    WDACC(3, t3, t4);
+    wd_produced(S, d, len);
+    WDT(t5);
+    WDACC(4, t4, t5);
   }
 }
 
@@ -760,20 +838,16 @@ __device__ __forceinline__ static int wd_block(InfSmem& S, WaveDec& d, uint32_t*
       wd_seek(d, (src + LEN) * 8);
       return WD_OK;
     }
-    if (d.o + LEN > d.omax) return WD_ANOMALY;
     for (uint32_t done = 0; done < LEN;) {
-      const uint32_t room = (uint32_t)(FLUSH - ((d.o - d.flushed) % FLUSH));
-      const uint32_t n = min(LEN - done, room);
+      const uint32_t n = min(LEN - done, FLUSH - d.unfl);
       for (uint32_t i = lane; i < n; i += 64) S.ring[(d.o + i) & (RING - 1)] = in8[src + done + i];
       WD_JOIN();
-      d.o += n;
       done += n;
-      wd_maybe_flush(S, d);
+      wd_produced(S, d, n);
     }
     wd_seek(d, (src + LEN) * 8);
     return WD_OK;
   }
-  uint32_t droot = DROOT;
   if (btype == 1) {  // fixed (src/huffman.ts:41-53; distance = 5 bits MSB-first, src/inflate.ts:107)
     for (uint32_t i = lane; i < 288; i += 64) S.lens[i] = (uint8_t)(i <= 143 ? 8 : i <= 255 ? 9 : i <= 279 ? 7 : 8);
     WD_JOIN();
@@ -846,8 +920,8 @@ __device__ __forceinline__ static int wd_block(InfSmem& S, WaveDec& d, uint32_t*
   }
   // (a call returns in a vector register: back to scalar, or everything behind the branch counts as divergent)
   if (!WD_SGPR(wd_build(S, 0, 288, LROOT, S.lut_l, S.syms_l, S.first_l, S.cnt_l, S.offs_l))) return WD_ANOMALY;
-  if (!WD_SGPR(wd_build(S, 288, 32, droot, S.lut_d, S.syms_d, S.first_d, S.cnt_d, S.offs_d))) return WD_ANOMALY;
-  return wd_symbols<MARK>(S, d, droot);
+  if (!WD_SGPR(wd_build(S, 288, 32, DROOT, S.lut_d, S.syms_d, S.first_d, S.cnt_d, S.offs_d))) return WD_ANOMALY;
+  return wd_symbols<MARK>(S, d);
 }
 
 
@@ -865,9 +939,13 @@ __global__ __launch_bounds__(64) void k_inf_decode(const uint8_t* __restrict__ d
   d.out = d_out + out_off;
   d.cap = cap;
   d.ostart = 0;
-  d.avail = 0;
-  d.omax = ~0ull >> 1;
+  d.reach = 0;
+  d.unfl = 0;
   d.oi = 0;
+#ifdef WD_PROFILE
+  for (int i = 0; i < 6; i++) d.pt[i] = 0;
+  const uint64_t tk0 = (uint64_t)__builtin_readcyclecounter();
+#endif
   wd_seek(d, 16);
   uint32_t bfinal = 0;
   int rc = WD_OK;
@@ -882,6 +960,12 @@ __global__ __launch_bounds__(64) void k_inf_decode(const uint8_t* __restrict__ d
       break;
     }
   }
+#ifdef WD_PROFILE
+  if (g_wd_dbg && lane == 0) {
+    for (int i = 0; i < 6; i++) g_wd_dbg[i] = d.pt[i];
+    g_wd_dbg[6] = (uint64_t)__builtin_readcyclecounter() - tk0;
+  }
+#endif
   if (rc == WD_OK) {
     wd_flush_range(S, d, d.flushed, d.o);
     if (lane == 0) {
@@ -941,8 +1025,8 @@ __global__ __launch_bounds__(64) void k_inf_seg_scan(const uint8_t* __restrict__
   d.out = nullptr;
   d.cap = 0;
   d.ostart = 0;
-  d.avail = 0;
-  d.omax = ~0ull >> 1;
+  d.reach = 0;
+  d.unfl = 0;
   d.oi = ZES_WINDOW;
   uint16_t* r16 = reinterpret_cast<uint16_t*>(S.ring);
   for (uint32_t i = lane; i < ZES_WINDOW; i += 64) r16[i] = (uint16_t)(256u + i);  // window byte i of the previous segment
@@ -1112,8 +1196,8 @@ __global__ __launch_bounds__(64) void k_inf_seg_decode(const uint8_t* __restrict
   d.ostart = pre & 15u;
   d.o = d.ostart;
   d.flushed = 0;
-  d.avail = min(pre, (uint64_t)ZES_WINDOW);
-  d.omax = d.ostart + r.out_len;
+  d.reach = (uint32_t)min(pre, (uint64_t)ZES_WINDOW);
+  d.unfl = (uint32_t)d.ostart;
   d.oi = 0;
   if (k > 0) {  // window bytes in front of the segment: positions ostart - 32768 .. ostart - 1
     const uint32_t* wv = reinterpret_cast<const uint32_t*>(wins + (size_t)(k - 1) * ZES_WINDOW);

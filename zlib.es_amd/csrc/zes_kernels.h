@@ -62,6 +62,9 @@ __global__ void k_inf_chain(const ZesInfBuf*, const uint32_t*, const uint32_t*, 
 __global__ void k_inf_exact(const uint8_t*, uint64_t, uint64_t, uint8_t*, uint64_t, uint64_t, const uint64_t*, ZesRes*);
 // deflate direction (zes_deflate.hip)
 void zes_sort_set_dbg(unsigned long long*);
+#ifdef WD_PROFILE
+void zes_wd_set_dbg(unsigned long long*);
+#endif
 void zes_parse_set_dbg(unsigned long long*);
 void zes_lazy_set_dbg(unsigned long long*);
 void zes_huff_set_dbg(unsigned long long*);
