@@ -1,5 +1,6 @@
+"""Cycle profile of the serial wavefront decoder (build the library with -DWD_PROFILE; not a pytest)."""
 import os, sys, time, zlib as pz
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge
 import numpy as np, torch
 z = ge.load(); z.init(0)

@@ -36,7 +36,7 @@ struct Ctx {
   // deflate scratch
   DevBuf bufs, blks, idx_a, idx_b, inv, hists, codes, hdrs, adler, res;
   // inflate scratch
-  DevBuf surv, cand, cand_sorted, counters, cres, map, resume, dbg, ibufs, ibufs2, mvlist, scratch, sres, maps, seglist, segprefix, wins;
+  DevBuf surv, cand, cand_sorted, counters, cres, map, resume, dbg, ibufs, ibufs2, mvlist, scratch, sres, maps, seglist, segprefix, wins, sym16, segorder;
   // staging for the host-pointer API
   DevBuf st_in, st_out;
   void* pinned = nullptr;  // small pinned area for read-backs
@@ -714,21 +714,31 @@ int inflate_segments(const uint8_t* d_in, uint8_t* d_out, InfJob& j) {
   if ((rc = ensure(g.maps, (size_t)nwork * ZES_WINDOW * 2))) return rc;
   if ((rc = ensure(g.seglist, (size_t)nwork * 4))) return rc;
   if ((rc = ensure(g.segprefix, (size_t)nwork * 8))) return rc;
+  // symbol store: `ratio` 16-bit symbols per compressed byte (a segment that inflates further is decoded twice)
+  // (as many as a 2 GiB store holds, up to DEFLATE's own limit of 1032 bytes per compressed byte)
+  uint32_t ratio = (uint32_t)std::min<uint64_t>(1032, (2ull << 30) / (2 * (j.c + 64))) & ~1u;
+  if (ratio < 4) ratio = 0;
+  if (ratio && ensure(g.sym16, (size_t)(j.c + 64) * ratio * 2)) ratio = 0;  // no memory for it: two decodes
+  if ((rc = ensure(g.segorder, (size_t)nwork * 4))) return rc;
+  hipLaunchKernelGGL(k_inf_seg_order, dim3(1), dim3(1024), 0, g.stream, (const uint32_t*)g.cand_sorted.p, ncand, j.c, (uint32_t*)g.segorder.p);
+  uint32_t* fail = counters + 3;  // [3] failure flag of the output passes, [2] chain segments that are not in the store
+  HIPCHK(hipMemsetAsync(counters + 2, 0, 8, g.stream));
   {
     Timed t("k_inf_seg_scan");
     hipLaunchKernelGGL(k_inf_seg_scan, dim3(nwork), dim3(64), 0, g.stream, d_in, j.in_off, j.c, (const uint32_t*)g.cand_sorted.p, ncand,
-                       (ZesSegRes*)g.sres.p, (uint32_t*)g.maps.p);
+                       (ZesSegRes*)g.sres.p, (uint32_t*)g.maps.p, (uint32_t*)g.sym16.p, ratio, (const uint32_t*)g.segorder.p);
   }
   {
     Timed t("k_inf_seg_chain");
     hipLaunchKernelGGL(k_inf_seg_chain, dim3(1), dim3(256), 0, g.stream, (const ZesSegRes*)g.sres.p, nwork, (uint32_t*)g.seglist.p,
-                       (uint64_t*)g.segprefix.p, (ZesRes*)g.res.p);
+                       (uint64_t*)g.segprefix.p, (ZesRes*)g.res.p, counters + 2);
   }
+  HIPCHK(hipMemcpyAsync((uint8_t*)g.pinned + 64, counters + 2, 4, hipMemcpyDeviceToHost, g.stream));
   ZesRes hr;
   if ((rc = read_res(&hr))) return rc;
   if (getenv("ZES_DEBUG"))
-    fprintf(stderr, "zes T2: c=%llu candidates=%u chain status=%d segments=%u out_len=%llu\n", (unsigned long long)j.c, ncand, hr.status,
-            hr.aux, (unsigned long long)hr.out_len);
+    fprintf(stderr, "zes T2: c=%llu candidates=%u chain status=%d segments=%u (%u decoded twice) out_len=%llu\n", (unsigned long long)j.c,
+            ncand, hr.status, hr.aux, *(const uint32_t*)((const uint8_t*)g.pinned + 64), (unsigned long long)hr.out_len);
   if (hr.status != 0 || hr.aux == 0) return ZES_OK;
   const uint32_t nseg = hr.aux;
   if (hr.out_len > j.cap) {  // the caller learns the size without the second decode
@@ -738,18 +748,24 @@ int inflate_segments(const uint8_t* d_in, uint8_t* d_out, InfJob& j) {
     return ZES_OK;
   }
   if ((rc = ensure(g.wins, (size_t)nseg * ZES_WINDOW))) return rc;
-  uint32_t* fail = counters + 3;
-  HIPCHK(hipMemsetAsync(fail, 0, 4, g.stream));
+  const uint32_t novf = *(const uint32_t*)((const uint8_t*)g.pinned + 64);
   if (nseg > 1) {
     Timed t("k_inf_seg_windows");
     hipLaunchKernelGGL(k_inf_seg_windows, dim3(1), dim3(1024), 0, g.stream, (const uint32_t*)g.maps.p, (const uint32_t*)g.seglist.p, nseg,
                        (uint8_t*)g.wins.p);
   }
-  {
+  if (novf < nseg) {
+    Timed t("k_inf_seg_translate");
+    const uint32_t ny = std::max(1u, std::min(16u, 2048u / nseg));  // few long segments: split each over several workgroups
+    hipLaunchKernelGGL(k_inf_seg_translate, dim3(nseg, ny), dim3(256), 0, g.stream, d_out, j.out_off, j.cap, (const uint32_t*)g.cand_sorted.p,
+                       (const ZesSegRes*)g.sres.p, (const uint32_t*)g.seglist.p, (const uint64_t*)g.segprefix.p, (const uint8_t*)g.wins.p,
+                       (const uint32_t*)g.sym16.p, ratio, fail);
+  }
+  if (novf > 0) {
     Timed t("k_inf_seg_decode");
     hipLaunchKernelGGL(k_inf_seg_decode, dim3(nseg), dim3(64), 0, g.stream, d_in, j.in_off, j.c, d_out, j.out_off, j.cap,
                        (const uint32_t*)g.cand_sorted.p, (const ZesSegRes*)g.sres.p, (const uint32_t*)g.seglist.p,
-                       (const uint64_t*)g.segprefix.p, (const uint8_t*)g.wins.p, fail);
+                       (const uint64_t*)g.segprefix.p, (const uint8_t*)g.wins.p, fail, novf < nseg ? 1u : 0u);
   }
   HIPCHK(hipMemcpyAsync(hc, fail, 4, hipMemcpyDeviceToHost, g.stream));
   HIPCHK(hipStreamSynchronize(g.stream));
@@ -913,7 +929,7 @@ int zes_shutdown(void) {
   (void)hipStreamSynchronize(g.stream);
   DevBuf* all[] = {&g.bufs, &g.blks, &g.idx_a, &g.idx_b, &g.inv, &g.hists, &g.codes, &g.hdrs, &g.adler, &g.res, &g.surv, &g.cand,
                    &g.cand_sorted, &g.counters, &g.cres, &g.map, &g.resume, &g.dbg, &g.ibufs, &g.ibufs2, &g.mvlist, &g.scratch, &g.st_in, &g.st_out,
-                   &g.sres, &g.maps, &g.seglist, &g.segprefix, &g.wins};
+                   &g.sres, &g.maps, &g.seglist, &g.segprefix, &g.wins, &g.sym16, &g.segorder};
   for (DevBuf* b : all) {
     if (b->p) (void)hipFree(b->p);
     b->p = nullptr;

@@ -456,6 +456,9 @@ struct WaveDec {
   uint32_t reach;  // how far back a match may go: min(32768, bytes produced + history preloaded into the ring)
   uint32_t unfl;   // o - flushed
   uint32_t oi;     // marker mode: ring index of output position o
+  uint32_t* sym;   // marker mode: where the segment's 16-bit symbols go (pairs), or nullptr
+  uint64_t sym_cap;  // symbols that fit there; sym_ovf is set once the segment has outgrown it
+  uint32_t sym_ovf;
 #ifdef WD_PROFILE
   uint64_t pt[6];  // cycles: lit/len entry, literal path, distance entry, copy, flush test; pt[5] tokens
 #endif
@@ -507,6 +510,7 @@ __device__ __forceinline__ static void wd_seek(WaveDec& d, uint64_t bit) {
     d.vnxt = wd_fetch_raw(d, d.idx + 64 + zes_lane());
   }
 }
+#define WD_UNLIKELY(x) __builtin_expect(!!(x), 0)
 __device__ __forceinline__ static bool wd_refill(WaveDec& d) {  // guarantees nb >= 33; true if a dword was taken in
   const bool take = d.nb <= 32u;
   if (take) {
@@ -514,7 +518,7 @@ __device__ __forceinline__ static bool wd_refill(WaveDec& d) {  // guarantees nb
     d.bb |= (uint64_t)w << d.nb;
     d.nb += 32u;
     d.idx++;
-    if (((uint32_t)d.idx & 63u) == 0) {  // the load issued one window ago is waited for here
+    if (WD_UNLIKELY(((uint32_t)d.idx & 63u) == 0)) {  // the load issued one window ago is waited for here
       d.vcur = wd_fetch_fix(d, d.vnxt, d.idx + zes_lane());
       d.vnxt = wd_fetch_raw(d, d.idx + 64 + zes_lane());
     }
@@ -546,7 +550,7 @@ __device__ __forceinline__ static void wd_produced(InfSmem& S, WaveDec& d, uint3
   d.o += n;
   d.reach = min(d.reach + n, ZES_WINDOW);
   d.unfl += n;
-  while (d.unfl >= FLUSH) {
+  while (WD_UNLIKELY(d.unfl >= FLUSH)) {
     wd_flush_range(S, d, d.flushed, d.flushed + FLUSH);
     d.flushed += FLUSH;
     d.unfl -= FLUSH;
@@ -684,6 +688,34 @@ __device__ __forceinline__ static uint32_t wd_mod(uint32_t i, uint32_t dist, flo
   return (uint32_t)r;
 }
 
+// Marker mode keeps the decoded symbols: every FLUSH symbols the ring's unflushed part goes to the segment's
+// region of the symbol store (k_inf_seg_translate turns it into bytes once the windows are known).
+__device__ __forceinline__ static void wd_mark_flush(InfSmem& S, WaveDec& d, uint32_t count) {  // the oldest `count` unflushed symbols
+  const uint16_t* r16 = reinterpret_cast<const uint16_t*>(S.ring);
+  const uint64_t first = d.o - d.unfl;  // symbol offset inside the segment; a multiple of FLUSH
+  if (d.sym == nullptr || first + count > d.sym_cap) {
+    d.sym_ovf = 1;
+  } else {
+    uint32_t base = d.oi + RING16 - d.unfl;  // ring index of the first unflushed symbol
+    if (base >= RING16) base -= RING16;
+    uint32_t* dst = d.sym + first / 2;
+    for (uint32_t i2 = zes_lane(); i2 < (count + 1) / 2; i2 += 64) {
+      uint32_t a = base + 2 * i2, b = a + 1;
+      if (a >= RING16) a -= RING16;
+      if (b >= RING16) b -= RING16;
+      const uint32_t lo = r16[a], hi = 2 * i2 + 1 < count ? (uint32_t)r16[b] : 0u;
+      dst[i2] = lo | (hi << 16);
+    }
+    WD_JOIN();
+  }
+  d.unfl -= count;
+}
+__device__ __forceinline__ static void wd_mark_produced(InfSmem& S, WaveDec& d, uint32_t n) {  // n symbols entered the ring
+  d.o += n;
+  d.unfl += n;  // never more than FLUSH + 257, so the unflushed symbols are all still in the ring
+  if (WD_UNLIKELY(d.unfl >= FLUSH)) wd_mark_flush(S, d, FLUSH);
+}
+
 // Decodes the symbols of one fixed/dynamic block whose tables are built.  Uniform control flow.
 // MARK: 16-bit symbols in the marker ring (values >= 256 stand for bytes of the unknown window in
 // front of the segment), nothing is stored and every distance is allowed.
@@ -695,11 +727,20 @@ __device__ __forceinline__ static int wd_symbols(InfSmem& S, WaveDec& d) {
   // the exact test against the end of the data is made at the end of the block
   const uint64_t idx_lim = d.nbytes / 4 + 3;
   uint16_t* r16 = reinterpret_cast<uint16_t*>(S.ring);
+  // The two root tables move into vector registers (entry r * 64 + lane in register r): a lookup is then an
+  // indexed register move plus a readlane, a handful of cycles, where an LDS read costs the lone wave a
+  // round trip of ~200 cycles per symbol.
+  uint32_t tl[(1u << LROOT) / 64], td[(1u << DROOT) / 64];
+#pragma unroll
+  for (uint32_t r = 0; r < (1u << LROOT) / 64; r++) tl[r] = S.lut_l[r * 64 + lane];
+#pragma unroll
+  for (uint32_t r = 0; r < (1u << DROOT) / 64; r++) td[r] = S.lut_d[r * 64 + lane];
   for (;;) {
     WDT(t0);
-    if (wd_refill(d) && d.idx > idx_lim) return WD_ANOMALY;
-    uint32_t e = WD_SGPR(S.lut_l[(uint32_t)d.bb & ((1u << LROOT) - 1u)]);
-    if ((e & 31u) == 0) {
+    if (WD_UNLIKELY(wd_refill(d) && d.idx > idx_lim)) return WD_ANOMALY;
+    const uint32_t il = (uint32_t)d.bb & ((1u << LROOT) - 1u);
+    uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)tl[il >> 6], (int)(il & 63u));
+    if (WD_UNLIKELY((e & 31u) == 0)) {
       e = WD_SGPR(wd_long(d.bb, LROOT, S.syms_l, S.first_l, S.cnt_l, S.offs_l, false));
       if (e == 0) return WD_ANOMALY;
     }
@@ -716,7 +757,7 @@ __device__ __forceinline__ static int wd_symbols(InfSmem& S, WaveDec& d) {
         if (lane == 0) r16[d.oi] = (uint16_t)(e >> 16);
         WD_JOIN();
         d.oi = d.oi + 1u == RING16 ? 0u : d.oi + 1u;
-        d.o++;
+        wd_mark_produced(S, d, 1);
       } else {
         if (lane == 0) S.ring[d.o & (RING - 1)] = (uint8_t)(e >> 16);
         WD_JOIN();
@@ -726,7 +767,7 @@ __device__ __forceinline__ static int wd_symbols(InfSmem& S, WaveDec& d) {
       WDACC(1, t1, t2);
       continue;
     }
-    if (kind != WE_BASE) {
+    if (WD_UNLIKELY(kind != WE_BASE)) {
       d.bb >>= tot;
       d.nb -= tot;
       return kind == WE_EOB && wd_pos(d) <= limit ? WD_OK : WD_ANOMALY;
@@ -734,13 +775,14 @@ __device__ __forceinline__ static int wd_symbols(InfSmem& S, WaveDec& d) {
     const uint32_t len = (e >> 16) + (((uint32_t)(d.bb >> cl)) & ((1u << (tot - cl)) - 1u));  // code (<= 15) + extra (<= 5) bits fit one refill
     d.bb >>= tot;
     d.nb -= tot;
-    if (wd_refill(d) && d.idx > idx_lim) return WD_ANOMALY;  // (both refills: either one may be the only one that ever takes a dword)
-    uint32_t e2 = WD_SGPR(S.lut_d[(uint32_t)d.bb & ((1u << DROOT) - 1u)]);
-    if ((e2 & 31u) == 0) {
+    if (WD_UNLIKELY(wd_refill(d) && d.idx > idx_lim)) return WD_ANOMALY;  // (both refills: either one may be the only one that ever takes a dword)
+    const uint32_t id = (uint32_t)d.bb & ((1u << DROOT) - 1u);
+    uint32_t e2 = (uint32_t)__builtin_amdgcn_readlane((int)td[id >> 6], (int)(id & 63u));
+    if (WD_UNLIKELY((e2 & 31u) == 0)) {
       e2 = WD_SGPR(wd_long(d.bb, DROOT, S.syms_d, S.first_d, S.cnt_d, S.offs_d, true));
       if (e2 == 0) return WD_ANOMALY;
     }
-    if (((e2 >> 9) & 3u) != WE_BASE) return WD_ANOMALY;
+    if (WD_UNLIKELY(((e2 >> 9) & 3u) != WE_BASE)) return WD_ANOMALY;
     const uint32_t tot2 = e2 & 31u, cl2 = (e2 >> 5) & 15u;
     const uint32_t dist = (e2 >> 16) + (((uint32_t)(d.bb >> cl2)) & ((1u << (tot2 - cl2)) - 1u));  // <= 15 + 13 bits
     d.bb >>= tot2;
@@ -773,10 +815,10 @@ __device__ __forceinline__ static int wd_symbols(InfSmem& S, WaveDec& d) {
       }
       d.oi += len;
       if (d.oi >= RING16) d.oi -= RING16;
-      d.o += len;
+      wd_mark_produced(S, d, len);
       continue;
     }
-    if (dist > d.reach) return WD_NEEDS_HISTORY;  // behind the first output byte of the stream
+    if (WD_UNLIKELY(dist > d.reach)) return WD_NEEDS_HISTORY;  // behind the first output byte of the stream
     const uint32_t srcb = (uint32_t)(d.o - dist), dstb = (uint32_t)d.o;
     if (!overlap) {
       for (uint32_t i0 = 0; i0 < len; i0 += 64) {
@@ -823,7 +865,7 @@ __device__ __forceinline__ static int wd_block(InfSmem& S, WaveDec& d, uint32_t*
     if (MARK) {
       uint16_t* r16 = reinterpret_cast<uint16_t*>(S.ring);
       for (uint32_t done = 0; done < LEN;) {
-        const uint32_t n = min(LEN - done, FLUSH);
+        const uint32_t n = min(LEN - done, FLUSH - d.unfl);  // unflushed symbols never exceed FLUSH + 258: they stay inside the ring
         for (uint32_t i = lane; i < n; i += 64) {
           uint32_t b = d.oi + i;
           if (b >= RING16) b -= RING16;
@@ -832,7 +874,7 @@ __device__ __forceinline__ static int wd_block(InfSmem& S, WaveDec& d, uint32_t*
         WD_JOIN();
         d.oi += n;
         if (d.oi >= RING16) d.oi -= RING16;
-        d.o += n;
+        wd_mark_produced(S, d, n);
         done += n;
       }
       wd_seek(d, (src + LEN) * 8);
@@ -941,6 +983,9 @@ __global__ __launch_bounds__(64) void k_inf_decode(const uint8_t* __restrict__ d
   d.ostart = 0;
   d.reach = 0;
   d.unfl = 0;
+  d.sym = nullptr;
+  d.sym_cap = 0;
+  d.sym_ovf = 0;
   d.oi = 0;
 #ifdef WD_PROFILE
   for (int i = 0; i < 6; i++) d.pt[i] = 0;
@@ -998,11 +1043,44 @@ __device__ __forceinline__ static uint32_t seg_ring_idx(uint32_t oi, uint32_t i)
   return a;
 }
 
+// Launch order of the work items: by compressed span to the next work item, longest first (the span is the only
+// estimate of a segment's decode time there is before decoding it).  Rank sort in LDS; identity for huge lists.
+#define SEGORDER_LDS 12288u
+__global__ __launch_bounds__(1024) void k_inf_seg_order(const uint32_t* __restrict__ cand, uint32_t ncand, uint64_t c,
+                                                        uint32_t* __restrict__ order) {
+  __shared__ uint32_t s_span[SEGORDER_LDS];
+  const uint32_t nwork = ncand + 1, tid = threadIdx.x;
+  if (nwork > SEGORDER_LDS) {
+    for (uint32_t w = tid; w < nwork; w += 1024) order[w] = w;
+    return;
+  }
+  const uint32_t endbit = (uint32_t)min(c * 8, (uint64_t)0xFFFFFFFFu);
+  for (uint32_t w = tid; w < nwork; w += 1024) {
+    const uint32_t st = w ? cand[w - 1] : 0u;
+    const uint32_t nx = w < ncand ? cand[w] : endbit;
+    s_span[w] = (w > 0 && st == 0) ? 0u : nx - st;  // the duplicate of work item 0 returns at once
+  }
+  __syncthreads();
+  if (tid == 0 && ncand > 0 && cand[0] == 0) s_span[0] = ncand > 1 ? cand[1] : endbit;
+  __syncthreads();
+  for (uint32_t w = tid; w < nwork; w += 1024) {
+    const uint32_t v = s_span[w];
+    uint32_t r = 0;
+    for (uint32_t j = 0; j < nwork; j++) {
+      const uint32_t u = s_span[j];
+      r += (u > v) || (u == v && j < w);
+    }
+    order[r] = w;
+  }
+}
+
 __global__ __launch_bounds__(64) void k_inf_seg_scan(const uint8_t* __restrict__ d_in, uint64_t in_off, uint64_t c,
                                                      const uint32_t* __restrict__ cand, uint32_t ncand,
-                                                     ZesSegRes* __restrict__ sres, uint32_t* __restrict__ maps) {
+                                                     ZesSegRes* __restrict__ sres, uint32_t* __restrict__ maps,
+                                                     uint32_t* __restrict__ sym16, uint32_t sym_ratio,
+                                                     const uint32_t* __restrict__ order) {
   __shared__ __align__(16) InfSmem S;
-  const uint32_t w = blockIdx.x, lane = threadIdx.x;
+  const uint32_t w = order[blockIdx.x], lane = threadIdx.x;  // longest compressed span first: the short ones fill the tail
   ZesSegRes r;
   r.end_bit = 0;
   r.out_len = 0;
@@ -1028,6 +1106,16 @@ __global__ __launch_bounds__(64) void k_inf_seg_scan(const uint8_t* __restrict__
   d.reach = 0;
   d.unfl = 0;
   d.oi = ZES_WINDOW;
+  // symbol store: the work item that starts at compressed byte b owns symbols [b * ratio, b' * ratio), b' the start of
+  // the next work item (the end of the stream for the last one); a segment that outgrows its share is decoded twice
+  {
+    uint32_t nx = w;  // candidate that starts the next work item (candidate 0 at bit 16 duplicates work item 0)
+    if (w == 0 && ncand > 0 && cand[0] == 0) nx = 1;
+    const uint64_t b0 = (start - 16) / 8, b1 = nx < ncand ? (uint64_t)cand[nx] / 8 : c;
+    d.sym = sym_ratio ? sym16 + b0 * sym_ratio / 2 : nullptr;
+    d.sym_cap = (b1 - b0) * sym_ratio;
+    d.sym_ovf = sym_ratio ? 0u : 1u;
+  }
   uint16_t* r16 = reinterpret_cast<uint16_t*>(S.ring);
   for (uint32_t i = lane; i < ZES_WINDOW; i += 64) r16[i] = (uint16_t)(256u + i);  // window byte i of the previous segment
   wd_seek(d, start);
@@ -1062,9 +1150,10 @@ __global__ __launch_bounds__(64) void k_inf_seg_scan(const uint8_t* __restrict__
     const uint32_t lo16 = r16[seg_ring_idx(d.oi, 2 * i2)], hi16 = r16[seg_ring_idx(d.oi, 2 * i2 + 1)];
     mp[i2] = lo16 | (hi16 << 16);
   }
+  if (d.unfl) wd_mark_flush(S, d, d.unfl);  // the tail of the symbol store
   r.end_bit = wd_pos(d);
   r.out_len = d.o;
-  r.flags = 1u | (bfinal ? 2u : 0u);
+  r.flags = 1u | (bfinal ? 2u : 0u) | (d.sym_ovf ? 4u : 0u);
   if (lane == 0) sres[w] = r;
 }
 
@@ -1072,7 +1161,8 @@ __global__ __launch_bounds__(64) void k_inf_seg_scan(const uint8_t* __restrict__
 // res->status 0: seg[0..aux) / prefix[] hold the chain, out_len the total; 1: not a clean chain.
 #define SEGCHAIN_LDS 8192u
 __global__ __launch_bounds__(256) void k_inf_seg_chain(const ZesSegRes* __restrict__ sres, uint32_t nwork, uint32_t* __restrict__ seg,
-                                                       uint64_t* __restrict__ prefix, ZesRes* __restrict__ res) {
+                                                       uint64_t* __restrict__ prefix, ZesRes* __restrict__ res,
+                                                       uint32_t* __restrict__ novf) {
   __shared__ uint32_t s_nf[SEGCHAIN_LDS];  // next | flags << 30
   __shared__ unsigned long long s_part[256];
   __shared__ uint32_t s_nseg;
@@ -1112,7 +1202,12 @@ __global__ __launch_bounds__(256) void k_inf_seg_chain(const ZesSegRes* __restri
   const uint32_t per = (nseg + 255u) / 256u;
   const uint32_t k0 = min(nseg, tid * per), k1 = min(nseg, k0 + per);
   unsigned long long sum = 0;
-  for (uint32_t k = k0; k < k1; k++) sum += sres[seg[k]].out_len;
+  uint32_t ovf = 0;
+  for (uint32_t k = k0; k < k1; k++) {
+    sum += sres[seg[k]].out_len;
+    ovf += (sres[seg[k]].flags >> 2) & 1u;
+  }
+  if (ovf) atomicAdd(novf, ovf);  // segments whose symbols did not fit the store: decoded a second time
   s_part[tid] = sum;
   __syncthreads();
   if (tid == 0) {
@@ -1176,16 +1271,69 @@ __global__ __launch_bounds__(1024) void k_inf_seg_windows(const uint32_t* __rest
   }
 }
 
+// Chain segment k from the symbol store: bytes as they are, markers through the window in front of the segment.
+// A marker that points in front of the first byte of the stream (src/inflate.ts:287-290 would read outside the
+// buffer) raises *fail: the serial tiers then reproduce what the reference does.
+__global__ __launch_bounds__(256) void k_inf_seg_translate(uint8_t* __restrict__ d_out, uint64_t out_off, uint64_t cap,
+                                                           const uint32_t* __restrict__ cand, const ZesSegRes* __restrict__ sres,
+                                                           const uint32_t* __restrict__ seg, const uint64_t* __restrict__ prefix,
+                                                           const uint8_t* __restrict__ wins, const uint32_t* __restrict__ sym16,
+                                                           uint32_t sym_ratio, uint32_t* __restrict__ fail) {
+  __shared__ __align__(16) uint8_t W[ZES_WINDOW];
+  const uint32_t k = blockIdx.x, tid = threadIdx.x;
+  const uint32_t w = seg[k];
+  const ZesSegRes r = sres[w];
+  if (r.flags & 4u) return;  // not in the store: k_inf_seg_decode
+  const uint64_t pre = prefix[k];
+  if (k > 0) {
+    const uint4* wv = reinterpret_cast<const uint4*>(wins + (size_t)(k - 1) * ZES_WINDOW);
+    for (uint32_t i = tid; i < ZES_WINDOW / 16; i += 256) reinterpret_cast<uint4*>(W)[i] = wv[i];
+  }
+  __syncthreads();
+  const uint32_t first_ok = pre >= ZES_WINDOW ? 0u : ZES_WINDOW - (uint32_t)pre;  // window positions below this do not exist
+  const uint64_t b0 = w ? (uint64_t)cand[w - 1] / 8 : 0;
+  const uint16_t* sy = reinterpret_cast<const uint16_t*>(sym16 + b0 * sym_ratio / 2);
+  uint8_t* dst = d_out + out_off;
+  const uint64_t end = min(pre + r.out_len, cap);
+  uint32_t bad = 0;
+  // 8 output bytes per thread and step, groups aligned in the output
+  // (blockIdx.y: several workgroups share a long segment)
+  for (uint64_t g = (pre & ~7ull) + ((uint64_t)blockIdx.y * 256 + tid) * 8; g < end; g += (uint64_t)gridDim.y * 256 * 8) {
+    uint32_t o2[2] = {0, 0};
+    const bool whole = g >= pre && g + 8 <= end;
+#pragma unroll
+    for (uint32_t q = 0; q < 8; q++) {
+      const uint64_t a = g + q;
+      uint32_t b = 0;
+      if (a >= pre && a < end) {
+        const uint32_t v = sy[a - pre];
+        if (v >= 256u) {
+          bad |= (v - 256u) < first_ok;
+          b = W[(v - 256u) & (ZES_WINDOW - 1)];
+        } else {
+          b = v;
+        }
+        if (!whole) dst[a] = (uint8_t)b;
+      }
+      o2[q >> 2] |= b << ((q & 3u) * 8u);
+    }
+    if (whole) *reinterpret_cast<uint2*>(dst + g) = make_uint2(o2[0], o2[1]);
+  }
+  if (bad) atomicOr(fail, 1u);
+}
+
 // Chain segment k again, this time with its window and into its place.
 __global__ __launch_bounds__(64) void k_inf_seg_decode(const uint8_t* __restrict__ d_in, uint64_t in_off, uint64_t c,
                                                        uint8_t* __restrict__ d_out, uint64_t out_off, uint64_t cap,
                                                        const uint32_t* __restrict__ cand, const ZesSegRes* __restrict__ sres,
                                                        const uint32_t* __restrict__ seg, const uint64_t* __restrict__ prefix,
-                                                       const uint8_t* __restrict__ wins, uint32_t* __restrict__ fail) {
+                                                       const uint8_t* __restrict__ wins, uint32_t* __restrict__ fail,
+                                                       uint32_t only_overflowed) {
   __shared__ __align__(16) InfSmem S;
   const uint32_t k = blockIdx.x, lane = threadIdx.x;
   const uint32_t w = seg[k];
   const ZesSegRes r = sres[w];
+  if (only_overflowed && !(r.flags & 4u)) return;  // k_inf_seg_translate has this one
   const uint64_t pre = prefix[k];
   const uint64_t base = pre & ~15ull;
   WaveDec d;

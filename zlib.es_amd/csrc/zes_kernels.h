@@ -38,7 +38,7 @@ struct ZesCandRes {
 struct ZesSegRes {
   uint64_t end_bit;   // absolute bit where the segment stopped
   uint64_t out_len;   // bytes the segment produces
-  uint32_t flags;     // bit0 ok, bit1 the segment ends with the final block
+  uint32_t flags;     // bit0 ok, bit1 the segment ends with the final block, bit2 its symbols did not fit the symbol store
   uint32_t next;      // work item that starts at end_bit (0 = none)
 };
 
@@ -50,11 +50,15 @@ __global__ void k_inf_set_table1(ZesInfBuf, ZesInfBuf, ZesInfBuf*, uint32_t*, ui
 __global__ void k_inf_verify(const uint8_t*, const ZesInfBuf*, const unsigned long long*, uint32_t, uint32_t*, uint32_t*, uint32_t*, uint32_t);
 __global__ void k_inf_ranksort(const ZesInfBuf*, const uint32_t*, const uint32_t*, uint32_t*);
 __global__ void k_inf_decode(const uint8_t*, uint64_t, uint64_t, uint8_t*, uint64_t, uint64_t, ZesRes*, uint64_t*);
-__global__ void k_inf_seg_scan(const uint8_t*, uint64_t, uint64_t, const uint32_t*, uint32_t, ZesSegRes*, uint32_t*);
-__global__ void k_inf_seg_chain(const ZesSegRes*, uint32_t, uint32_t*, uint64_t*, ZesRes*);
+__global__ void k_inf_seg_order(const uint32_t*, uint32_t, uint64_t, uint32_t*);
+__global__ void k_inf_seg_scan(const uint8_t*, uint64_t, uint64_t, const uint32_t*, uint32_t, ZesSegRes*, uint32_t*, uint32_t*, uint32_t,
+                               const uint32_t*);
+__global__ void k_inf_seg_chain(const ZesSegRes*, uint32_t, uint32_t*, uint64_t*, ZesRes*, uint32_t*);
+__global__ void k_inf_seg_translate(uint8_t*, uint64_t, uint64_t, const uint32_t*, const ZesSegRes*, const uint32_t*, const uint64_t*,
+                                    const uint8_t*, const uint32_t*, uint32_t, uint32_t*);
 __global__ void k_inf_seg_windows(const uint32_t*, const uint32_t*, uint32_t, uint8_t*);
 __global__ void k_inf_seg_decode(const uint8_t*, uint64_t, uint64_t, uint8_t*, uint64_t, uint64_t, const uint32_t*, const ZesSegRes*,
-                                 const uint32_t*, const uint64_t*, const uint8_t*, uint32_t*);
+                                 const uint32_t*, const uint64_t*, const uint8_t*, uint32_t*, uint32_t);
 __global__ void k_inf_block_par(const uint8_t*, uint8_t*, const ZesInfBuf*, uint32_t, const uint32_t*, const uint32_t*, const uint32_t*,
                                 ZesCandRes*, unsigned long long*, const uint32_t*);
 __global__ void k_inf_move_slots(uint8_t*, const uint8_t*, const uint32_t*, const uint32_t*, uint32_t);
