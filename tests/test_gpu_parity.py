@@ -149,9 +149,14 @@ def test_deflate_batch_api(z, oracle, gpu):
 def test_inflate_batch_api(z, oracle, gpu):
     import torch
 
-    specs = [("itext", 61, 300000), ("xorshift", 62, 131072), ("lowent4k", 63, 500000), ("itext", 64, 2)]
+    import zlib as pz
+
+    specs = [("itext", 61, 300000), ("xorshift", 62, 131072), ("lowent4k", 63, 500000), ("itext", 64, 2),
+             ("itext", 65, 1 << 20), ("itext", 66, 700001)]
     raws = [z.gen(k, s, n) for k, s, n in specs]
-    comps = [oracle.deflate(r) for r in raws]
+    comps = [oracle.deflate(r) for r in raws[:4]]
+    # two streams of another encoder in the same call: the segment-parallel tier next to the block-parallel one
+    comps += [np.frombuffer(pz.compress(r.tobytes(), lvl), dtype=np.uint8) for r, lvl in zip(raws[4:], (6, 1))]
     comps.append(np.frombuffer(bytes([0x77, 0x9C, 1, 2, 3]), dtype=np.uint8))  # not deflate
     comps.append(np.frombuffer(bytes([0x78, 0x9C, 7, 0, 0, 0]), dtype=np.uint8))  # BTYPE 3
     in_off, out_off, caps = [], [], []
@@ -192,6 +197,14 @@ def test_raw_deflate_and_offset_inflate_entry_points(z, oracle, gpu):
         # embedded in a container: 7 foreign bytes in front, 9 behind (stay readable, like the zlib trailer)
         boxed = np.concatenate([np.arange(7, dtype=np.uint8), raw, np.full(9, 0xEE, dtype=np.uint8)])
         assert z.inflate_raw(boxed, 7).tobytes() == oracle.inflate_raw(boxed, 7).tobytes() == a.tobytes()
+    # a raw stream of another encoder (history across blocks), at an odd offset
+    import zlib as pz
+
+    a = z.gen("itext", 75, 900000)
+    co = pz.compressobj(6, pz.DEFLATED, -15)
+    raw = np.frombuffer(co.compress(a.tobytes()) + co.flush(), dtype=np.uint8)
+    boxed = np.concatenate([np.arange(3, dtype=np.uint8), raw])
+    assert z.inflate_raw(boxed, 3).tobytes() == a.tobytes() and z.last_inflate_tier() == 2
     with pytest.raises(z.ZlibEsError, match="Data is corrupted"):
         z.deflate_raw(np.zeros(1, dtype=np.uint8))
     # the raw path has no CM-nibble check: garbage is reported by the decoder itself, as by the reference
