@@ -861,6 +861,8 @@ __device__ __forceinline__ static int wd_block(InfSmem& S, WaveDec& d, uint32_t*
     if (LEN + NLEN != 65535u) return WD_ANOMALY;
     const uint64_t src = wd_pos(d) >> 3;
     if (src + LEN > d.nbytes) return WD_ANOMALY;
+    // (a lone wave moves ~1 GiB/s here whatever the width of its loads — four bytes per lane through a byte funnel
+    // was slower than this loop, which the compiler pipelines; long stored runs want a copy kernel of their own)
     const uint8_t* in8 = reinterpret_cast<const uint8_t*>(d.in32);
     if (MARK) {
       uint16_t* r16 = reinterpret_cast<uint16_t*>(S.ring);
@@ -1091,6 +1093,7 @@ __global__ __launch_bounds__(64) void k_inf_seg_scan(const uint8_t* __restrict__
     const uint32_t c0 = cand[w - 1];
     if (c0 == 0) {  // the stream start is work item 0 already
       if (lane == 0) sres[w] = r;
+      WD_JOIN();
       return;
     }
     start = (uint64_t)c0 + 16;
