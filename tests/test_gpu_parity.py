@@ -333,6 +333,35 @@ def test_inflate_foreign_streams_in_parallel_segments(z, gpu):
         assert bytes(z.inflate(comp, z.ZES_F_NO_FASTPATH)) == plain, name
 
 
+def test_inflate_foreign_stream_sweep(z, gpu):
+    """Encoder settings that change the block structure: strategies, window and memory levels (memLevel 1 =
+    blocks of a few hundred symbols: thousands of segments), dictionary-less restarts.  Checked against the plain
+    input; every stream must come out of the segment-parallel tier."""
+    import zlib as pz
+
+    rng = np.random.default_rng(2024)
+    text = z.gen("itext", 81, 3 << 20)
+    low = z.gen("lowent4k", 82, 3 << 20)
+    skew = (rng.integers(0, 256, 3 << 20, dtype=np.uint8) & rng.integers(0, 256, 3 << 20, dtype=np.uint8)
+            & rng.integers(0, 256, 3 << 20, dtype=np.uint8))  # compressible only by its symbol statistics
+    mixed = np.concatenate([text[:700000], skew[:500000], low[:300000], text[700000:1400000]])
+    cases = []
+    for name, data in (("text", text), ("pattern", low), ("skewed bytes", skew), ("mixed", mixed)):
+        for level, wbits, mem, strat in ((6, 15, 8, pz.Z_DEFAULT_STRATEGY), (1, 15, 9, pz.Z_DEFAULT_STRATEGY),
+                                         (9, 15, 1, pz.Z_DEFAULT_STRATEGY), (6, 9, 8, pz.Z_DEFAULT_STRATEGY),
+                                         (6, 12, 4, pz.Z_FILTERED), (6, 15, 8, pz.Z_HUFFMAN_ONLY), (6, 15, 2, pz.Z_RLE)):
+            co = pz.compressobj(level, pz.DEFLATED, wbits, mem, strat)
+            cases.append(("%s level %d wbits %d mem %d strategy %d" % (name, level, wbits, mem, strat), co.compress(data.tobytes()) + co.flush(), data))
+    slow = []
+    for name, comp, data in cases:
+        out = z.inflate(comp)  # (wbits 9 makes the first byte 0x18: still CM 8, accepted like any other, src/zlib.ts:13-16)
+        assert out.tobytes() == data.tobytes(), name
+        # short streams, and streams of stored blocks only (nothing to cut at), go to the serial wavefront by design
+        if len(comp) >= 32768 and len(comp) < 0.98 * data.size and z.last_inflate_tier() != 2:
+            slow.append(name)
+    assert not slow, slow
+
+
 def test_inflate_reports_needed_size(z, oracle, gpu):
     import torch
 
