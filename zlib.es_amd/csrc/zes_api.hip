@@ -406,7 +406,10 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
     b.cap = j.cap;
     b.first_chunk = (uint32_t)chunks;
     b.cand_base = (uint32_t)cands;
-    b.cand_cap = (uint32_t)(j.c / 64 + 64);
+    // a reference-made stream has one block per 131072 bytes of output: more candidates than the caller's capacity
+    // has blocks (plus room for false ones) means another encoder wrote the stream — counted as an overflow, and the
+    // sort never sees more than this many (a zlib stream with 250-byte blocks has 250 000 of them)
+    b.cand_cap = (uint32_t)std::min<uint64_t>(j.c / 64 + 64, j.cap / ZES_BLK + 65);
     b.work_first = 0;
     chunks += (j.c + INF_SCAN_BYTES - 1) / INF_SCAN_BYTES;
     cands += b.cand_cap;
@@ -418,7 +421,7 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
   hb[nbuf].cand_base = (uint32_t)cands;
   if (nbuf == 1) {  // see the single-synchronisation path below
     hb[1].work_first = ZES_WORK_AUTO;
-    hb[1].cand_cap = (uint32_t)std::min<uint64_t>(hb[0].cand_cap, hb[0].cap / ZES_BLK + 65);
+    hb[1].cand_cap = hb[0].cand_cap;
   }
   const uint32_t surv_cap = (uint32_t)std::min<uint64_t>(total_c / 4 + 1024ull * nbuf, 1ull << 30);
   const size_t cnt_bytes = 16 + (size_t)nbuf * 4 + (((size_t)nbuf + 3) & ~(size_t)3);  // counters[4], cnt[nbuf], first bytes [nbuf]
@@ -700,9 +703,14 @@ int inflate_segments(const uint8_t* d_in, uint8_t* d_out, InfJob& j) {
                        counters, (uint32_t*)g.cand.p, cnt, 1u);
   }
   {
-    Timed t("k_inf_ranksort");
-    hipLaunchKernelGGL(k_inf_ranksort, dim3(1), dim3(256), 0, g.stream, dbufs, (const uint32_t*)cnt, (const uint32_t*)g.cand.p,
-                       (uint32_t*)g.cand_sorted.p);
+    // one candidate per bucket of the stream, in order (at most SEG_BUCKETS segments whatever the block size)
+    Timed t("k_inf_cand_thin");
+    const uint32_t bucket_bits = (uint32_t)((j.c * 8 + SEG_BUCKETS - 1) / SEG_BUCKETS);
+    if ((rc = ensure(g.mvlist, SEG_BUCKETS * 4))) return rc;
+    HIPCHK(hipMemsetAsync(g.mvlist.p, 0xFF, SEG_BUCKETS * 4, g.stream));
+    hipLaunchKernelGGL(k_inf_cand_bucket, dim3((uint32_t)std::min<uint64_t>(cand_cap / 256 + 1, 1024)), dim3(256), 0, g.stream,
+                       (const uint32_t*)g.cand.p, (const uint32_t*)cnt, cand_cap, bucket_bits, (uint32_t*)g.mvlist.p);
+    hipLaunchKernelGGL(k_inf_cand_compact, dim3(1), dim3(1024), 0, g.stream, (const uint32_t*)g.mvlist.p, (uint32_t*)g.cand_sorted.p, cnt);
   }
   uint32_t* hc = (uint32_t*)g.pinned;
   HIPCHK(hipMemcpyAsync(hc, g.counters.p, cnt_bytes, hipMemcpyDeviceToHost, g.stream));

@@ -1045,6 +1045,49 @@ __device__ __forceinline__ static uint32_t seg_ring_idx(uint32_t oi, uint32_t i)
   return a;
 }
 
+// T2 keeps at most one candidate per bucket of the compressed stream (the first one): the list comes out sorted
+// without a sort, and the number of segments — each costs a 64 KiB map and a 32 KiB window — stays bounded
+// however small the encoder made its blocks.  A dropped candidate only makes a segment longer.
+__global__ __launch_bounds__(256) void k_inf_cand_bucket(const uint32_t* __restrict__ cand, const uint32_t* __restrict__ cnt,
+                                                         uint32_t cand_cap, uint32_t bucket_bits, uint32_t* __restrict__ bmin) {
+  const uint32_t n = min(cnt[0], cand_cap);
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const uint32_t v = cand[i];
+    atomicMin(&bmin[min(v / bucket_bits, SEG_BUCKETS - 1u)], v);
+  }
+}
+__global__ __launch_bounds__(1024) void k_inf_cand_compact(const uint32_t* __restrict__ bmin, uint32_t* __restrict__ out,
+                                                           uint32_t* __restrict__ out_count) {
+  __shared__ uint32_t s_wave[16];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  constexpr uint32_t PER = SEG_BUCKETS / 1024u;  // <= 4: the ballots below scan three bits of the count
+  uint32_t v[PER], have = 0;
+#pragma unroll
+  for (uint32_t q = 0; q < PER; q++) {
+    v[q] = bmin[tid * PER + q];
+    have += v[q] != 0xFFFFFFFFu;
+  }
+  // exclusive prefix of `have` over the workgroup: in-wave by ballots of each count bit, then across waves
+  uint32_t pre = 0;
+#pragma unroll
+  for (int b = 0; b < 3; b++) pre += (uint32_t)__popcll(__ballot((have >> b) & 1u) & zes_lanemask_lt()) << b;
+  uint32_t wtot = 0;
+#pragma unroll
+  for (int b = 0; b < 3; b++) wtot += (uint32_t)__popcll(__ballot((have >> b) & 1u)) << b;
+  if (lane == 0) s_wave[wave] = wtot;
+  __syncthreads();
+  uint32_t base = 0, total = 0;
+  for (uint32_t k = 0; k < 16; k++) {
+    if (k < wave) base += s_wave[k];
+    total += s_wave[k];
+  }
+  uint32_t o = base + pre;
+#pragma unroll
+  for (uint32_t q = 0; q < PER; q++)
+    if (v[q] != 0xFFFFFFFFu) out[o++] = v[q];
+  if (tid == 0) *out_count = total;
+}
+
 // Launch order of the work items: by compressed span to the next work item, longest first (the span is the only
 // estimate of a segment's decode time there is before decoding it).  Rank sort in LDS; identity for huge lists.
 #define SEGORDER_LDS 12288u
@@ -1162,7 +1205,7 @@ __global__ __launch_bounds__(64) void k_inf_seg_scan(const uint8_t* __restrict__
 
 // One workgroup per stream: the chain of segments from work item 0 to the final block.
 // res->status 0: seg[0..aux) / prefix[] hold the chain, out_len the total; 1: not a clean chain.
-#define SEGCHAIN_LDS 8192u
+#define SEGCHAIN_LDS 8192u  // (T2 has at most SEG_BUCKETS + 1 work items)
 __global__ __launch_bounds__(256) void k_inf_seg_chain(const ZesSegRes* __restrict__ sres, uint32_t nwork, uint32_t* __restrict__ seg,
                                                        uint64_t* __restrict__ prefix, ZesRes* __restrict__ res,
                                                        uint32_t* __restrict__ novf) {
@@ -1405,7 +1448,7 @@ __global__ __launch_bounds__(256) void k_inf_chain(const ZesInfBuf* __restrict__
     res->aux = 0;
   }
   __syncthreads();
-  if (ncand == 0 || cand[0] != 0) return;
+  if (ncand == 0 || nwork == 0 || cand[0] != 0 || cnt[blockIdx.x] > bf.cand_cap) return;  // (no work items: the buffer was left out, results would be stale)
   if (autow && ncand > nwork) return;  // more candidates than work items were launched: the host falls back
   // Fast check, all work items in parallel: item k is ok, non-final items give exactly one slot
   // and end where item k+1 starts, the first final item closes the chain.

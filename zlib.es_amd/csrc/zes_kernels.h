@@ -14,6 +14,7 @@
 #define PAR_WAVES (PAR_THREADS / 64)
 #define INF_SCAN_THREADS 256
 #define INF_SCAN_BYTES 8192u
+#define SEG_BUCKETS 2048u  // T2: at most this many candidate block starts are kept (one per bucket of the compressed stream)
 
 // One entry per buffer of an inflate call (T1); entry [nbuf] is a sentinel carrying the totals.
 struct ZesInfBuf {
@@ -50,6 +51,8 @@ __global__ void k_inf_set_table1(ZesInfBuf, ZesInfBuf, ZesInfBuf*, uint32_t*, ui
 __global__ void k_inf_verify(const uint8_t*, const ZesInfBuf*, const unsigned long long*, uint32_t, uint32_t*, uint32_t*, uint32_t*, uint32_t);
 __global__ void k_inf_ranksort(const ZesInfBuf*, const uint32_t*, const uint32_t*, uint32_t*);
 __global__ void k_inf_decode(const uint8_t*, uint64_t, uint64_t, uint8_t*, uint64_t, uint64_t, ZesRes*, uint64_t*);
+__global__ void k_inf_cand_bucket(const uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*);
+__global__ void k_inf_cand_compact(const uint32_t*, uint32_t*, uint32_t*);
 __global__ void k_inf_seg_order(const uint32_t*, uint32_t, uint64_t, uint32_t*);
 __global__ void k_inf_seg_scan(const uint8_t*, uint64_t, uint64_t, const uint32_t*, uint32_t, ZesSegRes*, uint32_t*, uint32_t*, uint32_t,
                                const uint32_t*);
