@@ -187,6 +187,51 @@ def test_inflate_batch_api(z, oracle, gpu):
     assert status[len(raws)] == -1 and status[len(raws) + 1] == -2
 
 
+def test_inflate_batch_of_many_foreign_streams(z, oracle, gpu):
+    """A batch of another encoder's streams: the left-over streams of a call are decoded side by side (one serial
+    wavefront each); a malformed one among them still ends as the reference does."""
+    import torch
+    import zlib as pz
+
+    raws, comps = [], []
+    for i in range(40):
+        r = z.gen(("itext", "lowent4k", "xorshift")[i % 3], 900 + i, 5000 + 37111 * (i % 7) + 1000 * i)
+        raws.append(r)
+        comps.append(np.frombuffer(pz.compress(r.tobytes(), (1, 6, 9)[i % 3]), dtype=np.uint8))
+    raws.append(z.gen("itext", 990, 400000))
+    comps.append(oracle.deflate(raws[-1]))  # one the reference wrote, among them
+    bad = bytearray(comps[1].tobytes())
+    bad[len(bad) // 2] ^= 0x55  # damaged in the middle: error or other bytes, whatever the reference makes of it
+    try:
+        exp_bad = ("out", oracle.inflate(np.frombuffer(bytes(bad), dtype=np.uint8)).tobytes())
+    except oracle.OracleError as ex:
+        exp_bad = ("err", ex.code)
+    comps.append(np.frombuffer(bytes(bad), dtype=np.uint8))
+    cnt = len(comps)
+    in_off, out_off, caps = [], [], []
+    pos = opos = 0
+    for i, cdat in enumerate(comps):
+        in_off.append(pos)
+        pos += (len(cdat) + 15) // 16 * 16
+        cap = len(raws[i]) if i < len(raws) else 1 << 20
+        caps.append(cap)
+        out_off.append(opos)
+        opos += (cap + 15) // 16 * 16
+    big = np.zeros(pos, dtype=np.uint8)
+    for cdat, o in zip(comps, in_off):
+        big[o:o + len(cdat)] = cdat
+    d_out = torch.zeros(opos, dtype=torch.uint8, device=gpu)
+    olen, st = z.inflate_batch_tensor(dev(big, gpu), in_off, [len(x) for x in comps], d_out, out_off, caps)
+    host = d_out.cpu().numpy()
+    for i, r in enumerate(raws):
+        assert st[i] == 0 and olen[i] == len(r), i
+        assert (host[out_off[i]:out_off[i] + len(r)] == r).all(), i
+    if exp_bad[0] == "err":
+        assert st[cnt - 1] == exp_bad[1]
+    else:
+        assert st[cnt - 1] == 0 and host[out_off[cnt - 1]:out_off[cnt - 1] + olen[cnt - 1]].tobytes() == exp_bad[1]
+
+
 def test_raw_deflate_and_offset_inflate_entry_points(z, oracle, gpu):
     """src/deflate.ts:14 and src/inflate.ts:16: the raw forms the zlib wrapper of src/zlib.ts encloses."""
     for kind, seed, n in (("itext", 71, 200000), ("xorshift", 72, 131073 + 5), ("lowent4k", 73, 300001), ("itext", 74, 2)):

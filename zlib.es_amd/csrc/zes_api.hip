@@ -664,6 +664,8 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
 // (blocks of every type, 32 KiB history across blocks).  Leaves j.tier at 0 when the stream is not a clean
 // chain of blocks; the serial tiers then reproduce the reference's result.
 constexpr uint64_t SEG_MIN_C = 32768;  // shorter streams go straight to the serial wavefront
+constexpr size_t SERIAL_BATCH_MIN_JOBS = 16;        // this many left-over streams of a call: one serial wavefront each, side by side
+constexpr uint64_t SERIAL_BATCH_MAX_C = 16ull << 20;  // (longer ones are worth their own segment-parallel run)
 int inflate_segments(const uint8_t* d_in, uint8_t* d_out, InfJob& j) {
   int rc;
   ZesInfBuf* hb = (ZesInfBuf*)((uint8_t*)g.pinned + PIN_UP);
@@ -799,8 +801,16 @@ int inflate_slow(const uint8_t* d_in, uint8_t* d_out, InfJob& j) {
     zes_wd_set_dbg((unsigned long long*)g.dbg.p);
 #endif
     {
+      ZesInfBuf b0;
+      memset(&b0, 0, sizeof b0);
+      b0.in_off = j.in_off;
+      b0.c = j.c;
+      b0.out_off = j.out_off;
+      b0.cap = j.cap;
+      if ((rc = ensure(g.ibufs, sizeof(ZesInfBuf) * 2))) return rc;
+      hipLaunchKernelGGL(k_inf_set_table1, dim3(1), dim3(64), 0, g.stream, b0, b0, (ZesInfBuf*)g.ibufs.p, (uint32_t*)nullptr, 0u);
       Timed t("k_inf_decode_seq");
-      hipLaunchKernelGGL(k_inf_decode, dim3(1), dim3(64), 0, g.stream, d_in, j.in_off, j.c, d_out, j.out_off, j.cap, (ZesRes*)g.res.p,
+      hipLaunchKernelGGL(k_inf_decode, dim3(1), dim3(64), 0, g.stream, d_in, d_out, (const ZesInfBuf*)g.ibufs.p, (ZesRes*)g.res.p,
                          (uint64_t*)g.resume.p);
     }
     if ((rc = read_res(&hr))) return rc;
@@ -877,6 +887,47 @@ int inflate_jobs(const uint8_t* d_in, uint8_t* d_out, std::vector<InfJob>& jobs,
   for (size_t g0 = 0; g0 < ids.size(); g0 += INF_GROUP) {
     const uint32_t nb = (uint32_t)std::min<size_t>(INF_GROUP, ids.size() - g0);
     if ((rc = inflate_t1_group(d_in, d_out, jobs.data(), ids.data() + g0, nb, firsts == nullptr, flags))) return rc;
+  }
+  // Many streams the block-parallel tier left over (a batch of another encoder's streams): one serial wavefront
+  // per stream, all at once — 512 of them run side by side, where the per-buffer tiers would take the streams one
+  // after the other.  Streams that fail here go on to the per-buffer tiers.
+  {
+    std::vector<uint32_t> rest;
+    for (uint32_t i : todo)
+      if (jobs[i].tier == 0 && jobs[i].status == ZES_OK && jobs[i].c >= 3 && jobs[i].c < SERIAL_BATCH_MAX_C) rest.push_back(i);
+    if (rest.size() >= SERIAL_BATCH_MIN_JOBS) {
+      for (size_t g0 = 0; g0 < rest.size(); g0 += INF_GROUP) {
+        const uint32_t nb = (uint32_t)std::min<size_t>(INF_GROUP, rest.size() - g0);
+        ZesInfBuf* hb = (ZesInfBuf*)((uint8_t*)g.pinned + PIN_UP);
+        memset(hb, 0, sizeof(ZesInfBuf) * nb);
+        for (uint32_t k = 0; k < nb; k++) {
+          const InfJob& j = jobs[rest[g0 + k]];
+          hb[k].in_off = j.in_off;
+          hb[k].c = j.c;
+          hb[k].out_off = j.out_off;
+          hb[k].cap = j.cap;
+        }
+        if ((rc = ensure(g.ibufs, sizeof(ZesInfBuf) * nb))) return rc;
+        if ((rc = ensure(g.res, sizeof(ZesRes) * nb))) return rc;
+        if ((rc = ensure(g.resume, (size_t)16 * nb))) return rc;
+        HIPCHK(hipMemcpyAsync(g.ibufs.p, hb, sizeof(ZesInfBuf) * nb, hipMemcpyHostToDevice, g.stream));
+        {
+          Timed t("k_inf_decode_seq");
+          hipLaunchKernelGGL(k_inf_decode, dim3(nb), dim3(64), 0, g.stream, d_in, d_out, (const ZesInfBuf*)g.ibufs.p, (ZesRes*)g.res.p,
+                             (uint64_t*)g.resume.p);
+        }
+        ZesRes* hres = (ZesRes*)((uint8_t*)g.pinned + 128 * 1024);
+        HIPCHK(hipMemcpyAsync(hres, g.res.p, sizeof(ZesRes) * nb, hipMemcpyDeviceToHost, g.stream));
+        HIPCHK(hipStreamSynchronize(g.stream));
+        for (uint32_t k = 0; k < nb; k++) {
+          if (hres[k].status != 0) continue;
+          InfJob& j = jobs[rest[g0 + k]];
+          j.tier = 3;
+          j.out_len = hres[k].out_len;
+          j.status = hres[k].out_len > j.cap ? ZES_E_NOSPACE : ZES_OK;
+        }
+      }
+    }
   }
   int worst = 0;
   for (uint32_t i : todo) {

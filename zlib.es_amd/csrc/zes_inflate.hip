@@ -969,12 +969,17 @@ __device__ __forceinline__ static int wd_block(InfSmem& S, WaveDec& d, uint32_t*
 }
 
 
-// T3: a single wavefront decodes the whole stream from bit 16.
-__global__ __launch_bounds__(64) void k_inf_decode(const uint8_t* __restrict__ d_in, uint64_t in_off, uint64_t c,
-                                                   uint8_t* __restrict__ d_out, uint64_t out_off, uint64_t cap,
-                                                   ZesRes* __restrict__ res, uint64_t* __restrict__ resume) {
+// T3: a single wavefront decodes a whole stream from bit 16; work item = entry of the job table (several
+// streams of a batch call decode side by side).
+__global__ __launch_bounds__(64) void k_inf_decode(const uint8_t* __restrict__ d_in, uint8_t* __restrict__ d_out,
+                                                   const ZesInfBuf* __restrict__ jobs, ZesRes* __restrict__ res_all,
+                                                   uint64_t* __restrict__ resume_all) {
   __shared__ __align__(16) InfSmem S;
   const uint32_t lane = threadIdx.x;
+  const ZesInfBuf jb = jobs[blockIdx.x];
+  const uint64_t in_off = jb.in_off, c = jb.c, out_off = jb.out_off, cap = jb.cap;
+  ZesRes* res = res_all + blockIdx.x;
+  uint64_t* resume = resume_all + 2 * (size_t)blockIdx.x;
   WaveDec d;
   d.in32 = reinterpret_cast<const uint32_t*>(d_in + in_off);
   d.nbytes = c;
