@@ -90,10 +90,11 @@ __device__ __forceinline__ static uint32_t buf_of_chunk(const ZesInfBuf* bufs, u
   return lo;
 }
 
+#define SCAN_FINAL_ZONE_BITS (160u * 1024u * 8u)
 __global__ __launch_bounds__(INF_SCAN_THREADS) void k_inf_scan(const uint8_t* __restrict__ d_in, const ZesInfBuf* __restrict__ bufs,
                                                                uint32_t nbuf, unsigned long long* __restrict__ surv,
                                                                uint32_t surv_cap, uint32_t* __restrict__ counters,
-                                                               uint8_t* __restrict__ first_bytes) {
+                                                               uint8_t* __restrict__ first_bytes, uint32_t loose) {
   // Each thread owns 32 consecutive bit positions at a time.  The fixed-field tests (BTYPE = 2,
   // HLIT <= 29, HDIST <= 29) run on all 32 positions at once as shifted word logic; only the
   // surviving positions (about one in five) pay for the Kraft sum of the code-length code.
@@ -148,6 +149,10 @@ __global__ __launch_bounds__(INF_SCAN_THREADS) void k_inf_scan(const uint8_t* __
     uint32_t m = (uint32_t)(~(w0 >> 1) & (w0 >> 2) & ~((w0 >> 4) & (w0 >> 5) & (w0 >> 6) & (w0 >> 7)) &
                             ~((w0 >> 9) & (w0 >> 10) & (w0 >> 11) & (w0 >> 12)));
     const uint64_t abs_base = b0 * 8 + (uint64_t)grp * 32;
+    // Only the last block of a stream has BFINAL set, and a block this tier decodes has at most 144 KiB of
+    // compressed data: further from the end than that, a position with bit0 = 1 is not a block start (half of
+    // all positions, so half of the survivors the verify kernel would have to decode).
+    if (!loose && abs_base + 32 + SCAN_FINAL_ZONE_BITS <= end_bits) m &= (uint32_t)~w0;
     while (m) {
       const uint32_t i = (uint32_t)__builtin_ctz(m);
       m &= m - 1u;
