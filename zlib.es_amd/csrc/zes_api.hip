@@ -500,7 +500,7 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
   }
   {
     Timed t("k_inf_ranksort");
-    hipLaunchKernelGGL(k_inf_ranksort, dim3(nbuf), dim3(256), 0, g.stream, dbufs, (const uint32_t*)cnt, (const uint32_t*)g.cand.p,
+    hipLaunchKernelGGL(k_inf_ranksort, dim3(nbuf), dim3(nbuf == 1 ? 1024 : 256), 0, g.stream, dbufs, (const uint32_t*)cnt, (const uint32_t*)g.cand.p,
                        (uint32_t*)g.cand_sorted.p);
   }
   {

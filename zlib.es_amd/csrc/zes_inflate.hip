@@ -388,7 +388,7 @@ __global__ __launch_bounds__(64) void k_inf_verify(const uint8_t* __restrict__ d
 }
 
 // rank sort of each buffer's candidate list (a few to a few thousand entries); one workgroup per buffer
-__global__ __launch_bounds__(256) void k_inf_ranksort(const ZesInfBuf* __restrict__ bufs, const uint32_t* __restrict__ cnt,
+__global__ __launch_bounds__(1024) void k_inf_ranksort(const ZesInfBuf* __restrict__ bufs, const uint32_t* __restrict__ cnt,
                                                       const uint32_t* __restrict__ cand, uint32_t* __restrict__ out) {
   __shared__ uint32_t s_c[RANK_LDS];  // the list itself when it fits (it does: one entry per block of the stream)
   const ZesInfBuf bf = bufs[blockIdx.x];
@@ -397,11 +397,11 @@ __global__ __launch_bounds__(256) void k_inf_ranksort(const ZesInfBuf* __restric
   uint32_t* o = out + bf.cand_base;
   const bool lds = n <= RANK_LDS;
   if (lds) {
-    for (uint32_t i = threadIdx.x; i < n; i += 256) s_c[i] = in[i];
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) s_c[i] = in[i];
     __syncthreads();
   }
   const uint32_t* src = lds ? s_c : in;
-  for (uint32_t i = threadIdx.x; i < n; i += 256) {
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
     const uint32_t v = src[i];
     uint32_t r = 0;
     uint32_t j = 0;
