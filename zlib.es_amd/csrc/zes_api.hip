@@ -36,7 +36,7 @@ struct Ctx {
   // deflate scratch
   DevBuf bufs, blks, idx_a, idx_b, inv, hists, codes, hdrs, adler, res;
   // inflate scratch
-  DevBuf surv, cand, cand_sorted, counters, cres, map, resume, dbg, ibufs, ibufs2, mvlist, scratch, sres, maps, seglist, segprefix, wins, sym16, segorder;
+  DevBuf surv, cand, cand_sorted, counters, cres, map, resume, dbg, ibufs, ibufs2, mvlist, scratch, sres, maps, seglist, segprefix, wins, sym16, segorder, segjobs;
   // staging for the host-pointer API
   DevBuf st_in, st_out;
   void* pinned = nullptr;  // small pinned area for read-backs
@@ -662,129 +662,225 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
   return ZES_OK;
 }
 
-// T2 for one buffer the block-parallel tier did not settle: segment-parallel decode of any valid stream
-// (blocks of every type, 32 KiB history across blocks).  Leaves j.tier at 0 when the stream is not a clean
-// chain of blocks; the serial tiers then reproduce the reference's result.
+// T2 for the buffers the block-parallel tier did not settle: segment-parallel decode of any valid stream
+// (blocks of every type, 32 KiB history across blocks).  The candidate search runs buffer by buffer; the segment
+// decode — nearly all of the time — and the window pass take all buffers of a group in one launch.  A buffer whose
+// stream is not a clean chain of blocks keeps tier 0: the serial tiers then reproduce the reference's result.
 constexpr uint64_t SEG_MIN_C = 32768;  // shorter streams go straight to the serial wavefront
 constexpr size_t SERIAL_BATCH_MIN_JOBS = 16;        // this many left-over streams of a call: one serial wavefront each, side by side
 constexpr uint64_t SERIAL_BATCH_MAX_C = 16ull << 20;  // (longer ones are worth their own segment-parallel run)
-int inflate_segments(const uint8_t* d_in, uint8_t* d_out, InfJob& j) {
+constexpr uint32_t SEG_GROUP_BUFS = 64;      // buffers whose candidates are searched before the first read-back
+constexpr uint32_t SEG_GROUP_WORK = 8192;    // work items per segment launch (each owns a 64 KiB map)
+
+// One group: buffers ids[0..nb) with their sorted candidate lists at cand_sorted + cbase[k], ncand[k] entries.
+int inflate_segments_run(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const uint32_t* ids, const uint32_t* cbase, const uint32_t* ncand,
+                         uint32_t nb, uint32_t* dscratch /* 2 * nb words: chain segments not in the store, failure flags */) {
   int rc;
-  ZesInfBuf* hb = (ZesInfBuf*)((uint8_t*)g.pinned + PIN_UP);
-  memset(hb, 0, sizeof(ZesInfBuf) * 2);
-  hb[0].in_off = j.in_off;
-  hb[0].c = j.c;
-  hb[0].out_off = j.out_off;
-  hb[0].cap = j.cap;
-  hb[0].cand_cap = (uint32_t)(j.c / 64 + 64);
-  const uint32_t chunks = (uint32_t)((j.c + INF_SCAN_BYTES - 1) / INF_SCAN_BYTES);
-  hb[1].first_chunk = chunks;
-  hb[1].cand_base = hb[0].cand_cap;
-  const uint32_t cand_cap = hb[0].cand_cap;
-  const uint32_t surv_cap = (uint32_t)std::min<uint64_t>(j.c / 4 + 1024ull, 1ull << 30);
-  const size_t cnt_bytes = 16 + 4 + 4;
-  if ((rc = ensure(g.ibufs, sizeof(ZesInfBuf) * 2))) return rc;
-  if ((rc = ensure(g.surv, (size_t)surv_cap * 8))) return rc;
-  if ((rc = ensure(g.cand, (size_t)cand_cap * 4))) return rc;
-  if ((rc = ensure(g.cand_sorted, (size_t)cand_cap * 4))) return rc;
-  if ((rc = ensure(g.counters, cnt_bytes))) return rc;
-  if ((rc = ensure(g.res, sizeof(ZesRes)))) return rc;
-  const ZesInfBuf* dbufs = (const ZesInfBuf*)g.ibufs.p;
-  uint32_t* counters = (uint32_t*)g.counters.p;
-  uint32_t* cnt = counters + 4;
-  hipLaunchKernelGGL(k_inf_set_table1, dim3(1), dim3(64), 0, g.stream, hb[0], hb[1], (ZesInfBuf*)g.ibufs.p, counters,
-                     (uint32_t)(cnt_bytes / 4));
-  {
-    Timed t("k_inf_scan");
-    hipLaunchKernelGGL(k_inf_scan, dim3(chunks), dim3(INF_SCAN_THREADS), 0, g.stream, d_in, dbufs, 1u, (unsigned long long*)g.surv.p,
-                       surv_cap, counters, (uint8_t*)(cnt + 1), 1u);
-  }
-  {
-    // foreign encoders do not follow the reference's run-length rules for code lengths: loose candidates
-    Timed t("k_inf_verify");
-    const uint32_t nwg = (uint32_t)std::min<uint64_t>(j.c / 16384 + 1, 8192);
-    hipLaunchKernelGGL(k_inf_verify, dim3(nwg), dim3(64), 0, g.stream, d_in, dbufs, (const unsigned long long*)g.surv.p, surv_cap,
-                       counters, (uint32_t*)g.cand.p, cnt, 1u);
-  }
-  {
-    // one candidate per bucket of the stream, in order (at most SEG_BUCKETS segments whatever the block size)
-    Timed t("k_inf_cand_thin");
-    const uint32_t bucket_bits = (uint32_t)((j.c * 8 + SEG_BUCKETS - 1) / SEG_BUCKETS);
-    if ((rc = ensure(g.mvlist, SEG_BUCKETS * 4))) return rc;
-    HIPCHK(hipMemsetAsync(g.mvlist.p, 0xFF, SEG_BUCKETS * 4, g.stream));
-    hipLaunchKernelGGL(k_inf_cand_bucket, dim3((uint32_t)std::min<uint64_t>(cand_cap / 256 + 1, 1024)), dim3(256), 0, g.stream,
-                       (const uint32_t*)g.cand.p, (const uint32_t*)cnt, cand_cap, bucket_bits, (uint32_t*)g.mvlist.p);
-    hipLaunchKernelGGL(k_inf_cand_compact, dim3(1), dim3(1024), 0, g.stream, (const uint32_t*)g.mvlist.p, (uint32_t*)g.cand_sorted.p, cnt);
-  }
-  uint32_t* hc = (uint32_t*)g.pinned;
-  HIPCHK(hipMemcpyAsync(hc, g.counters.p, cnt_bytes, hipMemcpyDeviceToHost, g.stream));
-  HIPCHK(hipStreamSynchronize(g.stream));
-  const uint32_t nsurv = hc[0], ncand = hc[4];
-  if (nsurv > surv_cap || ncand > cand_cap || ncand < 2) return ZES_OK;  // nothing to cut the stream with
-  const uint32_t nwork = ncand + 1;
-  if ((rc = ensure(g.sres, sizeof(ZesSegRes) * nwork))) return rc;
-  if ((rc = ensure(g.maps, (size_t)nwork * ZES_WINDOW * 2))) return rc;
-  if ((rc = ensure(g.seglist, (size_t)nwork * 4))) return rc;
-  if ((rc = ensure(g.segprefix, (size_t)nwork * 8))) return rc;
-  // symbol store: `ratio` 16-bit symbols per compressed byte (a segment that inflates further is decoded twice)
-  // (as many as a 2 GiB store holds, up to DEFLATE's own limit of 1032 bytes per compressed byte)
-  uint32_t ratio = (uint32_t)std::min<uint64_t>(1032, (2ull << 30) / (2 * (j.c + 64))) & ~1u;
+  ZesSegJob* hj = (ZesSegJob*)((uint8_t*)g.pinned + PIN_UP);
+  uint32_t work = 0;
+  uint64_t csum = 0;
+  for (uint32_t k = 0; k < nb; k++) csum += jobs[ids[k]].c + 64;
+  // symbol store: `ratio` 16-bit symbols per compressed byte (a segment that inflates further is decoded twice);
+  // as many as a 2 GiB store holds, up to DEFLATE's own limit of 1032 bytes per compressed byte
+  uint32_t ratio = (uint32_t)std::min<uint64_t>(1032, (2ull << 30) / (2 * csum)) & ~1u;
   if (ratio < 4) ratio = 0;
-  if (ratio && ensure(g.sym16, (size_t)(j.c + 64) * ratio * 2)) ratio = 0;  // no memory for it: two decodes
-  if ((rc = ensure(g.segorder, (size_t)nwork * 4))) return rc;
-  hipLaunchKernelGGL(k_inf_seg_order, dim3(1), dim3(1024), 0, g.stream, (const uint32_t*)g.cand_sorted.p, ncand, j.c, (uint32_t*)g.segorder.p);
-  uint32_t* fail = counters + 3;  // [3] failure flag of the output passes, [2] chain segments that are not in the store
-  HIPCHK(hipMemsetAsync(counters + 2, 0, 8, g.stream));
+  if (ratio && ensure(g.sym16, (size_t)csum * ratio * 2)) ratio = 0;  // no memory for it: two decodes
+  uint64_t sym_base = 0;
+  for (uint32_t k = 0; k < nb; k++) {
+    const InfJob& j = jobs[ids[k]];
+    hj[k].in_off = j.in_off;
+    hj[k].c = j.c;
+    hj[k].sym_base = sym_base;
+    hj[k].cand_base = cbase[k];
+    hj[k].ncand = ncand[k];
+    hj[k].work_first = work;
+    hj[k].nseg = 0;
+    work += ncand[k] + 1;
+    sym_base += (j.c + 64) * ratio / 2;
+  }
+  if ((rc = ensure(g.segjobs, sizeof(ZesSegJob) * nb))) return rc;
+  if ((rc = ensure(g.sres, sizeof(ZesSegRes) * work))) return rc;
+  if ((rc = ensure(g.maps, (size_t)work * ZES_WINDOW * 2))) return rc;
+  if ((rc = ensure(g.seglist, (size_t)work * 4))) return rc;
+  if ((rc = ensure(g.segprefix, (size_t)work * 8))) return rc;
+  if ((rc = ensure(g.segorder, (size_t)work * 4))) return rc;
+  if ((rc = ensure(g.res, sizeof(ZesRes) * nb))) return rc;
+  HIPCHK(hipMemcpyAsync(g.segjobs.p, hj, sizeof(ZesSegJob) * nb, hipMemcpyHostToDevice, g.stream));
+  HIPCHK(hipMemsetAsync(dscratch, 0, (size_t)nb * 8, g.stream));
+  uint32_t* novf_d = dscratch;
+  uint32_t* fail_d = dscratch + nb;
+  const uint32_t* cs = (const uint32_t*)g.cand_sorted.p;
+  for (uint32_t k = 0; k < nb; k++)
+    hipLaunchKernelGGL(k_inf_seg_order, dim3(1), dim3(1024), 0, g.stream, cs + cbase[k], ncand[k], jobs[ids[k]].c,
+                       (uint32_t*)g.segorder.p + hj[k].work_first);
   {
     Timed t("k_inf_seg_scan");
-    hipLaunchKernelGGL(k_inf_seg_scan, dim3(nwork), dim3(64), 0, g.stream, d_in, j.in_off, j.c, (const uint32_t*)g.cand_sorted.p, ncand,
-                       (ZesSegRes*)g.sres.p, (uint32_t*)g.maps.p, (uint32_t*)g.sym16.p, ratio, (const uint32_t*)g.segorder.p);
+    hipLaunchKernelGGL(k_inf_seg_scan, dim3(work), dim3(64), 0, g.stream, d_in, (const ZesSegJob*)g.segjobs.p, nb, cs, (ZesSegRes*)g.sres.p,
+                       (uint32_t*)g.maps.p, (uint32_t*)g.sym16.p, ratio, (const uint32_t*)g.segorder.p);
   }
   {
     Timed t("k_inf_seg_chain");
-    hipLaunchKernelGGL(k_inf_seg_chain, dim3(1), dim3(256), 0, g.stream, (const ZesSegRes*)g.sres.p, nwork, (uint32_t*)g.seglist.p,
-                       (uint64_t*)g.segprefix.p, (ZesRes*)g.res.p, counters + 2);
+    for (uint32_t k = 0; k < nb; k++)
+      hipLaunchKernelGGL(k_inf_seg_chain, dim3(1), dim3(256), 0, g.stream, (const ZesSegRes*)g.sres.p + hj[k].work_first, ncand[k] + 1,
+                         (uint32_t*)g.seglist.p + hj[k].work_first, (uint64_t*)g.segprefix.p + hj[k].work_first, (ZesRes*)g.res.p + k,
+                         novf_d + k);
   }
-  HIPCHK(hipMemcpyAsync((uint8_t*)g.pinned + 64, counters + 2, 4, hipMemcpyDeviceToHost, g.stream));
-  ZesRes hr;
-  if ((rc = read_res(&hr))) return rc;
-  if (getenv("ZES_DEBUG"))
-    fprintf(stderr, "zes T2: c=%llu candidates=%u chain status=%d segments=%u (%u decoded twice) out_len=%llu\n", (unsigned long long)j.c,
-            ncand, hr.status, hr.aux, *(const uint32_t*)((const uint8_t*)g.pinned + 64), (unsigned long long)hr.out_len);
-  if (hr.status != 0 || hr.aux == 0) return ZES_OK;
-  const uint32_t nseg = hr.aux;
-  if (hr.out_len > j.cap) {  // the caller learns the size without the second decode
-    j.tier = 2;
-    j.out_len = hr.out_len;
-    j.status = ZES_E_NOSPACE;
-    return ZES_OK;
+  uint32_t* hs = (uint32_t*)g.pinned;  // [0, nb): not-in-store counts, later failure flags
+  ZesRes* hres = (ZesRes*)((uint8_t*)g.pinned + 128 * 1024);
+  HIPCHK(hipMemcpyAsync(hs, novf_d, (size_t)nb * 4, hipMemcpyDeviceToHost, g.stream));
+  HIPCHK(hipMemcpyAsync(hres, g.res.p, sizeof(ZesRes) * nb, hipMemcpyDeviceToHost, g.stream));
+  HIPCHK(hipStreamSynchronize(g.stream));  // (the job table upload has completed too: hj may be rewritten)
+  std::vector<uint32_t> novf(hs, hs + nb);
+  std::vector<ZesRes> hr(hres, hres + nb);
+  std::vector<char> go(nb, 0);
+  bool any = false;
+  for (uint32_t k = 0; k < nb; k++) {
+    InfJob& j = jobs[ids[k]];
+    if (getenv("ZES_DEBUG"))
+      fprintf(stderr, "zes T2: c=%llu candidates=%u chain status=%d segments=%u (%u decoded twice) out_len=%llu\n", (unsigned long long)j.c,
+              ncand[k], hr[k].status, hr[k].aux, novf[k], (unsigned long long)hr[k].out_len);
+    if (hr[k].status != 0 || hr[k].aux == 0) continue;
+    if (hr[k].out_len > j.cap) {  // the caller learns the size without the output passes
+      j.tier = 2;
+      j.out_len = hr[k].out_len;
+      j.status = ZES_E_NOSPACE;
+      continue;
+    }
+    go[k] = 1;
+    any = true;
+    hj[k].nseg = hr[k].aux;
   }
-  if ((rc = ensure(g.wins, (size_t)nseg * ZES_WINDOW))) return rc;
-  const uint32_t novf = *(const uint32_t*)((const uint8_t*)g.pinned + 64);
-  if (nseg > 1) {
+  if (!any) return ZES_OK;
+  if ((rc = ensure(g.wins, (size_t)work * ZES_WINDOW))) return rc;
+  HIPCHK(hipMemcpyAsync(g.segjobs.p, hj, sizeof(ZesSegJob) * nb, hipMemcpyHostToDevice, g.stream));
+  {
     Timed t("k_inf_seg_windows");
-    hipLaunchKernelGGL(k_inf_seg_windows, dim3(1), dim3(1024), 0, g.stream, (const uint32_t*)g.maps.p, (const uint32_t*)g.seglist.p, nseg,
-                       (uint8_t*)g.wins.p);
+    hipLaunchKernelGGL(k_inf_seg_windows, dim3(nb), dim3(1024), 0, g.stream, (const uint32_t*)g.maps.p, (const uint32_t*)g.seglist.p,
+                       (const ZesSegJob*)g.segjobs.p, (uint8_t*)g.wins.p);
   }
-  if (novf < nseg) {
-    Timed t("k_inf_seg_translate");
-    const uint32_t ny = std::max(1u, std::min(16u, 2048u / nseg));  // few long segments: split each over several workgroups
-    hipLaunchKernelGGL(k_inf_seg_translate, dim3(nseg, ny), dim3(256), 0, g.stream, d_out, j.out_off, j.cap, (const uint32_t*)g.cand_sorted.p,
-                       (const ZesSegRes*)g.sres.p, (const uint32_t*)g.seglist.p, (const uint64_t*)g.segprefix.p, (const uint8_t*)g.wins.p,
-                       (const uint32_t*)g.sym16.p, ratio, fail);
+  for (uint32_t k = 0; k < nb; k++) {
+    if (!go[k]) continue;
+    const InfJob& j = jobs[ids[k]];
+    const uint32_t nseg = hr[k].aux, wf = hj[k].work_first;
+    if (novf[k] < nseg) {
+      Timed t("k_inf_seg_translate");
+      const uint32_t ny = std::max(1u, std::min(16u, 2048u / nseg));  // few long segments: split each over several workgroups
+      hipLaunchKernelGGL(k_inf_seg_translate, dim3(nseg, ny), dim3(256), 0, g.stream, d_out, j.out_off, j.cap, cs + cbase[k],
+                         (const ZesSegRes*)g.sres.p + wf, (const uint32_t*)g.seglist.p + wf, (const uint64_t*)g.segprefix.p + wf,
+                         (const uint8_t*)g.wins.p + (size_t)wf * ZES_WINDOW, (const uint32_t*)g.sym16.p + hj[k].sym_base, ratio, fail_d + k);
+    }
+    if (novf[k] > 0) {
+      Timed t("k_inf_seg_decode");
+      hipLaunchKernelGGL(k_inf_seg_decode, dim3(nseg), dim3(64), 0, g.stream, d_in, j.in_off, j.c, d_out, j.out_off, j.cap, cs + cbase[k],
+                         (const ZesSegRes*)g.sres.p + wf, (const uint32_t*)g.seglist.p + wf, (const uint64_t*)g.segprefix.p + wf,
+                         (const uint8_t*)g.wins.p + (size_t)wf * ZES_WINDOW, fail_d + k, novf[k] < nseg ? 1u : 0u);
+    }
   }
-  if (novf > 0) {
-    Timed t("k_inf_seg_decode");
-    hipLaunchKernelGGL(k_inf_seg_decode, dim3(nseg), dim3(64), 0, g.stream, d_in, j.in_off, j.c, d_out, j.out_off, j.cap,
-                       (const uint32_t*)g.cand_sorted.p, (const ZesSegRes*)g.sres.p, (const uint32_t*)g.seglist.p,
-                       (const uint64_t*)g.segprefix.p, (const uint8_t*)g.wins.p, fail, novf < nseg ? 1u : 0u);
-  }
-  HIPCHK(hipMemcpyAsync(hc, fail, 4, hipMemcpyDeviceToHost, g.stream));
+  HIPCHK(hipMemcpyAsync(hs, fail_d, (size_t)nb * 4, hipMemcpyDeviceToHost, g.stream));
   HIPCHK(hipStreamSynchronize(g.stream));
-  if (hc[0] != 0) return ZES_OK;  // a match behind the first byte of the stream: the serial tiers decide
-  j.tier = 2;
-  j.out_len = hr.out_len;
-  j.status = ZES_OK;
+  for (uint32_t k = 0; k < nb; k++) {
+    if (!go[k] || hs[k] != 0) continue;  // (a match behind the first byte of the stream: the serial tiers decide)
+    InfJob& j = jobs[ids[k]];
+    j.tier = 2;
+    j.out_len = hr[k].out_len;
+    j.status = ZES_OK;
+  }
+  return ZES_OK;
+}
+
+int inflate_segments(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const std::vector<uint32_t>& all) {
+  int rc;
+  for (size_t g0 = 0; g0 < all.size(); g0 += SEG_GROUP_BUFS) {
+    const uint32_t nb = (uint32_t)std::min<size_t>(SEG_GROUP_BUFS, all.size() - g0);
+    const uint32_t* ids = all.data() + g0;
+    // ---- candidates, buffer by buffer (each search has the chip to itself) ----
+    std::vector<uint32_t> cbase(nb), ccap(nb);
+    uint64_t cands = 0, max_c = 0;
+    for (uint32_t k = 0; k < nb; k++) {
+      const InfJob& j = jobs[ids[k]];
+      cbase[k] = (uint32_t)cands;
+      ccap[k] = (uint32_t)(j.c / 64 + 64);
+      cands += ccap[k];
+      max_c = std::max(max_c, j.c);
+    }
+    const uint32_t surv_cap = (uint32_t)std::min<uint64_t>(max_c / 4 + 1024ull, 1ull << 30);
+    const size_t cnt_words = 4 + (size_t)nb + 2 * (size_t)nb + 4;  // scan/verify scratch, counts, run scratch, first-byte sink
+    if ((rc = ensure(g.ibufs, sizeof(ZesInfBuf) * 2))) return rc;
+    if ((rc = ensure(g.surv, (size_t)surv_cap * 8))) return rc;
+    if ((rc = ensure(g.cand, (size_t)cands * 4))) return rc;
+    if ((rc = ensure(g.cand_sorted, (size_t)cands * 4))) return rc;
+    if ((rc = ensure(g.counters, cnt_words * 4))) return rc;
+    if ((rc = ensure(g.mvlist, SEG_BUCKETS * 4))) return rc;
+    uint32_t* counters = (uint32_t*)g.counters.p;
+    uint32_t* cnt = counters + 4;
+    uint32_t* dscratch = cnt + nb;
+    uint8_t* sink = (uint8_t*)(dscratch + 2 * nb);
+    HIPCHK(hipMemsetAsync(counters, 0, cnt_words * 4, g.stream));
+    const ZesInfBuf* dbufs = (const ZesInfBuf*)g.ibufs.p;
+    for (uint32_t k = 0; k < nb; k++) {
+      const InfJob& j = jobs[ids[k]];
+      ZesInfBuf b0, b1;
+      memset(&b0, 0, sizeof b0);
+      memset(&b1, 0, sizeof b1);
+      b0.in_off = j.in_off;
+      b0.c = j.c;
+      b0.out_off = j.out_off;
+      b0.cap = j.cap;
+      b0.cand_base = cbase[k];
+      b0.cand_cap = ccap[k];
+      const uint32_t chunks = (uint32_t)((j.c + INF_SCAN_BYTES - 1) / INF_SCAN_BYTES);
+      b1.first_chunk = chunks;
+      hipLaunchKernelGGL(k_inf_set_table1, dim3(1), dim3(64), 0, g.stream, b0, b1, (ZesInfBuf*)g.ibufs.p, counters, 4u);
+      {
+        Timed t("k_inf_scan");
+        // (the BFINAL rule of the scan holds for every encoder's streams: it stays on; only the verify rules are the reference's own)
+        hipLaunchKernelGGL(k_inf_scan, dim3(chunks), dim3(INF_SCAN_THREADS), 0, g.stream, d_in, dbufs, 1u, (unsigned long long*)g.surv.p,
+                           surv_cap, counters, sink, 0u);
+      }
+      {
+        // other encoders do not follow the reference's run-length rules for code lengths: loose candidates
+        Timed t("k_inf_verify");
+        const uint32_t nwg = (uint32_t)std::min<uint64_t>(j.c / 16384 + 1, 8192);
+        hipLaunchKernelGGL(k_inf_verify, dim3(nwg), dim3(64), 0, g.stream, d_in, dbufs, (const unsigned long long*)g.surv.p, surv_cap,
+                           counters, (uint32_t*)g.cand.p, cnt + k, 1u);
+      }
+      {
+        // one candidate per bucket of the stream, in order (at most SEG_BUCKETS segments whatever the block size)
+        Timed t("k_inf_cand_thin");
+        const uint32_t bucket_bits = (uint32_t)((j.c * 8 + SEG_BUCKETS - 1) / SEG_BUCKETS);
+        HIPCHK(hipMemsetAsync(g.mvlist.p, 0xFF, SEG_BUCKETS * 4, g.stream));
+        hipLaunchKernelGGL(k_inf_cand_bucket, dim3((uint32_t)std::min<uint64_t>(ccap[k] / 256 + 1, 1024)), dim3(256), 0, g.stream,
+                           (const uint32_t*)g.cand.p + cbase[k], (const uint32_t*)(cnt + k), ccap[k], bucket_bits, (uint32_t*)g.mvlist.p);
+        hipLaunchKernelGGL(k_inf_cand_compact, dim3(1), dim3(1024), 0, g.stream, (const uint32_t*)g.mvlist.p,
+                           (uint32_t*)g.cand_sorted.p + cbase[k], cnt + k);
+      }
+    }
+    uint32_t* hc = (uint32_t*)g.pinned;
+    HIPCHK(hipMemcpyAsync(hc, cnt, (size_t)nb * 4, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    std::vector<uint32_t> nc(hc, hc + nb);
+    // ---- segment runs: as many buffers as fit the work-item budget at a time ----
+    std::vector<uint32_t> rid, rbase, rn;
+    uint32_t work = 0;
+    auto flush = [&]() -> int {
+      if (rid.empty()) return ZES_OK;
+      const int r = inflate_segments_run(d_in, d_out, jobs, rid.data(), rbase.data(), rn.data(), (uint32_t)rid.size(), dscratch);
+      rid.clear();
+      rbase.clear();
+      rn.clear();
+      work = 0;
+      return r;
+    };
+    for (uint32_t k = 0; k < nb; k++) {
+      if (nc[k] < 2 || nc[k] > SEG_BUCKETS) continue;  // nothing to cut the stream with (or a poisoned count)
+      if (work + nc[k] + 1 > SEG_GROUP_WORK && (rc = flush())) return rc;
+      rid.push_back(ids[k]);
+      rbase.push_back(cbase[k]);
+      rn.push_back(nc[k]);
+      work += nc[k] + 1;
+    }
+    if ((rc = flush())) return rc;
+  }
   return ZES_OK;
 }
 
@@ -931,11 +1027,14 @@ int inflate_jobs(const uint8_t* d_in, uint8_t* d_out, std::vector<InfJob>& jobs,
       }
     }
   }
+  if (!(flags & ZES_F_NO_FASTPATH)) {
+    std::vector<uint32_t> segs;
+    for (uint32_t i : todo)
+      if (jobs[i].tier == 0 && jobs[i].status == ZES_OK && jobs[i].c >= SEG_MIN_C && jobs[i].c < (1ull << 29)) segs.push_back(i);
+    if (!segs.empty() && (rc = inflate_segments(d_in, d_out, jobs.data(), segs))) return rc;
+  }
   int worst = 0;
   for (uint32_t i : todo) {
-    if (jobs[i].tier == 0 && jobs[i].status == ZES_OK && !(flags & ZES_F_NO_FASTPATH) && jobs[i].c >= SEG_MIN_C && jobs[i].c < (1ull << 29) &&
-        (rc = inflate_segments(d_in, d_out, jobs[i])))
-      return rc;
     if (jobs[i].tier == 0 && jobs[i].status == ZES_OK && (rc = inflate_slow(d_in, d_out, jobs[i]))) return rc;
     worst = std::max(worst, jobs[i].tier);
   }
@@ -990,7 +1089,7 @@ int zes_shutdown(void) {
   (void)hipStreamSynchronize(g.stream);
   DevBuf* all[] = {&g.bufs, &g.blks, &g.idx_a, &g.idx_b, &g.inv, &g.hists, &g.codes, &g.hdrs, &g.adler, &g.res, &g.surv, &g.cand,
                    &g.cand_sorted, &g.counters, &g.cres, &g.map, &g.resume, &g.dbg, &g.ibufs, &g.ibufs2, &g.mvlist, &g.scratch, &g.st_in, &g.st_out,
-                   &g.sres, &g.maps, &g.seglist, &g.segprefix, &g.wins, &g.sym16, &g.segorder};
+                   &g.sres, &g.maps, &g.seglist, &g.segprefix, &g.wins, &g.sym16, &g.segorder, &g.segjobs};
   for (DevBuf* b : all) {
     if (b->p) (void)hipFree(b->p);
     b->p = nullptr;

@@ -1129,13 +1129,30 @@ __global__ __launch_bounds__(1024) void k_inf_seg_order(const uint32_t* __restri
   }
 }
 
-__global__ __launch_bounds__(64) void k_inf_seg_scan(const uint8_t* __restrict__ d_in, uint64_t in_off, uint64_t c,
-                                                     const uint32_t* __restrict__ cand, uint32_t ncand,
-                                                     ZesSegRes* __restrict__ sres, uint32_t* __restrict__ maps,
-                                                     uint32_t* __restrict__ sym16, uint32_t sym_ratio,
+__global__ __launch_bounds__(64) void k_inf_seg_scan(const uint8_t* __restrict__ d_in, const ZesSegJob* __restrict__ jobs, uint32_t njobs,
+                                                     const uint32_t* __restrict__ cand_all, ZesSegRes* __restrict__ sres_all,
+                                                     uint32_t* __restrict__ maps_all, uint32_t* __restrict__ sym16_all, uint32_t sym_ratio,
                                                      const uint32_t* __restrict__ order) {
   __shared__ __align__(16) InfSmem S;
-  const uint32_t w = order[blockIdx.x], lane = threadIdx.x;  // longest compressed span first: the short ones fill the tail
+  const uint32_t lane = threadIdx.x;
+  // buffer of this work item: the last one whose first work item is <= blockIdx.x
+  uint32_t bi = 0;
+  {
+    uint32_t lo = 0, hi = njobs;
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (jobs[mid].work_first <= blockIdx.x) lo = mid; else hi = mid;
+    }
+    bi = lo;
+  }
+  const ZesSegJob jb = jobs[bi];
+  const uint64_t in_off = jb.in_off, c = jb.c;
+  const uint32_t ncand = jb.ncand;
+  const uint32_t* cand = cand_all + jb.cand_base;
+  ZesSegRes* sres = sres_all + jb.work_first;
+  uint32_t* maps = maps_all + (size_t)jb.work_first * (ZES_WINDOW / 2);
+  uint32_t* sym16 = sym16_all + jb.sym_base;
+  const uint32_t w = order[blockIdx.x];  // (a buffer's part of order[] holds its own work items) longest compressed span first
   ZesSegRes r;
   r.end_bit = 0;
   r.out_len = 0;
@@ -1287,8 +1304,13 @@ __global__ __launch_bounds__(256) void k_inf_seg_chain(const ZesSegRes* __restri
 
 // The 32 KiB window behind each chain segment, in order: wins[k] = the bytes in front of segment k+1.
 // One workgroup; every step rewrites the window through the segment's map.
-__global__ __launch_bounds__(1024) void k_inf_seg_windows(const uint32_t* __restrict__ maps, const uint32_t* __restrict__ seg,
-                                                          uint32_t nseg, uint8_t* __restrict__ wins) {
+__global__ __launch_bounds__(1024) void k_inf_seg_windows(const uint32_t* __restrict__ maps_all, const uint32_t* __restrict__ seg_all,
+                                                          const ZesSegJob* __restrict__ jobs, uint8_t* __restrict__ wins_all) {
+  const ZesSegJob jb = jobs[blockIdx.x];  // one workgroup per buffer of the group
+  const uint32_t nseg = jb.nseg;
+  const uint32_t* maps = maps_all + (size_t)jb.work_first * (ZES_WINDOW / 2);
+  const uint32_t* seg = seg_all + jb.work_first;
+  uint8_t* wins = wins_all + (size_t)jb.work_first * ZES_WINDOW;
   __shared__ __align__(16) uint8_t W[2][ZES_WINDOW];
   const uint32_t tid = threadIdx.x;
   for (uint32_t i = tid; i < ZES_WINDOW / 4; i += 1024) reinterpret_cast<uint32_t*>(W[0])[i] = 0;

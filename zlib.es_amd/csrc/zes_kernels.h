@@ -43,6 +43,17 @@ struct ZesSegRes {
   uint32_t next;      // work item that starts at end_bit (0 = none)
 };
 
+// T2: one entry per buffer of a group; the per-work-item arrays (sres, maps, order, seg, prefix, wins) are laid out
+// buffer after buffer, a buffer's part starting at index work_first
+struct ZesSegJob {
+  uint64_t in_off, c;
+  uint64_t sym_base;   // first dword of the buffer's share of the symbol store
+  uint32_t cand_base;  // the buffer's candidates in the sorted list
+  uint32_t ncand;
+  uint32_t work_first;
+  uint32_t nseg;       // length of the buffer's chain (0 = not decoded by this tier): k_inf_seg_windows
+};
+
 #ifdef __HIPCC__
 // inflate direction (zes_inflate.hip)
 __global__ void k_inf_first_bytes(const uint8_t*, const uint64_t*, uint8_t*, uint32_t);
@@ -54,12 +65,12 @@ __global__ void k_inf_decode(const uint8_t*, uint8_t*, const ZesInfBuf*, ZesRes*
 __global__ void k_inf_cand_bucket(const uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*);
 __global__ void k_inf_cand_compact(const uint32_t*, uint32_t*, uint32_t*);
 __global__ void k_inf_seg_order(const uint32_t*, uint32_t, uint64_t, uint32_t*);
-__global__ void k_inf_seg_scan(const uint8_t*, uint64_t, uint64_t, const uint32_t*, uint32_t, ZesSegRes*, uint32_t*, uint32_t*, uint32_t,
+__global__ void k_inf_seg_scan(const uint8_t*, const ZesSegJob*, uint32_t, const uint32_t*, ZesSegRes*, uint32_t*, uint32_t*, uint32_t,
                                const uint32_t*);
 __global__ void k_inf_seg_chain(const ZesSegRes*, uint32_t, uint32_t*, uint64_t*, ZesRes*, uint32_t*);
 __global__ void k_inf_seg_translate(uint8_t*, uint64_t, uint64_t, const uint32_t*, const ZesSegRes*, const uint32_t*, const uint64_t*,
                                     const uint8_t*, const uint32_t*, uint32_t, uint32_t*);
-__global__ void k_inf_seg_windows(const uint32_t*, const uint32_t*, uint32_t, uint8_t*);
+__global__ void k_inf_seg_windows(const uint32_t*, const uint32_t*, const ZesSegJob*, uint8_t*);
 __global__ void k_inf_seg_decode(const uint8_t*, uint64_t, uint64_t, uint8_t*, uint64_t, uint64_t, const uint32_t*, const ZesSegRes*,
                                  const uint32_t*, const uint64_t*, const uint8_t*, uint32_t*, uint32_t);
 __global__ void k_inf_block_par(const uint8_t*, uint8_t*, const ZesInfBuf*, uint32_t, const uint32_t*, const uint32_t*, const uint32_t*,
