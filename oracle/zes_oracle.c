@@ -12,6 +12,14 @@
  *       package-merge code lengths, error cases and truncated/corrupted streams,
  *   (c) the live reference when /root/reference and node are present (skipped otherwise).
  *
+ * One deliberate difference, on inputs the reference itself cannot finish: readRange() refills with zero bits
+ * past the end of the data without setting isEnd (src/utils/BitReadStream.ts:33-42), so a truncated stream whose
+ * zero bits decode as (length, distance) tokens with extra bits is decoded for ever — the reference ends with a
+ * RangeError when memory runs out.  Past the end every bit is zero, so the token loop is a cycle over the
+ * handful of reader states: once the reader is 1 KiB past the end (or, as a second fence, the output has passed
+ * DEFLATE's 1032:1 limit + 64 KiB) the oracle — and the product path's exact decoder, the same way — stops
+ * with 'Lack of data length'.
+ *
  * Single-threaded plain C.  Each function names the reference lines it follows
  * (paths relative to /root/reference).  The structure (arrays, radix-sorted index instead of
  * JS objects) is this repo's own; only behaviour is restated.
@@ -569,8 +577,14 @@ static uint32_t br_coded(zor_br* r, int length) {
 typedef struct {
   uint8_t* buf;
   uint64_t cap, idx;
+  uint64_t limit; /* see the file header: more output than any stream of this length can hold */
+  int runaway;
 } zor_out;
 static void out_write(zor_out* o, uint8_t v) {
+  if (o->idx >= o->limit) {
+    o->runaway = 1;
+    return;
+  }
   if (o->idx >= o->cap) {
     o->cap = o->cap ? o->cap * 2 : 65536;
     o->buf = (uint8_t*)realloc(o->buf, o->cap);
@@ -647,6 +661,8 @@ static int dtab_decode(const zor_dtab* t, zor_br* r, int* err) {
 static int inflate_symbols(zor_br* r, zor_out* o, const zor_dtab* lt, const zor_dtab* dt, int fixed) {
   int err = 0;
   while (!r->is_end) {
+    /* (file header) all-zero bits for 1 KiB past the end: the token loop has settled into a cycle that never ends */
+    if (o->runaway || r->idx > (int64_t)r->len + 1024) return ZOR_E_LACK;
     int v = dtab_decode(lt, r, &err);
     if (v < 0) return err;
     if (v < 256) {
@@ -747,7 +763,8 @@ static int inflate_stored(zor_br* r, zor_out* o) { /* src/inflate.ts:42-55 */
 
 /* raw inflate from byte offset — src/inflate.ts:16-40.  *out is malloc'ed (free with zor_free). */
 int zor_inflate_raw(const uint8_t* in, uint64_t c, uint64_t offset, uint8_t** out, uint64_t* out_len) {
-  zor_out o = {NULL, 0, 0};
+  zor_out o = {NULL, 0, 0, 0, 0};
+  o.limit = 1032ull * (offset < c ? c - offset : 0) + 65536;
   zor_br r;
   br_init(&r, in, c, offset);
   int bfinal = 0, rc = ZOR_OK;
@@ -758,6 +775,7 @@ int zor_inflate_raw(const uint8_t* in, uint64_t c, uint64_t offset, uint8_t** ou
     else if (btype == 1) rc = inflate_fixed(&r, &o);
     else if (btype == 2) rc = inflate_dynamic(&r, &o);
     else rc = ZOR_E_BTYPE3;
+    if (!rc && o.runaway) rc = ZOR_E_LACK;
     if (rc) break;
     if (bfinal == 0 && r.is_end) { /* :34-36 */
       rc = ZOR_E_INSUFFICIENT;

@@ -1,0 +1,103 @@
+"""Randomised differential run (not a pytest; run on the GPU box): deflate vs the oracle, inflate of own / foreign /
+damaged streams vs the oracle, single and batch entry points.  usage: gpu_fuzz.py [seconds] [seed]"""
+import os, sys, time, zlib as pz
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import __graft_entry__ as ge
+import numpy as np, torch
+import _oracle as oracle
+z = ge.load(); z.init(0)
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+kinds = ("itext", "lowent4k", "xorshift")
+t_end = time.time() + budget
+n_cases = n_batch = 0
+
+def ref_inflate(comp):
+    try:
+        return ("out", oracle.inflate(comp).tobytes())
+    except oracle.OracleError as ex:
+        return ("err", ex.code)
+
+def gpu_inflate(comp, flags=0):
+    try:
+        return ("out", z.inflate(comp, flags).tobytes())
+    except z.ZlibEsError as ex:
+        return ("err", ex.code)
+
+while time.time() < t_end:
+    kind = kinds[int(rng.integers(3))]
+    n = int(rng.choice([2, 3, 100, 4097, 65536, 131071, 131072, 131074, 262144 + 5, 400000, 1 << 20, 3000000, int(rng.integers(2, 2500000))]))
+    if n % 131072 in (0, 1) and n < 3:
+        n = 5
+    if n % 131072 == 1:
+        n += 1
+    a = z.gen(kind, int(rng.integers(1 << 30)), n)
+    # own deflate vs the oracle (sizes the oracle finishes quickly)
+    if n <= 1500000:
+        exp = oracle.deflate(a).tobytes()
+        got = z.deflate(a).tobytes()
+        assert got == exp, ("deflate", kind, n)
+        comp = np.frombuffer(exp, dtype=np.uint8)
+    else:
+        comp = z.deflate(a)
+    assert z.inflate(comp).tobytes() == a.tobytes(), ("inflate own", kind, n)
+    # another encoder's stream, random settings
+    level = int(rng.integers(0, 10)); mem = int(rng.integers(1, 10)); wb = int(rng.integers(9, 16))
+    strat = int(rng.choice([pz.Z_DEFAULT_STRATEGY, pz.Z_FILTERED, pz.Z_HUFFMAN_ONLY, pz.Z_RLE, pz.Z_FIXED]))
+    co = pz.compressobj(level, pz.DEFLATED, wb, mem, strat)
+    parts = []
+    step = max(1, n // int(rng.integers(1, 6)))
+    for o in range(0, n, step):
+        parts.append(co.compress(a[o:o + step].tobytes()))
+        if rng.integers(4) == 0:
+            parts.append(co.flush(int(rng.choice([pz.Z_SYNC_FLUSH, pz.Z_FULL_FLUSH]))))
+    parts.append(co.flush())
+    fz = np.frombuffer(b"".join(parts), dtype=np.uint8)
+    assert z.inflate(fz).tobytes() == a.tobytes(), ("inflate foreign", kind, n, level, mem, wb, strat)
+    # damaged copies: same result as the oracle (error code or bytes), whichever tier ends up with it
+    for src in (comp, fz):
+        if len(src) < 8 or len(src) > 600000:
+            continue
+        bad = src.copy()
+        pos = int(rng.integers(2, len(bad)))
+        bad[pos] ^= np.uint8(1 << int(rng.integers(8)))
+        if rng.integers(3) == 0:
+            bad = bad[:int(rng.integers(2, len(bad)))]
+        if os.environ.get("FUZZ_TRACE"):
+            print("damaged", kind, n, pos, len(bad), "cases", n_cases, flush=True)
+            if n_cases >= int(os.environ["FUZZ_TRACE"]):
+                os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                open(os.path.join(ROOT, "gpurun_out", "fuzz_last.bin"), "wb").write(bad.tobytes())
+        t0 = time.time()
+        assert gpu_inflate(bad) == ref_inflate(bad), ("damaged", kind, n, pos, len(bad))
+        if time.time() - t0 > 5:
+            print("slow damaged case: %.1f s" % (time.time() - t0), kind, n, pos, len(bad), flush=True)
+    n_cases += 1
+    # now and then: a batch of mixed streams through the batch entry point
+    if n_cases % 5 == 0:
+        raws, comps = [], []
+        for i in range(int(rng.integers(2, 24))):
+            m = int(rng.integers(2, 600000))
+            if m % 131072 == 1:
+                m += 1
+            r = z.gen(kinds[int(rng.integers(3))], int(rng.integers(1 << 30)), m)
+            raws.append(r)
+            comps.append(oracle.deflate(r) if rng.integers(2) else np.frombuffer(pz.compress(r.tobytes(), int(rng.integers(0, 10))), dtype=np.uint8))
+        in_off, out_off, pos, opos = [], [], 0, 0
+        for r, cdat in zip(raws, comps):
+            in_off.append(pos); pos += (len(cdat) + 15) // 16 * 16
+            out_off.append(opos); opos += (len(r) + 15) // 16 * 16
+        big = np.zeros(pos, dtype=np.uint8)
+        for cdat, o in zip(comps, in_off):
+            big[o:o + len(cdat)] = cdat
+        d_out = torch.zeros(opos, dtype=torch.uint8, device="cuda")
+        olen, st = z.inflate_batch_tensor(torch.from_numpy(big).cuda(), in_off, [len(x) for x in comps], d_out, out_off, [len(r) for r in raws])
+        host = d_out.cpu().numpy()
+        for i, r in enumerate(raws):
+            assert st[i] == 0 and olen[i] == len(r) and (host[out_off[i]:out_off[i] + len(r)] == r).all(), ("batch", i, len(r))
+        n_batch += 1
+    if n_cases % 20 == 0:
+        print("cases %d batches %d" % (n_cases, n_batch), flush=True)
+print("fuzz ok: %d cases, %d batches" % (n_cases, n_batch), flush=True)

@@ -293,6 +293,18 @@ def test_inflate_malformed_streams_raise_the_reference_error(z, gpu):
         assert got == exp, e["name"]
 
 
+def test_inflate_truncated_stream_the_reference_never_finishes(z, gpu):
+    """tests/test_oracle_golden.py::test_truncated_stream_the_reference_never_finishes, through the product path:
+    the decode must end (with 'Lack of data length'), whatever capacity the caller offers."""
+    import torch
+
+    data = open(os.path.join(GOLDEN, "truncated_runaway.zz"), "rb").read()
+    with pytest.raises(z.ZlibEsError, match="Lack of data length"):
+        z.inflate(data)
+    with pytest.raises(z.ZlibEsError, match="Lack of data length"):
+        z.inflate_tensor(dev(np.frombuffer(data, dtype=np.uint8), gpu), torch.empty(1 << 20, dtype=torch.uint8, device=gpu))
+
+
 def test_inflate_foreign_streams(z, gpu):
     for f in golden("foreign.json"):
         comp = open(os.path.join(GOLDEN, f["file"]), "rb").read()

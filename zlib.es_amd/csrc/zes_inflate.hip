@@ -1661,9 +1661,17 @@ __device__ static int xt_decode(const XTab& t, XReader& r, int* err) {  // src/i
 struct XOut {
   uint8_t* buf;
   uint64_t cap, idx;
-  int overflow;
+  uint64_t limit;  // more output than any stream of this length can hold (1032:1): see runaway
+  int overflow, runaway;
 };
 __device__ static inline void xo_write(XOut& o, uint8_t v) {
+  // The reference refills with zero bits past the end of the data without noticing (readRange,
+  // src/utils/BitReadStream.ts:33-42), so a truncated stream whose zero bits decode as tokens with extra bits is
+  // decoded for ever, until its process runs out of memory.  This decoder stops with 'Lack of data length'.
+  if (o.idx >= o.limit) {
+    o.runaway = 1;
+    return;
+  }
   if (o.idx < o.cap) o.buf[o.idx] = v; else o.overflow = 1;
   o.idx++;
 }
@@ -1671,6 +1679,8 @@ __device__ static inline void xo_write(XOut& o, uint8_t v) {
 __device__ static int x_symbols(XReader& r, XOut& o, const XTab& lt, const XTab* dt) {  // src/inflate.ts:78-117, 237-291
   int err = 0;
   while (!r.is_end) {
+    // all-zero bits for 1 KiB past the end: the token loop has settled into a cycle that never ends (see xo_write)
+    if (o.runaway || r.idx > (int64_t)r.len + 1024) return ZES_E_LACK;
     const int v = xt_decode(lt, r, &err);
     if (v < 0) return err;
     if (v < 256) {
@@ -1724,6 +1734,8 @@ __global__ void k_inf_exact(const uint8_t* __restrict__ d_in, uint64_t in_off, u
   o.cap = cap;
   o.idx = resume ? resume[1] : 0;
   o.overflow = 0;
+  o.runaway = 0;
+  o.limit = 1032ull * (c > 2 ? c - 2 : 0) + 65536;
   int bfinal = 0, rc = 0;
   while (bfinal != 1) {  // src/inflate.ts:22-37
     bfinal = (int)xr_range(r, 1);
@@ -1789,6 +1801,7 @@ __global__ void k_inf_exact(const uint8_t* __restrict__ d_in, uint64_t in_off, u
     } else {
       rc = ZES_E_BTYPE3;
     }
+    if (!rc && o.runaway) rc = ZES_E_LACK;
     if (rc) break;
     if (bfinal == 0 && r.is_end) {  // :34-36
       rc = ZES_E_INSUFFICIENT;
