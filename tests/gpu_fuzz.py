@@ -56,6 +56,12 @@ while time.time() < t_end:
     parts.append(co.flush())
     fz = np.frombuffer(b"".join(parts), dtype=np.uint8)
     assert z.inflate(fz).tobytes() == a.tobytes(), ("inflate foreign", kind, n, level, mem, wb, strat)
+    if os.environ.get("FUZZ_DUMP") and n_cases == int(os.environ["FUZZ_DUMP"]):
+        od = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(od, exist_ok=True)
+        np.save(os.path.join(od, "fuzz_dump_a.npy"), a)
+        np.save(os.path.join(od, "fuzz_dump_comp.npy"), np.asarray(comp))
+        np.save(os.path.join(od, "fuzz_dump_fz.npy"), fz)
     # damaged copies: same result as the oracle (error code or bytes), whichever tier ends up with it
     for src in (comp, fz):
         if len(src) < 8 or len(src) > 600000:
@@ -71,7 +77,19 @@ while time.time() < t_end:
                 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
                 open(os.path.join(ROOT, "gpurun_out", "fuzz_last.bin"), "wb").write(bad.tobytes())
         t0 = time.time()
-        assert gpu_inflate(bad) == ref_inflate(bad), ("damaged", kind, n, pos, len(bad))
+        got, exp = gpu_inflate(bad), ref_inflate(bad)
+        if got != exp:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            name = os.path.join(ROOT, "gpurun_out", "fuzz_fail_%d.bin" % n_cases)
+            open(name, "wb").write(bad.tobytes())
+            desc = lambda r: (r[0], len(r[1]) if r[0] == "out" else r[1])
+            print("MISMATCH", name, "tier", z.last_inflate_tier(), "gpu", desc(got), "oracle", desc(exp), flush=True)
+            if got[0] == exp[0] == "out":
+                a1, a2 = np.frombuffer(got[1], dtype=np.uint8), np.frombuffer(exp[1], dtype=np.uint8)
+                m = min(len(a1), len(a2))
+                d = np.nonzero(a1[:m] != a2[:m])[0]
+                print("   first difference at", int(d[0]) if len(d) else None, "of", len(a1), len(a2), flush=True)
+            raise SystemExit(1)
         if time.time() - t0 > 5:
             print("slow damaged case: %.1f s" % (time.time() - t0), kind, n, pos, len(bad), flush=True)
     n_cases += 1

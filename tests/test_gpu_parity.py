@@ -305,6 +305,30 @@ def test_inflate_truncated_stream_the_reference_never_finishes(z, gpu):
         z.inflate_tensor(dev(np.frombuffer(data, dtype=np.uint8), gpu), torch.empty(1 << 20, dtype=torch.uint8, device=gpu))
 
 
+def test_inflate_truncated_inside_the_last_code_with_live_bytes_behind(z, oracle, gpu):
+    """The device entry point gets a length, not a zero-padded copy: what lies behind the stream in memory must not
+    count.  Here the bytes behind a truncated stream are its own continuation, so a decoder that reads on finds the
+    end-of-block code it is missing (found by tests/gpu_fuzz.py: the block decoder tested 'end of block' before
+    'behind the data').  Every length around the end of the stream must end as the reference does."""
+    import torch
+
+    for kind, n in (("lowent4k", 65536), ("itext", 131072), ("xorshift", 40000), ("itext", 300000)):
+        a = z.gen(kind, 77, n)
+        full = oracle.deflate(a)
+        d = dev(full, gpu)
+        for c in range(len(full) - 12, len(full) + 1):
+            try:
+                exp = ("out", oracle.inflate(full[:c]).tobytes())
+            except oracle.OracleError as ex:
+                exp = ("err", ex.code)
+            out = torch.empty(n + 4096, dtype=torch.uint8, device=gpu)  # (a cut stream can come out a few bytes longer)
+            try:
+                got = ("out", z.inflate_tensor(d[:c], out).cpu().numpy().tobytes())
+            except z.ZlibEsError as ex:
+                got = ("err", ex.code)
+            assert got == exp, (kind, n, c, len(full))
+
+
 def test_inflate_foreign_streams(z, gpu):
     for f in golden("foreign.json"):
         comp = open(os.path.join(GOLDEN, f["file"]), "rb").read()

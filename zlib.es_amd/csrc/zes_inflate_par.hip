@@ -675,12 +675,12 @@ __device__ __forceinline__ static void seg_decode(ParSmem& S, const BitSrc& src,
   while (b.pos < stop) {
     uint32_t v = 0, len = 0, dist = 0;
     const uint32_t kind = tok_step<LDS>(S, b, src, v, len, dist);
-    if (kind == T_EOB) {
-      fl |= F_EOB;
+    if (kind == T_FAIL || b.pos > limit) {  // (an end-of-block code whose bits lie behind the data counts as well:
+      fl |= F_FAIL;                         //  the reference throws 'Lack of data length' there)
       break;
     }
-    if (kind == T_FAIL || b.pos > limit) {
-      fl |= F_FAIL;
+    if (kind == T_EOB) {
+      fl |= F_EOB;
       break;
     }
     if (kind == T_LIT) {
@@ -778,12 +778,12 @@ __device__ __forceinline__ static void seg_run(ParSmem& S, const BitSrc& src, ui
     b.bb >>= adv;
     b.nb -= adv;
     b.pos += adv;
-    if (act && kind == 1u) {
-      fl |= F_EOB;
+    if (act && (bad || b.pos > limit)) {  // (before the end-of-block test: its code must lie inside the data too)
+      fl |= F_FAIL;
       act = false;
     }
-    if (act && (bad || b.pos > limit)) {
-      fl |= F_FAIL;
+    if (act && kind == 1u) {
+      fl |= F_EOB;
       act = false;
     }
     if (act) {
