@@ -92,6 +92,32 @@ while time.time() < t_end:
             raise SystemExit(1)
         if time.time() - t0 > 5:
             print("slow damaged case: %.1f s" % (time.time() - t0), kind, n, pos, len(bad), flush=True)
+    # device entry point on a view: random cut with the rest of the stream live behind it
+    for src in (comp, fz):
+        if len(src) < 16 or len(src) > 400000:
+            continue
+        d = torch.from_numpy(np.ascontiguousarray(src)).cuda()
+        c = int(rng.integers(2, len(src) + 1)) if rng.integers(2) else len(src) - int(rng.integers(0, 10))
+        exp = ref_inflate(np.ascontiguousarray(src[:c]))
+        out = torch.empty((len(exp[1]) if exp[0] == "out" else n) + int(rng.integers(0, 64)), dtype=torch.uint8, device="cuda")
+        try:
+            got = ("out", z.inflate_tensor(d[:c], out).cpu().numpy().tobytes())
+        except z.ZlibEsError as ex:
+            got = ("err", ex.code)
+        if got != exp:
+            name = os.path.join(ROOT, "gpurun_out", "fuzz_view_%d.bin" % n_cases)
+            os.makedirs(os.path.dirname(name), exist_ok=True)
+            open(name, "wb").write(np.ascontiguousarray(src).tobytes())
+            print("MISMATCH view", name, "c", c, "tier", z.last_inflate_tier(), got[0], exp[0], (got[1] if got[0] == "err" else len(got[1])),
+                  (exp[1] if exp[0] == "err" else len(exp[1])), flush=True)
+            raise SystemExit(1)
+    # raw forms with an offset
+    if n <= 1500000 and rng.integers(3) == 0:
+        raw = z.deflate_raw(a)
+        assert raw.tobytes() == oracle.deflate_raw(a).tobytes(), ("deflate_raw", kind, n)
+        k = int(rng.integers(0, 40))
+        boxed = np.concatenate([rng.integers(0, 256, k, dtype=np.uint8), raw, rng.integers(0, 256, int(rng.integers(0, 40)), dtype=np.uint8)])
+        assert z.inflate_raw(boxed, k).tobytes() == a.tobytes(), ("inflate_raw", kind, n, k)
     n_cases += 1
     # now and then: a batch of mixed streams through the batch entry point
     if n_cases % 5 == 0:
@@ -115,6 +141,31 @@ while time.time() < t_end:
         host = d_out.cpu().numpy()
         for i, r in enumerate(raws):
             assert st[i] == 0 and olen[i] == len(r) and (host[out_off[i]:out_off[i] + len(r)] == r).all(), ("batch", i, len(r))
+        # the same batch with some members damaged: status (or bytes) per member as the oracle has them
+        dcomps = []
+        for cdat in comps:
+            cdat = np.array(cdat, copy=True)
+            if rng.integers(3) == 0 and len(cdat) > 8:
+                cdat[int(rng.integers(2, len(cdat)))] ^= np.uint8(1 << int(rng.integers(8)))
+            dcomps.append(cdat)
+        big2 = np.zeros(pos, dtype=np.uint8)
+        for cdat, o in zip(dcomps, in_off):
+            big2[o:o + len(cdat)] = cdat
+        caps = [len(r) + 70000 for r in raws]
+        out_off2, opos2 = [], 0
+        for cp in caps:
+            out_off2.append(opos2); opos2 += (cp + 15) // 16 * 16
+        d_out2 = torch.zeros(opos2, dtype=torch.uint8, device="cuda")
+        olen2, st2 = z.inflate_batch_tensor(torch.from_numpy(big2).cuda(), in_off, [len(x) for x in dcomps], d_out2, out_off2, caps)
+        host2 = d_out2.cpu().numpy()
+        for i, cdat in enumerate(dcomps):
+            exp = ref_inflate(cdat)
+            if exp[0] == "err":
+                assert st2[i] == exp[1], ("batch damaged status", i, st2[i], exp[1])
+            elif len(exp[1]) > caps[i]:
+                assert st2[i] == -16 and olen2[i] == len(exp[1]), ("batch damaged nospace", i, st2[i], olen2[i], len(exp[1]))
+            else:
+                assert st2[i] == 0 and olen2[i] == len(exp[1]) and host2[out_off2[i]:out_off2[i] + olen2[i]].tobytes() == exp[1], ("batch damaged out", i, st2[i], olen2[i], len(exp[1]))
         n_batch += 1
     if n_cases % 20 == 0:
         print("cases %d batches %d" % (n_cases, n_batch), flush=True)
