@@ -1312,24 +1312,26 @@ __global__ __launch_bounds__(1024) void k_inf_seg_windows(const uint32_t* __rest
   const uint32_t* seg = seg_all + jb.work_first;
   uint8_t* wins = wins_all + (size_t)jb.work_first * ZES_WINDOW;
   __shared__ __align__(16) uint8_t W[2][ZES_WINDOW];
+  __shared__ uint32_t s_seg[SEG_BUCKETS + 1];  // the chain itself: a map's address must not wait for another trip to memory
   const uint32_t tid = threadIdx.x;
   for (uint32_t i = tid; i < ZES_WINDOW / 4; i += 1024) reinterpret_cast<uint32_t*>(W[0])[i] = 0;
   if (nseg < 2) return;
-  uint4 cur[4], nxt[4];
-  {
-    const uint4* m = reinterpret_cast<const uint4*>(maps + (size_t)seg[0] * (ZES_WINDOW / 2));
+  for (uint32_t i = tid; i < nseg && i <= SEG_BUCKETS; i += 1024) s_seg[i] = seg[i];
+  __syncthreads();
+  // maps are fetched two segments ahead: a step is short (~1 us) against the latency of the loads
+  uint4 cur[4], nx1[4], nx2[4];
+  auto fetch = [&](uint32_t k, uint4* dst) __attribute__((always_inline)) {
+    const uint4* m = reinterpret_cast<const uint4*>(maps + (size_t)s_seg[k] * (ZES_WINDOW / 2));
 #pragma unroll
-    for (int j = 0; j < 4; j++) cur[j] = m[j * 1024 + tid];
-  }
+    for (int j = 0; j < 4; j++) dst[j] = m[j * 1024 + tid];
+  };
+  fetch(0, cur);
+  if (nseg > 2) fetch(1, nx1);
   for (uint32_t k = 0; k + 1 < nseg; k++) {
     __syncthreads();
     const uint8_t* Wo = W[k & 1];
     uint8_t* Wn = W[(k & 1) ^ 1];
-    if (k + 2 < nseg) {
-      const uint4* m = reinterpret_cast<const uint4*>(maps + (size_t)seg[k + 1] * (ZES_WINDOW / 2));
-#pragma unroll
-      for (int j = 0; j < 4; j++) nxt[j] = m[j * 1024 + tid];
-    }
+    if (k + 3 < nseg) fetch(k + 2, nx2);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const uint32_t wsrc[4] = {cur[j].x, cur[j].y, cur[j].z, cur[j].w};
@@ -1345,7 +1347,10 @@ __global__ __launch_bounds__(1024) void k_inf_seg_windows(const uint32_t* __rest
       *reinterpret_cast<uint2*>(&wins[(size_t)k * ZES_WINDOW + e]) = make_uint2(o2[0], o2[1]);
     }
 #pragma unroll
-    for (int j = 0; j < 4; j++) cur[j] = nxt[j];
+    for (int j = 0; j < 4; j++) {
+      cur[j] = nx1[j];
+      nx1[j] = nx2[j];
+    }
   }
 }
 
