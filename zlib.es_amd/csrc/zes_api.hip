@@ -39,6 +39,7 @@ struct Ctx {
   DevBuf surv, cand, cand_sorted, counters, cres, map, resume, dbg, ibufs, ibufs2, mvlist, scratch, sres, maps, seglist, segprefix, wins, sym16, segorder, segjobs;
   // staging for the host-pointer API
   DevBuf st_in, st_out;
+  DevBuf kraft;  // k_inf_scan's table: Kraft contribution of four 3-bit code-length fields at once
   void* pinned = nullptr;  // small pinned area for read-backs
   size_t pinned_cap = 0;
   // profiling
@@ -96,6 +97,18 @@ int init_locked(int device) {
   HIPCHK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
   g.pinned_cap = 1 << 20;
   HIPCHK(hipHostMalloc(&g.pinned, g.pinned_cap, hipHostMallocDefault));
+  {
+    // units of 2^-7, a field of 0 adds nothing; saturated at 200 so that an over-full group can never sum back to exactly 128
+    uint8_t tab[4096];
+    for (uint32_t i = 0; i < 4096; i++) {
+      uint32_t k = 0;
+      for (uint32_t f = 0; f < 4; f++) k += (128u >> ((i >> (3 * f)) & 7u)) & 127u;
+      tab[i] = (uint8_t)std::min(k, 200u);
+    }
+    HIPCHK(hipMalloc(&g.kraft.p, 4096));
+    g.kraft.cap = 4096;
+    HIPCHK(hipMemcpy(g.kraft.p, tab, 4096, hipMemcpyHostToDevice));
+  }
   g.device = device;
   g.ready = true;
   return ZES_OK;
@@ -447,7 +460,8 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
   {
     Timed t("k_inf_scan");
     hipLaunchKernelGGL(k_inf_scan, dim3((uint32_t)chunks), dim3(INF_SCAN_THREADS), 0, g.stream, d_in, dbufs, nbuf,
-                       (unsigned long long*)g.surv.p, surv_cap, counters, dfirst, (flags & ZES_F_LOOSE_CANDIDATES) ? 1u : 0u);
+                       (unsigned long long*)g.surv.p, surv_cap, counters, dfirst, (flags & ZES_F_LOOSE_CANDIDATES) ? 1u : 0u,
+                       (const uint8_t*)g.kraft.p);
   }
   {
     // persistent lanes pulling survivors from a counter: the grid only has to be large enough to fill the chip
@@ -835,7 +849,7 @@ int inflate_segments(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const st
         Timed t("k_inf_scan");
         // (the BFINAL rule of the scan holds for every encoder's streams: it stays on; only the verify rules are the reference's own)
         hipLaunchKernelGGL(k_inf_scan, dim3(chunks), dim3(INF_SCAN_THREADS), 0, g.stream, d_in, dbufs, 1u, (unsigned long long*)g.surv.p,
-                           surv_cap, counters, sink, 0u);
+                           surv_cap, counters, sink, 0u, (const uint8_t*)g.kraft.p);
       }
       {
         // other encoders do not follow the reference's run-length rules for code lengths: loose candidates
@@ -1089,7 +1103,7 @@ int zes_shutdown(void) {
   (void)hipStreamSynchronize(g.stream);
   DevBuf* all[] = {&g.bufs, &g.blks, &g.idx_a, &g.idx_b, &g.inv, &g.hists, &g.codes, &g.hdrs, &g.adler, &g.res, &g.surv, &g.cand,
                    &g.cand_sorted, &g.counters, &g.cres, &g.map, &g.resume, &g.dbg, &g.ibufs, &g.ibufs2, &g.mvlist, &g.scratch, &g.st_in, &g.st_out,
-                   &g.sres, &g.maps, &g.seglist, &g.segprefix, &g.wins, &g.sym16, &g.segorder, &g.segjobs};
+                   &g.sres, &g.maps, &g.seglist, &g.segprefix, &g.wins, &g.sym16, &g.segorder, &g.segjobs, &g.kraft};
   for (DevBuf* b : all) {
     if (b->p) (void)hipFree(b->p);
     b->p = nullptr;

@@ -94,7 +94,8 @@ __device__ __forceinline__ static uint32_t buf_of_chunk(const ZesInfBuf* bufs, u
 __global__ __launch_bounds__(INF_SCAN_THREADS) void k_inf_scan(const uint8_t* __restrict__ d_in, const ZesInfBuf* __restrict__ bufs,
                                                                uint32_t nbuf, unsigned long long* __restrict__ surv,
                                                                uint32_t surv_cap, uint32_t* __restrict__ counters,
-                                                               uint8_t* __restrict__ first_bytes, uint32_t loose) {
+                                                               uint8_t* __restrict__ first_bytes, uint32_t loose,
+                                                               const uint8_t* __restrict__ kraft_tab) {
   // Each thread owns 32 consecutive bit positions at a time.  The fixed-field tests (BTYPE = 2,
   // HLIT <= 29, HDIST <= 29) run on all 32 positions at once as shifted word logic; only the
   // surviving positions (about one in five) pay for the Kraft sum of the code-length code.
@@ -103,14 +104,12 @@ __global__ __launch_bounds__(INF_SCAN_THREADS) void k_inf_scan(const uint8_t* __
   __shared__ uint32_t s_cnt, s_base;
   // Kraft contribution of four 3-bit code-length fields at once (units of 2^-7; a field of 0 adds
   // nothing); saturated at 200 so that an over-full group can never sum back to exactly 128
-  __shared__ uint8_t s_kraft[4096];
+  __shared__ __align__(16) uint8_t s_kraft[4096];
   const uint32_t tid = threadIdx.x;
   if (tid == 0) s_cnt = 0;
-  for (uint32_t i = tid; i < 4096; i += INF_SCAN_THREADS) {
-    uint32_t k = 0;
-    for (uint32_t f = 0; f < 4; f++) k += (128u >> ((i >> (3 * f)) & 7u)) & 127u;
-    s_kraft[i] = (uint8_t)min(k, 200u);
-  }
+  // (the table comes ready-made from global memory: filling it in every workgroup was ~40 % of this kernel's instructions)
+  static_assert(INF_SCAN_THREADS * 16 == 4096, "one 16-byte load per thread");
+  reinterpret_cast<uint4*>(s_kraft)[tid] = reinterpret_cast<const uint4*>(kraft_tab)[tid];
   const uint32_t bi = buf_of_chunk(bufs, nbuf, blockIdx.x);
   const uint64_t in_off = bufs[bi].in_off, c = bufs[bi].c;
   const uint64_t b0 = (uint64_t)(blockIdx.x - bufs[bi].first_chunk) * SCAN_BYTES;
