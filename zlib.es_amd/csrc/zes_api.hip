@@ -36,7 +36,7 @@ struct Ctx {
   // deflate scratch
   DevBuf bufs, blks, idx_a, idx_b, inv, hists, codes, hdrs, adler, res;
   // inflate scratch
-  DevBuf surv, cand, cand_sorted, counters, cres, map, resume, dbg, ibufs, ibufs2, mvlist, scratch, sres, maps, seglist, segprefix, wins, sym16, segorder, segjobs;
+  DevBuf surv, cand, cand_sorted, counters, cres, map, resume, dbg, ibufs, ibufs2, mvlist, scratch, sres, maps, seglist, segprefix, wins, sym16, segorder, segjobs, pw16, gwins;
   // staging for the host-pointer API
   DevBuf st_in, st_out;
   DevBuf kraft;  // k_inf_scan's table: Kraft contribution of four 3-bit code-length fields at once
@@ -768,9 +768,19 @@ int inflate_segments_run(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, cons
   if ((rc = ensure(g.wins, (size_t)work * ZES_WINDOW))) return rc;
   HIPCHK(hipMemcpyAsync(g.segjobs.p, hj, sizeof(ZesSegJob) * nb, hipMemcpyHostToDevice, g.stream));
   {
+    // windows: groups of maps composed in parallel, the groups chained, every window finished in parallel
+    uint32_t max_nseg = 0;
+    for (uint32_t k = 0; k < nb; k++) max_nseg = std::max(max_nseg, hj[k].nseg);
+    const uint32_t max_groups = (max_nseg + SEGWIN_GROUP - 1) / SEGWIN_GROUP;
+    if ((rc = ensure(g.pw16, (size_t)work * ZES_WINDOW * 2))) return rc;
+    if ((rc = ensure(g.gwins, ((size_t)work / SEGWIN_GROUP + nb + 1) * ZES_WINDOW))) return rc;  // (work_first / group) + buffer index + group
     Timed t("k_inf_seg_windows");
-    hipLaunchKernelGGL(k_inf_seg_windows, dim3(nb), dim3(1024), 0, g.stream, (const uint32_t*)g.maps.p, (const uint32_t*)g.seglist.p,
-                       (const ZesSegJob*)g.segjobs.p, (uint8_t*)g.wins.p);
+    hipLaunchKernelGGL(k_inf_seg_win_group, dim3(max_groups, nb), dim3(1024), 0, g.stream, (const uint32_t*)g.maps.p,
+                       (const uint32_t*)g.seglist.p, (const ZesSegJob*)g.segjobs.p, (uint32_t*)g.pw16.p);
+    hipLaunchKernelGGL(k_inf_seg_win_top, dim3(nb), dim3(1024), 0, g.stream, (const uint32_t*)g.pw16.p, (const ZesSegJob*)g.segjobs.p,
+                       (uint8_t*)g.gwins.p);
+    hipLaunchKernelGGL(k_inf_seg_win_fin, dim3(max_nseg, nb), dim3(1024), 0, g.stream, (const uint32_t*)g.pw16.p,
+                       (const ZesSegJob*)g.segjobs.p, (const uint8_t*)g.gwins.p, (uint8_t*)g.wins.p);
   }
   for (uint32_t k = 0; k < nb; k++) {
     if (!go[k]) continue;
@@ -1103,7 +1113,7 @@ int zes_shutdown(void) {
   (void)hipStreamSynchronize(g.stream);
   DevBuf* all[] = {&g.bufs, &g.blks, &g.idx_a, &g.idx_b, &g.inv, &g.hists, &g.codes, &g.hdrs, &g.adler, &g.res, &g.surv, &g.cand,
                    &g.cand_sorted, &g.counters, &g.cres, &g.map, &g.resume, &g.dbg, &g.ibufs, &g.ibufs2, &g.mvlist, &g.scratch, &g.st_in, &g.st_out,
-                   &g.sres, &g.maps, &g.seglist, &g.segprefix, &g.wins, &g.sym16, &g.segorder, &g.segjobs, &g.kraft};
+                   &g.sres, &g.maps, &g.seglist, &g.segprefix, &g.wins, &g.sym16, &g.segorder, &g.segjobs, &g.kraft, &g.pw16, &g.gwins};
   for (DevBuf* b : all) {
     if (b->p) (void)hipFree(b->p);
     b->p = nullptr;

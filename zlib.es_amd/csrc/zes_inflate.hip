@@ -15,7 +15,7 @@
 //                          (16-bit ring): gives its end bit, its length and the last 32 Ki
 //                          symbols as a map "literal | index into the previous window"
 //        k_inf_seg_chain   follows the segments from bit 16 to the final block; output offsets
-//        k_inf_seg_windows resolves the window behind every segment, in order
+//        k_inf_seg_win_*   resolve the window behind every segment (groups of maps composed in parallel)
 //        k_inf_seg_decode  decodes each segment again, now with its window, into its place
 //  T3  k_inf_decode: one wavefront walks all blocks of the stream in order.
 //  T4  k_inf_exact: single-lane state-for-state restatement of the reference reader and block
@@ -1301,39 +1301,74 @@ __global__ __launch_bounds__(256) void k_inf_seg_chain(const ZesSegRes* __restri
   }
 }
 
-// The 32 KiB window behind each chain segment, in order: wins[k] = the bytes in front of segment k+1.
-// One workgroup; every step rewrites the window through the segment's map.
-__global__ __launch_bounds__(1024) void k_inf_seg_windows(const uint32_t* __restrict__ maps_all, const uint32_t* __restrict__ seg_all,
-                                                          const ZesSegJob* __restrict__ jobs, uint8_t* __restrict__ wins_all) {
-  const ZesSegJob jb = jobs[blockIdx.x];  // one workgroup per buffer of the group
-  const uint32_t nseg = jb.nseg;
+// The 32 KiB window behind each chain segment: wins[k] = the bytes in front of segment k+1 = map k applied to
+// window k-1.  Applying maps is associative, so the chain is cut into groups of SEGWIN_GROUP segments:
+//   k_inf_seg_win_group  one workgroup per group composes its maps from the identity: per segment the window
+//                        as 16-bit symbols over the window in front of the *group* (pw16)
+//   k_inf_seg_win_top    one workgroup per buffer walks the groups: the byte window in front of each group (gw)
+//   k_inf_seg_win_fin    one workgroup per segment: pw16 through gw -> wins
+// (the serial part is groups + group size steps instead of one per segment: 666 segments 1.4 ms -> 0.2 ms)
+__global__ __launch_bounds__(1024) void k_inf_seg_win_group(const uint32_t* __restrict__ maps_all, const uint32_t* __restrict__ seg_all,
+                                                            const ZesSegJob* __restrict__ jobs, uint32_t* __restrict__ pw16_all) {
+  const ZesSegJob jb = jobs[blockIdx.y];
+  const uint32_t nseg = jb.nseg, tid = threadIdx.x;
+  if (nseg < 2) return;
+  const uint32_t k0 = blockIdx.x * SEGWIN_GROUP, k1 = min(k0 + SEGWIN_GROUP, nseg - 1);  // windows k0 .. k1-1
+  if (k0 >= k1) return;
   const uint32_t* maps = maps_all + (size_t)jb.work_first * (ZES_WINDOW / 2);
   const uint32_t* seg = seg_all + jb.work_first;
-  uint8_t* wins = wins_all + (size_t)jb.work_first * ZES_WINDOW;
-  __shared__ __align__(16) uint8_t W[2][ZES_WINDOW];
-  __shared__ uint32_t s_seg[SEG_BUCKETS + 1];  // the chain itself: a map's address must not wait for another trip to memory
-  const uint32_t tid = threadIdx.x;
-  for (uint32_t i = tid; i < ZES_WINDOW / 4; i += 1024) reinterpret_cast<uint32_t*>(W[0])[i] = 0;
-  if (nseg < 2) return;
-  for (uint32_t i = tid; i < nseg && i <= SEG_BUCKETS; i += 1024) s_seg[i] = seg[i];
-  __syncthreads();
-  // maps are fetched two segments ahead: a step is short (~1 us) against the latency of the loads
-  uint4 cur[4], nx1[4], nx2[4];
-  auto fetch = [&](uint32_t k, uint4* dst) __attribute__((always_inline)) {
-    const uint4* m = reinterpret_cast<const uint4*>(maps + (size_t)s_seg[k] * (ZES_WINDOW / 2));
-#pragma unroll
-    for (int j = 0; j < 4; j++) dst[j] = m[j * 1024 + tid];
-  };
-  fetch(0, cur);
-  if (nseg > 2) fetch(1, nx1);
-  for (uint32_t k = 0; k + 1 < nseg; k++) {
+  uint32_t* pw16 = pw16_all + (size_t)jb.work_first * (ZES_WINDOW / 2);
+  __shared__ __align__(16) uint16_t W[2][ZES_WINDOW];  // 128 KiB: the composed window, 16-bit symbols
+  for (uint32_t i = tid; i < ZES_WINDOW; i += 1024) W[0][i] = (uint16_t)(256u + i);  // identity: byte i of the group's own front window
+  for (uint32_t k = k0; k < k1; k++) {
     __syncthreads();
-    const uint8_t* Wo = W[k & 1];
-    uint8_t* Wn = W[(k & 1) ^ 1];
-    if (k + 3 < nseg) fetch(k + 2, nx2);
+    const uint16_t* Wo = W[(k - k0) & 1];
+    uint16_t* Wn = W[((k - k0) & 1) ^ 1];
+    const uint4* m = reinterpret_cast<const uint4*>(maps + (size_t)seg[k] * (ZES_WINDOW / 2));
+    uint4 cur[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) cur[j] = m[j * 1024 + tid];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const uint32_t wsrc[4] = {cur[j].x, cur[j].y, cur[j].z, cur[j].w};
+      uint32_t o4[4];
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const uint32_t v = (wsrc[q >> 1] >> ((q & 1) * 16)) & 0xFFFFu;
+        const uint32_t b = v < 256u ? v : (uint32_t)Wo[(v - 256u) & (ZES_WINDOW - 1)];
+        o4[q >> 1] = (q & 1) ? (o4[q >> 1] | (b << 16)) : b;
+      }
+      const uint32_t e = (j * 1024 + tid) * 8;  // entry index
+      *reinterpret_cast<uint4*>(&Wn[e]) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+      *reinterpret_cast<uint4*>(&pw16[(size_t)k * (ZES_WINDOW / 2) + e / 2]) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_inf_seg_win_top(const uint32_t* __restrict__ pw16_all, const ZesSegJob* __restrict__ jobs,
+                                                          uint8_t* __restrict__ gw_all) {
+  const ZesSegJob jb = jobs[blockIdx.x];
+  const uint32_t nseg = jb.nseg, tid = threadIdx.x;
+  if (nseg < 2) return;
+  const uint32_t ngroups = (nseg - 1 + SEGWIN_GROUP - 1) / SEGWIN_GROUP;
+  const uint32_t* pw16 = pw16_all + (size_t)jb.work_first * (ZES_WINDOW / 2);
+  uint8_t* gw = gw_all + (size_t)jb.work_first / SEGWIN_GROUP * ZES_WINDOW + (size_t)blockIdx.x * ZES_WINDOW;  // see the host: room per buffer
+  __shared__ __align__(16) uint8_t W[2][ZES_WINDOW];
+  for (uint32_t i = tid; i < ZES_WINDOW / 4; i += 1024) reinterpret_cast<uint32_t*>(W[0])[i] = 0;  // nothing in front of the stream
+  for (uint32_t gi = 0; gi < ngroups; gi++) {
+    __syncthreads();
+    const uint8_t* Wo = W[gi & 1];
+    uint8_t* Wn = W[(gi & 1) ^ 1];
+    // the window in front of group gi goes out; the group's last composed window takes it to the next group
+    for (uint32_t i = tid; i < ZES_WINDOW / 16; i += 1024)
+      reinterpret_cast<uint4*>(gw + (size_t)gi * ZES_WINDOW)[i] = reinterpret_cast<const uint4*>(Wo)[i];
+    if (gi + 1 == ngroups) break;
+    const uint32_t klast = (gi + 1) * SEGWIN_GROUP - 1;
+    const uint4* m = reinterpret_cast<const uint4*>(pw16 + (size_t)klast * (ZES_WINDOW / 2));
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint4 c4 = m[j * 1024 + tid];
+      const uint32_t wsrc[4] = {c4.x, c4.y, c4.z, c4.w};
       uint32_t o2[2] = {0, 0};
 #pragma unroll
       for (int q = 0; q < 8; q++) {
@@ -1341,15 +1376,36 @@ __global__ __launch_bounds__(1024) void k_inf_seg_windows(const uint32_t* __rest
         const uint32_t b = v < 256u ? v : (uint32_t)Wo[(v - 256u) & (ZES_WINDOW - 1)];
         o2[q >> 2] |= b << ((q & 3) * 8);
       }
-      const uint32_t e = (j * 1024 + tid) * 8;
-      *reinterpret_cast<uint2*>(&Wn[e]) = make_uint2(o2[0], o2[1]);
-      *reinterpret_cast<uint2*>(&wins[(size_t)k * ZES_WINDOW + e]) = make_uint2(o2[0], o2[1]);
+      *reinterpret_cast<uint2*>(&Wn[(j * 1024 + tid) * 8]) = make_uint2(o2[0], o2[1]);
     }
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_inf_seg_win_fin(const uint32_t* __restrict__ pw16_all, const ZesSegJob* __restrict__ jobs,
+                                                         const uint8_t* __restrict__ gw_all, uint8_t* __restrict__ wins_all) {
+  const ZesSegJob jb = jobs[blockIdx.y];
+  const uint32_t nseg = jb.nseg, tid = threadIdx.x, k = blockIdx.x;
+  if (nseg < 2 || k + 1 >= nseg) return;
+  const uint32_t* pw16 = pw16_all + (size_t)jb.work_first * (ZES_WINDOW / 2);
+  const uint8_t* gw = gw_all + (size_t)jb.work_first / SEGWIN_GROUP * ZES_WINDOW + (size_t)blockIdx.y * ZES_WINDOW +
+                      (size_t)(k / SEGWIN_GROUP) * ZES_WINDOW;
+  uint8_t* wins = wins_all + (size_t)jb.work_first * ZES_WINDOW;
+  __shared__ __align__(16) uint8_t W[ZES_WINDOW];
+  for (uint32_t i = tid; i < ZES_WINDOW / 16; i += 1024) reinterpret_cast<uint4*>(W)[i] = reinterpret_cast<const uint4*>(gw)[i];
+  __syncthreads();
+  const uint4* m = reinterpret_cast<const uint4*>(pw16 + (size_t)k * (ZES_WINDOW / 2));
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      cur[j] = nx1[j];
-      nx1[j] = nx2[j];
+  for (int j = 0; j < 4; j++) {
+    const uint4 c4 = m[j * 1024 + tid];
+    const uint32_t wsrc[4] = {c4.x, c4.y, c4.z, c4.w};
+    uint32_t o2[2] = {0, 0};
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const uint32_t v = (wsrc[q >> 1] >> ((q & 1) * 16)) & 0xFFFFu;
+      const uint32_t b = v < 256u ? v : (uint32_t)W[(v - 256u) & (ZES_WINDOW - 1)];
+      o2[q >> 2] |= b << ((q & 3) * 8);
     }
+    *reinterpret_cast<uint2*>(&wins[(size_t)k * ZES_WINDOW + (j * 1024 + tid) * 8]) = make_uint2(o2[0], o2[1]);
   }
 }
 

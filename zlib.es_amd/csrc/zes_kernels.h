@@ -71,7 +71,10 @@ __global__ void k_inf_seg_scan(const uint8_t*, const ZesSegJob*, uint32_t, const
 __global__ void k_inf_seg_chain(const ZesSegRes*, uint32_t, uint32_t*, uint64_t*, ZesRes*, uint32_t*);
 __global__ void k_inf_seg_translate(uint8_t*, uint64_t, uint64_t, const uint32_t*, const ZesSegRes*, const uint32_t*, const uint64_t*,
                                     const uint8_t*, const uint32_t*, uint32_t, uint32_t*);
-__global__ void k_inf_seg_windows(const uint32_t*, const uint32_t*, const ZesSegJob*, uint8_t*);
+#define SEGWIN_GROUP 32u
+__global__ void k_inf_seg_win_group(const uint32_t*, const uint32_t*, const ZesSegJob*, uint32_t*);
+__global__ void k_inf_seg_win_top(const uint32_t*, const ZesSegJob*, uint8_t*);
+__global__ void k_inf_seg_win_fin(const uint32_t*, const ZesSegJob*, const uint8_t*, uint8_t*);
 __global__ void k_inf_seg_decode(const uint8_t*, uint64_t, uint64_t, uint8_t*, uint64_t, uint64_t, const uint32_t*, const ZesSegRes*,
                                  const uint32_t*, const uint64_t*, const uint8_t*, uint32_t*, uint32_t);
 __global__ void k_inf_block_par(const uint8_t*, uint8_t*, const ZesInfBuf*, uint32_t, const uint32_t*, const uint32_t*, const uint32_t*,
