@@ -73,4 +73,20 @@ it('malformed-stream cases (every 7th)', () => {
     assert.deepStrictEqual(got, c.error ? {error: c.error} : {output: c.output}, c.name);
   }
 });
-console.log('all ' + n + ' host checks passed');
+// Promise-returning forms: same bytes, same messages, several in flight at once
+(async () => {
+  const outs = await Promise.all([zlibes.deflateAsync(RAW), zlibes.deflateAsync(RAW_BIN), zlibes.inflateAsync(CMP_BIN),
+                                  zlibes.inflateAsync(fromHex(kat.kat.DYNAMIC))]);
+  it('deflateAsync bytes == deflate', () => assert.strictEqual(hex(outs[0]), hex(zlibes.deflate(RAW))));
+  it('deflateAsync binary data == deflate', () => assert.strictEqual(hex(outs[1]), hex(zlibes.deflate(RAW_BIN))));
+  it('inflateAsync binary data', () => assert.ok(Buffer.from(outs[2]).equals(Buffer.from(RAW_BIN))));
+  it('inflateAsync DYNAMIC', () => assert.deepStrictEqual(outs[3], RAW));
+  it('async result is an exact-size Uint8Array', () => assert.ok(outs[0] instanceof Uint8Array && outs[0].byteOffset === 0 && outs[0].buffer.byteLength === outs[0].length));
+  let msg = null;
+  try { await zlibes.inflateAsync(new Uint8Array([0x78, 0x9c, 7, 0, 0, 0])); } catch (e) { msg = e instanceof Error ? e.message : String(e); }
+  it('inflateAsync rejects with the reference message', () => assert.strictEqual(msg, 'Not supported BTYPE : 3'));
+  msg = null;
+  try { await zlibes.deflateAsync(new Uint8Array(1)); } catch (e) { msg = e.message; }
+  it('deflateAsync rejects with the reference message', () => assert.strictEqual(msg, 'Data is corrupted'));
+  console.log('all ' + n + ' host checks passed');
+})().catch((e) => { console.error(e); process.exit(1); });

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Erases the type annotations of zlib.ts into CommonJS zlib.js (this image has no tsc).
 
-Supports exactly the subset zlib.ts keeps to: `export function name(arg: T, ...): R {`.
+Supports exactly the subset zlib.ts keeps to: `export function name(arg: T, ...): R {` (R may be `Promise<T>`).
 """
 import os
 import re
@@ -19,7 +19,7 @@ def fn(m):
     return "function %s(%s) {" % (name, params)
 
 
-out = re.sub(r"export function (\w+)\(([^)]*)\)\s*:\s*[\w\[\]]+\s*\{", fn, src)
+out = re.sub(r"export function (\w+)\(([^)]*)\)\s*:\s*[\w\[\]<>]+\s*\{", fn, src)
 if "export " in out or re.search(r"\w\s*:\s*(Uint8Array|number|void)\b", out.split("*/", 1)[-1].replace("input: Uint8Array", "")):
     pass  # nothing else to erase in the supported subset
 out = "'use strict';\n// GENERATED from zlib.ts by strip_types.py — do not edit.\n" + out

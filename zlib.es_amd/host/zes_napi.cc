@@ -1,7 +1,8 @@
 // zes_napi.cc — N-API addon: the binding between the TypeScript façade (zlib.ts) and the C-ABI of
 // include/zes.h.  Thin on purpose: argument marshalling and error translation only; every byte
 // of work happens in libzes_hip.so (HIP kernels).  Synchronous like the reference's functions
-// (src/zlib.ts:11,25).  N-API version 3 calls only (Node >= 10).
+// (src/zlib.ts:11,25); deflateAsync / inflateAsync run the same calls on the libuv thread pool and return
+// Promises (the JS thread stays free while a GPU works).  N-API version 3 calls only (Node >= 10).
 #include <node_api.h>
 
 #include <cstdint>
@@ -183,12 +184,113 @@ napi_value Init(napi_env env, napi_callback_info info) {
   return v;
 }
 
+// ---- Promise-returning forms: the blocking C-ABI call runs on a libuv worker thread ----
+struct AsyncJob {
+  napi_async_work work = nullptr;
+  napi_deferred deferred = nullptr;
+  napi_ref input_ref = nullptr;  // keeps the caller's array alive (and its memory in place) while the worker reads it
+  const uint8_t* in = nullptr;
+  size_t n = 0;
+  bool inflate = false;
+  uint8_t* out = nullptr;
+  uint64_t out_len = 0;
+  int rc = 0;
+};
+
+void async_execute(napi_env, void* data) {  // worker thread: no N-API calls here
+  AsyncJob* j = static_cast<AsyncJob*>(data);
+  if (!j->inflate) {
+    uint64_t cap = 0;
+    zes_deflate_bound(j->n, &cap);
+    j->out = static_cast<uint8_t*>(malloc(cap ? cap : 1));
+    j->rc = j->out ? zes_deflate(j->in, j->n, j->out, cap, &j->out_len) : ZES_E_ARG;
+    return;
+  }
+  // grow-and-retry (the size/fetch pair of the synchronous form keeps state in the library between two calls,
+  // which another thread's call could replace)
+  uint64_t cap = (uint64_t)j->n * 4 + 65536;
+  for (int attempt = 0; attempt < 8; attempt++) {
+    j->out = static_cast<uint8_t*>(malloc(cap));
+    if (!j->out) {
+      j->rc = ZES_E_ARG;
+      return;
+    }
+    j->rc = zes_inflate(j->in, j->n, j->out, cap, &j->out_len, ZES_F_DEFAULT);
+    if (j->rc == ZES_E_NOSPACE && j->out_len > cap) {
+      free(j->out);
+      j->out = nullptr;
+      cap = j->out_len;
+      continue;
+    }
+    return;
+  }
+  j->rc = ZES_E_DEVICE;
+}
+
+void free_external(napi_env, void* data, void*) { free(data); }
+
+void async_complete(napi_env env, napi_status, void* data) {  // JS thread again
+  AsyncJob* j = static_cast<AsyncJob*>(data);
+  napi_value result = nullptr;
+  bool ok = j->rc == 0;
+  if (ok) {
+    napi_value ab;
+    // the worker's buffer becomes the result's ArrayBuffer (exact length, no copy on the JS thread)
+    if (napi_create_external_arraybuffer(env, j->out, (size_t)j->out_len, free_external, nullptr, &ab) == napi_ok &&
+        napi_create_typedarray(env, napi_uint8_array, (size_t)j->out_len, ab, 0, &result) == napi_ok) {
+      j->out = nullptr;  // owned by the ArrayBuffer now
+    } else {
+      ok = false;
+      j->rc = ZES_E_ARG;
+    }
+  }
+  if (ok) {
+    napi_resolve_deferred(env, j->deferred, result);
+  } else {
+    napi_value msg, err;
+    napi_create_string_utf8(env, zes_strerror(j->rc), NAPI_AUTO_LENGTH, &msg);
+    napi_create_error(env, nullptr, msg, &err);  // plain Error with the reference's message, as a rejection
+    napi_reject_deferred(env, j->deferred, err);
+  }
+  free(j->out);
+  napi_delete_reference(env, j->input_ref);
+  napi_delete_async_work(env, j->work);
+  delete j;
+}
+
+napi_value start_async(napi_env env, napi_callback_info info, bool inflate) {
+  size_t argc = 1;
+  napi_value argv[1];
+  napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr);
+  const uint8_t* in = nullptr;
+  size_t n = 0;
+  if (argc < 1 || !get_bytes(env, argv[0], &in, &n)) {
+    napi_throw_type_error(env, nullptr, inflate ? "inflateAsync(input): input must be a Uint8Array" : "deflateAsync(input): input must be a Uint8Array");
+    return nullptr;
+  }
+  AsyncJob* j = new AsyncJob();
+  j->in = in;
+  j->n = n;
+  j->inflate = inflate;
+  napi_value promise, name;
+  napi_create_promise(env, &j->deferred, &promise);
+  napi_create_reference(env, argv[0], 1, &j->input_ref);
+  napi_create_string_utf8(env, inflate ? "zes_inflate" : "zes_deflate", NAPI_AUTO_LENGTH, &name);
+  napi_create_async_work(env, nullptr, name, async_execute, async_complete, j, &j->work);
+  napi_queue_async_work(env, j->work);
+  return promise;
+}
+napi_value DeflateAsync(napi_env env, napi_callback_info info) { return start_async(env, info, false); }
+napi_value InflateAsync(napi_env env, napi_callback_info info) { return start_async(env, info, true); }
+
 napi_value ModuleInit(napi_env env, napi_value exports) {
   napi_property_descriptor props[] = {
       {"deflate", nullptr, Deflate, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"inflate", nullptr, Inflate, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"deflateRaw", nullptr, DeflateRaw, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"inflateRaw", nullptr, InflateRaw, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"deflateAsync", nullptr, DeflateAsync, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"inflateAsync", nullptr, InflateAsync, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"adler32", nullptr, Adler32, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"init", nullptr, Init, nullptr, nullptr, nullptr, napi_default, nullptr},
   };

@@ -34,6 +34,19 @@ function inflateRaw(input, offset) {
   return addon.inflateRaw(input, offset);
 }
 
+/**
+ * Promise-returning forms (not in the reference API, SURVEY §8f.4): the same work on a libuv worker thread, so the
+ * JS thread stays free while the GPU runs.  Resolve with the same bytes, reject with the same `Error` messages.
+ * The input array must not be modified until the promise settles.
+ */
+function deflateAsync(input) {
+  return addon.deflateAsync(input);
+}
+
+function inflateAsync(input) {
+  return addon.inflateAsync(input);
+}
+
 /** Extra (not in the reference API): Adler-32 of a buffer, computed on the GPU. */
 function adler32(input) {
   return addon.adler32(input);
@@ -48,5 +61,7 @@ exports.inflate = inflate;
 exports.deflate = deflate;
 exports.deflateRaw = deflateRaw;
 exports.inflateRaw = inflateRaw;
+exports.deflateAsync = deflateAsync;
+exports.inflateAsync = inflateAsync;
 exports.adler32 = adler32;
 exports.init = init;

@@ -32,6 +32,19 @@ export function inflateRaw(input: Uint8Array, offset: number = 0): Uint8Array {
   return addon.inflateRaw(input, offset);
 }
 
+/**
+ * Promise-returning forms (not in the reference API, SURVEY §8f.4): the same work on a libuv worker thread, so the
+ * JS thread stays free while the GPU runs.  Resolve with the same bytes, reject with the same `Error` messages.
+ * The input array must not be modified until the promise settles.
+ */
+export function deflateAsync(input: Uint8Array): Promise<Uint8Array> {
+  return addon.deflateAsync(input);
+}
+
+export function inflateAsync(input: Uint8Array): Promise<Uint8Array> {
+  return addon.inflateAsync(input);
+}
+
 /** Extra (not in the reference API): Adler-32 of a buffer, computed on the GPU. */
 export function adler32(input: Uint8Array): number {
   return addon.adler32(input);
