@@ -34,6 +34,12 @@ while time.time() < t_end:
     if n % 131072 == 1:
         n += 1
     a = z.gen(kind, int(rng.integers(1 << 30)), n)
+    shape = int(rng.integers(6))
+    if shape == 0:  # runs and short periods: maximal matches at tiny distances, chunked code-length runs
+        per = int(rng.choice([1, 2, 3, 5, 27, 257, 258, 259, 4097]))
+        a = np.resize(a[:per], n).copy()
+    elif shape == 1 and n > 1000:  # a few distinct byte values only
+        a = (a & np.uint8(int(rng.choice([1, 3, 15])))).copy()
     # own deflate vs the oracle (sizes the oracle finishes quickly)
     if n <= 1500000:
         exp = oracle.deflate(a).tobytes()
