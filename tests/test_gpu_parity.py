@@ -379,7 +379,8 @@ def _foreign_cases(z):
     low = z.gen("lowent4k", 63, 24 << 20).tobytes()
     cases = [("text level 6", pz.compress(text, 6), text, 2), ("text level 1", pz.compress(text, 1), text, 2),
              ("text level 9", pz.compress(text, 9), text, 2),
-             ("stored blocks", pz.compress(rnd, 6), rnd, None),  # no dynamic block to cut at: serial tier
+             ("stored blocks", pz.compress(rnd, 6), rnd, 2),  # nothing to decode: header walk + parallel copy
+             ("stored blocks, level 0", pz.compress(text[:1 << 20], 0), text[:1 << 20], 2),
              ("long blocks", pz.compress(low, 6), low, None)]
     co = pz.compressobj(6)
     parts, plain = [], []

@@ -908,6 +908,32 @@ int inflate_segments(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const st
   return ZES_OK;
 }
 
+// A stream of stored blocks only (tier 2 as well: parallel, any encoder).  Leaves j.tier at 0 if it is anything else.
+constexpr uint64_t STORED_MIN_C = 65536;  // below this the serial wavefront is as quick
+int inflate_stored(const uint8_t* d_in, uint8_t* d_out, InfJob& j) {
+  int rc;
+  const uint64_t cap_entries = std::min<uint64_t>(j.c / 5 + 1, 1ull << 22);
+  if ((rc = ensure(g.res, sizeof(ZesRes)))) return rc;
+  if ((rc = ensure(g.scratch, (size_t)cap_entries * sizeof(ZesStoredBlk)))) return rc;
+  {
+    Timed t("k_inf_stored_walk");
+    hipLaunchKernelGGL(k_inf_stored_walk, dim3(1), dim3(64), 0, g.stream, d_in, j.in_off, j.c, cap_entries, (ZesStoredBlk*)g.scratch.p,
+                       (ZesRes*)g.res.p);
+  }
+  ZesRes hr;
+  if ((rc = read_res(&hr))) return rc;
+  if (hr.status != 0) return ZES_OK;
+  j.tier = 2;
+  j.out_len = hr.out_len;
+  j.status = hr.out_len > j.cap ? ZES_E_NOSPACE : ZES_OK;
+  if (j.status == ZES_OK && hr.aux) {
+    Timed t("k_inf_stored_copy");
+    hipLaunchKernelGGL(k_inf_stored_copy, dim3(hr.aux), dim3(256), 0, g.stream, d_in, j.in_off, d_out, j.out_off, (const ZesStoredBlk*)g.scratch.p);
+    HIPCHK(hipStreamSynchronize(g.stream));
+  }
+  return ZES_OK;
+}
+
 // T3 then T4 for one buffer the parallel tiers did not settle.
 int inflate_slow(const uint8_t* d_in, uint8_t* d_out, InfJob& j) {
   int rc;
@@ -1052,6 +1078,8 @@ int inflate_jobs(const uint8_t* d_in, uint8_t* d_out, std::vector<InfJob>& jobs,
     }
   }
   if (!(flags & ZES_F_NO_FASTPATH)) {
+    for (uint32_t i : todo)
+      if (jobs[i].tier == 0 && jobs[i].status == ZES_OK && jobs[i].c >= STORED_MIN_C && (rc = inflate_stored(d_in, d_out, jobs[i]))) return rc;
     std::vector<uint32_t> segs;
     for (uint32_t i : todo)
       if (jobs[i].tier == 0 && jobs[i].status == ZES_OK && jobs[i].c >= SEG_MIN_C && jobs[i].c < (1ull << 29)) segs.push_back(i);

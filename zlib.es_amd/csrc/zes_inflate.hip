@@ -1042,6 +1042,60 @@ __global__ __launch_bounds__(64) void k_inf_decode(const uint8_t* __restrict__ d
 }
 
 // ------------------------------------------------------------------------------------------
+// Streams of stored blocks only (another encoder on incompressible data, or at level 0): nothing to decode and no
+// dynamic header to cut at.  One lane walks the block headers (src/inflate.ts:42-55: byte-aligned LEN / NLEN with
+// LEN + NLEN == 65535), then one workgroup per block copies.  Anything else in the chain — another block type, a bad
+// NLEN, data that ends early — and the walk reports "not mine": the other tiers take the stream.
+// ------------------------------------------------------------------------------------------
+__global__ void k_inf_stored_walk(const uint8_t* __restrict__ d_in, uint64_t in_off, uint64_t c, uint64_t cap_entries,
+                                  ZesStoredBlk* __restrict__ list, ZesRes* __restrict__ res) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const uint8_t* in = d_in + in_off;
+  res->status = 1;
+  res->out_len = 0;
+  res->aux = 0;
+  uint64_t pos = 2, dst = 0, n = 0;  // the first block header sits at bit 16, every later one behind a whole byte
+  for (;;) {
+    if (pos + 5 > c || n >= cap_entries) return;
+    const uint32_t h = in[pos];
+    if ((h >> 1) & 3u) return;  // not a stored block
+    const uint32_t LEN = in[pos + 1] | ((uint32_t)in[pos + 2] << 8), NLEN = in[pos + 3] | ((uint32_t)in[pos + 4] << 8);
+    if (LEN + NLEN != 65535u || pos + 5 + LEN > c) return;
+    ZesStoredBlk b;
+    b.src = pos + 5;
+    b.dst = dst;
+    b.len = LEN;
+    b.pad = 0;
+    list[n++] = b;
+    dst += LEN;
+    pos += 5 + (uint64_t)LEN;
+    if (h & 1u) break;  // BFINAL
+  }
+  res->out_len = dst;
+  res->aux = (uint32_t)n;
+  res->status = 0;
+}
+
+__global__ __launch_bounds__(256) void k_inf_stored_copy(const uint8_t* __restrict__ d_in, uint64_t in_off, uint8_t* __restrict__ d_out,
+                                                         uint64_t out_off, const ZesStoredBlk* __restrict__ list) {
+  const ZesStoredBlk b = list[blockIdx.x];
+  const uint8_t* src = d_in + in_off + b.src;
+  uint8_t* dst = d_out + out_off + b.dst;
+  const uint32_t len = b.len, tid = threadIdx.x;
+  // head up to the first 4-byte boundary of the destination, aligned dwords (source through a byte funnel), tail
+  const uint32_t head = min(len, (uint32_t)((4u - ((uintptr_t)dst & 3u)) & 3u));
+  if (tid < head) dst[tid] = src[tid];
+  const uint32_t ndw = (len - head) >> 2;
+  const uint8_t* s0 = src + head;
+  const uint32_t sh = (uint32_t)((uintptr_t)s0 & 3u);
+  const uint32_t* s32 = reinterpret_cast<const uint32_t*>(s0 - sh);  // aligned view: dword i + 1 may lie behind the block, inside the stream
+  uint32_t* d32 = reinterpret_cast<uint32_t*>(dst + head);
+  for (uint32_t i = tid; i < ndw; i += 256) d32[i] = sh ? __builtin_amdgcn_alignbyte(s32[i + 1], s32[i], sh) : s32[i];
+  const uint32_t done = head + ndw * 4u;
+  if (tid < len - done) dst[done + tid] = src[done + tid];
+}
+
+// ------------------------------------------------------------------------------------------
 // T2, segment-parallel decode of any valid stream.  Work item 0 starts at bit 16, work item
 // w > 0 at candidate w-1 (sorted).  A segment runs block after block (any BTYPE) until it lands
 // exactly on a candidate position, passes a final block, or fails; false candidates make

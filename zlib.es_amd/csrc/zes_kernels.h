@@ -43,6 +43,12 @@ struct ZesSegRes {
   uint32_t next;      // work item that starts at end_bit (0 = none)
 };
 
+// one stored block of a stream that consists of stored blocks only
+struct ZesStoredBlk {
+  uint64_t src, dst;  // byte offsets inside the stream / inside the output
+  uint32_t len, pad;
+};
+
 // T2: one entry per buffer of a group; the per-work-item arrays (sres, maps, order, seg, prefix, wins) are laid out
 // buffer after buffer, a buffer's part starting at index work_first
 struct ZesSegJob {
@@ -63,6 +69,8 @@ __global__ void k_inf_set_table1(ZesInfBuf, ZesInfBuf, ZesInfBuf*, uint32_t*, ui
 __global__ void k_inf_verify(const uint8_t*, const ZesInfBuf*, const unsigned long long*, uint32_t, uint32_t*, uint32_t*, uint32_t*, uint32_t);
 __global__ void k_inf_ranksort(const ZesInfBuf*, const uint32_t*, const uint32_t*, uint32_t*);
 __global__ void k_inf_decode(const uint8_t*, uint8_t*, const ZesInfBuf*, ZesRes*, uint64_t*);
+__global__ void k_inf_stored_walk(const uint8_t*, uint64_t, uint64_t, uint64_t, ZesStoredBlk*, ZesRes*);
+__global__ void k_inf_stored_copy(const uint8_t*, uint64_t, uint8_t*, uint64_t, const ZesStoredBlk*);
 __global__ void k_inf_cand_bucket(const uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*);
 __global__ void k_inf_cand_compact(const uint32_t*, uint32_t*, uint32_t*);
 __global__ void k_inf_seg_order(const uint32_t*, uint32_t, uint64_t, uint32_t*);
