@@ -1,20 +1,27 @@
 #!/usr/bin/env python3
-"""bench.py — deflate+inflate throughput of the MI355X DEFLATE engine on BASELINE.json's workload.
+"""bench.py — deflate+inflate throughput of the MI355X DEFLATE engine on BASELINE.json's workloads.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One step = one pass of the hot path over one batch of synthetic input: every rank deflates its
-own HBM-resident 64 MiB buffer (BASELINE.json configs[1]: xorshift32 bytes, seed 12345+rank) and
-inflates the result back, all through the C-ABI device entry points.  Buffers are independent
-units: weak scaling, no data-path collective; the only exchange is an all-gather of
-the per-shard compressed sizes (what a consumer needs to place the shards).
+One step = one pass of the hot path over one batch of synthetic input: every rank deflates its own
+HBM-resident 64 MiB buffer (BASELINE.json configs[1]: xorshift32 bytes, seed 12345+rank) and inflates
+the result back, all through the C-ABI device entry points.  Buffers are independent units (SURVEY
+§8e): weak scaling, no data-path collective.  With N > 1 every step ends with the result gather of
+the north_star: the compressed shards go from every rank's HBM to rank 0's HBM (zlib.es_amd/shard.py:
+all_reduce of the sizes, one exact-length send per rank over xGMI), in flight while the next step's
+kernels run and finished inside the timed region.
 
 Rank 0 prints ONE JSON line.  `value` is GiB/s of uncompressed bytes taken through
 deflate-then-inflate by the whole job (n * N * K / wall).  `roofline` prices the dominant kernel
 (by HIP-event time on the library's stream) against HBM; `cpu_baseline` is the CPU oracle (a port
 of the reference algorithm) timed on this box's host cores on the same buffer.
+
+The same process then runs the north-star workload as a second leg, reported under "text64" in the
+same line: BASELINE.json configs[2], a 64 MiB text-like buffer per GPU — its deflate, and the
+inflate-only hot loop over the reference-format stream (the >= 200 GiB/s aggregate target), with its
+own roofline and cpu_baseline records.  `--workload X` makes X the main leg instead (no second leg).
 """
 import argparse
 import hashlib
@@ -27,6 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+GIB = float(1 << 30)
 
 WORKLOADS = {
     # name: (generator, seed, bytes per buffer[, buffers per GPU])
@@ -41,16 +49,161 @@ WORKLOADS = {
 MIX = ("xorshift", "itext", "lowent4k")           # buffer i uses seed 12345+i, generators in turn
 
 
+class Leg:
+    """One workload on this rank: buffers in HBM, verification, the timed loops."""
+
+    def __init__(self, name, env):
+        import numpy as np
+        import torch
+
+        self.name, self.env = name, env
+        z, dev, rank = env["z"], env["dev"], env["rank"]
+        spec = WORKLOADS[name]
+        self.kind, self.seed, self.n1 = spec[0], spec[1], spec[2]
+        self.nbuf = spec[3] if len(spec) > 3 else 1
+        self.foreign = len(spec) > 4  # inflate-only workload: the compressed stream comes from CPython's zlib
+        self.n = self.n1 * self.nbuf  # uncompressed bytes per GPU and step
+        if self.nbuf == 1:
+            self.host = z.gen(self.kind, self.seed + rank, self.n1)
+        else:  # buffer i of the whole job: generator i % 3, seed + i
+            self.host = np.concatenate([z.gen(MIX[(rank * self.nbuf + i) % 3], self.seed + rank * self.nbuf + i, self.n1)
+                                        for i in range(self.nbuf)])
+        self.d_in = torch.from_numpy(self.host).to(dev)
+        self.d_foreign = self.foreign_bytes = None
+        if self.foreign:
+            import zlib as pyzlib
+
+            self.foreign_bytes = pyzlib.compress(self.host.tobytes(), 6)
+            self.d_foreign = torch.from_numpy(np.frombuffer(self.foreign_bytes, dtype=np.uint8).copy()).to(dev)
+        self.bound1 = (z.deflate_bound(self.n1) + 15) // 16 * 16
+        # two result arenas: with N > 1 the gather of step k reads one while step k+1 writes the other
+        self.d_comp = [torch.empty(self.bound1 * self.nbuf, dtype=torch.uint8, device=dev) for _ in range(2 if env["world"] > 1 else 1)]
+        self.d_back = torch.empty(self.n, dtype=torch.uint8, device=dev)
+        self.in_off = [i * self.n1 for i in range(self.nbuf)]
+        self.c_off = [i * self.bound1 for i in range(self.nbuf)]
+        self.ktimes = {"deflate": {}, "inflate": {}}
+
+    # ---- the two directions ----
+    def run_deflate(self, slot=0):
+        """-> compressed bytes of this GPU's buffers (a view for one buffer, a list of lengths for a batch)"""
+        z = self.env["z"]
+        if self.foreign:
+            return self.d_foreign
+        if self.nbuf == 1:
+            return z.deflate_tensor(self.d_in, self.d_comp[slot])
+        clen, st = z.deflate_batch_tensor(self.d_in, self.in_off, [self.n1] * self.nbuf, self.d_comp[slot], self.c_off, [self.bound1] * self.nbuf)
+        assert not any(st), st
+        return clen
+
+    def run_inflate(self, comp, slot=0):
+        z = self.env["z"]
+        if self.nbuf == 1:
+            return z.inflate_tensor(comp, self.d_back)
+        olen, st = z.inflate_batch_tensor(self.d_comp[slot], self.c_off, comp, self.d_back, self.in_off, [self.n1] * self.nbuf)
+        assert not any(st) and all(o == self.n1 for o in olen), (st[:4], olen[:4])
+        return self.d_back
+
+    def csize(self, comp):
+        return int(comp.numel()) if self.nbuf == 1 else int(sum(comp))
+
+    def local_result(self, comp, slot):
+        """This rank's compressed results back to back, as one device tensor (what the gather sends)."""
+        import torch
+
+        if self.nbuf == 1:
+            return comp, [int(comp.numel())]
+        arena = self.d_comp[slot]
+        return torch.cat([arena[o:o + l] for o, l in zip(self.c_off, comp)]), [int(x) for x in comp]
+
+    def note_times(self, direction):
+        for name, ms, launches in self.env["z"].last_kernel_times():
+            k = self.ktimes[direction].setdefault(name, [0.0, 0])
+            k[0] += ms
+            k[1] += launches
+
+    # ---- verification (untimed): bit-exact vs the reference's own output, and round trip ----
+    def verify(self):
+        comp = self.run_deflate()
+        back = self.run_inflate(comp)
+        self.c = self.csize(comp)
+        ok = bool(back.numel() == self.n and bool((back == self.d_in).all()))
+        golden = False
+        if self.env["rank"] == 0 and not self.foreign:
+            try:
+                if self.nbuf == 1:
+                    man = json.load(open(os.path.join(ROOT, "tests", "golden", "manifest.json")))
+                    e = [x for x in man["big"] if x["kind"] == self.kind and x["seed"] == self.seed and x["n"] == self.n][0]
+                    digest = hashlib.sha256(comp.cpu().numpy().tobytes()).hexdigest()
+                    ok = ok and self.c == e["deflate_len"] and digest == e["deflate_sha256"]
+                else:  # rank 0's share of configs[3]: every buffer against the reference's own output
+                    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "batch1m.json")))[: self.nbuf]
+                    hostc = self.d_comp[0].cpu().numpy()
+                    for k, e in enumerate(gold):
+                        digest = hashlib.sha256(hostc[self.c_off[k]: self.c_off[k] + comp[k]].tobytes()).hexdigest()
+                        ok = ok and comp[k] == e["deflate_len"] and digest == e["deflate_sha256"]
+                golden = True
+            except (OSError, IndexError, KeyError):
+                pass
+        self.verified, self.golden_checked = ok, golden
+        return ok
+
+    # ---- records ----
+    def roofline(self, direction, c):
+        """Dominant kernel of one direction (HIP events on the library's stream) against HBM: each direction reads its
+        input once and writes its output once = (n + c) bytes per launch."""
+        kt = self.ktimes[direction]
+        if not kt:
+            return None
+        name, (ms, launches) = max(kt.items(), key=lambda kv: kv[1][0])
+        avg_s = ms / 1e3 / max(launches, 1)
+        achieved = (self.n + c) / avg_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(self.name, {}).get(name)
+            except (OSError, ValueError):
+                traffic = None
+        return {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "traffic_source": None if traffic is None else "profiles/traffic.json: rocprofv3 --pmc passes of this workload (profiles/collect.sh), not collected in this run",
+                "algorithmic_bytes_per_launch": self.n + c, "avg_launch_ms": round(avg_s * 1e3, 4)}
+
+    def cpu_baseline(self):
+        """The oracle (port of the reference algorithm, 1 thread) on a bounded sample of this leg's input."""
+        import numpy as np
+
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import _oracle  # CPU restatement of the reference algorithm: the checker, timed as the baseline
+
+        ns = min(self.n, 64 << 20)  # bounded sample: at most 64 MiB of this GPU's input
+        sample = self.host[:ns]
+        t1 = time.perf_counter()
+        oc = np.frombuffer(self.foreign_bytes, dtype=np.uint8) if self.foreign else _oracle.deflate(sample)
+        t2 = time.perf_counter()
+        ob = _oracle.inflate(oc)
+        t3 = time.perf_counter()
+        assert len(ob) == ns
+        cores = os.cpu_count() or 0
+        if self.foreign:
+            return {"value": round(ns / (t3 - t2) / GIB, 5), "unit": "GiB/s", "cores": 1, "kind": "port",
+                    "sample": "the whole %d MiB stream once: inflate %.2f s, 1 thread of %d host cores" % (ns >> 20, t3 - t2, cores)}
+        return {"value": round(ns / (t3 - t1) / GIB, 5), "unit": "GiB/s", "cores": 1, "kind": "port",
+                "sample": "the first %d MiB of the %s input once: deflate %.2f s + inflate %.2f s, 1 thread of %d host cores"
+                          % (ns >> 20, self.kind, t2 - t1, t3 - t2, cores),
+                "deflate_gibs": round(ns / (t2 - t1) / GIB, 5), "inflate_gibs": round(ns / (t3 - t2) / GIB, 5)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="random64", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: leave the compressed shards where they are")
     args = ap.parse_args()
 
-    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -70,175 +223,160 @@ def main():
 
     z = ge.load()
     z.init(local_rank)
-    spec = WORKLOADS[args.workload]
-    kind, seed, n1 = spec[0], spec[1], spec[2]
-    nbuf = spec[3] if len(spec) > 3 else 1
-    foreign = len(spec) > 4  # inflate-only workload: the compressed stream comes from CPython's zlib
-    n = n1 * nbuf  # uncompressed bytes per GPU and step
-    if nbuf == 1:
-        host = z.gen(kind, seed + rank, n1)
-    else:  # buffer i of the whole job: generator i % 3, seed + i
-        host = np.concatenate([z.gen(MIX[(rank * nbuf + i) % 3], seed + rank * nbuf + i, n1) for i in range(nbuf)])
-    d_in = torch.from_numpy(host).to(dev)
-    d_foreign = None
-    if foreign:
-        import zlib as pyzlib
+    env = {"z": z, "dev": dev, "rank": rank, "world": world}
+    main_name = args.workload or "random64"
+    second_name = None if args.workload else "text64"
+    shard = None
+    if world > 1 and not args.no_gather:
+        import importlib.util
 
-        foreign_bytes = pyzlib.compress(host.tobytes(), 6)
-        d_foreign = torch.from_numpy(np.frombuffer(foreign_bytes, dtype=np.uint8).copy()).to(dev)
-    bound1 = (z.deflate_bound(n1) + 15) // 16 * 16
-    d_comp = torch.empty(bound1 * nbuf, dtype=torch.uint8, device=dev)
-    d_back = torch.empty(n, dtype=torch.uint8, device=dev)
-    sizes = torch.zeros(world, dtype=torch.int64, device=dev)
-    in_off = [i * n1 for i in range(nbuf)]
-    c_off = [i * bound1 for i in range(nbuf)]
-    state = {"clen": None}
-
-    def run_deflate():
-        """-> compressed bytes of this GPU's buffers (a view for one buffer, a count for a batch)"""
-        if foreign:
-            return d_foreign
-        if nbuf == 1:
-            return z.deflate_tensor(d_in, d_comp)
-        clen, st = z.deflate_batch_tensor(d_in, in_off, [n1] * nbuf, d_comp, c_off, [bound1] * nbuf)
-        assert not any(st), st
-        state["clen"] = clen
-        return clen
-
-    def run_inflate(comp):
-        if nbuf == 1:
-            return z.inflate_tensor(comp, d_back)
-        olen, st = z.inflate_batch_tensor(d_comp, c_off, comp, d_back, in_off, [n1] * nbuf)
-        assert not any(st) and all(o == n1 for o in olen), (st[:4], olen[:4])
-        return d_back
-
-    def csize(comp):
-        return int(comp.numel()) if nbuf == 1 else int(sum(comp))
-
-    def step():
-        comp = run_deflate()
-        back = run_inflate(comp)
-        if world > 1:  # exchange: every rank learns every shard's compressed size
-            mine = torch.tensor([csize(comp)], dtype=torch.int64, device=dev)
-            dist.all_gather_into_tensor(sizes, mine)
-        return comp, back
-
-    # --- verification (untimed): bit-exact vs the reference's own output, and round trip ---
-    comp, back = step()
-    c = csize(comp)
-    verified = bool(back.numel() == n and bool((back == d_in).all()))
-    golden_checked = False
-    if rank == 0 and nbuf == 1 and not foreign:
-        try:
-            man = json.load(open(os.path.join(ROOT, "tests", "golden", "manifest.json")))
-            e = [x for x in man["big"] if x["kind"] == kind and x["seed"] == seed and x["n"] == n][0]
-            digest = hashlib.sha256(comp.cpu().numpy().tobytes()).hexdigest()
-            golden_checked = True
-            verified = verified and c == e["deflate_len"] and digest == e["deflate_sha256"]
-        except (OSError, IndexError, KeyError):
-            pass
-
-    for _ in range(args.warmup):
-        step()
-
-    z.set_profiling(True)
-    ktimes = {}
-    t_def = t_inf = 0.0
+        sp = importlib.util.spec_from_file_location("zlibes_amd.shard", os.path.join(ROOT, "zlib.es_amd", "shard.py"))
+        shard = importlib.util.module_from_spec(sp)
+        sp.loader.exec_module(shard)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def reduce_time(elapsed, ok):
+        if world > 1:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+            okt = torch.tensor([1 if ok else 0], dtype=torch.int64, device=dev)
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            ok = bool(okt.item())
+        return elapsed, ok
+
+    # ------------------------------------------------------------------ main leg
+    leg = Leg(main_name, env)
+    verified = leg.verify()
+    owned = [[r * leg.nbuf + i for i in range(leg.nbuf)] for r in range(world)]
+    gathered_bytes = [0]
+
+    def finish(pending):
+        if pending is None:
+            return
+        got, works = pending
+        for w in works:
+            w.wait()
+        torch.cuda.current_stream(dev).synchronize()  # the library runs on its own stream: the host must know the transfer is over
+        if got is not None:
+            gathered_bytes[0] += int(got.arena.numel())
+
+    def step(k, pending, timed):
+        slot = k & 1 if world > 1 else 0
+        ta = time.perf_counter()
+        comp = leg.run_deflate(slot)
+        if timed and not leg.foreign:
+            leg.note_times("deflate")
+        tb = time.perf_counter()
+        leg.run_inflate(comp, slot)
+        if timed:
+            leg.note_times("inflate")
+        tc = time.perf_counter()
+        if shard is not None:
+            # the gather of the step before has had this step's kernels to hide behind; its arena is free again
+            finish(pending)
+            local, lens = leg.local_result(comp, slot)
+            pending = shard.gather_results(local, owned[rank], lens, [0] * leg.nbuf, owned, world * leg.nbuf, dst=0, async_op=True)
+        return pending, tb - ta, tc - tb
+
+    pending = None
+    for k in range(args.warmup):
+        pending, _, _ = step(k, pending, False)
+    finish(pending)
+    pending = None
+    gathered_bytes[0] = 0
+
+    z.set_profiling(True)
+    t_def = t_inf = 0.0
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ta = time.perf_counter()
-        comp = run_deflate()
-        for name, ms, launches in ([] if foreign else z.last_kernel_times()):
-            k = ktimes.setdefault(name, [0.0, 0])
-            k[0] += ms
-            k[1] += launches
-        tb = time.perf_counter()
-        back = run_inflate(comp)
-        for name, ms, launches in z.last_kernel_times():
-            k = ktimes.setdefault(name, [0.0, 0])
-            k[0] += ms
-            k[1] += launches
-        tc = time.perf_counter()
-        if world > 1:
-            mine = torch.tensor([csize(comp)], dtype=torch.int64, device=dev)
-            dist.all_gather_into_tensor(sizes, mine)
-        t_def += tb - ta
-        t_inf += tc - tb
+    for k in range(args.steps):
+        pending, d, i = step(k, pending, True)
+        t_def += d
+        t_inf += i
+    finish(pending)
     barrier()
     elapsed = time.perf_counter() - t0
     z.set_profiling(False)
+    elapsed, verified = reduce_time(elapsed, verified)
 
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        ok = torch.tensor([1 if verified else 0], dtype=torch.int64, device=dev)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        verified = bool(ok.item())
+    # ------------------------------------------------------------------ second leg: the north-star workload
+    text = None
+    if second_name:
+        tl = Leg(second_name, env)
+        tok = tl.verify()
+        comp = tl.run_deflate()
+        for _ in range(args.warmup):
+            tl.run_deflate()
+            tl.run_inflate(comp)
+        z.set_profiling(True)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            tl.run_deflate()
+            tl.note_times("deflate")
+        barrier()
+        t2 = time.perf_counter()
+        for _ in range(args.steps):  # the inflate-only hot loop of configs[2]
+            tl.run_inflate(comp)
+            tl.note_times("inflate")
+        barrier()
+        t3 = time.perf_counter()
+        z.set_profiling(False)
+        td, tok = reduce_time(t2 - t1, tok)
+        ti, tok = reduce_time(t3 - t2, tok)
+        verified = verified and tok
+        if rank == 0:
+            text = {
+                "workload": "text64: one 64 MiB itext buffer per GPU (seed 12345+rank), BASELINE.json configs[2]; deflate loop, then the inflate-only hot loop over the reference-format stream, HBM-resident",
+                "inflate_gibs": round(tl.n * world * args.steps / ti / GIB, 4),
+                "inflate_gibs_per_gpu": round(tl.n * args.steps / ti / GIB, 4),
+                "inflate_ms": round(ti / args.steps * 1e3, 4),
+                "deflate_gibs": round(tl.n * world * args.steps / td / GIB, 4),
+                "deflate_gibs_per_gpu": round(tl.n * args.steps / td / GIB, 4),
+                "deflate_ms": round(td / args.steps * 1e3, 4),
+                "compressed_bytes": tl.c,
+                "verified_bit_exact": tok,
+                "golden_sha256_checked": tl.golden_checked,
+                "roofline": tl.roofline("inflate", tl.c),
+                "roofline_deflate": tl.roofline("deflate", tl.c),
+                "cpu_baseline": None if (world > 1 or args.no_cpu_baseline) else tl.cpu_baseline(),
+                "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for d in ("deflate", "inflate")
+                                        for k, v in sorted(tl.ktimes[d].items(), key=lambda kv: -kv[1][0])},
+            }
+        del tl
 
     if rank == 0:
-        gib = float(1 << 30)
-        value = n * world * args.steps / elapsed / gib
-        # dominant kernel and its algorithmic traffic: each direction reads its input once and
-        # writes its output once = (n + c) bytes per launch (SURVEY §8d)
-        dom = max(ktimes.items(), key=lambda kv: kv[1][0]) if ktimes else None
-        roofline = None
-        if dom:
-            name, (ms, launches) = dom
-            avg_s = ms / 1e3 / max(launches, 1)
-            achieved = (n + c) / avg_s / 1e9
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath):
-                try:
-                    traffic = json.load(open(tpath)).get(args.workload, {}).get(name)
-                except (OSError, ValueError):
-                    traffic = None
-            roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                        "algorithmic_bytes_per_launch": n + c, "avg_launch_ms": round(avg_s * 1e3, 4)}
-        cpu = None
-        if world == 1 and not args.no_cpu_baseline:
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            import _oracle  # CPU restatement of the reference algorithm: the checker, timed as the baseline
-
-            ns = min(n, 64 << 20)  # bounded sample: at most 64 MiB of this GPU's input
-            sample = host[:ns]
-            t1 = time.perf_counter()
-            oc = np.frombuffer(foreign_bytes, dtype=np.uint8) if foreign else _oracle.deflate(sample)
-            t2 = time.perf_counter()
-            ob = _oracle.inflate(oc)
-            t3 = time.perf_counter()
-            assert len(ob) == ns
-            if foreign:
-                cpu = {"value": round(ns / (t3 - t2) / gib, 5), "unit": "GiB/s", "cores": 1, "kind": "port",
-                       "sample": "the whole %d MiB stream once: inflate %.2f s, 1 thread of %d host cores" % (ns >> 20, t3 - t2, os.cpu_count() or 0)}
-            else:
-                cpu = {"value": round(ns / (t3 - t1) / gib, 5), "unit": "GiB/s", "cores": 1, "kind": "port",
-                       "sample": "the first %d MiB of the %s input once: deflate %.2f s + inflate %.2f s, 1 thread of %d host cores"
-                                 % (ns >> 20, kind, t2 - t1, t3 - t2, os.cpu_count() or 0),
-                       "deflate_gibs": round(ns / (t2 - t1) / gib, 5), "inflate_gibs": round(ns / (t3 - t2) / gib, 5)}
+        n, c = leg.n, leg.c
+        value = n * world * args.steps / elapsed / GIB
+        both = dict(leg.ktimes["deflate"])
+        both.update(leg.ktimes["inflate"])
+        dom_dir = "inflate"
+        if both:
+            dom = max(both.items(), key=lambda kv: kv[1][0])[0]
+            dom_dir = "deflate" if dom in leg.ktimes["deflate"] else "inflate"
+        roofline = leg.roofline(dom_dir, c)
+        cpu = None if (world > 1 or args.no_cpu_baseline) else leg.cpu_baseline()
         # measured HBM copy bandwidth on this box (SURVEY §8d: report against vendor peak and a measured copy)
         torch.cuda.synchronize()
         tcp = time.perf_counter()
         for _ in range(20):
-            d_back.copy_(d_in)
+            leg.d_back.copy_(leg.d_in)
         torch.cuda.synchronize()
         copy_gbs = 2 * n * 20 / (time.perf_counter() - tcp) / 1e9
-        if roofline:
-            roofline["measured_copy_GBs"] = round(copy_gbs, 1)
-            roofline["frac_of_measured_copy"] = round(roofline["achieved"] / copy_gbs, 5)
+        for r in (roofline, text and text["roofline"], text and text["roofline_deflate"]):
+            if r:
+                r["measured_copy_GBs"] = round(copy_gbs, 1)
+                r["frac_of_measured_copy"] = round(r["achieved"] / copy_gbs, 5)
+        foreign = leg.foreign
         line = {
             "metric": ("GiB/s inflate of a 64 MiB zlib level-6 stream (uncompressed bytes / wall), output identical to the input" if foreign else
                        "GiB/s deflate+inflate round trip, %s (uncompressed bytes / wall), bit-exact vs reference"
-                       % ("64 MiB buffers" if args.workload.endswith("64") else args.workload)),
+                       % ("64 MiB buffers" if main_name.endswith("64") else main_name)),
             "value": round(value, 4),
             "unit": "GiB/s",
             "n_gpus": world,
@@ -251,17 +389,24 @@ def main():
             "dtype": "u8",
             "data": "synthetic",
             "config": {"workload": "%s: %d x %d MiB %s buffer(s) per GPU (seed %d+index), %s, HBM-resident"
-                                   % (args.workload, nbuf, n1 >> 20, kind, seed,
-                                      "compressed by CPython zlib level 6, inflate only" if foreign else "deflate then inflate"), "buffers_per_step": world * nbuf, "bytes_per_buffer": n1,
-                       "compressed_bytes": c, "parallelism": "independent buffers, one per GPU"},
-            "deflate_gibs_per_gpu": None if foreign else round(n * args.steps / t_def / gib, 4),
-            "inflate_gibs_per_gpu": round(n * args.steps / t_inf / gib, 4),
+                                   % (main_name, leg.nbuf, leg.n1 >> 20, leg.kind, leg.seed,
+                                      "compressed by CPython zlib level 6, inflate only" if foreign else "deflate then inflate"),
+                       "buffers_per_step": world * leg.nbuf, "bytes_per_buffer": leg.n1,
+                       "compressed_bytes": c, "parallelism": "independent buffers, one per GPU",
+                       "gather": (None if shard is None else
+                                  "every step's compressed shards gathered into rank 0's HBM over RCCL/xGMI (sizes all_reduce + one exact-length "
+                                  "send per rank), overlapped with the next step, completed inside the timed region: %d bytes received per step"
+                                  % (gathered_bytes[0] // max(args.steps, 1)))},
+            "deflate_gibs_per_gpu": None if foreign else round(n * args.steps / t_def / GIB, 4),
+            "inflate_gibs_per_gpu": round(n * args.steps / t_inf / GIB, 4),
             "verified_bit_exact": verified,
-            "golden_sha256_checked": golden_checked,
+            "golden_sha256_checked": leg.golden_checked,
             "roofline": roofline,
             "cpu_baseline": cpu,
-            "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(ktimes.items(), key=lambda kv: -kv[1][0])},
+            "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(both.items(), key=lambda kv: -kv[1][0])},
         }
+        if text:
+            line["text64"] = text
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

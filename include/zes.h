@@ -52,13 +52,22 @@ typedef enum zes_status {
 /* Exact reference message for a status (engine-defined codes get a descriptive string). */
 const char* zes_strerror(int status);
 
-/* Library/device lifecycle.  zes_init(device) binds the calling process to one HIP device
- * (one process per GPU; bench.py passes LOCAL_RANK).  Idempotent.  replaces: nothing (the
- * reference has no state); required because device scratch is pooled across calls. */
+/* Library/device lifecycle.  zes_init(device) binds the process to one HIP device (one process per GPU;
+ * bench.py passes LOCAL_RANK).  Idempotent; a second call with another device returns ZES_E_ARG.  Every entry
+ * point may be called from any thread: calls are serialised by one lock and each makes the bound device current
+ * on its calling thread for the duration of the call (HIP's current device is per thread).
+ * replaces: nothing (the reference has no state); required because device scratch is pooled across calls. */
 int zes_init(int device);
 int zes_shutdown(void);
 /* Fills name (<= cap bytes) with the device's gcnArchName, *cus with its CU count. */
 int zes_device_info(char* name, int cap, int* cus, uint64_t* hbm_bytes);
+
+/* Page-locked host memory the DMA engines can read and write directly.  The host-pointer entry points accept any
+ * memory; buffers from here skip the library's pinned staging ring (one pass less over the bytes on each side).
+ * A binding exposes it as an allocator for its callers' arrays (`allocPinned`).  Free before
+ * zes_shutdown.  replaces: nothing (the reference works on ordinary Uint8Arrays). */
+int zes_host_alloc(uint64_t n, void** p);
+int zes_host_free(void* p);
 
 /* Output capacity sufficient for zes_deflate of an n-byte input.
  * replaces: the `streamHeap` sizing in src/deflate.ts:16 (+6 for the zlib wrapper, src/zlib.ts:42). */
@@ -66,7 +75,9 @@ int zes_deflate_bound(uint64_t n, uint64_t* cap);
 
 /* zlib-wrapped compress: out = 78 9C | raw deflate | Adler-32 BE.  Bit-exact with
  * replaces: `export function deflate(input)` src/zlib.ts:25-49 (→ src/deflate.ts:14-39, src/lz77.ts, src/huffman.ts:55-153, src/adler32.ts).
- * n == 0, n == 1 and n % 131072 == 1 return ZES_E_CORRUPT exactly as the reference throws. */
+ * n == 0, n == 1 and n % 131072 == 1 return ZES_E_CORRUPT exactly as the reference throws.
+ * Device forms (here and below): d_in / d_out, and in the batch forms every in_off / out_off, must be 16-byte
+ * aligned — the kernels read and write whole 16-byte groups — else ZES_E_ARG.  The host forms take any alignment. */
 int zes_deflate(const uint8_t* in, uint64_t n, uint8_t* out, uint64_t cap, uint64_t* out_len);
 int zes_deflate_dev(const uint8_t* d_in, uint64_t n, uint8_t* d_out, uint64_t cap, uint64_t* out_len);
 
@@ -76,12 +87,15 @@ int zes_deflate_dev(const uint8_t* d_in, uint64_t n, uint8_t* d_out, uint64_t ca
  * ignores FCHECK/FDICT and the Adler-32 trailer).  On ZES_E_NOSPACE *out_len = bytes needed. */
 int zes_inflate(const uint8_t* in, uint64_t c, uint8_t* out, uint64_t cap, uint64_t* out_len, uint32_t flags);
 int zes_inflate_dev(const uint8_t* d_in, uint64_t c, uint8_t* d_out, uint64_t cap, uint64_t* out_len, uint32_t flags);
-/* Size-only pass (decodes, writes nothing to the caller): lets a binding allocate the exact
- * result the way the reference's growable Uint8WriteStream (src/utils/Uint8WriteStream.ts:1-25) does. */
+/* Size-only pass (decodes, writes nothing to the caller, keeps nothing). */
 int zes_inflate_size(const uint8_t* in, uint64_t c, uint64_t* n, uint32_t flags);
-/* Copies out what the zes_inflate_size call right before it decoded (it stays in the library's device buffer),
- * so that size-then-allocate bindings decode and cross PCIe once.  Any other call in between drops it (ZES_E_ARG). */
-int zes_inflate_fetch(uint8_t* out, uint64_t cap, uint64_t* out_len);
+/* Decode once, then let the caller allocate the exact result: after the stream has been decoded on the device,
+ * alloc(user, index, n) is called once, on the calling thread, for the n result bytes (n may be 0) and the bytes
+ * are copied into what it returns; NULL from alloc → ZES_E_ARG.  The whole call holds the library's lock: there is
+ * no state between calls.  index is 0 here (the batch form passes the buffer's index).
+ * replaces: the growable Uint8WriteStream of src/inflate.ts:17,39 (src/utils/Uint8WriteStream.ts:1-25). */
+typedef uint8_t* (*zes_alloc_fn)(void* user, uint32_t index, uint64_t n);
+int zes_inflate_alloc(const uint8_t* in, uint64_t c, zes_alloc_fn alloc, void* user, uint64_t* out_len, uint32_t flags);
 
 /* Raw DEFLATE, without the zlib wrapper, for callers that embed DEFLATE in another container.
  * zes_deflate_raw*  replaces: `export function deflate(input)` of src/deflate.ts:14-39 (what src/zlib.ts:35 wraps):
@@ -112,6 +126,33 @@ int zes_deflate_batch_dev(const uint8_t* d_in, const uint64_t* in_off, const uin
 int zes_inflate_batch_dev(const uint8_t* d_in, const uint64_t* in_off, const uint64_t* in_len,
                           uint8_t* d_out, const uint64_t* out_off, const uint64_t* out_cap,
                           uint64_t* out_len, int32_t* status, uint32_t count, uint32_t flags);
+/* The same over host pointers (what a binding's deflateBatch(Uint8Array[]) / inflateBatch hands over): in[i] has
+ * in_len[i] bytes.  Deflate writes buffer i to out[i] (capacity out_cap[i] >= zes_deflate_bound(in_len[i]));
+ * inflate asks alloc(user, i, n) for buffer i's n result bytes once it is decoded (not called for a buffer whose
+ * status is an error).  Per-buffer status[] / out_len[] as above; the return value is only non-zero when the call
+ * as a whole could not run. */
+int zes_deflate_batch(const uint8_t* const* in, const uint64_t* in_len, uint8_t* const* out, const uint64_t* out_cap,
+                      uint64_t* out_len, int32_t* status, uint32_t count);
+int zes_inflate_batch_alloc(const uint8_t* const* in, const uint64_t* in_len, zes_alloc_fn alloc, void* user,
+                            uint64_t* out_len, int32_t* status, uint32_t count, uint32_t flags);
+
+/* One buffer over several GPUs.  Blocks of the reference format are independent: every 131072-byte
+ * block gets its own LZ77 index and its own Huffman codes, and blocks are concatenated bit by bit
+ * (src/deflate.ts:20-37, src/lz77.ts:11-22).  So each GPU compresses a contiguous range of blocks and one of them
+ * joins the bit streams; the result is bit-identical to zes_deflate of the whole buffer.
+ * zes_deflate_range_dev: d_in = first byte of the range, n = its length (a multiple of 131072 unless final_range),
+ *   n_readable >= n = bytes readable from d_in — the match finder compares up to 258 bytes past a block's end
+ *   (src/lz77.ts:78-85), so a range that is not the last needs that much of the next one behind it.  final_range != 0
+ *   sets BFINAL on the range's last block (src/deflate.ts:21-27).  d_out receives the raw bit stream from bit 0
+ *   ((*out_bits + 7) / 8 bytes, zero padded; cap >= zes_deflate_bound(n)); *adler = Adler-32 of the range's bytes.
+ * zes_deflate_join_dev: 78 9C | the pieces, bit-concatenated | zero pad | Adler-32 of the whole (combined from the
+ *   pieces' values and lengths: src/adler32.ts:1-10 is associative in that sense), into d_out.  The pieces are device
+ *   pointers on this GPU (4-byte aligned), in order.
+ * replaces: the block loop of src/deflate.ts:20-34 and the wrapper of src/zlib.ts:25-49, split at block boundaries. */
+int zes_deflate_range_dev(const uint8_t* d_in, uint64_t n, uint64_t n_readable, int final_range, uint8_t* d_out, uint64_t cap,
+                          uint64_t* out_bits, uint32_t* adler);
+int zes_deflate_join_dev(const uint8_t* const* d_piece, const uint64_t* piece_bits, const uint32_t* piece_adler,
+                         const uint64_t* piece_len, uint32_t count, uint8_t* d_out, uint64_t cap, uint64_t* out_len);
 
 /* Stage-level entry points (device pointers) used by the kernel parity tests; each mirrors
  * one internal function of the reference. */

@@ -486,6 +486,33 @@ int zor_deflate_raw(const uint8_t* in, uint64_t n, uint8_t* out, uint64_t cap, u
   return ZOR_OK;
 }
 
+/* The block loop of src/deflate.ts:20-34 over the blocks [start, start + len) of an n-byte input only: the raw bit
+ * stream of that block range from bit 0 of `out`, BFINAL on its last block iff `final_range`, no padding beyond the
+ * last byte; *out_bits = its length in bits.  Checker for the multi-GPU split of one buffer: the
+ * ranges of a buffer, concatenated bit by bit, are the buffer's raw stream. */
+int zor_deflate_range(const uint8_t* in, uint64_t n, uint64_t start, uint64_t len, int final_range, uint8_t* out, uint64_t cap,
+                      uint64_t* out_bits) {
+  const uint64_t heap = (len < BLOCK_MAX / 2) ? BLOCK_MAX : len * 2;
+  if (cap < heap || (start % BLOCK_MAX) || start + len > n || len == 0) return ZOR_E_NOSPACE;
+  memset(out, 0, heap);
+  zor_bw w = {out, heap, 0, 0, 0, 0, 0};
+  uint32_t* tokens = (uint32_t*)malloc(sizeof(uint32_t) * (BLOCK_MAX + 2));
+  int rc = ZOR_OK;
+  for (uint64_t processed = start; processed < start + len; processed += BLOCK_MAX) {
+    const uint32_t target = (uint32_t)((start + len - processed < BLOCK_MAX) ? start + len - processed : BLOCK_MAX);
+    bw_range(&w, (final_range && processed + BLOCK_MAX >= start + len) ? 1 : 0, 1);
+    bw_range(&w, 2, 2);
+    rc = deflate_dynamic_block(&w, in, n, processed, target, tokens);
+    if (rc) break;
+  }
+  free(tokens);
+  if (rc) return rc;
+  if (w.err) return w.err;
+  *out_bits = w.idx * 8 + w.now_idx;
+  if (w.now_idx) out[w.idx] = (uint8_t)w.now_bits; /* the bits of the unfinished byte */
+  return ZOR_OK;
+}
+
 /* zlib wrapper — src/zlib.ts:25-49 */
 int zor_deflate(const uint8_t* in, uint64_t n, uint8_t* out, uint64_t cap, uint64_t* out_len) {
   uint64_t need;

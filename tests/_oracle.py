@@ -40,6 +40,7 @@ def lib():
         L.zor_inflate.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p), u64p]
         L.zor_inflate_raw.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p), u64p]
         L.zor_deflate_raw.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, u64p]
+        L.zor_deflate_range.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, u64p]
         L.zor_lz77_block.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, u32p]
         L.zor_huff_lengths.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.zor_free.argtypes = [C.c_void_p]
@@ -128,3 +129,15 @@ def huff_lengths(hist, maxlen):
     lens = np.zeros(h.size, dtype=np.uint8)
     lib().zor_huff_lengths(h.ctypes.data, h.size, maxlen, lens.ctypes.data)
     return lens
+
+
+def deflate_range(data, start, length, final):
+    """Raw bit stream of the blocks [start, start + length) of `data` -> (bytes, nbits)."""
+    a = _as_u8(data)
+    cap = max(2 * length, 131072) + 64
+    out = np.zeros(cap, dtype=np.uint8)
+    bits = C.c_uint64()
+    rc = lib().zor_deflate_range(a.ctypes.data, a.size, start, length, 1 if final else 0, out.ctypes.data, cap, C.byref(bits))
+    if rc:
+        raise OracleError(rc)
+    return out[: (bits.value + 7) // 8].copy(), bits.value

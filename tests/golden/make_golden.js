@@ -163,7 +163,10 @@ for (const kn of ['xorshift', 'lowent4k', 'itext']) {
 addCase('xorshift', 1, 131071); addCase('xorshift', 1, 131072); addCase('xorshift', 1, 131074);
 addCase('xorshift', 1, 131073);   /* throws */
 addCase('itext', 1, 4 * 1048576); addCase('lowent4k', 77, 3 * 1048576 + 17); addCase('xorshift', 5, 2 * 1048576 + 5);
-if (big) { addCase('xorshift', 12345, 64 * 1048576); addCase('itext', 12345, 64 * 1048576); addCase('lowent4k', 12345, 64 * 1048576); }
+if (big) {
+  addCase('xorshift', 12345, 64 * 1048576); addCase('itext', 12345, 64 * 1048576); addCase('lowent4k', 12345, 64 * 1048576);
+  addCase('lowent4k', 12345, 256 * 1048576);   /* BASELINE.json configs[4]: one of the 8 x 256 MiB low-entropy buffers */
+}
 /* zeros (SURVEY App. B) */
 const zeros = [];
 for (const n of [1000, 65535, 65536, 131072, 262144, 1048576]) {
@@ -179,6 +182,23 @@ try {
 const bigEntries = big ? manifest.filter((e) => e.n >= 64 * 1048576) : prevBig;
 fs.writeFileSync(path.join(OUT, 'manifest.json'), JSON.stringify(
   {cases: manifest.filter((e) => e.n < 64 * 1048576), zeros: zeros, big: bigEntries}, null, 1));
+
+/* ---- 2b. BASELINE.json configs[3]: 1024 x 1 MiB independent buffers, buffer i = generator i % 3 (xorshift, itext,
+ * lowent4k), seed 12345 + i (SURVEY §8d C4).  About ten minutes of the reference: only under GOLDEN_BATCH=1,
+ * otherwise the committed batch1m.json is left alone. ---- */
+if (process.env.GOLDEN_BATCH === '1') {
+  const MIX = ['xorshift', 'itext', 'lowent4k'];
+  const count = parseInt(process.env.GOLDEN_BATCH_COUNT || '1024', 10);
+  const entries = [];
+  for (let i = 0; i < count; i++) {
+    const kn = MIX[i % 3];
+    const input = GEN[KIND[kn]](1048576, 12345 + i);
+    const o = Z.deflate(input);
+    entries.push({i: i, kind: kn, seed: 12345 + i, n: 1048576, input_sha256: sha(input), deflate_len: o.length, deflate_sha256: sha(o)});
+    if (i % 64 === 63) console.log('batch1m', i + 1, '/', count);
+  }
+  fs.writeFileSync(path.join(OUT, 'batch1m.json'), JSON.stringify(entries));
+}
 
 /* ---- 3. stage-level: LZ77 tokens (token = literal byte | 0x80000000|(len-3)<<16|(dist-1)) ---- */
 function lzTokens(input, start, len) {

@@ -88,5 +88,82 @@ it('malformed-stream cases (every 7th)', () => {
   msg = null;
   try { await zlibes.deflateAsync(new Uint8Array(1)); } catch (e) { msg = e.message; }
   it('deflateAsync rejects with the reference message', () => assert.strictEqual(msg, 'Data is corrupted'));
+  // synchronous calls while Promise-returning ones are in flight on worker threads: the library keeps no state
+  // between calls (zes_inflate_alloc decodes and copies out under one lock), so they cannot disturb each other
+  {
+    const pending = [];
+    for (let k = 0; k < 6; k++) pending.push(k % 2 ? zlibes.inflateAsync(CMP_BIN) : zlibes.deflateAsync(RAW_BIN));
+    const syncOut = [];
+    for (let k = 0; k < 6; k++) syncOut.push(k % 2 ? zlibes.inflate(fromHex(kat.kat.DYNAMIC)) : zlibes.deflate(RAW));
+    const res = await Promise.all(pending);
+    it('sync calls interleaved with pending async ones', () => {
+      for (let k = 0; k < 6; k++) {
+        if (k % 2) { assert.deepStrictEqual(syncOut[k], RAW); assert.ok(Buffer.from(res[k]).equals(Buffer.from(RAW_BIN))); }
+        else { assert.strictEqual(hex(syncOut[k]), kat.small.RAW.deflate); assert.strictEqual(hex(res[k]), hex(outs[1])); }
+      }
+    });
+  }
+  // batch forms: element i is what deflate(inputs[i]) / inflate(inputs[i]) returns, or the Error it throws
+  {
+    const ins = [RAW, RAW_BIN, new Uint8Array(1), fromHex(kat.small.digits1023.input)];
+    const b = zlibes.deflateBatch(ins);
+    it('deflateBatch', () => {
+      assert.strictEqual(hex(b[0]), kat.small.RAW.deflate);
+      assert.strictEqual(hex(b[1]), hex(outs[1]));
+      assert.ok(b[2] instanceof Error && b[2].message === 'Data is corrupted');
+      assert.strictEqual(hex(b[3]), kat.small.digits1023.deflate);
+      assert.ok(b[0] instanceof Uint8Array && b[0].byteOffset === 0 && b[0].buffer.byteLength === b[0].length);
+    });
+    const back = zlibes.inflateBatch([b[0], CMP_BIN, new Uint8Array([0x78, 0x9c, 7, 0, 0, 0]), b[3], fromHex(kat.kat.FIXED)]);
+    it('inflateBatch', () => {
+      assert.deepStrictEqual(back[0], RAW);
+      assert.ok(Buffer.from(back[1]).equals(Buffer.from(RAW_BIN)));
+      assert.ok(back[2] instanceof Error && back[2].message === 'Not supported BTYPE : 3');
+      assert.strictEqual(hex(back[3]), kat.small.digits1023.input);
+      assert.deepStrictEqual(back[4], RAW);
+    });
+    const ab = await zlibes.deflateBatchAsync(ins);
+    const abk = await zlibes.inflateBatchAsync([ab[0], ab[1]]);
+    it('batch Async forms', () => {
+      assert.strictEqual(hex(ab[1]), hex(outs[1]));
+      assert.ok(ab[2] instanceof Error && ab[2].message === 'Data is corrupted');
+      assert.ok(Buffer.from(abk[1]).equals(Buffer.from(RAW_BIN)));
+    });
+    it('batch argument checks', () => assert.throws(() => zlibes.deflateBatch([RAW, 5]), TypeError));
+    it('inflateRaw offset checks', () => {
+      assert.throws(() => zlibes.inflateRaw(RAW, -1), TypeError);
+      assert.throws(() => zlibes.inflateRaw(RAW, 1.5), TypeError);
+      assert.throws(() => zlibes.inflateRaw(RAW, NaN), TypeError);
+    });
+  }
+  // pinned arrays are ordinary Uint8Arrays to every entry point
+  {
+    const p = zlibes.allocPinned(RAW_BIN.length);
+    p.set(RAW_BIN);
+    it('allocPinned input', () => assert.strictEqual(hex(zlibes.deflate(p)), hex(outs[1])));
+  }
+  // BASELINE.json configs[3], this GPU's share: 128 x 1 MiB buffers through the batch entry, every result against the
+  // reference's own output (tests/golden/batch1m.json; the inputs are written by the pytest wrapper from the same
+  // generators the fixture script restates)
+  if (process.env.ZES_BATCH1M_INPUT) {
+    const crypto = require('crypto');
+    const sha = (u8) => crypto.createHash('sha256').update(Buffer.from(u8.buffer, u8.byteOffset, u8.length)).digest('hex');
+    const gold = JSON.parse(fs.readFileSync(path.join(G, 'batch1m.json'), 'utf8')).slice(0, 128);
+    const all = new Uint8Array(fs.readFileSync(process.env.ZES_BATCH1M_INPUT));
+    assert.strictEqual(all.length, 128 << 20);
+    const ins = gold.map((e, k) => all.subarray(k << 20, (k + 1) << 20));
+    const t0 = Date.now();
+    const comp = zlibes.deflateBatch(ins);
+    const t1 = Date.now();
+    const back = await zlibes.inflateBatchAsync(comp);
+    const t2 = Date.now();
+    it('128 x 1 MiB deflateBatch == reference (' + (t1 - t0) + ' ms), inflateBatchAsync back (' + (t2 - t1) + ' ms)', () => {
+      for (let k = 0; k < 128; k++) {
+        assert.strictEqual(comp[k].length, gold[k].deflate_len, 'length of buffer ' + k);
+        assert.strictEqual(sha(comp[k]), gold[k].deflate_sha256, 'bytes of buffer ' + k);
+        assert.ok(Buffer.from(back[k]).equals(Buffer.from(ins[k].buffer, ins[k].byteOffset, ins[k].length)), 'round trip of buffer ' + k);
+      }
+    });
+  }
   console.log('all ' + n + ' host checks passed');
 })().catch((e) => { console.error(e); process.exit(1); });

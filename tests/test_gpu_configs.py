@@ -1,0 +1,256 @@
+"""BASELINE.json's larger configurations and the entry points around them, on the GPU, through the C-ABI:
+
+  configs[3]  this GPU's share of the 1024 x 1 MiB batch (128 buffers, generator i % 3, seed 12345 + i) through the
+              batch entry points, every buffer against the reference's own output (tests/golden/batch1m.json)
+  configs[4]  one 256 MiB low-entropy buffer against the reference's own output, round trip, block-parallel tier
+  multi-GPU   the gather of shard.py on the "nccl" backend (world size 1: all a one-GPU box allows), one buffer
+              split into block ranges and joined again
+  boundary    host-pointer batch forms, calls from other threads, pinned host memory, unaligned device views
+"""
+import ctypes as C
+import hashlib
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden
+
+pytestmark = pytest.mark.gpu
+MIX = ("xorshift", "itext", "lowent4k")
+
+
+def dev(a, gpu):
+    import torch
+
+    return torch.from_numpy(np.ascontiguousarray(a)).to(gpu)
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def load_shard():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("zlibes_amd_shard", os.path.join(ROOT, "zlib.es_amd", "shard.py"))
+    shard = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(shard)
+    return shard
+
+
+@pytest.fixture(scope="module")
+def nccl_group(gpu):
+    import torch.distributed as dist
+
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = "29533"
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=gpu)
+    yield dist.group.WORLD
+    dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------
+# configs[3]: this GPU's 128 of the 1024 x 1 MiB buffers
+# ---------------------------------------------------------------------------------------------
+def test_config3_batch_share_bit_exact_vs_reference(z, gpu):
+    import torch
+
+    entries = golden("batch1m.json")[:128]  # rank 0's share of the job (bench.py: buffer i of rank r = r * 128 + i)
+    n1 = 1 << 20
+    cnt = len(entries)
+    host = np.empty(cnt * n1, dtype=np.uint8)
+    for k, e in enumerate(entries):
+        assert e["kind"] == MIX[e["i"] % 3] and e["seed"] == 12345 + e["i"] and e["n"] == n1
+        host[k * n1:(k + 1) * n1] = z.gen(e["kind"], e["seed"], n1)
+        if k % 16 == 0:
+            assert sha(host[k * n1:(k + 1) * n1]) == e["input_sha256"]
+    d_in = dev(host, gpu)
+    bound = (z.deflate_bound(n1) + 15) // 16 * 16
+    d_comp = torch.empty(bound * cnt, dtype=torch.uint8, device=gpu)
+    in_off = [k * n1 for k in range(cnt)]
+    c_off = [k * bound for k in range(cnt)]
+    clen, st = z.deflate_batch_tensor(d_in, in_off, [n1] * cnt, d_comp, c_off, [bound] * cnt)
+    assert not any(st)
+    comp_h = d_comp.cpu().numpy()
+    for k, e in enumerate(entries):
+        assert clen[k] == e["deflate_len"], (k, clen[k], e["deflate_len"])
+        assert sha(comp_h[c_off[k]:c_off[k] + clen[k]]) == e["deflate_sha256"], k
+    d_back = torch.empty(cnt * n1, dtype=torch.uint8, device=gpu)
+    olen, st = z.inflate_batch_tensor(d_comp, c_off, clen, d_back, in_off, [n1] * cnt)
+    assert not any(st) and all(o == n1 for o in olen)
+    assert bool((d_back == d_in).all()) and z.last_inflate_tier() == 1
+
+
+# ---------------------------------------------------------------------------------------------
+# configs[4]: one 256 MiB low-entropy buffer
+# ---------------------------------------------------------------------------------------------
+def test_config4_256mib_lowent_bit_exact_vs_reference(z, gpu):
+    import torch
+
+    e = [x for x in golden("manifest.json")["big"] if x["kind"] == "lowent4k" and x["n"] == 256 << 20][0]
+    a = z.gen("lowent4k", e["seed"], e["n"])
+    assert sha(a) == e["input_sha256"]
+    t = dev(a, gpu)
+    comp = z.deflate_tensor(t)
+    assert comp.numel() == e["deflate_len"]
+    assert sha(comp.cpu().numpy()) == e["deflate_sha256"]
+    out = torch.empty(e["n"], dtype=torch.uint8, device=gpu)
+    back = z.inflate_tensor(comp.clone(), out)
+    assert back.numel() == e["n"] and bool((back == t).all())
+    assert z.last_inflate_tier() == 1
+    assert int.from_bytes(comp[-4:].cpu().numpy().tobytes(), "big") == z.adler32_tensor(t)
+
+
+# ---------------------------------------------------------------------------------------------
+# multi-GPU code paths on the one GPU there is
+# ---------------------------------------------------------------------------------------------
+def test_run_sharded_over_nccl(z, oracle, gpu, nccl_group):
+    shard = load_shard()
+    specs = [("itext", 1, 50000), ("xorshift", 2, 131074), ("lowent4k", 3, 9000), ("itext", 4, 1), ("xorshift", 5, 300), ("itext", 6, 262144)]
+    bufs = [z.gen(k, s, n) for k, s, n in specs]
+    run_deflate, run_inflate = shard.gpu_engines(z, gpu)
+    res = shard.run_sharded(bufs, run_deflate, group=nccl_group, device=gpu)
+    comps = []
+    for b, (st, data) in zip(bufs, res):
+        if len(b) == 1:
+            assert st == -3 and len(data) == 0  # 'Data is corrupted' (SURVEY A.7), carried through the gather
+            continue
+        assert st == 0 and data.tobytes() == oracle.deflate(b).tobytes()
+        comps.append((b, data))
+    back = shard.run_sharded([c for _, c in comps], run_inflate, group=nccl_group, device=gpu)
+    for (b, _), (st, data) in zip(comps, back):
+        assert st == 0 and data.tobytes() == b.tobytes()
+
+
+def test_block_ranges_join_to_the_whole_stream(z, oracle, gpu):
+    """zes_deflate_range_dev x 3 + zes_deflate_join_dev == zes_deflate_dev of the whole buffer == the oracle."""
+    for kind, seed, n, cuts in (("itext", 31, 5 * 131072 + 4321, (0, 2, 3, 6)), ("lowent4k", 32, 3 * 131072, (0, 1, 2, 3)),
+                                ("xorshift", 33, 2 * 131072 + 2, (0, 1, 1, 3))):
+        a = z.gen(kind, seed, n)
+        t = dev(a, gpu)
+        want = z.deflate_tensor(t).cpu().numpy()
+        assert want.tobytes() == oracle.deflate(a).tobytes()
+        pieces, bits, adlers, lens = [], [], [], []
+        for k in range(len(cuts) - 1):
+            lo, hi = cuts[k] * 131072, min(n, cuts[k + 1] * 131072)
+            if hi <= lo:
+                continue
+            p, nb, ad = z.deflate_range_tensor(t, lo, hi, final=(hi == n))
+            want_p, want_bits = oracle.deflate_range(a, lo, hi - lo, hi == n)
+            assert nb == want_bits and p.cpu().numpy().tobytes() == want_p.tobytes(), (kind, k)
+            assert ad == oracle.adler32(a[lo:hi])
+            pieces.append(p.clone())
+            bits.append(nb)
+            adlers.append(ad)
+            lens.append(hi - lo)
+        got = z.deflate_join_tensors(pieces, bits, adlers, lens).cpu().numpy()
+        assert got.tobytes() == want.tobytes(), kind
+
+
+def test_deflate_split_over_nccl(z, oracle, gpu, nccl_group):
+    shard = load_shard()
+    n = 3 * 131072 + 777
+    a = z.gen("itext", 55, n)
+    t = dev(a, gpu)
+    res = shard.deflate_split(n, lambda lo, hi, final: z.deflate_range_tensor(t, lo, hi, final), join=z.deflate_join_tensors,
+                              group=nccl_group, device=gpu)
+    assert res.cpu().numpy().tobytes() == oracle.deflate(a).tobytes()
+
+
+# ---------------------------------------------------------------------------------------------
+# boundary
+# ---------------------------------------------------------------------------------------------
+def test_host_batch_forms(z, oracle, gpu):
+    specs = [("itext", 1, 300000), ("xorshift", 2, 131074), ("lowent4k", 3, 70000), ("itext", 4, 2), ("xorshift", 5, 131073), ("itext", 6, 1)]
+    bufs = [z.gen(k, s, n) for k, s, n in specs]
+    outs = z.deflate_batch(bufs)
+    comps = []
+    for b, o in zip(bufs, outs):
+        if len(b) % 131072 == 1:
+            assert isinstance(o, z.ZlibEsError) and str(o) == "Data is corrupted"
+            continue
+        assert o.tobytes() == oracle.deflate(b).tobytes()
+        comps.append((b, o))
+    streams = [c for _, c in comps] + [np.frombuffer(bytes([0x78, 0x9C, 7, 0, 0, 0]), dtype=np.uint8), np.zeros(0, dtype=np.uint8),
+                                       oracle.deflate(np.zeros(3 << 20, dtype=np.uint8))]  # (the last one inflates far beyond the first guess)
+    back = z.inflate_batch(streams)
+    for (b, _), o in zip(comps, back):
+        assert o.tobytes() == b.tobytes()
+    assert isinstance(back[len(comps)], z.ZlibEsError) and str(back[len(comps)]) == "Not supported BTYPE : 3"
+    assert isinstance(back[len(comps) + 1], z.ZlibEsError) and str(back[len(comps) + 1]) == "Not compressed by deflate"
+    assert len(back[-1]) == 3 << 20 and not back[-1].any()
+
+
+def test_calls_from_other_threads(z, oracle, gpu):
+    """Every entry point makes the bound device current on its calling thread (HIP's current device is per thread)
+    and holds one lock: host calls from four threads at once give the single-thread results."""
+    bufs = [z.gen(MIX[i % 3], 700 + i, 200000 + 1111 * i) for i in range(8)]
+    want = [oracle.deflate(b) for b in bufs]
+    got = [None] * len(bufs)
+    errs = []
+
+    def work(i):
+        try:
+            c = z.deflate(bufs[i])
+            r = z.inflate(c)
+            a = z.adler32(bufs[i])
+            got[i] = (c.tobytes(), r.tobytes(), a)
+        except Exception as e:  # noqa: BLE001 - reported below
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(bufs))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for i, b in enumerate(bufs):
+        assert got[i] == (want[i].tobytes(), b.tobytes(), oracle.adler32(b))
+
+
+def test_pinned_host_memory_and_large_host_calls(z, oracle, gpu):
+    """The host forms stage pageable memory through a pinned ring (chunks of 4 MiB) and hand pinned memory to the
+    DMA engine as it is: both give the bytes of the device form."""
+    n = (9 << 20) + 12345  # three ring chunks, the last one short
+    a = z.gen("itext", 808, n)
+    want = oracle.deflate(a)
+    got = z.deflate(a)
+    assert got.tobytes() == want.tobytes()
+    assert z.inflate(got).tobytes() == a.tobytes()
+    pin = z.host_alloc(n)
+    try:
+        pin[:] = a
+        got2 = z.deflate(pin)
+        assert got2.tobytes() == want.tobytes()
+        assert z.adler32(pin) == oracle.adler32(a)
+    finally:
+        z.host_free(pin)
+
+
+def test_unaligned_device_views_are_staged(z, oracle, gpu):
+    import torch
+
+    a = z.gen("itext", 4141, 300003)
+    t = dev(a, gpu)
+    v = t[3:]  # data_ptr() % 16 == 3
+    assert v.data_ptr() % 16 != 0
+    comp = z.deflate_tensor(v)
+    assert comp.cpu().numpy().tobytes() == oracle.deflate(a[3:]).tobytes()
+    big = torch.zeros(comp.numel() + 5, dtype=torch.uint8, device=gpu)
+    big[5:] = comp
+    out = torch.empty(300000, dtype=torch.uint8, device=gpu)
+    back = z.inflate_tensor(big[5:], out)
+    assert back.cpu().numpy().tobytes() == a[3:].tobytes()
+    with pytest.raises(AssertionError):
+        z.inflate_tensor(comp, torch.empty(300016, dtype=torch.uint8, device=gpu)[1:])
+
+
+def test_inflate_size_keeps_nothing(z, oracle, gpu):
+    a = z.gen("lowent4k", 9, 500000)
+    c = oracle.deflate(a)
+    need = C.c_uint64()
+    assert z.lib().zes_inflate_size(c.ctypes.data, c.size, C.byref(need), 0) == 0 and need.value == a.size
+    assert not hasattr(z.lib(), "zes_inflate_fetch")

@@ -63,6 +63,79 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _load_shard():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("shard_mod", os.path.join(ROOT, "zlib.es_amd", "shard.py"))
+    shard = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(shard)
+    return shard
+
+
+def _split_worker(rank, world, port, q):
+    """One buffer over two ranks: block ranges, the (bits, adler, length) exchange, the gather of the
+    pieces and the shift-merge at a seam that is not on a byte boundary — against the oracle's deflate of the whole."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+
+    import __graft_entry__ as ge
+    import _oracle
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    z = ge.load()
+    shard = _load_shard()
+    ok = True
+    seams = []
+    for kind, seed, n in (("itext", 77, 4 * 131072 + 50001), ("lowent4k", 5, 2 * 131072), ("xorshift", 9, 131072 + 2), ("itext", 3, 70000)):
+        data = z.gen(kind, seed, n)  # 5 blocks -> 3 + 2; 2 -> 1 + 1; 2 -> 1 + 1 (a 2-byte last block); 1 -> 1 + 0
+
+        def rng(lo, hi, final):
+            piece, bits = _oracle.deflate_range(data, lo, hi - lo, final)
+            seams.append(bits & 7)
+            return piece, bits, _oracle.adler32(data[lo:hi])
+
+        res = shard.deflate_split(n, rng)
+        if rank == 0:
+            ok = ok and res.tobytes() == _oracle.deflate(data).tobytes()
+        else:
+            assert res is None
+    if rank == 0:
+        q.put(ok and any(seams))  # at least one piece ended inside a byte
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_split_one_buffer_over_two_ranks_gloo():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_split_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert q.get(timeout=5) is True
+
+
+def test_adler_combine_and_block_split():
+    import zlib as pyzlib
+
+    shard = _load_shard()
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 256, 300001, dtype=np.uint8).tobytes()
+    cuts = [0, 1, 70000, 70000, 131072, 300001]
+    parts = [(pyzlib.adler32(a[cuts[i]:cuts[i + 1]]), cuts[i + 1] - cuts[i]) for i in range(len(cuts) - 1)]
+    assert shard.adler_combine(parts) == pyzlib.adler32(a)
+    assert shard.split_blocks(5 * 131072 + 7, 4) == [(0, 2), (2, 4), (4, 5), (5, 6)]
+    assert shard.split_blocks(131072, 8)[0] == (0, 1) and shard.split_blocks(131072, 8)[7] == (1, 1)
+
+
 def test_partition_is_balanced_and_deterministic():
     import importlib.util
 

@@ -53,6 +53,9 @@ class ZesKTime(C.Structure):
     _fields_ = [("name", C.c_char_p), ("ms", C.c_float), ("launches", C.c_uint32)]
 
 
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64)  # zes_alloc_fn of include/zes.h
+
+
 def build(force=False):
     """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     srcdir = os.path.join(_HERE, "csrc")
@@ -81,7 +84,11 @@ def lib():
         for name in ("zes_inflate", "zes_inflate_dev"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, u64p, C.c_uint32]
         L.zes_inflate_size.argtypes = [C.c_void_p, C.c_uint64, u64p, C.c_uint32]
-        L.zes_inflate_fetch.argtypes = [C.c_void_p, C.c_uint64, u64p]
+        L.zes_inflate_alloc.argtypes = [C.c_void_p, C.c_uint64, ALLOC_FN, C.c_void_p, u64p, C.c_uint32]
+        L.zes_deflate_batch.argtypes = [C.POINTER(C.c_void_p), u64p, C.POINTER(C.c_void_p), u64p, u64p, i32p, C.c_uint32]
+        L.zes_inflate_batch_alloc.argtypes = [C.POINTER(C.c_void_p), u64p, ALLOC_FN, C.c_void_p, u64p, i32p, C.c_uint32, C.c_uint32]
+        L.zes_host_alloc.argtypes = [C.c_uint64, C.POINTER(C.c_void_p)]
+        L.zes_host_free.argtypes = [C.c_void_p]
         for name in ("zes_deflate_raw", "zes_deflate_raw_dev"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, u64p]
         for name in ("zes_inflate_raw", "zes_inflate_raw_dev"):
@@ -91,6 +98,8 @@ def lib():
         L.zes_deflate_batch_dev.argtypes = [C.c_void_p, u64p, u64p, C.c_void_p, u64p, u64p, u64p, i32p, C.c_uint32]
         L.zes_inflate_batch_dev.argtypes = [C.c_void_p, u64p, u64p, C.c_void_p, u64p, u64p, u64p, i32p, C.c_uint32,
                                             C.c_uint32]
+        L.zes_deflate_range_dev.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, u64p, u32p]
+        L.zes_deflate_join_dev.argtypes = [C.POINTER(C.c_void_p), u64p, u32p, u64p, C.c_uint32, C.c_void_p, C.c_uint64, u64p]
         L.zes_stage_lz77_dev.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, u32p]
         L.zes_stage_huff_lengths_dev.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.zes_last_kernel_times.argtypes = [C.POINTER(ZesKTime), C.c_int]
@@ -159,18 +168,76 @@ def deflate(data):
 
 
 def inflate(data, flags=0):
-    """``inflate(input)`` of src/zlib.ts:11 — same accept-set and errors as the reference."""
+    """``inflate(input)`` of src/zlib.ts:11 — same accept-set and errors as the reference.
+
+    One library call: it decodes on the device, then asks (callback) for the exact-size result array and copies
+    into it — the growable Uint8WriteStream of src/inflate.ts:17 without a second decode or hidden state.
+    """
     a = _as_u8(data)
-    need = C.c_uint64()
-    rc = lib().zes_inflate_size(a.ctypes.data, a.size, C.byref(need), flags)
-    if rc:
-        _raise(rc)
-    out = np.empty(max(need.value, 1), dtype=np.uint8)
+    got = []
+
+    def alloc(_user, _index, n):
+        got.append(np.empty(max(int(n), 1), dtype=np.uint8))
+        return got[0].ctypes.data
+
     n = C.c_uint64()
-    rc = lib().zes_inflate_fetch(out.ctypes.data, need.value, C.byref(n))  # the size call left the bytes on the device
+    rc = lib().zes_inflate_alloc(a.ctypes.data, a.size, ALLOC_FN(alloc), None, C.byref(n), flags)
     if rc:
         _raise(rc)
-    return out[: n.value]
+    return got[0][: n.value]
+
+
+def _ptr_array(arrs):
+    return (C.c_void_p * len(arrs))(*[x.ctypes.data for x in arrs])
+
+
+def deflate_batch(buffers):
+    """Host-pointer batch: a list of independent buffers in one call → list of uint8 arrays or ZlibEsError (not raised)."""
+    arrs = [_as_u8(b) for b in buffers]
+    cnt = len(arrs)
+    outs = [np.empty(deflate_bound(x.size), dtype=np.uint8) for x in arrs]
+    lens = (C.c_uint64 * cnt)(*[x.size for x in arrs])
+    caps = (C.c_uint64 * cnt)(*[o.size for o in outs])
+    out_len = (C.c_uint64 * cnt)()
+    status = (C.c_int32 * cnt)()
+    rc = lib().zes_deflate_batch(_ptr_array(arrs), lens, _ptr_array(outs), caps, out_len, status, cnt)
+    if rc:
+        _raise(rc)
+    return [outs[i][: out_len[i]].copy() if status[i] == 0 else ZlibEsError(status[i], strerror(status[i])) for i in range(cnt)]
+
+
+def inflate_batch(buffers, flags=0):
+    arrs = [_as_u8(b) for b in buffers]
+    cnt = len(arrs)
+    got = {}
+
+    def alloc(_user, index, n):
+        got[index] = np.empty(max(int(n), 1), dtype=np.uint8)
+        return got[index].ctypes.data
+
+    lens = (C.c_uint64 * cnt)(*[x.size for x in arrs])
+    out_len = (C.c_uint64 * cnt)()
+    status = (C.c_int32 * cnt)()
+    rc = lib().zes_inflate_batch_alloc(_ptr_array(arrs), lens, ALLOC_FN(alloc), None, out_len, status, cnt, flags)
+    if rc:
+        _raise(rc)
+    return [got[i][: out_len[i]] if status[i] == 0 else ZlibEsError(status[i], strerror(status[i])) for i in range(cnt)]
+
+
+def host_alloc(n):
+    """A uint8 numpy array of n bytes in page-locked memory (zes_host_alloc); free with host_free(arr)."""
+    p = C.c_void_p()
+    rc = lib().zes_host_alloc(n, C.byref(p))
+    if rc:
+        _raise(rc)
+    arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(max(n, 1),))[:n]
+    return arr
+
+
+def host_free(arr):
+    rc = lib().zes_host_free(arr.ctypes.data)
+    if rc:
+        _raise(rc)
 
 
 def deflate_raw(data):
@@ -212,15 +279,22 @@ def adler32(data):
 
 
 # ---- HBM-resident API (torch uint8 CUDA tensors; torch is plumbing for device memory) --------
+def _aligned(t):
+    """The device forms need 16-byte aligned pointers (include/zes.h); a sliced view such as t[3:] is copied once."""
+    return t if t.data_ptr() % 16 == 0 else t.clone()
+
+
 def deflate_tensor(t, out=None):
     """Compress a 1-D uint8 CUDA tensor; returns a view of ``out`` (allocated if None)."""
     import torch
 
     assert t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous()
+    t = _aligned(t)
     cap = deflate_bound(t.numel())
     if out is None:
         out = torch.empty(cap, dtype=torch.uint8, device=t.device)
     assert out.numel() >= cap
+    assert out.data_ptr() % 16 == 0, "deflate_tensor: `out` must start on a 16-byte boundary (include/zes.h: device forms)"
     torch.cuda.current_stream(t.device).synchronize()  # the library runs on its own stream
     n = C.c_uint64()
     rc = lib().zes_deflate_dev(t.data_ptr(), t.numel(), out.data_ptr(), out.numel(), C.byref(n))
@@ -234,11 +308,15 @@ def inflate_tensor(t, out, flags=0):
     import torch
 
     assert t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous()
+    t = _aligned(t)
+    assert out.data_ptr() % 16 == 0, "inflate_tensor: `out` must start on a 16-byte boundary (include/zes.h: device forms)"
     torch.cuda.current_stream(t.device).synchronize()
     n = C.c_uint64()
     rc = lib().zes_inflate_dev(t.data_ptr(), t.numel(), out.data_ptr(), out.numel(), C.byref(n), flags)
     if rc == ZES_E_NOSPACE:
-        raise ZlibEsError(rc, "%s (need %d bytes)" % (strerror(rc), n.value))
+        err = ZlibEsError(rc, "%s (need %d bytes)" % (strerror(rc), n.value))
+        err.need = n.value
+        raise err
     if rc:
         _raise(rc)
     return out[: n.value]
@@ -276,6 +354,43 @@ def deflate_batch_tensor(d_in, in_off, in_len, d_out, out_off, out_cap):
 
 def inflate_batch_tensor(d_in, in_off, in_len, d_out, out_off, out_cap, flags=0):
     return _batch_call(lib().zes_inflate_batch_dev, d_in, in_off, in_len, d_out, out_off, out_cap, flags)
+
+
+def deflate_range_tensor(t, lo, hi, final, out=None):
+    """Raw bit stream of the block range [lo, hi) of the CUDA tensor ``t`` (one buffer split over several GPUs,
+    SURVEY §8e-ii) -> (bytes view, nbits, adler32 of the range).  The 258-byte halo behind ``hi`` is read from ``t``."""
+    import torch
+
+    assert t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous() and lo % BLOCK_MAX_BUFFER_LEN == 0
+    view = _aligned(t[lo:])  # (lo is a block boundary: aligned whenever t is)
+    n = hi - lo
+    cap = deflate_bound(n)
+    if out is None:
+        out = torch.empty(cap, dtype=torch.uint8, device=t.device)
+    torch.cuda.current_stream(t.device).synchronize()
+    bits, ad = C.c_uint64(), C.c_uint32()
+    rc = lib().zes_deflate_range_dev(view.data_ptr(), n, min(view.numel(), n + 258), 1 if final else 0, out.data_ptr(), out.numel(),
+                                     C.byref(bits), C.byref(ad))
+    if rc:
+        _raise(rc)
+    return out[: (bits.value + 7) // 8], bits.value, ad.value
+
+
+def deflate_join_tensors(pieces, bits, adlers, lens, out=None):
+    """zlib stream of one buffer from the bit streams of its consecutive block ranges (CUDA tensors on this device)."""
+    import torch
+
+    cnt = len(pieces)
+    total = 2 + (sum(bits) + 7) // 8 + 4
+    if out is None:
+        out = torch.empty((total + 15) // 16 * 16, dtype=torch.uint8, device=pieces[0].device)
+    torch.cuda.current_stream(out.device).synchronize()
+    n = C.c_uint64()
+    rc = lib().zes_deflate_join_dev((C.c_void_p * cnt)(*[p.data_ptr() for p in pieces]), (C.c_uint64 * cnt)(*bits),
+                                    (C.c_uint32 * cnt)(*adlers), (C.c_uint64 * cnt)(*lens), cnt, out.data_ptr(), out.numel(), C.byref(n))
+    if rc:
+        _raise(rc)
+    return out[: n.value]
 
 
 def last_inflate_tier():

@@ -7,12 +7,15 @@
 #include "zes_kernels.h"
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 extern "C" int zes_gen(uint8_t* out, uint64_t n, uint32_t kind, uint32_t seed);
@@ -46,8 +49,6 @@ struct Ctx {
   bool profiling = false;
   std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending;
   std::vector<hipEvent_t> event_pool;
-  uint64_t kept_len = 0;     // zes_inflate_size left this many decoded bytes in st_out for zes_inflate_fetch
-  bool kept_valid = false;
   std::vector<std::pair<std::string, KTime>> last_times;
   std::vector<std::string> name_pool;
   int last_tier = 0;
@@ -83,7 +84,13 @@ int ensure(DevBuf& b, size_t bytes) {
 }
 
 int init_locked(int device) {
-  if (g.ready) return (device < 0 || device == g.device) ? ZES_OK : ZES_E_ARG;
+  if (g.ready) {
+    if (device >= 0 && device != g.device) return ZES_E_ARG;
+    // HIP's current device is per thread: a call from a thread that never made one current (a libuv worker, a Python
+    // thread) would allocate on device 0 while the stream belongs to g.device
+    HIPCHK(hipSetDevice(g.device));
+    return ZES_OK;
+  }
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return ZES_E_DEVICE;
   if (device < 0) device = 0;
@@ -111,6 +118,167 @@ int init_locked(int device) {
   }
   g.device = device;
   g.ready = true;
+  return ZES_OK;
+}
+
+// ---- host <-> device staging of the host-pointer entry points ----
+// A caller's buffer (a JS Uint8Array, a numpy array) is pageable: the DMA engines cannot read it.  It crosses in
+// chunks through a ring of pinned buffers: helper threads copy chunk k+1 into its pinned buffer while the DMA of
+// chunk k runs (and the other way round on the way back), so the trip costs max(memcpy, DMA) instead of their sum
+// and the memcpy is spread over several cores.  A buffer that already is pinned (zes_host_alloc) is handed to the
+// DMA engine as it is.
+constexpr size_t STAGE_CHUNK = 4u << 20;
+constexpr int STAGE_RING = 4;
+constexpr size_t STAGE_DIRECT_MAX = 256u << 10;  // below this one plain copy call is quicker than the ring
+
+struct CopyPool {
+  std::vector<std::thread> threads;
+  std::mutex mu;
+  std::condition_variable cv_work, cv_done;
+  uint8_t* dst = nullptr;
+  const uint8_t* src = nullptr;
+  size_t n = 0, part = 0;
+  uint32_t gen = 0, parts = 0;
+  std::atomic<uint32_t> next{0};
+  uint32_t done = 0;
+  bool stop = false;
+
+  void worker() {
+    uint32_t seen = 0;
+    std::unique_lock<std::mutex> lk(mu);
+    for (;;) {
+      cv_work.wait(lk, [&] { return stop || gen != seen; });
+      if (stop) return;
+      seen = gen;
+      lk.unlock();
+      const uint32_t did = run_parts();
+      lk.lock();
+      done += did;
+      if (done == parts) cv_done.notify_all();
+    }
+  }
+  uint32_t run_parts() {
+    uint32_t did = 0;
+    for (;;) {
+      const uint32_t k = next.fetch_add(1);
+      if (k >= parts) return did;
+      const size_t o = (size_t)k * part;
+      memcpy(dst + o, src + o, std::min(part, n - o));
+      did++;
+    }
+  }
+  void start() {
+    if (!threads.empty()) return;
+    const unsigned hw = std::thread::hardware_concurrency();
+    const unsigned nt = std::max(1u, std::min(6u, hw ? hw / 2 : 2u));
+    for (unsigned i = 0; i + 1 < nt; i++) threads.emplace_back([this] { worker(); });
+  }
+  // memcpy spread over the pool (the caller takes parts too); plain memcpy when it is short
+  void copy(uint8_t* d, const uint8_t* s_, size_t bytes) {
+    if (bytes < (512u << 10) || threads.empty()) {
+      memcpy(d, s_, bytes);
+      return;
+    }
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      dst = d;
+      src = s_;
+      n = bytes;
+      part = 256u << 10;
+      parts = (uint32_t)((bytes + part - 1) / part);
+      next.store(0);
+      done = 0;
+      gen++;
+    }
+    cv_work.notify_all();
+    const uint32_t did = run_parts();
+    std::unique_lock<std::mutex> lk(mu);
+    done += did;
+    cv_done.wait(lk, [&] { return done == parts; });
+  }
+  void shutdown() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      stop = true;
+    }
+    cv_work.notify_all();
+    for (auto& t : threads) t.join();
+    threads.clear();
+    stop = false;
+  }
+};
+
+CopyPool g_pool;
+uint8_t* g_stage[STAGE_RING] = {nullptr};
+hipEvent_t g_stage_ev[STAGE_RING] = {nullptr};
+
+int stage_ready() {
+  if (g_stage[0]) return ZES_OK;
+  for (int k = 0; k < STAGE_RING; k++) {
+    HIPCHK(hipHostMalloc((void**)&g_stage[k], STAGE_CHUNK, hipHostMallocDefault));
+    HIPCHK(hipEventCreateWithFlags(&g_stage_ev[k], hipEventDisableTiming));
+  }
+  g_pool.start();
+  return ZES_OK;
+}
+
+bool is_pinned(const void* p) {
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();  // an ordinary malloc'd pointer: not an error of ours
+    return false;
+  }
+  return a.type == hipMemoryTypeHost;
+}
+
+// host -> device on the library's stream; returns once the caller's memory has been read
+int upload(uint8_t* d_dst, const uint8_t* src, uint64_t n) {
+  if (!n) return ZES_OK;
+  if (n <= STAGE_DIRECT_MAX || is_pinned(src)) {
+    HIPCHK(hipMemcpyAsync(d_dst, src, n, hipMemcpyHostToDevice, g.stream));
+    return ZES_OK;
+  }
+  int rc = stage_ready();
+  if (rc) return rc;
+  uint64_t off = 0;
+  for (uint32_t k = 0; off < n; k++, off += STAGE_CHUNK) {
+    const int slot = (int)(k % STAGE_RING);
+    const size_t len = (size_t)std::min<uint64_t>(STAGE_CHUNK, n - off);
+    if (k >= STAGE_RING) HIPCHK(hipEventSynchronize(g_stage_ev[slot]));  // its previous DMA has read the pinned buffer
+    g_pool.copy(g_stage[slot], src + off, len);
+    HIPCHK(hipMemcpyAsync(d_dst + off, g_stage[slot], len, hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipEventRecord(g_stage_ev[slot], g.stream));
+  }
+  // the pinned ring is reused by the next call: its DMAs must have left it (the caller's memory was read above)
+  for (int k = 0; k < STAGE_RING; k++) HIPCHK(hipEventSynchronize(g_stage_ev[k]));
+  return ZES_OK;
+}
+
+// device -> host, complete on return
+int download(uint8_t* dst, const uint8_t* d_src, uint64_t n) {
+  if (n && (n <= STAGE_DIRECT_MAX || is_pinned(dst))) HIPCHK(hipMemcpyAsync(dst, d_src, n, hipMemcpyDeviceToHost, g.stream));
+  if (n <= STAGE_DIRECT_MAX || is_pinned(dst)) {
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return ZES_OK;
+  }
+  int rc = stage_ready();
+  if (rc) return rc;
+  const uint32_t chunks = (uint32_t)((n + STAGE_CHUNK - 1) / STAGE_CHUNK);
+  auto issue = [&](uint32_t k) -> int {
+    const uint64_t off = (uint64_t)k * STAGE_CHUNK;
+    const size_t len = (size_t)std::min<uint64_t>(STAGE_CHUNK, n - off);
+    HIPCHK(hipMemcpyAsync(g_stage[k % STAGE_RING], d_src + off, len, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipEventRecord(g_stage_ev[k % STAGE_RING], g.stream));
+    return ZES_OK;
+  };
+  for (uint32_t k = 0; k < chunks && k < (uint32_t)STAGE_RING - 1; k++)
+    if ((rc = issue(k))) return rc;
+  for (uint32_t k = 0; k < chunks; k++) {
+    if (k + STAGE_RING - 1 < chunks && (rc = issue(k + STAGE_RING - 1))) return rc;  // its slot was emptied in the round before
+    HIPCHK(hipEventSynchronize(g_stage_ev[k % STAGE_RING]));
+    const uint64_t off = (uint64_t)k * STAGE_CHUNK;
+    g_pool.copy(dst + off, g_stage[k % STAGE_RING], (size_t)std::min<uint64_t>(STAGE_CHUNK, n - off));
+  }
   return ZES_OK;
 }
 
@@ -172,7 +340,7 @@ uint64_t deflate_bound(uint64_t n) { return ((n < ZES_BLK / 2) ? (uint64_t)ZES_B
 // rejected on the host (throw cases, capacity) and are skipped by the device pass.
 int deflate_batch_core(const uint8_t* d_in, const uint64_t* in_off, const uint64_t* in_len, uint8_t* d_out,
                        const uint64_t* out_off, const uint64_t* out_cap, uint64_t* out_len, int32_t* status,
-                       uint32_t count) {
+                       uint32_t count, const uint64_t* in_read = nullptr, const uint32_t* bflags = nullptr, uint32_t* adler_out = nullptr) {
   std::vector<ZesBuf> hb;
   uint64_t nblk_total = 0;
   std::vector<uint32_t> live;
@@ -200,6 +368,9 @@ int deflate_batch_core(const uint8_t* d_in, const uint64_t* in_off, const uint64
     b.cap = out_cap[i];
     b.first_blk = (uint32_t)nblk_total;
     b.nblk = (uint32_t)((in_len[i] + ZES_BLK - 1) / ZES_BLK);
+    b.n_read = in_read ? std::max(in_read[i], in_len[i]) : in_len[i];
+    b.flags = bflags ? bflags[i] : 0u;
+    b.pad = 0;
     nblk_total += b.nblk;
     hb.push_back(b);
     live.push_back(i);
@@ -380,6 +551,7 @@ int deflate_batch_core(const uint8_t* d_in, const uint64_t* in_off, const uint64
   for (uint32_t k = 0; k < nbuf; k++) {
     out_len[live[k]] = r[k].out_len;
     status[live[k]] = r[k].status;
+    if (adler_out) adler_out[live[k]] = r[k].aux;
   }
   return ZES_OK;
 }
@@ -1138,6 +1310,7 @@ int zes_init(int device) {
 int zes_shutdown(void) {
   std::lock_guard<std::mutex> lk(g_mu);
   if (!g.ready) return ZES_OK;
+  (void)hipSetDevice(g.device);
   (void)hipStreamSynchronize(g.stream);
   DevBuf* all[] = {&g.bufs, &g.blks, &g.idx_a, &g.idx_b, &g.inv, &g.hists, &g.codes, &g.hdrs, &g.adler, &g.res, &g.surv, &g.cand,
                    &g.cand_sorted, &g.counters, &g.cres, &g.map, &g.resume, &g.dbg, &g.ibufs, &g.ibufs2, &g.mvlist, &g.scratch, &g.st_in, &g.st_out,
@@ -1149,11 +1322,38 @@ int zes_shutdown(void) {
   }
   if (g.pinned) (void)hipHostFree(g.pinned);
   g.pinned = nullptr;
+  g_pool.shutdown();
+  for (int k = 0; k < STAGE_RING; k++) {
+    if (g_stage[k]) (void)hipHostFree(g_stage[k]);
+    if (g_stage_ev[k]) (void)hipEventDestroy(g_stage_ev[k]);
+    g_stage[k] = nullptr;
+    g_stage_ev[k] = nullptr;
+  }
   for (hipEvent_t e : g.event_pool) (void)hipEventDestroy(e);
   g.event_pool.clear();
   (void)hipStreamDestroy(g.stream);
   g.stream = nullptr;
   g.ready = false;
+  return ZES_OK;
+}
+
+int zes_host_alloc(uint64_t n, void** p) {
+  if (!p) return ZES_E_ARG;
+  *p = nullptr;
+  std::lock_guard<std::mutex> lk(g_mu);
+  int rc = init_locked(-1);
+  if (rc) return rc;
+  HIPCHK(hipHostMalloc(p, n ? n : 1, hipHostMallocDefault));
+  return ZES_OK;
+}
+
+int zes_host_free(void* p) {
+  if (!p) return ZES_OK;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g.ready) return ZES_E_ARG;
+  (void)hipSetDevice(g.device);
+  HIPCHK(hipStreamSynchronize(g.stream));
+  HIPCHK(hipHostFree(p));
   return ZES_OK;
 }
 
@@ -1199,10 +1399,9 @@ int zes_deflate(const uint8_t* in, uint64_t n, uint8_t* out, uint64_t cap, uint6
     std::lock_guard<std::mutex> lk(g_mu);
     int rc = init_locked(-1);
     if (rc) return rc;
-    g.kept_valid = false;
     if ((rc = ensure(g.st_in, n + 64))) return rc;
     if ((rc = ensure(g.st_out, bound + 64))) return rc;
-    HIPCHK(hipMemcpyAsync(g.st_in.p, in, n, hipMemcpyHostToDevice, g.stream));
+    if ((rc = upload((uint8_t*)g.st_in.p, in, n))) return rc;
     uint64_t zero = 0, dl = 0;
     int32_t st = 0;
     rc = deflate_batch_core((const uint8_t*)g.st_in.p, &zero, &n, (uint8_t*)g.st_out.p, &zero, &bound, &dl, &st, 1);
@@ -1210,10 +1409,8 @@ int zes_deflate(const uint8_t* in, uint64_t n, uint8_t* out, uint64_t cap, uint6
     if (st) return st;
     *out_len = dl;
     if (dl > cap) return ZES_E_NOSPACE;
-    HIPCHK(hipMemcpyAsync(out, g.st_out.p, dl, hipMemcpyDeviceToHost, g.stream));
-    HIPCHK(hipStreamSynchronize(g.stream));
+    return download(out, (const uint8_t*)g.st_out.p, dl);
   }
-  return ZES_OK;
 }
 
 int zes_inflate_dev(const uint8_t* d_in, uint64_t c, uint8_t* d_out, uint64_t cap, uint64_t* out_len, uint32_t flags) {
@@ -1246,18 +1443,17 @@ int zes_inflate_batch_dev(const uint8_t* d_in, const uint64_t* in_off, const uin
 }
 
 static int inflate_host(const uint8_t* in, uint64_t c, uint8_t* out, uint64_t cap, uint64_t* out_len, uint32_t flags,
-                        bool size_only) {
+                        bool size_only, zes_alloc_fn alloc, void* user) {
   if (!out_len || (!in && c)) return ZES_E_ARG;
   *out_len = 0;
   if (c == 0 || (in[0] & 15u) != 8u) return ZES_E_NOT_DEFLATE;  // src/zlib.ts:13-16, decided before the device is touched
   std::lock_guard<std::mutex> lk(g_mu);
   int rc = init_locked(-1);
   if (rc) return rc;
-  g.kept_valid = false;
   if ((rc = ensure(g.st_in, c + 64))) return rc;
-  if (c) HIPCHK(hipMemcpyAsync(g.st_in.p, in, c, hipMemcpyHostToDevice, g.stream));
+  if ((rc = upload((uint8_t*)g.st_in.p, in, c))) return rc;
   // decode into pooled device memory: grow-and-retry like the reference's Uint8WriteStream
-  uint64_t dcap = std::max<uint64_t>(size_only ? 0 : cap, std::max<uint64_t>(c * 4, 1 << 20));
+  uint64_t dcap = std::max<uint64_t>((size_only || alloc) ? 0 : cap, std::max<uint64_t>(c * 4, 1 << 20));
   for (int attempt = 0; attempt < 8; attempt++) {
     if ((rc = ensure(g.st_out, dcap + 64))) return rc;
     uint64_t n = 0;
@@ -1268,44 +1464,127 @@ static int inflate_host(const uint8_t* in, uint64_t c, uint8_t* out, uint64_t ca
     }
     if (rc) return rc;
     *out_len = n;
-    if (size_only) {  // the decoded bytes stay on the device for zes_inflate_fetch
-      g.kept_len = n;
-      g.kept_valid = true;
-      return ZES_OK;
+    if (size_only) return ZES_OK;
+    if (alloc) {  // the caller allocates the exact result now that its size is known; still under the lock
+      out = alloc(user, 0, n);
+      if (!out) return ZES_E_ARG;
+      cap = n;
     }
     if (n > cap) return ZES_E_NOSPACE;
-    if (n) HIPCHK(hipMemcpyAsync(out, g.st_out.p, n, hipMemcpyDeviceToHost, g.stream));
-    HIPCHK(hipStreamSynchronize(g.stream));
-    return ZES_OK;
+    return download(out, (const uint8_t*)g.st_out.p, n);
   }
   return ZES_E_DEVICE;
 }
 
 int zes_inflate(const uint8_t* in, uint64_t c, uint8_t* out, uint64_t cap, uint64_t* out_len, uint32_t flags) {
-  return inflate_host(in, c, out, cap, out_len, flags, false);
+  return inflate_host(in, c, out, cap, out_len, flags, false, nullptr, nullptr);
 }
 int zes_inflate_size(const uint8_t* in, uint64_t c, uint64_t* n, uint32_t flags) {
-  return inflate_host(in, c, nullptr, 0, n, flags, true);
+  return inflate_host(in, c, nullptr, 0, n, flags, true, nullptr, nullptr);
+}
+int zes_inflate_alloc(const uint8_t* in, uint64_t c, zes_alloc_fn alloc, void* user, uint64_t* out_len, uint32_t flags) {
+  if (!alloc) return ZES_E_ARG;
+  return inflate_host(in, c, nullptr, 0, out_len, flags, false, alloc, user);
 }
 
-int zes_inflate_fetch(uint8_t* out, uint64_t cap, uint64_t* out_len) {
-  if (!out_len) return ZES_E_ARG;
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (!g.ready || !g.kept_valid) return ZES_E_ARG;  // nothing kept: zes_inflate_size must be the call right before
-  *out_len = g.kept_len;
-  if (g.kept_len > cap) return ZES_E_NOSPACE;
-  if (g.kept_len && !out) return ZES_E_ARG;
-  if (g.kept_len) HIPCHK(hipMemcpyAsync(out, g.st_out.p, g.kept_len, hipMemcpyDeviceToHost, g.stream));
-  HIPCHK(hipStreamSynchronize(g.stream));
-  g.kept_valid = false;
-  return ZES_OK;
-}
-
-int zes_adler32_dev(const uint8_t* d_in, uint64_t n, uint32_t* adler_out) {
-  if (!adler_out) return ZES_E_ARG;
+// ---- batch over host pointers: one arena up, the device batch, results down ----
+int zes_deflate_batch(const uint8_t* const* in, const uint64_t* in_len, uint8_t* const* out, const uint64_t* out_cap,
+                      uint64_t* out_len, int32_t* status, uint32_t count) {
+  if (!in || !in_len || !out || !out_cap || !out_len || !status) return ZES_E_ARG;
   std::lock_guard<std::mutex> lk(g_mu);
   int rc = init_locked(-1);
   if (rc) return rc;
+  std::vector<uint64_t> in_off(count), o_off(count), o_cap(count), dl(count);
+  uint64_t tin = 0, tout = 0;
+  for (uint32_t i = 0; i < count; i++) {
+    if (!in[i] && in_len[i]) return ZES_E_ARG;
+    in_off[i] = tin;
+    tin += (in_len[i] + 64 + 15) & ~15ull;
+    o_off[i] = tout;
+    o_cap[i] = deflate_bound(in_len[i]);
+    tout += (o_cap[i] + 15) & ~15ull;
+  }
+  if ((rc = ensure(g.st_in, tin + 64))) return rc;
+  if ((rc = ensure(g.st_out, tout + 64))) return rc;
+  for (uint32_t i = 0; i < count; i++)
+    if (!deflate_throws(in_len[i]) && (rc = upload((uint8_t*)g.st_in.p + in_off[i], in[i], in_len[i]))) return rc;
+  rc = deflate_batch_core((const uint8_t*)g.st_in.p, in_off.data(), in_len, (uint8_t*)g.st_out.p, o_off.data(), o_cap.data(), dl.data(), status, count);
+  if (rc) return rc;
+  for (uint32_t i = 0; i < count; i++) {
+    out_len[i] = dl[i];
+    if (status[i]) continue;
+    if (dl[i] > out_cap[i] || !out[i]) {
+      status[i] = out[i] ? ZES_E_NOSPACE : ZES_E_ARG;
+      continue;
+    }
+    if ((rc = download(out[i], (const uint8_t*)g.st_out.p + o_off[i], dl[i]))) return rc;
+  }
+  return ZES_OK;
+}
+
+int zes_inflate_batch_alloc(const uint8_t* const* in, const uint64_t* in_len, zes_alloc_fn alloc, void* user, uint64_t* out_len,
+                            int32_t* status, uint32_t count, uint32_t flags) {
+  if (!in || !in_len || !alloc || !out_len || !status) return ZES_E_ARG;
+  std::lock_guard<std::mutex> lk(g_mu);
+  int rc = init_locked(-1);
+  if (rc) return rc;
+  std::vector<uint64_t> in_off(count), o_off(count), o_cap(count);
+  std::vector<uint8_t> firsts(count);
+  uint64_t tin = 0;
+  for (uint32_t i = 0; i < count; i++) {
+    if (!in[i] && in_len[i]) return ZES_E_ARG;
+    in_off[i] = tin;
+    tin += (in_len[i] + 64 + 15) & ~15ull;
+    firsts[i] = in_len[i] ? in[i][0] : 0;
+    // first guess at the result size: a reference-made stream of c bytes rarely inflates beyond 4c; the retry below has exact sizes
+    o_cap[i] = std::max<uint64_t>(in_len[i] * 4, 1 << 16);
+    out_len[i] = 0;
+    status[i] = ZES_OK;
+  }
+  if ((rc = ensure(g.st_in, tin + 64))) return rc;
+  for (uint32_t i = 0; i < count; i++)
+    if ((rc = upload((uint8_t*)g.st_in.p + in_off[i], in[i], in_len[i]))) return rc;
+  std::vector<uint32_t> todo(count);
+  for (uint32_t i = 0; i < count; i++) todo[i] = i;
+  for (int attempt = 0; attempt < 8 && !todo.empty(); attempt++) {
+    uint64_t tout = 0;
+    std::vector<InfJob> jobs(todo.size());
+    std::vector<uint8_t> fb(todo.size());
+    for (size_t k = 0; k < todo.size(); k++) {
+      const uint32_t i = todo[k];
+      o_off[i] = tout;
+      tout += (o_cap[i] + 15) & ~15ull;
+      jobs[k] = InfJob{in_off[i], in_len[i], o_off[i], o_cap[i], 0, ZES_OK, 0};
+      fb[k] = firsts[i];
+    }
+    if ((rc = ensure(g.st_out, tout + 64))) return rc;
+    if ((rc = inflate_jobs((const uint8_t*)g.st_in.p, (uint8_t*)g.st_out.p, jobs, fb.data(), flags))) return rc;
+    std::vector<uint32_t> again;
+    for (size_t k = 0; k < todo.size(); k++) {
+      const uint32_t i = todo[k];
+      out_len[i] = jobs[k].out_len;
+      status[i] = jobs[k].status;
+      if (jobs[k].status == ZES_E_NOSPACE && jobs[k].out_len > o_cap[i]) {
+        o_cap[i] = jobs[k].out_len;
+        again.push_back(i);
+        continue;
+      }
+      if (jobs[k].status) continue;
+      uint8_t* dst = alloc(user, i, jobs[k].out_len);
+      if (!dst) {
+        status[i] = ZES_E_ARG;
+        continue;
+      }
+      if ((rc = download(dst, (const uint8_t*)g.st_out.p + o_off[i], jobs[k].out_len))) return rc;
+    }
+    todo.swap(again);
+  }
+  for (uint32_t i : todo) status[i] = ZES_E_DEVICE;
+  return ZES_OK;
+}
+
+static int adler32_locked(const uint8_t* d_in, uint64_t n, uint32_t* adler_out) {
+  int rc;
   if ((rc = ensure(g.adler, 16))) return rc;
   unsigned long long* acc = (unsigned long long*)g.adler.p;
   HIPCHK(hipMemsetAsync(acc, 0, 16, g.stream));
@@ -1322,6 +1601,81 @@ int zes_adler32_dev(const uint8_t* d_in, uint64_t n, uint32_t* adler_out) {
   const uint32_t s2 = (uint32_t)((n % 65521ull + h[1]) % 65521ull);
   *adler_out = (s2 << 16) | s1;
   return ZES_OK;
+}
+
+// ---- one buffer over several GPUs: block ranges and their join ----
+int zes_deflate_range_dev(const uint8_t* d_in, uint64_t n, uint64_t n_readable, int final_range, uint8_t* d_out, uint64_t cap,
+                          uint64_t* out_bits, uint32_t* adler) {
+  if (!out_bits || !d_in || !d_out || n == 0 || n_readable < n) return ZES_E_ARG;
+  if (!final_range && (n % ZES_BLK)) return ZES_E_ARG;  // only the input's last range may end inside a block
+  if ((n % ZES_BLK) == 1) return ZES_E_CORRUPT;         // the reference throws on a 1-byte last block
+  if ((((uintptr_t)d_in) & 15u) || (((uintptr_t)d_out) & 15u)) return ZES_E_ARG;
+  std::lock_guard<std::mutex> lk(g_mu);
+  int rc = init_locked(-1);
+  if (rc) return rc;
+  uint64_t zero = 0, bits = 0;
+  int32_t st = 0;
+  uint32_t fl = ZES_BUF_RANGE | (final_range ? 0u : ZES_BUF_NOTFINAL), ad = 1;
+  rc = deflate_batch_core(d_in, &zero, &n, d_out, &zero, &cap, &bits, &st, 1, &n_readable, &fl, &ad);
+  if (rc) return rc;
+  if (st) {
+    if (st == ZES_E_NOSPACE) *out_bits = bits;  // (the capacity needed, in bytes)
+    return st;
+  }
+  *out_bits = bits;
+  if (adler) *adler = ad;
+  return ZES_OK;
+}
+
+int zes_deflate_join_dev(const uint8_t* const* d_piece, const uint64_t* piece_bits, const uint32_t* piece_adler, const uint64_t* piece_len,
+                         uint32_t count, uint8_t* d_out, uint64_t cap, uint64_t* out_len) {
+  if (!d_piece || !piece_bits || !piece_adler || !piece_len || !d_out || !out_len || count == 0) return ZES_E_ARG;
+  if (((uintptr_t)d_out) & 15u) return ZES_E_ARG;
+  uint64_t bits = 0;
+  // Adler-32 of the concatenation (src/adler32.ts:1-10): s1 adds up; a piece's s2 also sees len * (s1 so far - 1)
+  uint64_t s1 = 1, s2 = 0;
+  for (uint32_t i = 0; i < count; i++) {
+    if (piece_bits[i] && (!d_piece[i] || (((uintptr_t)d_piece[i]) & 3u))) return ZES_E_ARG;
+    bits += piece_bits[i];
+    const uint64_t a1 = piece_adler[i] & 0xFFFFu, a2 = piece_adler[i] >> 16;
+    s2 = (s2 + a2 + (piece_len[i] % 65521u) * ((s1 + 65520u) % 65521u)) % 65521u;
+    s1 = (s1 + a1 + 65520u) % 65521u;
+  }
+  const uint64_t raw_end = 2 + (bits + 7) / 8, total = raw_end + 4;
+  *out_len = total;
+  if (total > cap) return ZES_E_NOSPACE;
+  std::lock_guard<std::mutex> lk(g_mu);
+  int rc = init_locked(-1);
+  if (rc) return rc;
+  HIPCHK(hipMemsetAsync(d_out, 0, (total + 3) & ~3ull, g.stream));  // (cap of a deflate result always has the slack: zes_deflate_bound)
+  uint64_t pos = 16;  // behind 78 9C
+  for (uint32_t i = 0; i < count; i++) {
+    if (!piece_bits[i]) continue;
+    Timed t("k_bits_place");
+    const uint64_t dwords = (piece_bits[i] + 63) / 32;
+    const uint32_t nwg = (uint32_t)std::min<uint64_t>((dwords + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_bits_place, dim3(nwg), dim3(256), 0, g.stream, (uint32_t*)d_out, pos, (const uint32_t*)d_piece[i], piece_bits[i]);
+    pos += piece_bits[i];
+  }
+  HIPCHK(hipGetLastError());
+  uint8_t* hp = (uint8_t*)g.pinned;
+  hp[0] = 0x78;  // src/zlib.ts:29-34
+  hp[1] = 0x9C;
+  const uint32_t ad = (uint32_t)((s2 << 16) | s1);
+  for (int k = 0; k < 4; k++) hp[8 + k] = (uint8_t)(ad >> (24 - 8 * k));  // big-endian trailer (src/zlib.ts:37-40)
+  HIPCHK(hipMemcpyAsync(d_out, hp, 2, hipMemcpyHostToDevice, g.stream));
+  HIPCHK(hipMemcpyAsync(d_out + raw_end, hp + 8, 4, hipMemcpyHostToDevice, g.stream));
+  HIPCHK(hipStreamSynchronize(g.stream));
+  collect_times();
+  return ZES_OK;
+}
+
+int zes_adler32_dev(const uint8_t* d_in, uint64_t n, uint32_t* adler_out) {
+  if (!adler_out) return ZES_E_ARG;
+  std::lock_guard<std::mutex> lk(g_mu);
+  int rc = init_locked(-1);
+  if (rc) return rc;
+  return adler32_locked(d_in, n, adler_out);
 }
 
 // ---- raw DEFLATE (src/deflate.ts:14, src/inflate.ts:16): thin forms over the wrapped pipeline ----
@@ -1353,9 +1707,8 @@ int zes_inflate_raw(const uint8_t* in, uint64_t c, uint64_t offset, uint8_t* out
   int rc = init_locked(-1);
   if (rc) return rc;
   const uint64_t n = offset < c ? c - offset : 0;
-  g.kept_valid = false;
   if ((rc = ensure(g.st_in, n + 2 + 64))) return rc;
-  if (n) HIPCHK(hipMemcpyAsync((uint8_t*)g.st_in.p + 2, in + offset, n, hipMemcpyHostToDevice, g.stream));
+  if ((rc = upload((uint8_t*)g.st_in.p + 2, in + offset, n))) return rc;
   // decode into pooled device memory: grow-and-retry like the reference's Uint8WriteStream
   uint64_t dcap = std::max<uint64_t>(cap, std::max<uint64_t>(n * 4, 1 << 20));
   for (int attempt = 0; attempt < 8; attempt++) {
@@ -1369,9 +1722,7 @@ int zes_inflate_raw(const uint8_t* in, uint64_t c, uint64_t offset, uint8_t* out
     if (rc) return rc;
     *out_len = m;
     if (m > cap) return ZES_E_NOSPACE;
-    if (m) HIPCHK(hipMemcpyAsync(out, g.st_out.p, m, hipMemcpyDeviceToHost, g.stream));
-    HIPCHK(hipStreamSynchronize(g.stream));
-    return ZES_OK;
+    return download(out, (const uint8_t*)g.st_out.p, m);
   }
   return ZES_E_DEVICE;
 }
@@ -1379,7 +1730,6 @@ int zes_inflate_raw(const uint8_t* in, uint64_t c, uint64_t offset, uint8_t* out
 static int deflate_raw_common(const uint8_t* d_in, uint64_t n, uint64_t* raw_len) {
   const uint64_t bound = deflate_bound(n);
   int rc;
-  g.kept_valid = false;
   if ((rc = ensure(g.st_out, bound + 64))) return rc;
   uint64_t zero = 0, dl = 0;
   int32_t st = 0;
@@ -1414,26 +1764,22 @@ int zes_deflate_raw(const uint8_t* in, uint64_t n, uint8_t* out, uint64_t cap, u
   int rc = init_locked(-1);
   if (rc) return rc;
   if ((rc = ensure(g.st_in, n + 64))) return rc;
-  HIPCHK(hipMemcpyAsync(g.st_in.p, in, n, hipMemcpyHostToDevice, g.stream));
+  if ((rc = upload((uint8_t*)g.st_in.p, in, n))) return rc;
   uint64_t rl = 0;
   if ((rc = deflate_raw_common((const uint8_t*)g.st_in.p, n, &rl))) return rc;
   *out_len = rl;
   if (rl > cap) return ZES_E_NOSPACE;
-  HIPCHK(hipMemcpyAsync(out, (const uint8_t*)g.st_out.p + 2, rl, hipMemcpyDeviceToHost, g.stream));
-  HIPCHK(hipStreamSynchronize(g.stream));
-  return ZES_OK;
+  return download(out, (const uint8_t*)g.st_out.p + 2, rl);
 }
 
 int zes_adler32(const uint8_t* in, uint64_t n, uint32_t* adler_out) {
   if (!adler_out || (!in && n)) return ZES_E_ARG;
-  {
-    std::lock_guard<std::mutex> lk(g_mu);
-    int rc = init_locked(-1);
-    if (rc) return rc;
-    if ((rc = ensure(g.st_in, n + 64))) return rc;
-    if (n) HIPCHK(hipMemcpyAsync(g.st_in.p, in, n, hipMemcpyHostToDevice, g.stream));
-  }
-  return zes_adler32_dev((const uint8_t*)g.st_in.p, n, adler_out);
+  std::lock_guard<std::mutex> lk(g_mu);  // staging and kernel under one lock: nobody else's call can replace st_in in between
+  int rc = init_locked(-1);
+  if (rc) return rc;
+  if ((rc = ensure(g.st_in, n + 64))) return rc;
+  if ((rc = upload((uint8_t*)g.st_in.p, in, n))) return rc;
+  return adler32_locked((const uint8_t*)g.st_in.p, n, adler_out);
 }
 
 int zes_stage_lz77_dev(const uint8_t* d_in, uint64_t n, uint64_t start, uint32_t len, uint32_t* h_tokens, uint32_t* ntokens) {
@@ -1445,6 +1791,7 @@ int zes_stage_lz77_dev(const uint8_t* d_in, uint64_t n, uint64_t start, uint32_t
   memset(&b, 0, sizeof b);
   b.in_off = 0;
   b.n = n;  // the halo reads up to the real input end
+  b.n_read = n;
   b.nblk = (uint32_t)((n + ZES_BLK - 1) / ZES_BLK);
   ZesBlk z;
   memset(&z, 0, sizeof z);

@@ -21,7 +21,13 @@ struct ZesBuf {
   uint64_t cap;       // capacity at out_off
   uint32_t first_blk; // global index of the buffer's first block
   uint32_t nblk;
+  uint64_t n_read;    // bytes readable from in_off (>= n): the match finder compares up to 258 bytes past a block's end
+                      // (SURVEY A.3); larger than n only when the buffer is a block range of a longer input
+  uint32_t flags;     // ZES_BUF_*
+  uint32_t pad;
 };
+#define ZES_BUF_RANGE 1u     // raw bit stream of a block range: starts at bit 0, no zlib header / trailer; res.out_len = bits
+#define ZES_BUF_NOTFINAL 2u  // the range's last block is not the input's last one: BFINAL stays 0
 
 // Result per buffer, written by the device, read back by the host.
 struct ZesRes {

@@ -496,7 +496,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match(const uint8_t* __res
   const uint32_t T = bk.len;
   const uint64_t S0 = (uint64_t)bk.blk * ZES_BLK;  // block start inside the buffer
   const uint8_t* src = d_in + bf.in_off + S0;
-  const uint64_t remain = bf.n - S0;  // bytes from block start to input end
+  const uint64_t remain = bf.n_read - S0;  // bytes from block start to input end
   const uint32_t avail = (uint32_t)(remain < (uint64_t)(T + ZES_MAXMATCH) ? remain : (uint64_t)(T + ZES_MAXMATCH));
   const uint32_t* idx = idx_a + (uint64_t)g * ZES_BLK;
   uint32_t* mo = match_out + (uint64_t)g * ZES_BLK;
@@ -810,7 +810,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match_lazy(const uint8_t* 
   const uint32_t T = bk.len;
   const uint64_t S0 = (uint64_t)bk.blk * ZES_BLK;  // block start inside the buffer
   const uint8_t* src = d_in + bf.in_off + S0;
-  const uint64_t remain = bf.n - S0;  // bytes from block start to input end
+  const uint64_t remain = bf.n_read - S0;  // bytes from block start to input end
   const uint32_t avail = (uint32_t)(remain < (uint64_t)(T + ZES_MAXMATCH) ? remain : (uint64_t)(T + ZES_MAXMATCH));
   uint32_t* mo = match_out + (uint64_t)g * ZES_BLK;
   const uint32_t cnt = T >= 3 ? T - 2 : 0;  // positions that have a 3-byte key
@@ -1912,7 +1912,7 @@ __global__ __launch_bounds__(256) void k_layout(uint8_t* __restrict__ d_out, con
     s_part[tid] = sum;
     __syncthreads();
     if (tid == 0) {
-      uint64_t off = 16;  // after the two zlib header bytes
+      uint64_t off = (bf.flags & ZES_BUF_RANGE) ? 0 : 16;  // after the two zlib header bytes
       for (uint32_t t = 0; t < 256; t++) {
         const uint64_t v = s_part[t];
         s_part[t] = off;
@@ -1929,8 +1929,9 @@ __global__ __launch_bounds__(256) void k_layout(uint8_t* __restrict__ d_out, con
   }
   __syncthreads();
   const uint64_t tot = s_tot;
+  const bool range = (bf.flags & ZES_BUF_RANGE) != 0;
   const uint64_t raw_end = (tot + 7) >> 3;      // byte index just past the padded deflate data
-  const uint64_t out_len = raw_end + 4;
+  const uint64_t out_len = raw_end + (range ? 0 : 4);
   // zero every dword touched atomically: block boundary dwords and everything from the last
   // block's final dword through the trailer
   for (uint32_t i = tid; i < bf.nblk; i += 256) {
@@ -1944,18 +1945,20 @@ __global__ __launch_bounds__(256) void k_layout(uint8_t* __restrict__ d_out, con
     const uint64_t end_dw = (out_len * 8 - 1) >> 5;
     for (uint64_t w = last_dw + 1; w <= end_dw; w++) out32[w] = 0;
     __threadfence();
-    // zlib header: 0x78 0x9C (src/zlib.ts:29-34)
-    atomicOr(&out32[0], 0x9C78u);
     const uint64_t n = bf.n;
     const uint32_t s1 = (uint32_t)((1ull + adler_acc[2 * b + 0]) % 65521ull);
     const uint32_t s2 = (uint32_t)((n % 65521ull + adler_acc[2 * b + 1]) % 65521ull);
     const uint32_t ad = (s2 << 16) | s1;
-    for (int k = 0; k < 4; k++) {  // big-endian trailer (src/zlib.ts:37-40)
-      const uint64_t pos = raw_end + k;
-      const uint32_t byte = (ad >> (24 - 8 * k)) & 0xffu;
-      atomicOr(&out32[pos >> 2], byte << (8 * (pos & 3)));
+    if (!range) {
+      // zlib header: 0x78 0x9C (src/zlib.ts:29-34)
+      atomicOr(&out32[0], 0x9C78u);
+      for (int k = 0; k < 4; k++) {  // big-endian trailer (src/zlib.ts:37-40)
+        const uint64_t pos = raw_end + k;
+        const uint32_t byte = (ad >> (24 - 8 * k)) & 0xffu;
+        atomicOr(&out32[pos >> 2], byte << (8 * (pos & 3)));
+      }
     }
-    res[b].out_len = out_len;
+    res[b].out_len = range ? tot : out_len;  // a range reports bits: its seam with the next range is a bit position
     res[b].status = 0;
     res[b].aux = ad;
   }
@@ -1999,7 +2002,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void k_emit(uint8_t* __restrict__ d_o
   if (tid == 0) S.carry = 0;
   const uint64_t blk_first_dw = bk.bit_off >> 5;
   const uint64_t blk_last_dw = (bk.bit_off + bk.bits - 1) >> 5;
-  const bool is_final = (bk.blk + 1 == bf.nblk);
+  const bool is_final = (bk.blk + 1 == bf.nblk) && !(bf.flags & ZES_BUF_NOTFINAL);
   const uint32_t nhdr_items = 1 + ((bk.hdr_bits + 31u) >> 5);  // block bits + header words
   // item space: the first tile holds only the header items, token i is item EMIT_TILE + i, so that a
   // thread's four tokens are one aligned 16-byte load (issued unconditionally: no wait under a branch)
@@ -2117,6 +2120,31 @@ __global__ __launch_bounds__(EMIT_THREADS) void k_emit(uint8_t* __restrict__ d_o
     __syncthreads();
     if (tid == 0) S.carry = carry_next;
     cur_bit += tile_bits;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_bits_place: ORs an nbits-long bit stream (from bit 0 of src) into dst at bit position pos.  The destination
+// was zeroed; interior dwords belong to this piece alone and are stored, the first and the last one are shared
+// with the neighbouring pieces (blocks are bit-concatenated, src/deflate.ts:20-37) and are OR-ed atomically.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bits_place(uint32_t* __restrict__ dst, uint64_t pos, const uint32_t* __restrict__ src, uint64_t nbits) {
+  if (!nbits) return;
+  const uint64_t first = pos >> 5, last = (pos + nbits - 1) >> 5;
+  const uint32_t sh = (uint32_t)(pos & 31u);
+  const uint64_t nsrc = (nbits + 31) >> 5;  // source dwords holding bits
+  for (uint64_t w = first + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w <= last; w += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t k = w - first;  // dst dword k takes src bits [32k - sh, 32k - sh + 32)
+    uint32_t lo = 0, hi = 0;
+    if (k < nsrc) hi = src[k];
+    if (k >= 1 && k - 1 < nsrc) lo = src[k - 1];
+    uint32_t v = sh ? ((hi << sh) | (lo >> (32u - sh))) : hi;
+    // bits of the piece's last source dword beyond nbits are not part of the stream
+    const uint64_t bit_lo = w << 5;  // absolute position of this dword's bit 0
+    if (bit_lo + 32 > pos + nbits) v &= (uint32_t)((1ull << (pos + nbits - bit_lo)) - 1ull);
+    if (bit_lo < pos) v &= ~(uint32_t)((1ull << (pos - bit_lo)) - 1ull);
+    if (w == first || w == last) atomicOr(&dst[w], v);
+    else dst[w] = v;
   }
 }
 

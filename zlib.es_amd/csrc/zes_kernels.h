@@ -110,4 +110,5 @@ __global__ void k_adler_blocks(const uint8_t*, const ZesBuf*, const ZesBlk*, uns
 __global__ void k_layout(uint8_t*, const ZesBuf*, ZesBlk*, const unsigned long long*, ZesRes*);
 __global__ void k_emit(uint8_t*, const ZesBuf*, const ZesBlk*, const uint32_t*, const uint32_t*, const uint32_t*);
 __global__ void k_zero_u64(unsigned long long*, uint32_t);
+__global__ void k_bits_place(uint32_t*, uint64_t, const uint32_t*, uint64_t);
 #endif

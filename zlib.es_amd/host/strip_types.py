@@ -19,6 +19,7 @@ def fn(m):
     return "function %s(%s) {" % (name, params)
 
 
+src = re.sub(r"^type \w+ = [^;]+;\n", "", src, flags=re.M)  # type aliases erase to nothing
 out = re.sub(r"export function (\w+)\(([^)]*)\)\s*:\s*[\w\[\]<>]+\s*\{", fn, src)
 if "export " in out or re.search(r"\w\s*:\s*(Uint8Array|number|void)\b", out.split("*/", 1)[-1].replace("input: Uint8Array", "")):
     pass  # nothing else to erase in the supported subset

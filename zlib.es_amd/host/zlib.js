@@ -13,6 +13,7 @@
  */
 const addon = require('./build/zes_napi.node');
 
+
 function inflate(input) {
   return addon.inflate(input);
 }
@@ -37,7 +38,7 @@ function inflateRaw(input, offset) {
 /**
  * Promise-returning forms (not in the reference API, SURVEY §8f.4): the same work on a libuv worker thread, so the
  * JS thread stays free while the GPU runs.  Resolve with the same bytes, reject with the same `Error` messages.
- * The input array must not be modified until the promise settles.
+ * The input array must not be modified, and its ArrayBuffer must not be transferred or detached, until the promise settles.
  */
 function deflateAsync(input) {
   return addon.deflateAsync(input);
@@ -45,6 +46,36 @@ function deflateAsync(input) {
 
 function inflateAsync(input) {
   return addon.inflateAsync(input);
+}
+
+/**
+ * Batch forms (not in the reference API; SURVEY §7 step 3): an array of independent buffers in one call — what a
+ * caller's loop over deflate()/inflate() (reference README.md:28-42) becomes when small buffers should share the GPU.
+ * Element i of the result is the Uint8Array deflate(inputs[i]) / inflate(inputs[i]) would return, or — instead of a
+ * throw — the `Error` it would have thrown (same message).  The Async forms run on a libuv worker thread.
+ */
+function deflateBatch(inputs) {
+  return addon.deflateBatch(inputs);
+}
+
+function inflateBatch(inputs) {
+  return addon.inflateBatch(inputs);
+}
+
+function deflateBatchAsync(inputs) {
+  return addon.deflateBatchAsync(inputs);
+}
+
+function inflateBatchAsync(inputs) {
+  return addon.inflateBatchAsync(inputs);
+}
+
+/**
+ * Extra: a Uint8Array of n bytes in page-locked memory.  Inputs that live in such an array cross PCIe without the
+ * library's staging copy (any Uint8Array is accepted everywhere; this is only faster).
+ */
+function allocPinned(n) {
+  return addon.allocPinned(n);
 }
 
 /** Extra (not in the reference API): Adler-32 of a buffer, computed on the GPU. */
@@ -63,5 +94,10 @@ exports.deflateRaw = deflateRaw;
 exports.inflateRaw = inflateRaw;
 exports.deflateAsync = deflateAsync;
 exports.inflateAsync = inflateAsync;
+exports.deflateBatch = deflateBatch;
+exports.inflateBatch = inflateBatch;
+exports.deflateBatchAsync = deflateBatchAsync;
+exports.inflateBatchAsync = inflateBatchAsync;
+exports.allocPinned = allocPinned;
 exports.adler32 = adler32;
 exports.init = init;

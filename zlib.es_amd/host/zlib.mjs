@@ -8,5 +8,10 @@ export const inflateRaw = z.inflateRaw;
 export const deflateRaw = z.deflateRaw;
 export const inflateAsync = z.inflateAsync;
 export const deflateAsync = z.deflateAsync;
+export const deflateBatch = z.deflateBatch;
+export const inflateBatch = z.inflateBatch;
+export const deflateBatchAsync = z.deflateBatchAsync;
+export const inflateBatchAsync = z.inflateBatchAsync;
+export const allocPinned = z.allocPinned;
 export const adler32 = z.adler32;
 export const init = z.init;

@@ -11,6 +11,8 @@
  */
 const addon = require('./build/zes_napi.node');
 
+type BatchResult = Uint8Array | Error;
+
 export function inflate(input: Uint8Array): Uint8Array {
   return addon.inflate(input);
 }
@@ -35,7 +37,7 @@ export function inflateRaw(input: Uint8Array, offset: number = 0): Uint8Array {
 /**
  * Promise-returning forms (not in the reference API, SURVEY §8f.4): the same work on a libuv worker thread, so the
  * JS thread stays free while the GPU runs.  Resolve with the same bytes, reject with the same `Error` messages.
- * The input array must not be modified until the promise settles.
+ * The input array must not be modified, and its ArrayBuffer must not be transferred or detached, until the promise settles.
  */
 export function deflateAsync(input: Uint8Array): Promise<Uint8Array> {
   return addon.deflateAsync(input);
@@ -43,6 +45,36 @@ export function deflateAsync(input: Uint8Array): Promise<Uint8Array> {
 
 export function inflateAsync(input: Uint8Array): Promise<Uint8Array> {
   return addon.inflateAsync(input);
+}
+
+/**
+ * Batch forms (not in the reference API; SURVEY §7 step 3): an array of independent buffers in one call — what a
+ * caller's loop over deflate()/inflate() (reference README.md:28-42) becomes when small buffers should share the GPU.
+ * Element i of the result is the Uint8Array deflate(inputs[i]) / inflate(inputs[i]) would return, or — instead of a
+ * throw — the `Error` it would have thrown (same message).  The Async forms run on a libuv worker thread.
+ */
+export function deflateBatch(inputs: Uint8Array[]): BatchResult[] {
+  return addon.deflateBatch(inputs);
+}
+
+export function inflateBatch(inputs: Uint8Array[]): BatchResult[] {
+  return addon.inflateBatch(inputs);
+}
+
+export function deflateBatchAsync(inputs: Uint8Array[]): Promise<BatchResult[]> {
+  return addon.deflateBatchAsync(inputs);
+}
+
+export function inflateBatchAsync(inputs: Uint8Array[]): Promise<BatchResult[]> {
+  return addon.inflateBatchAsync(inputs);
+}
+
+/**
+ * Extra: a Uint8Array of n bytes in page-locked memory.  Inputs that live in such an array cross PCIe without the
+ * library's staging copy (any Uint8Array is accepted everywhere; this is only faster).
+ */
+export function allocPinned(n: number): Uint8Array {
+  return addon.allocPinned(n);
 }
 
 /** Extra (not in the reference API): Adler-32 of a buffer, computed on the GPU. */

@@ -1,14 +1,26 @@
-"""Sharding of independent buffers over the GPUs of one node (BASELINE.json configs 4/5).
+"""Sharding of independent buffers over the GPUs of one node (BASELINE.json configs 3/4).
 
 One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI, or "gloo" in the CPU
 tests).  Buffers are independent units: every rank compresses / decompresses the buffers it
 owns with no data-path collective; the only exchange is the result gather to one rank:
 
-    sizes    all_reduce(SUM) of an int64[count] vector in which each rank filled its own entries
-    payload  one gather of the per-rank concatenations, padded to the largest rank total
+    sizes    all_reduce(SUM) of an int64[2 * count] vector (length, status) in which each rank filled
+             the entries of the buffers it owns
+    payload  every rank sends ONE message — the concatenation of its results, exact length — to the
+             destination rank, which posts the matching receives into one arena (grouped send/recv:
+             RCCL has no variable-length gather, and a padded `gather` would move the largest rank
+             total world times)
+
+Payloads stay where they are produced: on a GPU run the results are device tensors from the C-ABI's
+device entry points, the messages leave HBM over xGMI and land in the destination's HBM; nothing goes
+through host memory.  xGMI is point to point: the destination receives over one link per peer at once.
 
 The reference has no counterpart (it is single-threaded: README.md:28-42 shows a caller's loop);
 the per-buffer semantics (result bytes, thrown error) are exactly those of deflate()/inflate().
+
+Single-buffer deflate over several GPUs is `deflate_split` below: blocks of the
+reference format are independent (src/deflate.ts:20-34, src/lz77.ts:11-22), so contiguous block
+ranges go to the ranks, and the seams are closed from three numbers per rank.
 """
 from typing import Callable, List, Optional, Sequence, Tuple
 
@@ -29,12 +41,83 @@ def partition(sizes: Sequence[int], world: int) -> List[List[int]]:
     return owned
 
 
-def run_sharded(buffers: Sequence[np.ndarray], engine: Callable[[np.ndarray], Tuple[int, np.ndarray]], group=None,
+class Gathered:
+    """What the destination rank holds after a gather: one arena with every buffer's result.
+
+    arena   uint8 tensor (on the destination's device)
+    offset  offset[i], length[i] — result i is arena[offset[i] : offset[i] + length[i]]
+    status  status[i] — 0 or the zes_status the per-buffer call returned (its bytes are then empty)
+    """
+
+    def __init__(self, arena, offset, length, status):
+        self.arena, self.offset, self.length, self.status = arena, offset, length, status
+
+    def result(self, i):
+        return self.arena[self.offset[i]: self.offset[i] + self.length[i]]
+
+
+def gather_results(local, my_ids: Sequence[int], my_len: Sequence[int], my_status: Sequence[int], owned: List[List[int]],
+                   count: int, group=None, dst: int = 0, async_op: bool = False):
+    """The exchange step.  `local` = this rank's results back to back, in the order of `my_ids` (a uint8
+    tensor on this rank's device; for "nccl" a CUDA tensor, and it never leaves the device).
+
+    Returns a Gathered on `dst`, None elsewhere.  With async_op=True returns (gathered_or_None, works): the
+    transfers are in flight until every work in `works` has been waited for (bench.py overlaps them with the
+    next step's kernels).
+    """
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = local.device
+    meta = torch.zeros(2 * count, dtype=torch.int64, device=dev)
+    if len(my_ids):
+        ids = torch.as_tensor(list(my_ids), dtype=torch.int64, device=dev)
+        meta[ids] = torch.as_tensor(list(my_len), dtype=torch.int64, device=dev)
+        meta[ids + count] = torch.as_tensor(list(my_status), dtype=torch.int64, device=dev)
+    dist.all_reduce(meta, op=dist.ReduceOp.SUM, group=group)
+    meta_h = meta.cpu().numpy()
+    length = [int(x) for x in meta_h[:count]]
+    status = [int(x) for x in meta_h[count:]]
+    totals = [sum(length[i] for i in owned[r]) for r in range(world)]
+    assert totals[rank] == local.numel(), (totals[rank], local.numel())
+    ops, out = [], None
+    if rank == dst:
+        base, pos = [0] * world, 0
+        for r in range(world):
+            base[r] = pos
+            pos += totals[r]
+        arena = torch.empty(max(pos, 1), dtype=torch.uint8, device=dev)
+        offset = [0] * count
+        for r in range(world):
+            p = base[r]
+            for i in owned[r]:
+                offset[i] = p
+                p += length[i]
+            if r == rank:
+                arena[base[r]: base[r] + totals[r]].copy_(local)
+            elif totals[r]:
+                ops.append(dist.P2POp(dist.irecv, arena[base[r]: base[r] + totals[r]], r, group=group))
+        out = Gathered(arena, offset, length, status)
+    elif totals[rank]:
+        ops.append(dist.P2POp(dist.isend, local, dst, group=group))
+    works = dist.batch_isend_irecv(ops) if ops else []
+    if async_op:
+        return out, works
+    for w in works:
+        w.wait()
+    return out
+
+
+def run_sharded(buffers: Sequence[np.ndarray], engine: Callable[[np.ndarray], Tuple[int, object]], group=None,
                 dst: int = 0, device=None) -> Optional[List[Tuple[int, np.ndarray]]]:
     """Runs `engine` (buffer -> (status, bytes)) on this rank's share and gathers everything on `dst`.
 
-    Every rank passes the same `buffers` list (only the owned ones are touched).  Returns, on
-    `dst`, a list of (status, bytes) in the original order; None elsewhere.
+    Every rank passes the same `buffers` list (only the owned ones are touched).  `engine` may return its
+    bytes as a numpy array or as a torch tensor on `device` (the GPU engines do: results stay in HBM until
+    the destination asks for them).  Returns, on `dst`, a list of (status, bytes) in the original order;
+    None elsewhere.
     """
     import torch
     import torch.distributed as dist
@@ -44,57 +127,158 @@ def run_sharded(buffers: Sequence[np.ndarray], engine: Callable[[np.ndarray], Tu
     count = len(buffers)
     owned = partition([len(b) for b in buffers], world)
     mine = owned[rank]
-    results = {i: engine(buffers[i]) for i in mine}
-
     dev = device if device is not None else torch.device("cpu")
-    sizes = torch.zeros(count, dtype=torch.int64, device=dev)
-    status = torch.zeros(count, dtype=torch.int64, device=dev)
-    for i, (st, data) in results.items():
-        sizes[i] = len(data)
-        status[i] = st
-    dist.all_reduce(sizes, op=dist.ReduceOp.SUM, group=group)
-    dist.all_reduce(status, op=dist.ReduceOp.SUM, group=group)
-    sizes_h = sizes.cpu().numpy()
-    totals = [int(sum(int(sizes_h[i]) for i in owned[r])) for r in range(world)]
-    pad = max(max(totals), 1)
-    local = np.zeros(pad, dtype=np.uint8)
-    pos = 0
+    parts, lens, stats = [], [], []
     for i in mine:
-        d = results[i][1]
-        local[pos:pos + len(d)] = d
-        pos += len(d)
-    local_t = torch.from_numpy(local).to(dev)
-    gathered = [torch.empty(pad, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == dst else None
-    dist.gather(local_t, gathered, dst=dst, group=group)
-    if rank != dst:
+        st, data = engine(buffers[i])
+        t = data if isinstance(data, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(data, dtype=np.uint8))
+        parts.append(t.to(dev))
+        lens.append(int(t.numel()))
+        stats.append(int(st))
+    local = torch.cat(parts) if parts else torch.empty(0, dtype=torch.uint8, device=dev)
+    g = gather_results(local, mine, lens, stats, owned, count, group=group, dst=dst)
+    if g is None:
         return None
-    out: List[Optional[Tuple[int, np.ndarray]]] = [None] * count
-    status_h = status.cpu().numpy()
-    for r in range(world):
-        blob = gathered[r].cpu().numpy()
-        pos = 0
-        for i in owned[r]:
-            n = int(sizes_h[i])
-            out[i] = (int(status_h[i]), blob[pos:pos + n].copy())
-            pos += n
-    return out  # type: ignore[return-value]
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+    host = g.arena.cpu().numpy()
+    return [(g.status[i], host[g.offset[i]: g.offset[i] + g.length[i]].copy()) for i in range(count)]
 
 
 def gpu_engines(z, device):
-    """(deflate_engine, inflate_engine) running one buffer through the HBM-resident C-ABI entry points."""
+    """(deflate_engine, inflate_engine) running one buffer through the HBM-resident C-ABI entry points;
+    the results are CUDA tensors (they go into the gather without touching host memory)."""
     import torch
 
     def run_deflate(buf: np.ndarray):
         t = torch.from_numpy(np.ascontiguousarray(buf)).to(device)
         try:
-            return 0, z.deflate_tensor(t).cpu().numpy()
+            return 0, z.deflate_tensor(t)
         except z.ZlibEsError as e:
-            return e.code, np.zeros(0, dtype=np.uint8)
+            return e.code, torch.empty(0, dtype=torch.uint8, device=device)
 
     def run_inflate(buf: np.ndarray):
-        try:
-            return 0, z.inflate(buf)
-        except z.ZlibEsError as e:
-            return e.code, np.zeros(0, dtype=np.uint8)
+        t = torch.from_numpy(np.ascontiguousarray(buf)).to(device)
+        cap = max(4 * t.numel(), 1 << 20)
+        for _ in range(8):
+            out = torch.empty(cap, dtype=torch.uint8, device=device)
+            try:
+                return 0, z.inflate_tensor(t, out)
+            except z.ZlibEsError as e:
+                need = getattr(e, "need", 0)
+                if e.code == z.ZES_E_NOSPACE and need > cap:
+                    cap = need
+                    continue
+                return e.code, torch.empty(0, dtype=torch.uint8, device=device)
+        return z.ZES_E_DEVICE, torch.empty(0, dtype=torch.uint8, device=device)
 
     return run_deflate, run_inflate
+
+
+# ---------------------------------------------------------------------------------------------
+# One buffer over several GPUs (SURVEY §8e-ii)
+# ---------------------------------------------------------------------------------------------
+ADLER_MOD = 65521
+BLOCK = 131072  # src/const.ts:7
+
+
+def split_blocks(n: int, world: int) -> List[Tuple[int, int]]:
+    """Contiguous block ranges [first, last) per rank, as even as the block count allows."""
+    nblk = (n + BLOCK - 1) // BLOCK
+    per, extra = divmod(nblk, world)
+    out, b = [], 0
+    for r in range(world):
+        k = per + (1 if r < extra else 0)
+        out.append((b, b + k))
+        b += k
+    return out
+
+
+def adler_combine(parts: Sequence[Tuple[int, int]]) -> int:
+    """Adler-32 of a concatenation from the (adler32, length) of its pieces (src/adler32.ts:1-10 is
+    associative in this sense: s1 adds up, s2 picks up len_after * (s1 - 1) of every piece before)."""
+    s1, s2 = 1, 0
+    for a, ln in parts:
+        a1, a2 = a & 0xFFFF, (a >> 16) & 0xFFFF
+        # appending a piece whose own sums started from s1 = 1: shift its s2 by len * (current s1 - 1)
+        s2 = (s2 + a2 + (ln % ADLER_MOD) * ((s1 + ADLER_MOD - 1) % ADLER_MOD)) % ADLER_MOD
+        s1 = (s1 + a1 + ADLER_MOD - 1) % ADLER_MOD
+    return (s2 << 16) | s1
+
+
+def join_host(pieces, bits: Sequence[int], adlers: Sequence[int], lens: Sequence[int]) -> np.ndarray:
+    """The join on host memory (numpy): 78 9C | pieces bit-concatenated | zero pad | combined Adler-32 BE.
+    The device form is zes_deflate_join_dev (z.deflate_join_tensors); this one serves callers without a GPU on the
+    destination rank and the CPU test of the exchange."""
+    total_bits = int(sum(bits))
+    out = np.zeros(2 + (total_bits + 7) // 8 + 4, dtype=np.uint8)
+    out[0], out[1] = 0x78, 0x9C  # src/zlib.ts:28-34
+    body = out[2: len(out) - 4]
+    pos = 0
+    for p, nbits in zip(pieces, bits):
+        if not nbits:
+            continue
+        p = np.asarray(p, dtype=np.uint8)
+        nb = (nbits + 7) // 8
+        sh, byte0 = pos & 7, pos >> 3
+        w = p[:nb].astype(np.uint16) << sh  # the piece's bit k lands on bit pos + k: shift-merge at the seam
+        body[byte0: byte0 + nb] |= (w & 0xFF).astype(np.uint8)
+        hi8 = (w >> 8).astype(np.uint8)
+        m = min(nb, len(body) - (byte0 + 1))
+        body[byte0 + 1: byte0 + 1 + m] |= hi8[:m]
+        assert not hi8[m:].any()
+        pos += nbits
+    a = adler_combine([(int(x), int(ln)) for x, ln in zip(adlers, lens) if ln])
+    out[-4:] = np.frombuffer(int(a).to_bytes(4, "big"), dtype=np.uint8)  # src/zlib.ts:36-40
+    return out
+
+
+def deflate_split(n: int, deflate_range: Callable[[int, int, bool], Tuple[object, int, int]], join=join_host, group=None, dst: int = 0,
+                  device=None):
+    """deflate() of ONE n-byte buffer by all ranks of the group: bit-exact with the single-GPU result.
+
+    Rank r takes the contiguous block range split_blocks(n, world)[r].  `deflate_range(lo, hi, final)` returns
+    (bytes, nbits, adler32 of input[lo:hi]): the bit stream of the blocks of input[lo:hi] with BFINAL on the last
+    block only if `final`, not padded beyond the last byte (z.deflate_range_tensor → zes_deflate_range_dev on a GPU;
+    the oracle's zor_deflate_range in the gloo test).  The exchange: all_reduce of (nbits, adler32, length) per rank —
+    the 8-element scan of SURVEY §8e — and the gather of the pieces (one message per rank, device to device under
+    "nccl"); `dst` then calls `join(pieces, bits, adlers, lens)` — z.deflate_join_tensors on a GPU: every piece is
+    shifted to its bit offset and the seam dwords are OR-ed (blocks are bit-concatenated: src/deflate.ts:20-37),
+    `78 9C` in front, the combined Adler-32 behind (src/zlib.ts:28-46).  Returns join's result on `dst`, None
+    elsewhere.  The reference's throw cases (n = 0, 1, n ≡ 1 mod 131072) are the caller's to reject first, exactly
+    as zes_deflate does before it launches anything.
+    """
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = device if device is not None else torch.device("cpu")
+    ranges = split_blocks(n, world)
+    b0, b1 = ranges[rank]
+    lo, hi = b0 * BLOCK, min(n, b1 * BLOCK)
+    last_rank = max(r for r in range(world) if ranges[r][1] > ranges[r][0])
+    if b1 > b0:
+        piece, nbits, ad = deflate_range(lo, hi, rank == last_rank)
+        my = (int(nbits), int(ad), hi - lo)
+    else:
+        piece, my = np.zeros(0, dtype=np.uint8), (0, 1, 0)
+    t = piece if isinstance(piece, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(piece, dtype=np.uint8))
+    t = t.to(dev)
+    pad = (-int(t.numel())) % 16  # pieces start on 16-byte boundaries of the destination's arena (the join reads dwords)
+    if pad:
+        t = torch.cat([t, torch.zeros(pad, dtype=torch.uint8, device=dev)])
+    meta = torch.zeros(3 * world, dtype=torch.int64, device=dev)
+    meta[3 * rank: 3 * rank + 3] = torch.tensor(my, dtype=torch.int64, device=dev)
+    dist.all_reduce(meta, op=dist.ReduceOp.SUM, group=group)
+    mh = [int(x) for x in meta.cpu().numpy()]
+    g = gather_results(t, [rank], [int(t.numel())], [0], [[r] for r in range(world)], world, group=group, dst=dst)
+    if g is None:
+        return None
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+    pieces = [g.result(r) for r in range(world)]
+    if join is join_host:
+        host = g.arena.cpu().numpy()
+        pieces = [host[g.offset[r]: g.offset[r] + g.length[r]] for r in range(world)]
+    return join(pieces, [mh[3 * r] for r in range(world)], [mh[3 * r + 1] for r in range(world)], [mh[3 * r + 2] for r in range(world)])
