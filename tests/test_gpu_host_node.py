@@ -24,7 +24,7 @@ def test_reference_suite_through_napi_facade(gpu, z, tmp_path):
         for i in range(128):
             f.write(z.gen(mix[i % 3], 12345 + i, 1 << 20).tobytes())
     env = dict(os.environ, ZES_BATCH1M_INPUT=path)
-    out = subprocess.run([node, os.path.join(ROOT, "tests", "host_node_test.js")], capture_output=True, text=True, timeout=600, env=env)
+    out = subprocess.run([node, os.path.join(ROOT, "tests", "host_node_test.js")], capture_output=True, text=True, timeout=240, env=env)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "host checks passed" in out.stdout
 

@@ -206,6 +206,9 @@ struct CopyPool {
     threads.clear();
     stop = false;
   }
+  // a process that never calls zes_shutdown still has to get rid of the helpers: destroying a joinable std::thread
+  // at exit calls std::terminate (seen as a host process that never exits)
+  ~CopyPool() { shutdown(); }
 };
 
 CopyPool g_pool;
@@ -680,8 +683,8 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
   }
   unsigned long long* dbg = nullptr;
   if (getenv("ZES_DEBUG_PHASES")) {
-    if ((rc = ensure(g.dbg, (size_t)work * 192))) return rc;
-    HIPCHK(hipMemsetAsync(g.dbg.p, 0, (size_t)work * 192, g.stream));
+    if ((rc = ensure(g.dbg, (size_t)work * ZES_PAR_DBG_ROW * 8))) return rc;
+    HIPCHK(hipMemsetAsync(g.dbg.p, 0, (size_t)work * ZES_PAR_DBG_ROW * 8, g.stream));
     dbg = (unsigned long long*)g.dbg.p;
   }
   {
@@ -717,12 +720,12 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
   }
   std::vector<ZesRes> r1(hres, hres + nbuf);
   if (dbg) {  // average shader-clock cycles per phase of k_inf_block_par
-    std::vector<unsigned long long> h((size_t)work * 24);
+    std::vector<unsigned long long> h((size_t)work * ZES_PAR_DBG_ROW);
     HIPCHK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
-    double acc[8] = {0}, t0[3] = {0}, t15[3] = {0}, fb_lanes = 0, fb_waves = 0, hs[5] = {0};
+    double acc[8] = {0}, t0[3] = {0}, t15[3] = {0}, fb_lanes = 0, fb_waves = 0, hs[5] = {0}, p4[5] = {0};
     uint32_t cntd = 0;
     for (uint32_t i = 0; i < work; i++) {
-      const unsigned long long* r = &h[(size_t)i * 24];
+      const unsigned long long* r = &h[(size_t)i * ZES_PAR_DBG_ROW];
       if (!r[7]) continue;
       cntd++;
       for (int k = 1; k < 8; k++) acc[k] += (double)(r[k] - r[k - 1]);
@@ -732,6 +735,7 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
       }
       hs[0] += (double)(r[16] - r[0]);
       for (int k = 1; k < 5; k++) hs[k] += (double)(r[16 + k] - r[15 + k]);
+      for (int k = 0; k < 5; k++) p4[k] += (double)r[24 + k];
       fb_lanes += (double)r[11];
       fb_waves += (double)r[15];
     }
@@ -741,6 +745,8 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
             t0[0] / cntd, t0[1] / cntd, t0[2] / cntd, t15[0] / cntd, t15[1] / cntd, t15[2] / cntd);
     fprintf(stderr, "zes header steps (avg cycles): staging %.0f fixed fields + code-length code %.0f code lengths %.0f lit/len tables %.0f distance tables %.0f\n",
             hs[0] / cntd, hs[1] / cntd, hs[2] / cntd, hs[3] / cntd, hs[4] / cntd);
+    fprintf(stderr, "zes resolve steps (avg cycles): carry+clear %.0f fill %.0f jumping %.0f copy %.0f | %.1f barrier rounds per block\n", p4[0] / cntd,
+            p4[1] / cntd, p4[2] / cntd, p4[3] / cntd, p4[4] / cntd);
     fprintf(stderr, "zes 8-bit table path: %.2f lanes in %.2f waves per block fell back to the generic construction\n", fb_lanes / cntd, fb_waves / cntd);
   }
   if (getenv("ZES_DEBUG")) {

@@ -17,8 +17,9 @@
 //   P2  count pass from the true entries; workgroup scan of bytes produced -> output offsets
 //   P3  emit decode: literals go straight into the LDS image of the block; a match leaves a
 //       3-byte (distance, length) record at its own destination and a bit in the bitmap
-//   P4  wave 0 walks the bitmap in order and resolves matches 64 at a time; a lane may copy as
-//       soon as its source lies below the first unresolved match (src/inflate.ts:287-290)
+//   P4  match resolution by all waves, 4 KiB of the image at a time: per byte the distance to an
+//       ancestor, pointer jumping until every byte points at a final one, one parallel copy
+//       (src/inflate.ts:287-290)
 //   P5  the 128 KiB image leaves LDS as coalesced 16-byte stores
 //
 // Anything unusual (non-dynamic block, over-subscribed or incomplete code that gets hit,
@@ -34,7 +35,9 @@
 #define F_VOID 4u
 #define F_HIST 8u
 
-#define P4_WIN 512u  // output positions per bitmap window in the match resolution
+#define RES_W 4096u    // P4: bytes of the image resolved at a time (a multiple of PAR_THREADS and of 8)
+#define RES_REPS 4u    // pointer-jumping steps between two barriers
+#define RES_EXT 258u   // a match that starts in a window can run this far past its end
 #define STAGE_DW ((ZES_BLK + ZES_BLK / 8) / 4)  // compressed bytes staged over the image + bitmap until P3
 struct ParSmem {
   uint8_t out[ZES_BLK];            // P0-P2: first part of the staged compressed block (swizzled dwords)
@@ -50,12 +53,15 @@ struct ParSmem {
   uint8_t lens[352];
   uint8_t cl_lut[128];
   uint32_t wave_sum[PAR_WAVES];
-  uint16_t mlist[704];                    // P4: match positions of the current 2048-byte window
   uint8_t wtab[PAR_WAVES][48];   // composed transfer table of each wave
   uint8_t wentry[PAR_WAVES];      // entry code of each wave's first segment
   uint32_t hdr_end, status, tail_entry, bfinal, tail_bytes, tail_end;
+  uint32_t res_flag[3];       // P4: "a pointer moved in this step"
   uint32_t f8lo, f8n, f8off;  // 8-bit literal codes: first code value, how many (0 = fast path off), index into syms_l
 };
+
+static_assert(offsetof(ParSmem, cl_lut) - offsetof(ParSmem, lut_l) >= (RES_W + RES_EXT) * 2u, "P4's distance array lies over the decode tables");
+static_assert(RES_W % PAR_THREADS == 0 && RES_W % 8u == 0, "P4 lane mapping");
 
 // LUT entry: [3:0] code length (0 = not in the root table), [7:4] extra bits, [9:8] kind
 // (0 literal, 1 end of block, 2 length or distance base, 3 symbol outside the tables), [31:16] value
@@ -1020,7 +1026,7 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __
   __shared__ __align__(16) ParSmem S;
 #define STAMP(i)                                                     \
   do {                                                               \
-    if (dbg && threadIdx.x == 0) dbg[(size_t)blockIdx.x * 24 + (i)] = (unsigned long long)clock64(); \
+    if (dbg && threadIdx.x == 0) dbg[(size_t)blockIdx.x * ZES_PAR_DBG_ROW + (i)] = (unsigned long long)clock64(); \
   } while (0)
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   // buffer of this work item: the last entry whose first work item is <= blockIdx.x
@@ -1078,7 +1084,7 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __
     }
     __syncthreads();
     if (wave == 0 && use_lds) {
-      const bool ok = par_header<true>(S, src, limit, start, dbg ? dbg + (size_t)blockIdx.x * 24 : nullptr);
+      const bool ok = par_header<true>(S, src, limit, start, dbg ? dbg + (size_t)blockIdx.x * ZES_PAR_DBG_ROW : nullptr);
       if (!ok && lane == 0) S.status = 1;
     }
     __syncthreads();
@@ -1096,14 +1102,43 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __
     base = (uint32_t)(b_me64 < 0xFFFFFF00ull ? b_me64 : 0xFFFFFF00ull);
     stop = (uint32_t)((b_me64 + seglen) < 0xFFFFFF00ull ? (b_me64 + seglen) : 0xFFFFFF00ull);
     SegTab tab = {0, 0, 0, 0, 0, 0, 0, 0};
-    seg_table<true>(S, src, limit, base, stop, f8, tab, dbg ? dbg + (size_t)blockIdx.x * 24 : nullptr);
+    seg_table<true>(S, src, limit, base, stop, f8, tab, dbg ? dbg + (size_t)blockIdx.x * ZES_PAR_DBG_ROW : nullptr);
     STAMP(2);
+    // Composition.  With room behind the staged block (compressible data: the block's bytes fill a third of the
+    // staging area) every lane parks its table in LDS, 52 bytes apart, and a step of the walks below is one byte
+    // read; otherwise (incompressible data) the tables stay in registers and a step broadcasts a lane's table.
+    const uint32_t tab_off = ((src.s_count + 31u) & ~31u) * 4u;  // the swizzle permutes inside rows of 32 dwords
+    const bool lds_tabs = tab_off + PAR_THREADS * 52u <= STAGE_DW * 4u;  // uniform
+    const uint8_t* tb = S.out + tab_off + wave * 64u * 52u;  // this wave's 64 tables
+    if (lds_tabs) {
+      uint32_t* tw = reinterpret_cast<uint32_t*>(S.out + tab_off) + tid * 13u;
+      tw[0] = (uint32_t)tab.a;
+      tw[1] = (uint32_t)(tab.a >> 32);
+      tw[2] = (uint32_t)tab.b;
+      tw[3] = (uint32_t)(tab.b >> 32);
+      tw[4] = (uint32_t)tab.c;
+      tw[5] = (uint32_t)(tab.c >> 32);
+      tw[6] = (uint32_t)tab.d;
+      tw[7] = (uint32_t)(tab.d >> 32);
+      tw[8] = (uint32_t)tab.e;
+      tw[9] = (uint32_t)(tab.e >> 32);
+      tw[10] = (uint32_t)tab.f;
+      tw[11] = (uint32_t)(tab.f >> 32);
+      __syncthreads();
+    }
     {
-      // composition over the 64 segments of this wave: lane j (< 48) carries input offset j
+      // over the 64 segments of this wave: lane j (< 48) carries input offset j
       uint32_t cur = lane;
-      for (uint32_t sgm = 0; sgm < 64u; sgm++) {
-        const SegTab ws = tab_bcast(tab, sgm);
-        if (cur < 48u) cur = tab_get(ws, cur);
+      if (lds_tabs) {
+        for (uint32_t sgm = 0; sgm < 64u; sgm++) {
+          const uint32_t v = tb[sgm * 52u + (cur < 48u ? cur : 0u)];
+          cur = cur < 48u ? v : cur;  // (end of block / fail stay what they are)
+        }
+      } else {
+        for (uint32_t sgm = 0; sgm < 64u; sgm++) {
+          const SegTab ws = tab_bcast(tab, sgm);
+          if (cur < 48u) cur = tab_get(ws, cur);
+        }
       }
       if (lane < 48u) S.wtab[wave][lane] = (uint8_t)cur;
     }
@@ -1117,12 +1152,21 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __
       S.tail_entry = e;  // state after the last segment: offset past its end, or EOB / fail
     }
     __syncthreads();
-    uint32_t e = S.wentry[wave];  // uniform
+    // the wave's true entry walks through its 64 segments
+    uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.wentry[wave]);
     uint32_t mine = C_FAIL;
-    for (uint32_t sgm = 0; sgm < 64u; sgm++) {
-      if (lane == sgm) mine = e;
-      const SegTab ws = tab_bcast(tab, sgm);
-      if (e < 48u) e = tab_get(ws, e);
+    if (lds_tabs) {
+      for (uint32_t sgm = 0; sgm < 64u; sgm++) {
+        if (lane == sgm) mine = e;
+        if (e < 48u) e = (uint32_t)__builtin_amdgcn_readfirstlane((int)tb[sgm * 52u + e]);
+      }
+    } else {
+      // every lane looks the (uniform) entry up in its own table and the owning lane's answer is broadcast
+      for (uint32_t sgm = 0; sgm < 64u; sgm++) {
+        if (lane == sgm) mine = e;
+        const uint32_t own = e < 48u ? tab_get(tab, e) : e;
+        e = (uint32_t)__builtin_amdgcn_readlane((int)own, (int)sgm);
+      }
     }
     ecode = mine;
     tail_code = S.tail_entry;
@@ -1251,124 +1295,110 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __
     }
 
     STAMP(5);
-    // ---- P4: match resolution, in order, by wave 0: a lane may copy as soon as its source lies
-    // below the first unresolved match (src/inflate.ts:287-290).  (A 16-range multi-wave variant
-    // with per-wave watermarks was measured slower: text distances stagger the ranges.) ----
-    if (wave == 0) {
-      uint16_t* ml = S.mlist;
-      // Matches are listed per window of the image.  A block with few matches (incompressible data:
-      // ~250) takes 8 KiB windows, four bitmap words per lane: the per-window scan is the whole cost there.
-      uint32_t nmatch = 0;
-      for (uint32_t i = lane; i < ZES_BLK / 32; i += 64) nmatch += (uint32_t)__popc(S.bitmap[i]);
-#pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) nmatch += __shfl_xor(nmatch, d);
-      const uint32_t wwords = nmatch <= 512u ? 4u : 1u;  // bitmap words per lane and window (uniform); 512 <= the list's 704
-      const uint32_t wbytes = wwords * 2048u;
-      for (uint32_t wb = 0; wb < total; wb += wbytes) {
-        uint32_t nwin;
-        if (wwords == 1u) {  // uniform
-          const uint32_t wi = (wb >> 5) + lane;
-          uint32_t bits = (wi < ZES_BLK / 32) ? S.bitmap[wi] : 0u;
-          const uint32_t cntb = (uint32_t)__popc(bits);
-          uint32_t inc2 = cntb;
-#pragma unroll
-          for (int dlt = 1; dlt < 64; dlt <<= 1) {
-            const uint32_t t = __shfl_up(inc2, dlt);
-            if ((int)lane >= dlt) inc2 += t;
-          }
-          nwin = __shfl(inc2, 63);
-          uint32_t slot = inc2 - cntb;
+    // ---- P4: match resolution by all 16 waves, window by window (src/inflate.ts:287-290).
+    // A copy may read bytes that an earlier copy produced, and on text such chains are hundreds of copies deep
+    // (every phrase copies its nearest earlier occurrence), so neither "in order, 64 at a time" (one wave: 40 %
+    // of this kernel on text) nor "everything that is ready, round after round" (hundreds of rounds) scales.
+    // Per BYTE the structure is a forest: byte b of a match has the parent b - D, a literal byte is a root.  For
+    // one window of RES_W bytes at a time (everything below the window is final) every match byte gets its
+    // distance to an ancestor in dist[] (u16: < RES_W + 32768), pointer jumping dist[b] += dist[b - dist[b]]
+    // halves the depth per round until every pointer ends on a final byte — a literal of the window or a byte
+    // below it — and then all bytes of the window are copied at once.  Overlapping copies (distance < length)
+    // need no special case: byte p+5 of a run with D = 1 simply has the parent p+4.
+    {
+      uint16_t* dist = reinterpret_cast<uint16_t*>(S.lut_l);  // the decode tables are dead: [RES_W + RES_EXT] entries over them
+      if (tid < 3u) S.res_flag[tid] = 0u;
+      unsigned long long tacc[4] = {0, 0, 0, 0}, tlast = dbg ? clock64() : 0ull, nrounds = 0;  // ZES_DEBUG_PHASES: cycles of the four steps
+#define P4LAP(i)                                         \
+  do {                                                   \
+    if (dbg && tid == 0) {                               \
+      const unsigned long long now_ = clock64();         \
+      tacc[i] += now_ - tlast;                           \
+      tlast = now_;                                      \
+    }                                                    \
+  } while (0)
+      const uint8_t* bm8 = reinterpret_cast<const uint8_t*>(S.bitmap);
+      for (uint32_t ws = 0; ws < total; ws += RES_W) {
+        const uint32_t wlen = min(RES_W, total - ws);
+        // (a) the part of a match that ran past the previous window's end is carried over; the rest starts at 0
+        uint32_t carry = 0;
+        if (ws != 0u && tid < RES_EXT) carry = dist[RES_W + tid];
+        __syncthreads();
+        for (uint32_t i = tid; i < RES_W + RES_EXT; i += PAR_THREADS) dist[i] = (uint16_t)(i < RES_EXT ? carry : 0u);
+        __syncthreads();
+        P4LAP(0);
+        // (b) every match that starts in the window writes its distance over its bytes: one lane per 8 positions
+        // (at most three matches start there: a match is at least 3 bytes long)
+        if (tid < RES_W / 8u && tid * 8u < wlen) {
+          uint32_t bits = bm8[(ws >> 3) + tid];
           while (bits) {
             const uint32_t t = (uint32_t)__builtin_ctz(bits);
             bits &= bits - 1u;
-            ml[slot++] = (uint16_t)((lane << 5) + t);
-          }
-        } else {
-          uint32_t wbits[4];
-          uint32_t cntb = 0;
-#pragma unroll
-          for (uint32_t q = 0; q < 4; q++) {
-            const uint32_t wi = (wb >> 5) + lane * 4u + q;
-            wbits[q] = (wi < ZES_BLK / 32) ? S.bitmap[wi] : 0u;
-            cntb += (uint32_t)__popc(wbits[q]);
-          }
-          uint32_t inc2 = cntb;
-#pragma unroll
-          for (int dlt = 1; dlt < 64; dlt <<= 1) {
-            const uint32_t t = __shfl_up(inc2, dlt);
-            if ((int)lane >= dlt) inc2 += t;
-          }
-          nwin = __shfl(inc2, 63);
-          uint32_t slot = inc2 - cntb;
-#pragma unroll
-          for (uint32_t q = 0; q < 4; q++) {
-            uint32_t bits = wbits[q];
-            while (bits) {
-              const uint32_t t = (uint32_t)__builtin_ctz(bits);
-              bits &= bits - 1u;
-              ml[slot++] = (uint16_t)(((lane * 4u + q) << 5) + t);
-            }
+            const uint32_t rel = tid * 8u + t, p = ws + rel;
+            const uint32_t D = ((uint32_t)S.out[p] | ((uint32_t)S.out[p + 1] << 8)) + 1u;
+            const uint32_t L = (uint32_t)S.out[p + 2] + 3u;
+            for (uint32_t j = 0; j < L; j++) dist[rel + j] = (uint16_t)D;  // rel + j < RES_W + RES_EXT
           }
         }
-        for (uint32_t k = 0; k < nwin; k += 64) {
-          const uint32_t i = k + lane;
-          const bool have = i < nwin;
-          uint32_t p = 0, L = 0, D = 1;
-          if (have) {
-            p = wb + ml[i];
-            D = ((uint32_t)S.out[p] | ((uint32_t)S.out[p + 1] << 8)) + 1u;
-            L = (uint32_t)S.out[p + 2] + 3u;
-          }
-          const uint32_t src = p - D;
-          const uint32_t srcend = min(src + L, p);
-          uint64_t U = __ballot(have);
-          while (U) {
-            const uint32_t f = (uint32_t)__builtin_ctzll(U);
-            const uint32_t pf = __shfl(p, (int)f);
-            const bool ready = have && ((U >> lane) & 1ull) && srcend <= pf;
-            if (ready) {
-              if (D >= 8u) {
-                // rounds of 8 independent loads, then up to 8 stores: the LDS round trip is paid once
-                // per 8 bytes whatever the length (loads past the match end stay inside the LDS block)
-                uint32_t j = 0;
-                for (; j + 8u <= L; j += 8u) {  // whole rounds
-                  const uint32_t sb = src + j, pb = p + j;
-                  const uint8_t t0 = S.out[sb], t1 = S.out[sb + 1], t2 = S.out[sb + 2], t3 = S.out[sb + 3], t4 = S.out[sb + 4],
-                                t5 = S.out[sb + 5], t6 = S.out[sb + 6], t7 = S.out[sb + 7];
-                  S.out[pb] = t0;
-                  S.out[pb + 1] = t1;
-                  S.out[pb + 2] = t2;
-                  S.out[pb + 3] = t3;
-                  S.out[pb + 4] = t4;
-                  S.out[pb + 5] = t5;
-                  S.out[pb + 6] = t6;
-                  S.out[pb + 7] = t7;
-                }
-                if (j < L) {
-                  // last partial round: offsets past the match end are clamped onto its last byte, so
-                  // every load and store stays unconditional (the duplicates rewrite the same value)
-                  const uint32_t last = L - j - 1u;
-                  const uint32_t o1 = min(1u, last), o2 = min(2u, last), o3 = min(3u, last), o4 = min(4u, last), o5 = min(5u, last),
-                                 o6 = min(6u, last);
-                  const uint32_t sb = src + j, pb = p + j;
-                  const uint8_t t0 = S.out[sb], t1 = S.out[sb + o1], t2 = S.out[sb + o2], t3 = S.out[sb + o3], t4 = S.out[sb + o4],
-                                t5 = S.out[sb + o5], t6 = S.out[sb + o6];
-                  S.out[pb] = t0;
-                  S.out[pb + o1] = t1;
-                  S.out[pb + o2] = t2;
-                  S.out[pb + o3] = t3;
-                  S.out[pb + o4] = t4;
-                  S.out[pb + o5] = t5;
-                  S.out[pb + o6] = t6;
-                }
-              } else {
-                for (uint32_t j = 0; j < L; j++) S.out[p + j] = S.out[src + j];
-              }
-            }
-            U &= ~__ballot(ready);
-          }
+        __syncthreads();
+        P4LAP(1);
+        // (c) pointer jumping until nothing moves.  A lane owns the entries of its bytes (only it writes them) and
+        // keeps them in registers; an entry is live while its ancestor is an unresolved byte of this window.  Updates
+        // are in place: whatever a lane reads from another byte's entry is the distance to one of that byte's
+        // ancestors, at any moment.  RES_REPS steps per barrier (progress travels through LDS without one; the barrier
+        // is there to find out that nothing moves any more); a wave whose bytes are settled skips its steps.
+        uint32_t d[RES_W / PAR_THREADS];
+        bool live[RES_W / PAR_THREADS];
+#pragma unroll
+        for (uint32_t k = 0; k < RES_W / PAR_THREADS; k++) {
+          const uint32_t b = tid + k * PAR_THREADS;
+          d[k] = b < wlen ? dist[b] : 0u;
+          live[k] = d[k] != 0u && d[k] <= b;  // (d > b: the ancestor lies below the window: final)
         }
+        for (uint32_t rnd = 0;; rnd++) {
+          bool moved = false;
+#pragma unroll
+          for (uint32_t rep = 0; rep < RES_REPS; rep++) {
+            bool anylive = false;
+#pragma unroll
+            for (uint32_t k = 0; k < RES_W / PAR_THREADS; k++) anylive = anylive || live[k];
+            if (!__ballot(anylive)) break;  // this wave's bytes are settled
+            uint32_t da[RES_W / PAR_THREADS];
+#pragma unroll
+            for (uint32_t k = 0; k < RES_W / PAR_THREADS; k++) da[k] = dist[live[k] ? tid + k * PAR_THREADS - d[k] : 0u];  // one LDS round trip for all
+#pragma unroll
+            for (uint32_t k = 0; k < RES_W / PAR_THREADS; k++) {
+              const bool mv = live[k] && da[k] != 0u;
+              d[k] += mv ? da[k] : 0u;
+              if (mv) dist[tid + k * PAR_THREADS] = (uint16_t)d[k];
+              moved = moved || mv;
+              live[k] = mv && d[k] <= tid + k * PAR_THREADS;  // an ancestor that is final stays final
+            }
+          }
+          // "did anything move": three flags in rotation, so that clearing one never meets a wave that is a step ahead
+          if (__ballot(moved) && lane == 0) S.res_flag[rnd % 3u] = 1u;
+          __syncthreads();
+          const bool any = S.res_flag[rnd % 3u] != 0u;
+          if (tid == 0) S.res_flag[(rnd + 2u) % 3u] = 0u;
+          nrounds++;
+          if (!any) break;
+        }
+        P4LAP(2);
+        // (d) every match byte of the window takes its value from its final ancestor
+#pragma unroll
+        for (uint32_t k = 0; k < RES_W / PAR_THREADS; k++) {
+          const uint32_t b = tid + k * PAR_THREADS;
+          if (d[k] != 0u) S.out[ws + b] = S.out[ws + b - d[k]];
+        }
+        P4LAP(3);
+        // (the next round's first barrier separates these reads of dist[] from its rewrite)
       }
+      if (dbg && tid == 0) {
+        unsigned long long* row = dbg + (size_t)blockIdx.x * ZES_PAR_DBG_ROW;
+        for (int k = 0; k < 4; k++) row[24 + k] = tacc[k];
+        row[28] = nrounds;
+      }
+#undef P4LAP
     }
     __syncthreads();
 

@@ -10,6 +10,7 @@
 #define HUFF_THREADS_HOST 256
 #define ADLER_THREADS 256
 #define ADLER_CHUNK 65536u
+#define ZES_PAR_DBG_ROW 32  // u64 slots per work item of k_inf_block_par's ZES_DEBUG_PHASES stamps
 #define PAR_THREADS 1024
 #define PAR_WAVES (PAR_THREADS / 64)
 #define INF_SCAN_THREADS 256
