@@ -26,7 +26,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libzes_hip.so")
+_LIB_PATH = os.environ.get("ZES_LIB") or os.path.join(_HERE, "libzes_hip.so")  # (ZES_LIB: development builds of the same library)
 _lib = None
 
 BLOCK_MAX_BUFFER_LEN = 131072  # src/const.ts:7

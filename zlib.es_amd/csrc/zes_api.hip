@@ -37,7 +37,7 @@ struct Ctx {
   int device = -1;
   hipStream_t stream = nullptr;
   // deflate scratch
-  DevBuf bufs, blks, idx_a, idx_b, inv, hists, codes, hdrs, adler, res;
+  DevBuf bufs, blks, idx_a, idx_b, inv, sdelta, hists, codes, hdrs, adler, res;
   // inflate scratch
   DevBuf surv, cand, cand_sorted, counters, cres, map, resume, dbg, ibufs, ibufs2, mvlist, scratch, sres, maps, seglist, segprefix, wins, sym16, segorder, segjobs, pw16, gwins;
   // staging for the host-pointer API
@@ -387,6 +387,7 @@ int deflate_batch_core(const uint8_t* d_in, const uint64_t* in_off, const uint64
   if ((rc = ensure(g.idx_a, (size_t)nblk * ZES_BLK * 4))) return rc;
   if ((rc = ensure(g.idx_b, (size_t)nblk * ZES_BLK * 4))) return rc;
   if ((rc = ensure(g.inv, (size_t)nblk * ZES_BLK * 4))) return rc;
+  if ((rc = ensure(g.sdelta, (size_t)nblk * ZES_BLK * 2 + 64))) return rc;
   if ((rc = ensure(g.hists, (size_t)nblk * 320 * 4))) return rc;
   if ((rc = ensure(g.codes, (size_t)nblk * 320 * 4))) return rc;
   if ((rc = ensure(g.hdrs, (size_t)nblk * ZES_HDR_WORDS * 4))) return rc;
@@ -431,7 +432,7 @@ int deflate_batch_core(const uint8_t* d_in, const uint64_t* in_off, const uint64
   }
   {
     Timed t("k_lz_sort");
-    hipLaunchKernelGGL(k_lz_sort, dim3(nblk), dim3(SORT_THREADS), 0, g.stream, d_in, dbufs, dblks, idx_a, idx_b, (uint32_t*)g.inv.p);
+    hipLaunchKernelGGL(k_lz_sort, dim3(nblk), dim3(SORT_THREADS), 0, g.stream, d_in, dbufs, dblks, idx_a, idx_b, (uint32_t*)g.inv.p, (uint16_t*)g.sdelta.p);
   }
   if (sort_dbg) {  // average shader-clock cycles per step of k_lz_sort
     HIPCHK(hipStreamSynchronize(g.stream));
@@ -461,7 +462,7 @@ int deflate_batch_core(const uint8_t* d_in, const uint64_t* in_off, const uint64
   {
     Timed t("k_lz_match_lazy");  // the blocks k_lz_sort flagged (most positions kept); the others return at once
     hipLaunchKernelGGL(k_lz_match_lazy, dim3(nblk), dim3(MATCH_THREADS), 0, g.stream, d_in, dbufs, dblks, idx_a,
-                       (const uint32_t*)g.inv.p, idx_b);
+                       (const uint32_t*)g.inv.p, (const uint16_t*)g.sdelta.p, idx_b);
   }
   if (sort_dbg) {  // average shader-clock cycles per phase of k_lz_match_lazy
     HIPCHK(hipStreamSynchronize(g.stream));
@@ -478,8 +479,8 @@ int deflate_batch_core(const uint8_t* d_in, const uint64_t* in_off, const uint64
       acc[7] += (double)h[(size_t)i * 8 + 7];
     }
     if (n)
-      fprintf(stderr, "zes lazy match steps (avg cycles over %u blocks): stage %.0f tail %.0f window chains %.0f entry chains %.0f true chain %.0f | first wave, window chains: %.0f loop rounds, %.0f with starts\n", n,
-              acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[5] / n, acc[6] / n, acc[7] / n);
+      fprintf(stderr, "zes lazy match steps (avg cycles over %u blocks): stage %.0f tail %.0f window chains %.0f entry chains %.0f true chain (only unmerged blocks) %.0f | first wave, window chains: %.0f loop turns\n", n,
+              acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[5] / n, acc[6] / n);
   }
   if (sort_dbg) {
     HIPCHK(hipMemsetAsync(g.dbg.p, 0, (size_t)nblk * 64, g.stream));
@@ -1318,7 +1319,7 @@ int zes_shutdown(void) {
   if (!g.ready) return ZES_OK;
   (void)hipSetDevice(g.device);
   (void)hipStreamSynchronize(g.stream);
-  DevBuf* all[] = {&g.bufs, &g.blks, &g.idx_a, &g.idx_b, &g.inv, &g.hists, &g.codes, &g.hdrs, &g.adler, &g.res, &g.surv, &g.cand,
+  DevBuf* all[] = {&g.bufs, &g.blks, &g.idx_a, &g.idx_b, &g.inv, &g.sdelta, &g.hists, &g.codes, &g.hdrs, &g.adler, &g.res, &g.surv, &g.cand,
                    &g.cand_sorted, &g.counters, &g.cres, &g.map, &g.resume, &g.dbg, &g.ibufs, &g.ibufs2, &g.mvlist, &g.scratch, &g.st_in, &g.st_out,
                    &g.sres, &g.maps, &g.seglist, &g.segprefix, &g.wins, &g.sym16, &g.segorder, &g.segjobs, &g.kraft, &g.pw16, &g.gwins};
   for (DevBuf* b : all) {
@@ -1809,15 +1810,16 @@ int zes_stage_lz77_dev(const uint8_t* d_in, uint64_t n, uint64_t start, uint32_t
   if ((rc = ensure(g.idx_a, (size_t)ZES_BLK * 4))) return rc;
   if ((rc = ensure(g.idx_b, (size_t)ZES_BLK * 4))) return rc;
   if ((rc = ensure(g.inv, (size_t)ZES_BLK * 4))) return rc;
+  if ((rc = ensure(g.sdelta, (size_t)ZES_BLK * 2 + 64))) return rc;
   if ((rc = ensure(g.hists, 320 * 4))) return rc;
   HIPCHK(hipMemcpyAsync(g.bufs.p, &b, sizeof b, hipMemcpyHostToDevice, g.stream));
   HIPCHK(hipMemcpyAsync(g.blks.p, &z, sizeof z, hipMemcpyHostToDevice, g.stream));
   hipLaunchKernelGGL(k_lz_sort, dim3(1), dim3(SORT_THREADS), 0, g.stream, d_in, (const ZesBuf*)g.bufs.p, (const ZesBlk*)g.blks.p,
-                     (uint32_t*)g.idx_a.p, (uint32_t*)g.idx_b.p, (uint32_t*)g.inv.p);
+                     (uint32_t*)g.idx_a.p, (uint32_t*)g.idx_b.p, (uint32_t*)g.inv.p, (uint16_t*)g.sdelta.p);
   hipLaunchKernelGGL(k_lz_match, dim3(1), dim3(MATCH_THREADS), 0, g.stream, d_in, (const ZesBuf*)g.bufs.p,
                      (const ZesBlk*)g.blks.p, (const uint32_t*)g.idx_a.p, (uint32_t*)g.idx_b.p);
   hipLaunchKernelGGL(k_lz_match_lazy, dim3(1), dim3(MATCH_THREADS), 0, g.stream, d_in, (const ZesBuf*)g.bufs.p,
-                     (const ZesBlk*)g.blks.p, (const uint32_t*)g.idx_a.p, (const uint32_t*)g.inv.p, (uint32_t*)g.idx_b.p);
+                     (const ZesBlk*)g.blks.p, (const uint32_t*)g.idx_a.p, (const uint32_t*)g.inv.p, (const uint16_t*)g.sdelta.p, (uint32_t*)g.idx_b.p);
   hipLaunchKernelGGL(k_lz_parse, dim3(1), dim3(PARSE_THREADS), 0, g.stream, d_in, (const ZesBuf*)g.bufs.p, (ZesBlk*)g.blks.p,
                      (const uint32_t*)g.idx_b.p, (uint32_t*)g.idx_a.p, (uint32_t*)g.hists.p);
   HIPCHK(hipGetLastError());

@@ -103,7 +103,7 @@ __device__ __forceinline__ static uint4 sort_ld16(const uint8_t* __restrict__ sr
 
 __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restrict__ d_in, const ZesBuf* __restrict__ bufs,
                                                           const ZesBlk* __restrict__ blks, uint32_t* __restrict__ idx_a,
-                                                          uint32_t* __restrict__ idx_b, uint32_t* __restrict__ inv_all) {
+                                                          uint32_t* __restrict__ idx_b, uint32_t* __restrict__ inv_all, uint16_t* __restrict__ sd_all) {
   __shared__ __align__(16) SortSmem S;
   const uint32_t g = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const ZesBlk bk = blks[g];
@@ -267,8 +267,11 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
   SSTAMP(4);
   // Blocks that keep most of their positions (text, periodic data) go to the lazy match finder, which
   // evaluates positions along greedy chains and needs the sorted slot of a position: inv[p].
+#ifdef NO_LAZY
+  const bool lazy = false;
+#else
   const bool lazy = inv_all != nullptr && ns * 2u >= cnt;
-  uint32_t* inv = inv_all ? inv_all + (uint64_t)g * ZES_BLK : nullptr;
+#endif
   if (tid == 0) A[ZES_BLK - 1] = ns | (lazy ? ZES_SORT_LAZY : 0u);
   if (ns == 0) return;  // uniform
 
@@ -403,13 +406,19 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
     __syncthreads();
     SSTAMP(6 + (pass == 2));
   }
-  // For the lazy match finder: inv[p] = sorted slot of p (17 bits) | distance - 1 to the nearest earlier
-  // position with the same key (15 bits), or ZES_INV_NONE when there is none inside the 32768-byte window
-  // (then no candidate is: src/lz77.ts:49) or the filter dropped p.  Scattering the entries straight to
-  // memory costs a whole memory transaction each, so the table is built in LDS in four slices of 32768
-  // positions (the staged block is no longer needed once the same-key flags are taken) and each slice
-  // leaves with coalesced 16-byte stores; the sorted list is re-read per slice (it sits in the L2).
+  // For the lazy match finder, which walks the candidates of a position most recent first (src/lz77.ts:65):
+  //   sd[r]   distance from the position in sorted slot r to the one in slot r-1 when both hold the same key and lie
+  //           within 32768 of each other, else 0: the candidates of the position in slot r are reached by subtracting
+  //           sd[r], sd[r-1], ... until a 0 — consecutive 2-byte entries, one cache line for 32 candidates;
+  //   inv[p]  sorted slot of p (17 bits) | sd of that slot - 1 (15 bits), or ZES_INV_NONE when p has no candidate
+  //           (none inside the window: src/lz77.ts:49, or the filter dropped p).
+  // sd[] leaves with coalesced stores.  Scattering inv[] straight to memory costs a whole memory transaction per
+  // entry, so it is built in LDS in four slices of 32768 positions (the staged block is no longer needed once the
+  // same-key flags are taken) and each slice leaves with coalesced 16-byte stores; the sorted list is re-read per
+  // slice (it sits in the L2).
   if (lazy) {
+    uint32_t* inv = inv_all + (uint64_t)g * ZES_BLK;
+    uint16_t* sd = sd_all + (uint64_t)g * ZES_BLK;
     uint32_t* same = reinterpret_cast<uint32_t*>(&S.whist[0][0][0]);  // [4096] bit r: slot r holds the key of slot r-1
     for (uint32_t wd = tid; wd < ZES_BLK / 32; wd += SORT_THREADS) same[wd] = 0;
     __syncthreads();
@@ -443,10 +452,11 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
 #pragma unroll
         for (uint32_t k = 0; k < 8; k++) {
           const uint32_t r = rb + k * SORT_THREADS;
-          if (r < ns && (pos[k] >> 15) == b) {
+          if (r < ns) {
             const uint32_t delta = pos[k] - prv[k];  // > 0: equal keys are in ascending position order
             const bool has = ((same[r >> 5] >> (r & 31u)) & 1u) && delta <= ZES_WINDOW;
-            stage[pos[k] & 32767u] = has ? (r | ((delta - 1u) << 17)) : ZES_INV_NONE;
+            if (b == 0u) sd[r] = (uint16_t)(has ? delta : 0u);  // (lanes of a wave write 64 consecutive entries)
+            if ((pos[k] >> 15) == b) stage[pos[k] & 32767u] = has ? (r | ((delta - 1u) << 17)) : ZES_INV_NONE;
           }
         }
       }
@@ -676,18 +686,27 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match(const uint8_t* __res
 // The greedy parse only ever asks for the match at the positions of its chain p -> p + len | p + 1
 // (about one position in five on text, one in a hundred on long periodic matches), but which positions
 // those are is only known once the earlier ones are evaluated.  So:
+//   0  the last LAZY_TAIL keyed positions of the block are evaluated up front, one lane each (a match that
+//      would run into the block's last three bytes is dropped whole, src/lz77.ts:95: on repetitive data
+//      every position there pays a full compare and stays a literal)
 //   1  every 128-byte window gets the chain that starts at its first byte, evaluated position by
-//      position by one lane (1024 chains in flight); the positions it visits are kept as a bit mask
+//      position by one lane (1024 chains in flight); the positions it stands on are kept as a bit mask
 //      V1 and the position where it leaves the window as xw[w]
-//   2  the chain that really enters a window starts wherever the previous window's chain left off:
-//      from each xw[u] a second chain is followed until it lands on a V1 position (greedy chains on
-//      text merge within a few tokens) or leaves the window; the outcome is e2[u]
-//   3  one wavefront walks the true chain from position 0 through these tables (a few LDS reads per
-//      window).  Where it arrives at a position nobody evaluated (periodic data: chains of maximal
-//      matches never merge) the position is evaluated on the spot, all 64 lanes sharing the
-//      candidates.
-// Afterwards every position of the true chain carries its exact match word; the others are zero
-// ("literal"), which k_lz_parse never looks at on the chain it resolves.
+//   2  the chain that really enters a window starts wherever an earlier window's chain left off: from
+//      each xw[u] a second chain is followed until it stands on a V1 position (greedy chains on text
+//      merge within a few tokens).  By induction the true chain from position 0 is then evaluated
+//      everywhere: window 0's own chain up to xw[0], the second chain from there up to a V1 position,
+//      that window's own chain up to its xw, and so on.
+//   3  only when a second chain gave up after LAZY_MERGE_CAP bytes without meeting a V1 position
+//      (periodic data: chains of maximal matches never merge): one wavefront walks the true chain
+//      from position 0 and evaluates what nobody has evaluated, the 64 lanes sharing each compare.
+// Candidates come from k_lz_sort's tables: inv[p] gives the sorted slot r of p and the distance to its
+// nearest candidate; the ones after it follow by subtracting sd[r-1], sd[r-2], ... (0 ends the list) —
+// consecutive 2-byte entries, fetched four at a time (one 8-byte load per four candidates, 32 candidates
+// per cache line) one group ahead of their use.
+// Afterwards every position of the true chain carries its match word (a match, or LAZY_EVAL_LIT);
+// the others are zero or whatever a side chain left there, which k_lz_parse never looks at on the
+// chain it resolves.
 // ------------------------------------------------------------------------------------------
 __device__ unsigned long long* g_lazy_dbg = nullptr;  // ZES_DEBUG_PHASES: cycle stamps [g][8]
 void zes_lazy_set_dbg(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lazy_dbg), &p, sizeof p); }
@@ -695,116 +714,336 @@ void zes_lazy_set_dbg(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBO
   do {                                                                                                   \
     if (g_lazy_dbg && threadIdx.x == 0) g_lazy_dbg[(size_t)blockIdx.x * 8 + (i)] = (unsigned long long)clock64(); \
   } while (0)
-#define LAZY_WIN 128u
+#define LAZY_WIN 512u
 #define LAZY_NWIN (ZES_BLK / LAZY_WIN)
-#define LAZY_NONE 0xFFFFFFFFu
-#define LAZY_TAIL 512u  // positions at the block end that are evaluated up front, one lane each
-#ifndef LAZY_START_MIN
-#define LAZY_START_MIN 1u  // lanes that must be waiting before a batch of evaluations is started (measured: 1 best)
-#endif
-#ifndef LAZY_CMP_MIN
-#define LAZY_CMP_MIN 1u    // lanes that must be waiting before a batch of compares is run (measured: 1 best)
-#endif
+#define LAZY_TAIL 512u         // positions at the block end that are evaluated up front, one lane each
+#define LAZY_EVAL_LIT 1u       // match word of an evaluated position that stays a literal (no match bit: k_lz_parse reads a literal)
+#define LAZY_MERGE_CAP 1024u   // a second chain that has met no window chain after this many bytes gives up
 struct LazySmem {
   uint32_t in[(MATCH_IN_DWORDS + 31) / 32 * 32];  // block + halo, swizzled like MatchSmem::in
   uint32_t v1[ZES_BLK / 32];                      // positions on the window-start chains
   uint16_t xw[LAZY_NWIN];                         // chain of window w leaves it at 128 w + xw[w]
-  uint16_t e2[LAZY_NWIN];                         // the chain entering at 128 u + xw[u] leaves that window at 128 u + e2[u]
   uint16_t tail[LAZY_TAIL];                       // hop (1 or match length) of the block's last LAZY_TAIL keyed positions
   uint32_t wq;                                    // next work item to hand out
+  uint32_t unmerged;                              // a second chain gave up: the true chain may hold unevaluated positions
 };
 
-// common prefix of the strings at q and p (q < p, first three bytes known equal), capped at maxl
-__device__ __forceinline__ static uint32_t lazy_lcp(const uint32_t* in, uint32_t q, uint32_t p, uint32_t maxl) {
-  uint32_t L = 3;
-  const uint32_t qo = q + 3u, po = p + 3u;
-  uint32_t qi = qo >> 2, pi = po >> 2;
-  const uint32_t qs = qo & 3u, ps = po & 3u;
-  uint32_t qlo = in[mswz(qi)], plo = in[mswz(pi)];
-  while (L < maxl) {
-    const uint32_t qm = in[mswz(qi + 1)], pm = in[mswz(pi + 1)];
-    const uint32_t qhi = in[mswz(qi + 2)], phi = in[mswz(pi + 2)];
-    const uint32_t x1 = __builtin_amdgcn_alignbyte(qm, qlo, qs) ^ __builtin_amdgcn_alignbyte(pm, plo, ps);
-    const uint32_t x2 = __builtin_amdgcn_alignbyte(qhi, qm, qs) ^ __builtin_amdgcn_alignbyte(phi, pm, ps);
-    const uint32_t f1 = ((uint32_t)__ffs((int)x1) - 1u) >> 3, f2 = ((uint32_t)__ffs((int)x2) - 1u) >> 3;
-    L += x1 ? f1 : (x2 ? 4u + f2 : 8u);
-    if (x1 | x2) break;
-    qi += 2;
-    pi += 2;
-    qlo = qhi;
-    plo = phi;
-  }
-  return min(L, maxl);
-}
-
-// Match at position p by the whole wavefront (p uniform): lane k takes candidate k of a round of 64.
-// Returns the match word (0 = literal).  Candidate order, early exits and tie rule of src/lz77.ts:49-95.
-__device__ static uint32_t lazy_wave_eval(const LazySmem& S, const uint32_t* __restrict__ idx, const uint32_t iv, uint32_t p, uint32_t T,
-                                          uint32_t avail) {
+// Match at position p by the whole wavefront (p uniform): the candidates one after the other, every compare
+// shared by the 64 lanes (four bytes each).  Candidate order, early exits and tie rule of src/lz77.ts:49-95.
+__device__ static uint32_t lazy_wave_eval(const LazySmem& S, uint32_t iv, const uint16_t* __restrict__ sd, uint32_t p, uint32_t T, uint32_t avail) {
   const uint32_t lane = zes_lane();
-  if (iv == ZES_INV_NONE) return 0u;  // no earlier position with this key inside the window
-  const uint32_t r = iv & 0x1FFFFu;
-  const uint32_t keyp = m_ld32u(S.in, p) & 0xffffffu;
   const uint32_t maxl = min(ZES_MAXMATCH, avail - p);
-  uint32_t best = 0, bestq = 0;
-  if (maxl == ZES_MAXMATCH) {
-    // Periodic data: the nearest candidate already matches at full length and ends the scan (:89-91).
-    // All lanes compare that one candidate, four bytes each (the halo covers p + 258).
-    const uint32_t q0 = p - ((iv >> 17) + 1u);
-    {
-      const uint32_t x = m_ld32u(S.in, q0 + 4u * lane) ^ m_ld32u(S.in, p + 4u * lane);
-      const uint64_t full = __ballot(x == 0u);                                // dwords 0..63 = bytes 0..255
-      const uint32_t t = m_ld32u(S.in, q0 + 256u) ^ m_ld32u(S.in, p + 256u);  // bytes 256, 257
-      if (full == ~0ull && (t & 0xffffu) == 0u) {
-        if (p + ZES_MAXMATCH + 3u <= T) return ZES_TOK_MATCH | ((ZES_MAXMATCH - 3u) << 16) | (p - q0 - 1u);  // :95
-        return 0u;
-      }
+  uint32_t best = 0, bestq = 0, check = 0, q = p;
+  if (iv == ZES_INV_NONE) return LAZY_EVAL_LIT;
+  uint32_t s = iv & 0x1FFFFu;  // slot whose sd entry leads from the current candidate to the next
+  uint32_t dq = (iv >> 17) + 1u, dqv = 0;
+  bool pending = false;  // dqv (requested while the candidate before was compared) still has to be read
+  const uint32_t pd = m_ld32u(S.in, p + 4u * lane), pt = m_ld32u(S.in, p + 256u);
+  for (;;) {
+    if (check >= 128u || (best >= 8u && check >= 16u) || best >= maxl) break;  // :66-69, :89-91 (before the wait: a full match needs no further distance)
+    if (pending) dq = (uint32_t)__builtin_amdgcn_readfirstlane((int)dqv);
+    if (dq == 0u) break;
+    const uint32_t q2 = q - dq;
+    if (p - q2 > ZES_WINDOW) break;  // :49
+    q = q2;
+    check++;
+    s--;
+    dqv = sd[s];  // (slot 0 has nobody in front of it: sd[0] is 0)
+    pending = true;
+    const uint32_t x = m_ld32u(S.in, q + 4u * lane) ^ pd;
+    const uint64_t mism = __ballot(x != 0u);
+    uint32_t L;
+    if (mism) {
+      const uint32_t fl = (uint32_t)__builtin_ctzll(mism);
+      const uint32_t xf = (uint32_t)__builtin_amdgcn_readlane((int)x, (int)fl);
+      L = 4u * fl + ((uint32_t)__builtin_ctz(xf) >> 3);
+    } else {
+      const uint32_t t = (m_ld32u(S.in, q + 256u) ^ pt) & 0xffffu;  // bytes 256, 257
+      L = t ? 256u + ((uint32_t)__builtin_ctz(t) >> 3) : ZES_MAXMATCH;
     }
-  }
-  for (uint32_t round = 0; round < 2u; round++) {  // at most 128 candidates (:66)
-    const uint32_t k = round * 64u + lane;
-    const int32_t slot = (int32_t)r - 1 - (int32_t)k;
-    const uint32_t q = idx[slot > 0 ? slot : 0];
-    const bool ok = slot >= 0 && (m_ld32u(S.in, q) & 0xffffffu) == keyp && (p - q) <= ZES_WINDOW;  // same key, inside the window (:49)
-    const uint64_t okm = __ballot(ok);
-    const uint32_t nrun = (~okm) ? (uint32_t)__builtin_ctzll(~okm) : 64u;  // candidates are one run of slots
-    const uint32_t L = lane < nrun ? lazy_lcp(S.in, q, p, maxl) : 0u;
-    // best length before candidate k is looked at = running maximum over the nearer candidates
-    uint32_t incl = L;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t t = (uint32_t)__shfl_up((int)incl, d);
-      if ((int)lane >= d) incl = max(incl, t);
+    L = min(L, maxl);
+    if (L > best) {  // strictly longer only: the nearest candidate wins ties (:86-88)
+      best = L;
+      bestq = q;
     }
-    uint32_t excl = (uint32_t)__shfl_up((int)incl, 1);
-    excl = max(lane ? excl : 0u, best);
-    // the scan stops in front of candidate k when the run is over, when a match of 8 is in hand after
-    // 16 candidates (:66-69), or right after a full-length match (:89-91)
-    const uint64_t stopm = __ballot(lane >= nrun || (k >= 16u && excl >= 8u) || excl >= ZES_MAXMATCH);
-    const uint32_t kstop = stopm ? (uint32_t)__builtin_ctzll(stopm) : 64u;
-    const uint32_t Lx = lane < kstop ? L : 0u;
-    uint32_t bm = Lx;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) bm = max(bm, (uint32_t)__shfl_xor((int)bm, d));
-    if (bm > best) {  // strictly longer only: the nearest candidate wins ties (:86-88)
-      const uint64_t who = __ballot(Lx == bm);
-      best = bm;
-      bestq = (uint32_t)__shfl((int)q, (int)__builtin_ctzll(who));
-    }
-    if (kstop < 64u) break;
   }
   if (best >= 3u && p + best + 3u <= T) return ZES_TOK_MATCH | ((best - 3u) << 16) | (p - bestq - 1u);  // :95
-  return 0u;
+  return LAZY_EVAL_LIT;
+}
+
+#define LZ_IDLE 0u   // no chain
+#define LZ_PROBE 1u  // looking at the candidates of p
+#define LZ_DONE 2u   // the match at p is known
+#define LZ_STAND 3u  // the chain stands at p: leave, merge, hop or evaluate
+#define LZ_WAIT 4u   // a position has started: its inv entry is on the way
+
+// Phases 0-2: one chain per group of 16 lanes (a DPP row), four chains per wavefront, 64 per workgroup.
+// A turn of the loop evaluates one position of every chain: its sixteen nearest candidates at once, lane k the
+// k-th — their distances are sixteen consecutive 2-byte entries of sd[] (one 32-byte access), the positions a
+// prefix sum over the row, every lane's common prefix with p computed side by side, and the reference's
+// one-after-the-other rule (src/lz77.ts:65-93) read off a prefix maximum: on text a position has 19 candidates on
+// average and 17 of them cannot beat what is already in hand, which a chain-per-lane loop (one candidate per turn)
+// finds out one turn at a time.  A position with more than sixteen candidates takes further rounds of sixteen while
+// the rule allows (less than 8 bytes in hand after 16 candidates, 128 at most: src/lz77.ts:66-69).
+// Control is the same for the sixteen lanes of a row (every lane keeps a copy of the chain's state), so what
+// diverges inside a wavefront are only the four chains.
+#define LAZY_G 16u
+template <int N>
+__device__ __forceinline__ static uint32_t row_shr(uint32_t x) {  // lane i of a row gets lane i-N's value, 0 for the first N lanes
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x110 + N, 0xf, 0xf, false);
+}
+
+template <uint32_t PHASE>
+__device__ __forceinline__ static uint32_t lazy_chains(LazySmem& S, const uint32_t* __restrict__ inv, const uint16_t* __restrict__ sd,
+                                                       uint32_t* __restrict__ mo, uint32_t T, uint32_t cnt, uint32_t avail, uint32_t tbase,
+                                                       uint32_t nitems) {
+  const uint32_t lane = zes_lane(), sub = lane & (LAZY_G - 1u), g0 = lane & ~(LAZY_G - 1u);  // g0: first lane of this row
+  uint32_t mode = LZ_IDLE, item = 0, p = 0, wend = 0, cstart = 0;  // the same in the 16 lanes of a row
+  uint32_t wcur = 0, wnxt = 0, wpend = 0, wb = 0x40000000u;  // inv entries of positions [wb, wb+16) and [wb+16, wb+32), lane k the k-th
+  bool fw = false;                                           // wpend holds this row's next window
+  uint32_t sdp = 0, sdp_r = 0;                               // first sixteen distances requested ahead for slot sdp_r
+  bool sdp_ok = false;
+  bool drained = false;  // no work items left (uniform)
+  uint32_t niter = 0;
+#ifdef LAZY_PROF
+  unsigned long long lap[6] = {0, 0, 0, 0, 0, 0}, tl = clock64(), nlcp = 0, nrnd = 0;
+#define LLAP(i)                              \
+  do {                                       \
+    const unsigned long long n_ = clock64(); \
+    lap[i] += n_ - tl;                       \
+    tl = n_;                                 \
+  } while (0)
+#else
+#define LLAP(i)
+#endif
+  for (;;) {
+    niter++;
+    wnxt = fw ? wpend : wnxt;  // the window requested in an earlier turn has arrived
+    fw = false;
+    // ---- hand out work items to rows without a chain ----
+    {
+      const uint64_t idle = __ballot(mode == LZ_IDLE) & 0x0001000100010001ull;  // one bit per row
+      if (idle && !drained) {
+        uint32_t firsti = 0;
+        const uint32_t nidle = (uint32_t)__popcll(idle);
+        if (lane == 0) firsti = atomicAdd(&S.wq, nidle);
+        firsti = (uint32_t)__builtin_amdgcn_readfirstlane((int)firsti);
+        if (firsti >= nitems) drained = true;
+        const uint32_t mine = firsti + (uint32_t)__popcll(idle & ((1ull << g0) - 1ull));
+        const bool take = mode == LZ_IDLE && mine < nitems;
+        item = take ? mine : item;
+        uint32_t np, nw;
+        if (PHASE == 0u) {
+          np = tbase + mine;
+          nw = np + 1u;
+        } else if (PHASE == 1u) {
+          np = mine * LAZY_WIN;
+          nw = min(np + LAZY_WIN, T);
+        } else {
+          np = mine * LAZY_WIN + S.xw[take ? mine : 0u];
+          nw = T;  // (np >= T: the chain ended with the block)
+        }
+        p = take ? np : p;
+        cstart = take ? np : cstart;
+        wend = take ? nw : wend;
+        mode = take ? LZ_STAND : mode;
+      }
+    }
+    if (!__ballot(mode != LZ_IDLE) && drained) break;
+    // ---- chain control: leave the window, merge, step over pre-evaluated or keyless positions, or evaluate ----
+    bool ev;
+    {
+      const bool st = mode == LZ_STAND;
+      const bool leave = st && p >= wend;
+      bool merged = false, gaveup = false;
+      if (PHASE == 2u) {
+        const uint32_t pc = min(p, ZES_BLK - 1u);
+        const uint32_t vb = (S.v1[pc >> 5] >> (pc & 31u)) & 1u;
+        merged = st && !leave && vb != 0u;  // from here on it is a window's own chain
+        gaveup = st && !leave && !merged && p - cstart >= LAZY_MERGE_CAP;
+        if (gaveup && sub == 0u) S.unmerged = 1u;
+      }
+      const bool go = st && !leave && !merged && !gaveup;
+      if (PHASE == 1u) {
+        if (go && sub == 0u) atomicOr(&S.v1[p >> 5], 1u << (p & 31u));
+        if (leave && sub == 0u) S.xw[item] = (uint16_t)(p - item * LAZY_WIN);
+      }
+      const bool keyless = go && p >= cnt;  // the block's last two bytes are always literals (src/lz77.ts:116-117)
+      bool intail = false;
+      uint32_t hop = 0;
+      if (PHASE != 0u) {
+        intail = go && !keyless && p >= tbase;  // evaluated in phase 0
+        hop = S.tail[intail ? p - tbase : 0u];
+      }
+      ev = go && !keyless && !intail;
+      p += keyless ? 1u : (intail ? hop : 0u);
+      mode = (leave || merged || gaveup) ? LZ_IDLE : mode;
+    }
+    LLAP(0);
+    // ---- the match at p (src/lz77.ts:49-95) ----
+    if (__ballot(ev)) {
+      // sorted slot of p from the row's two windows of inv entries (sixteen positions each, lane k the k-th); a chain
+      // moves on by a few bytes per position, so the window behind the current one was requested turns ago
+      if (__ballot(ev && p - wb >= 2u * LAZY_G)) {  // far jump (or a new work item): both windows from memory
+        const bool far = ev && p - wb >= 2u * LAZY_G;
+        const uint32_t nb = p & ~(LAZY_G - 1u);
+        const uint32_t a0 = inv[far ? min(nb + sub, ZES_BLK - 1u) : 0u], a1 = inv[far ? min(nb + LAZY_G + sub, ZES_BLK - 1u) : 0u];
+        wcur = far ? a0 : wcur;
+        wnxt = far ? a1 : wnxt;
+        wb = far ? nb : wb;
+      }
+      {
+        const bool step = ev && p - wb >= LAZY_G;  // into the window behind: it becomes the current one, the next is requested
+        wcur = step ? wnxt : wcur;
+        wb += step ? LAZY_G : 0u;
+        if (__ballot(step)) {
+          const uint32_t a1 = inv[step ? min(wb + LAZY_G + sub, ZES_BLK - 1u) : 0u];
+          wpend = a1;  // read at the top of a later turn (fw: this row's request)
+          fw = step;
+        }
+      }
+      const uint32_t iv = (uint32_t)__shfl((int)wcur, (int)(g0 + ((ev ? p - wb : 0u) & (LAZY_G - 1u))));
+      LLAP(1);
+      const uint32_t r = iv & 0x1FFFFu;  // sorted slot of p: the distance to candidate k is the sum of sd[r], sd[r-1], ... sd[r-k]
+      const uint32_t maxl = min(ZES_MAXMATCH, avail - (ev ? p : 0u));  // = min(258, n - p)
+      uint32_t best = 0, bestq = 0, base = 0, lastq = p;
+      bool more = ev && iv != ZES_INV_NONE;
+      // the distances of a round are requested one round ahead (round 0: at the end of the turn before, when the chain's
+      // next position was known — sdp/sdp_r say for which slot)
+      uint32_t dnext;
+      {
+        const bool hit = more && sdp_ok && sdp_r == r;
+        if (__ballot(more && !hit)) {
+          const uint32_t t = sd[(more && sub <= r) ? r - sub : 0u];
+          sdp = hit ? sdp : t;
+        }
+        dnext = sdp;
+      }
+      while (__ballot(more)) {
+        const uint32_t k = base + sub;
+        const bool inl = more && k <= r;  // (slot 0 has nobody in front of it: sd[0] is 0)
+        uint32_t d = inl ? dnext : 0u;
+        {
+          const uint32_t k2 = k + LAZY_G;
+          dnext = sd[(more && k2 <= r) ? r - k2 : 0u];  // next round's sixteen, in flight while this round is worked on
+        }
+        LLAP(2);
+        // candidate positions: prefix sum of the distances over the row
+        uint32_t ps = d;
+        ps += row_shr<1>(ps);
+        ps += row_shr<2>(ps);
+        ps += row_shr<4>(ps);
+        ps += row_shr<8>(ps);
+        const uint32_t qk = lastq - ps;
+        // the list ends at the first 0 (another key, or further than 32768 from its neighbour: src/lz77.ts:49 — the
+        // window test on the candidate itself comes on top), and at 128 candidates (:66)
+        const uint32_t zm = (uint32_t)(__ballot(d == 0u || (p - qk) > ZES_WINDOW || k >= 128u) >> g0) & 0xffffu;
+        const uint32_t nv = zm ? (uint32_t)__builtin_ctz(zm) : LAZY_G;  // valid candidates of this round
+        const bool v = more && sub < nv;
+        // common prefix of the strings at qk and p (first three bytes equal by the key), capped at maxl
+        uint32_t L = 3;
+        LLAP(3);
+        {
+          const uint32_t qo = (v ? qk : 0u) + 3u, po = p + 3u;
+          uint32_t qi = qo >> 2, pi = po >> 2;
+          const uint32_t qs = qo & 3u, ps2 = po & 3u;
+          uint32_t qlo = S.in[mswz(qi)], plo = S.in[mswz(pi)];
+          bool run = v;
+          while (__ballot(run && L < maxl)) {  // 8 bytes per step
+            const uint32_t qm = S.in[mswz(qi + 1)], pm = S.in[mswz(pi + 1)];
+            const uint32_t qhi = S.in[mswz(qi + 2)], phi = S.in[mswz(pi + 2)];
+            const uint32_t x1 = __builtin_amdgcn_alignbyte(qm, qlo, qs) ^ __builtin_amdgcn_alignbyte(pm, plo, ps2);
+            const uint32_t x2 = __builtin_amdgcn_alignbyte(qhi, qm, qs) ^ __builtin_amdgcn_alignbyte(phi, pm, ps2);
+            const bool live = run && L < maxl;
+            const uint32_t f1 = ((uint32_t)__ffs((int)x1) - 1u) >> 3, f2 = ((uint32_t)__ffs((int)x2) - 1u) >> 3;
+            const uint32_t add = x1 ? f1 : (x2 ? 4u + f2 : 8u);
+            L += live ? add : 0u;
+            run = run && !(live && (x1 | x2));
+            qi += 2;
+            pi += 2;
+            qlo = qhi;
+            plo = phi;
+#ifdef LAZY_PROF
+            nlcp++;
+#endif
+          }
+        }
+        LLAP(4);
+        L = v ? min(L, maxl) : 0u;
+        // what is in hand before candidate k is looked at: the running maximum over the nearer ones
+        uint32_t incl = L;
+        incl = max(incl, row_shr<1>(incl));
+        incl = max(incl, row_shr<2>(incl));
+        incl = max(incl, row_shr<4>(incl));
+        incl = max(incl, row_shr<8>(incl));
+        const uint32_t excl = max(row_shr<1>(incl), best);
+        // candidate k is looked at unless 8 bytes are in hand after 16 candidates (:66-69) or a full-length match has
+        // ended the scan (:89-91); both tests only ever cut off a tail of the row
+        const bool ex = v && (base == 0u || excl < 8u) && excl < maxl;
+        const uint32_t xm = (uint32_t)(__ballot(ex) >> g0) & 0xffffu;  // a prefix of the valid ones
+        const uint32_t nx = (uint32_t)__popc(xm);
+        const uint32_t top = (uint32_t)__shfl((int)incl, (int)(g0 + (nx ? nx - 1u : 0u)));  // maximum over the candidates looked at
+        const uint32_t gmax = nx ? top : 0u;
+        if (__ballot(more && gmax > best)) {
+          // strictly longer only, and the nearest of the longest: the nearest candidate wins ties (:86-88)
+          const uint32_t who = (uint32_t)(__ballot(ex && L == gmax) >> g0) & 0xffffu;
+          const uint32_t kb = who ? (uint32_t)__builtin_ctz(who) : 0u;
+          const uint32_t qb = (uint32_t)__shfl((int)qk, (int)(g0 + kb));
+          const bool up = more && gmax > best;
+          bestq = up ? qb : bestq;
+          best = up ? gmax : best;
+        }
+        // another round: all sixteen were there and were looked at, fewer than 128 so far, and the rule lets candidate
+        // 16 (32, ...) be looked at: less than 8 bytes in hand, no full-length match
+        const uint32_t lq = (uint32_t)__shfl((int)qk, (int)(g0 + LAZY_G - 1u));
+        lastq = more ? lq : lastq;
+        base += LAZY_G;
+        more = more && nx == LAZY_G && base < 128u && best < 8u && best < maxl;
+#ifdef LAZY_PROF
+        nrnd++;
+#endif
+      }
+      const bool acc = best >= 3u && p + best + 3u <= T;  // src/lz77.ts:95
+      if (ev && sub == 0u) mo[p] = acc ? (ZES_TOK_MATCH | ((best - 3u) << 16) | (p - bestq - 1u)) : LAZY_EVAL_LIT;
+      if (PHASE == 0u) {
+        if (ev && sub == 0u) S.tail[item] = (uint16_t)(acc ? best : 1u);
+      }
+      p += ev ? (acc ? best : 1u) : 0u;
+      // the first sixteen distances of the position the chain stands on now, for the next turn (when that position
+      // is still inside the two windows of inv entries, and if chain control does not move the chain elsewhere)
+      {
+        const uint32_t off = p - wb;
+        const bool in2 = ev && off < 2u * LAZY_G && p < cnt;
+        const uint32_t e0 = (uint32_t)__shfl((int)wcur, (int)(g0 + (off & (LAZY_G - 1u))));
+        const uint32_t e1 = (uint32_t)__shfl((int)wnxt, (int)(g0 + (off & (LAZY_G - 1u))));
+        const uint32_t ivn = off < LAZY_G ? e0 : e1;
+        const bool want = in2 && ivn != ZES_INV_NONE && !(fw && off >= LAZY_G);  // (a window still on its way: not this time)
+        const uint32_t rn = ivn & 0x1FFFFu;
+        if (__ballot(want)) sdp = sd[(want && sub <= rn) ? rn - sub : 0u];
+        sdp_ok = want;
+        sdp_r = rn;
+      }
+    }
+    LLAP(5);
+  }
+#ifdef LAZY_PROF
+  if (PHASE == 1u && blockIdx.x == 7 && threadIdx.x == 0)
+    printf("lazy prof: turns %u rounds %llu | control %llu inv-wait %llu sd-wait %llu prefix %llu lcp %llu (%llu steps) rule+store %llu\n", niter, nrnd,
+           lap[0], lap[1], lap[2], lap[3], lap[4], nlcp, lap[5]);
+#endif
+#undef LLAP
+  return niter;
 }
 
 __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match_lazy(const uint8_t* __restrict__ d_in, const ZesBuf* __restrict__ bufs,
                                                                  const ZesBlk* __restrict__ blks, const uint32_t* __restrict__ idx_a,
-                                                                 const uint32_t* __restrict__ inv_all, uint32_t* __restrict__ match_out) {
+                                                                 const uint32_t* __restrict__ inv_all, const uint16_t* __restrict__ sd_all,
+                                                                 uint32_t* __restrict__ match_out) {
   __shared__ __align__(16) LazySmem S;
   const uint32_t g = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const uint32_t* idx = idx_a + (uint64_t)g * ZES_BLK;
-  if (!(idx[ZES_BLK - 1] & ZES_SORT_LAZY)) return;  // this block belongs to k_lz_match
+  if (!(idx_a[(uint64_t)g * ZES_BLK + ZES_BLK - 1] & ZES_SORT_LAZY)) return;  // this block belongs to k_lz_match
   const uint32_t* inv = inv_all + (uint64_t)g * ZES_BLK;
+  const uint16_t* sd = sd_all + (uint64_t)g * ZES_BLK;
   const ZesBlk bk = blks[g];
   const ZesBuf bf = bufs[bk.buf];
   const uint32_t T = bk.len;
@@ -849,231 +1088,112 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match_lazy(const uint8_t* 
     for (uint32_t i = tid; i < n4; i += MATCH_THREADS) mo4[i] = make_uint4(0, 0, 0, 0);
   }
   for (uint32_t i = tid; i < ZES_BLK / 32; i += MATCH_THREADS) S.v1[i] = 0;
-  if (tid == 0) S.wq = 0;
+  if (tid == 0) {
+    S.wq = 0;
+    S.unmerged = 0;
+  }
   __syncthreads();
 
   LSTAMP(1);
-  // ---- phase 0: the last positions of the block, one lane each.  A match that would run into the
-  // block's last three bytes is dropped whole (src/lz77.ts:95), so on repetitive data every position
-  // of the tail pays a full-length compare and stays a literal: as a chain that is 128 of them in a row.
-  // ---- phases 1 and 2: one chain per lane, positions evaluated one after the other ----
   const uint32_t tbase = cnt > LAZY_TAIL ? cnt - LAZY_TAIL : 0u;  // first pre-evaluated position
-  for (uint32_t phase = 0; phase <= 2u; phase++) {
-    const uint32_t nitems = phase == 0u ? cnt - tbase : nwin;
-    // lane state.  mode: 0 no chain, 5 chain standing at p, 6 p needs its match, 1 probing, 2 comparing, 3 match known
-    uint32_t mode = 0, item = 0, p = 0, wend = 0;
-    uint32_t best = 0, bestq = 0, check = 0, pprobe = 0, maxl = 0, keyp = 0, q = 0, cq = 0, cq2 = 0;
-    int32_t cslot = -1;
-    bool drained = false;  // no work items left (uniform)
-    uint32_t niter = 0, nstart = 0;
-    for (;;) {
-      niter++;
-      const uint64_t running = __ballot(mode == 1u || mode == 2u);
-      const uint64_t starting = __ballot(mode == 6u);
-      if (!running && !starting) {
-        if (!__ballot(mode != 0u) && drained) break;
-      }
-      // (D) start evaluations, batched (the global load stalls the whole wavefront).  One 4-byte load
-      // gives the sorted slot and the nearest candidate; a position without one is a literal at once.
-      if (starting && ((uint32_t)__popcll(starting) >= LAZY_START_MIN || !running)) {
-        nstart++;
-        const bool st = mode == 6u;
-        const uint32_t iv = inv[st ? p : 0u];
-        const bool lit = iv == ZES_INV_NONE;
-        const int32_t sl = (int32_t)(iv & 0x1FFFFu) - 1;  // slot of the nearest candidate
-        const uint32_t c1 = idx[(st && !lit && sl > 1) ? sl - 1 : 0];  // the one after it, for the next round
-        if (st) {
-          cslot = lit ? -1 : sl;
-          cq = p - ((iv >> 17) + 1u);
-          cq2 = c1;
-          best = 0;
-          bestq = 0;
-          check = 0;
-          maxl = min(ZES_MAXMATCH, avail - p);  // = min(258, n - p)
-          keyp = m_ld32u(S.in, p) & 0xffffffu;
-          mode = lit ? 3u : 1u;
-        }
-      }
-      // (E) compares, batched and run to completion (select code: see k_lz_match)
-      {
-        const uint32_t npend = (uint32_t)__popcll(__ballot(mode == 2u));
-        const uint32_t nprobe = (uint32_t)__popcll(__ballot(mode == 1u));
-        if (npend >= LAZY_CMP_MIN || (npend != 0u && nprobe == 0u)) {
-          bool cmp = mode == 2u;
-          uint32_t L = 3;
-          const uint32_t qo = q + 3u, po = p + 3u;
-          uint32_t qi = qo >> 2, pi = po >> 2;
-          const uint32_t qs = qo & 3u, ps = po & 3u;
-          uint32_t qlo = S.in[mswz(qi)], plo = S.in[mswz(pi)];
-          while (__ballot(cmp && L < maxl)) {  // 8 bytes per step
-            const uint32_t qm = S.in[mswz(qi + 1)], pm = S.in[mswz(pi + 1)];
-            const uint32_t qhi = S.in[mswz(qi + 2)], phi = S.in[mswz(pi + 2)];
-            const uint32_t x1 = __builtin_amdgcn_alignbyte(qm, qlo, qs) ^ __builtin_amdgcn_alignbyte(pm, plo, ps);
-            const uint32_t x2 = __builtin_amdgcn_alignbyte(qhi, qm, qs) ^ __builtin_amdgcn_alignbyte(phi, pm, ps);
-            const bool live = cmp && L < maxl;
-            const uint32_t f1 = ((uint32_t)__ffs((int)x1) - 1u) >> 3, f2 = ((uint32_t)__ffs((int)x2) - 1u) >> 3;
-            const uint32_t add = x1 ? f1 : (x2 ? 4u + f2 : 8u);
-            L += live ? add : 0u;
-            cmp = cmp && !(live && (x1 | x2));
-            qi += 2;
-            pi += 2;
-            qlo = qhi;
-            plo = phi;
-          }
-          const bool c2 = mode == 2u;
-          const uint32_t Lf = min(L, maxl);
-          const bool better = c2 && Lf > best;
-          best = better ? Lf : best;
-          bestq = better ? q : bestq;
-          if (__ballot(better)) {
-            const uint32_t pw = m_ld32u(S.in, p + (best >= 3u ? best - 3u : 0u));
-            pprobe = (better && best < maxl) ? pw : pprobe;
-          }
-          mode = c2 ? ((better && Lf >= ZES_MAXMATCH) ? 3u : 1u) : mode;
-        }
-      }
-      // (F) probe the next candidate: the slot before, while it holds the same key (select code)
-      if (__ballot(mode == 1u)) {
-        const bool pr = mode == 1u;
-        const uint32_t q2 = cq;
-        const bool same = cslot >= 0 && (m_ld32u(S.in, q2) & 0xffffffu) == keyp;
-        const bool stop0 = !same || check >= 128u || (best >= 8u && check >= 16u);  // src/lz77.ts:66-69
-        const bool far = (p - q2) > ZES_WINDOW;                                      // src/lz77.ts:49
-        const bool adv = pr && !stop0;
-        const bool cand = adv && !far;
-        // L > best needs bytes 0..best equal: one dword probe at best-3 rejects most candidates
-        const uint32_t pw = m_ld32u(S.in, q2 + (best >= 3u ? best - 3u : 0u));
-        const bool skip = (best >= maxl) || (best >= 3u && pw != pprobe);
-        q = adv ? q2 : q;
-        check += cand ? 1u : 0u;
-        const int32_t ns2 = adv ? cslot - 1 : cslot;
-        // two slots ahead is requested now: the load has two rounds to arrive
-        const uint32_t nq = idx[(pr && ns2 > 1) ? ns2 - 1 : 0];
-        cq = adv ? cq2 : cq;
-        cq2 = adv ? nq : cq2;
-        cslot = ns2;
-        mode = (pr && (stop0 || far)) ? 3u : ((cand && !skip) ? 2u : mode);
-      }
-      // (A) a finished evaluation moves its chain on
-      if (mode == 3u) {
-        const bool acc = best >= 3u && p + best + 3u <= T;  // src/lz77.ts:95
-        if (acc) mo[p] = ZES_TOK_MATCH | ((best - 3u) << 16) | (p - bestq - 1u);
-        if (phase == 0u) S.tail[item] = (uint16_t)(acc ? best : 1u);
-        p += acc ? best : 1u;
-        mode = 5u;
-      }
-      // (B) chain control: leave the window, merge, step over the keyless tail, or ask for a match
-      if (mode == 5u) {
-        const uint32_t w = (wend - 1u) / LAZY_WIN;  // the window being crossed
-        if (p >= wend) {
-          if (phase == 1u) S.xw[item] = (uint16_t)(p - item * LAZY_WIN);
-          if (phase == 2u) S.e2[item] = (uint16_t)(p - item * LAZY_WIN);
-          mode = 0u;
-        } else if (phase == 2u && ((S.v1[p >> 5] >> (p & 31u)) & 1u)) {
-          S.e2[item] = (uint16_t)(w * LAZY_WIN + S.xw[w] - item * LAZY_WIN);  // from here on it is window w's own chain
-          mode = 0u;
-        } else {
-          if (phase == 1u) atomicOr(&S.v1[p >> 5], 1u << (p & 31u));
-          if (p >= cnt) p += 1u;  // the block's last two bytes are always literals (src/lz77.ts:116-117)
-          else if (phase != 0u && p >= tbase) p += S.tail[p - tbase];  // evaluated in phase 0
-          else mode = 6u;
-        }
-      }
-      // (C) hand out work items to lanes without a chain
-      {
-        const uint64_t idle = __ballot(mode == 0u);
-        if (idle && !drained) {
-          uint32_t first = 0;
-          const uint32_t nidle = (uint32_t)__popcll(idle);
-          if (lane == 0) first = atomicAdd(&S.wq, nidle);
-          first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
-          if (first >= nitems) drained = true;
-          const uint32_t mine = first + (uint32_t)__popcll(idle & zes_lanemask_lt());
-          if (mode == 0u && mine < nitems) {
-            item = mine;
-            if (phase == 0u) {
-              p = tbase + item;
-              wend = p + 1u;
-              mode = 6u;
-            } else if (phase == 1u) {
-              p = item * LAZY_WIN;
-              wend = min(p + LAZY_WIN, T);
-              mode = 5u;
-            } else {
-              p = item * LAZY_WIN + S.xw[item];
-              if (p >= T) {
-                S.e2[item] = S.xw[item];  // the chain ends with the block
-              } else {
-                wend = min((p / LAZY_WIN + 1u) * LAZY_WIN, T);
-                mode = 5u;
-              }
-            }
-          }
-        }
-      }
-    }
-    if (g_lazy_dbg && tid == 0 && phase == 1u) {
-      g_lazy_dbg[(size_t)blockIdx.x * 8 + 6] = niter;
-      g_lazy_dbg[(size_t)blockIdx.x * 8 + 7] = nstart;
-    }
+  {
+    (void)lazy_chains<0u>(S, inv, sd, mo, T, cnt, avail, tbase, cnt - tbase);
     __syncthreads();
-    LSTAMP(2 + phase);
+    LSTAMP(2);
     if (tid == 0) S.wq = 0;
     __syncthreads();
+    const uint32_t niter = lazy_chains<1u>(S, inv, sd, mo, T, cnt, avail, tbase, nwin);
+    if (g_lazy_dbg && tid == 0) g_lazy_dbg[(size_t)blockIdx.x * 8 + 6] = niter;
+    __syncthreads();
+    LSTAMP(3);
+    if (tid == 0) S.wq = 0;
+    __syncthreads();
+    (void)lazy_chains<2u>(S, inv, sd, mo, T, cnt, avail, tbase, nwin);
+    __syncthreads();
+    LSTAMP(4);
   }
 
-  // ---- phase 3: the true chain, by one wavefront ----
-  if (wave == 0) {
+  // ---- phase 3 (periodic data only): the true chain, by one wavefront ----
+  if (S.unmerged && wave == 0) {
     uint32_t p = 0;
-    // chains of maximal matches (periodic data) are evaluated here one position after the other: the
-    // table entry of p + 258 is requested while p is being looked at
-    uint32_t spec_p = LAZY_NONE;
-    uint32_t spec_iv = 0u;
+    // The words of the chain's positions come 64 at a time (lane k: the word of position cb + k; the chunk behind is
+    // requested while this one is walked).  Chains of maximal matches move on by exactly 258: when a position has to
+    // be evaluated here, the chunk and the inv entry of p + 3 * 258 are requested — three evaluations ahead of their
+    // use (one trip to memory takes longer than one evaluation) — and handed down a three-deep queue.
+    // (Words written by the other waves of this workgroup: read past this CU's L1.)
+    uint32_t cb = 0xFFFFFFFFu, cw = 0, nb = 0xFFFFFFFFu, nw = 0;  // current chunk, next sequential chunk
+    uint32_t q1p = 0xFFFFFFFFu, q1iv = 0, q1w = 0, q2p = 0xFFFFFFFFu, q2iv = 0, q2w = 0, q3p = 0xFFFFFFFFu, q3iv = 0, q3w = 0;
+    // results are parked in registers, one per lane, and stored 64 at a time: a store followed by the next load would
+    // make every evaluation wait for the store to complete (loads and stores share one counter)
     uint32_t keep_p = 0, keep_m = 0, nkeep = 0;
     while (p < cnt) {
-      const uint32_t w = p / LAZY_WIN;
-      uint32_t np = 0;
-      if ((S.v1[p >> 5] >> (p & 31u)) & 1u) {
-        np = w * LAZY_WIN + S.xw[w];  // on window w's own chain
-      } else {
-        bool found = false;
-        for (uint32_t d = 1; d <= 3u && d <= w; d++) {  // a hop is at most 258 bytes: the entry came from one of three windows
-          const uint32_t u = w - d;
-          if (u * LAZY_WIN + S.xw[u] == p) {
-            np = u * LAZY_WIN + S.e2[u];
-            found = true;
-            break;
-          }
+      const uint32_t base = p & ~63u;
+      const bool predicted = p == q1p;
+      if (base != cb) {
+        if (predicted) {
+          cw = q1w;
+        } else if (base == nb) {
+          cw = nw;
+        } else {
+          cw = __hip_atomic_load(&mo[min(base + lane, ZES_BLK - 1u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (!found && p >= tbase) {
-          np = p + S.tail[p - tbase];  // evaluated in phase 0
-          found = true;
-        }
-        if (!found) {  // nobody evaluated this position yet
-          const uint32_t iv = (p == spec_p) ? spec_iv : inv[p];
-          spec_p = min(p + ZES_MAXMATCH, cnt - 1u);
-          spec_iv = inv[spec_p];
-          const uint32_t m = lazy_wave_eval(S, idx, iv, p, T, avail);
-          // results are parked in registers, one per lane, and stored 64 at a time: a store followed by
-          // the next table load would make every evaluation wait for the store to complete
-          if (m) {
-            if (lane == nkeep) {
-              keep_p = p;
-              keep_m = m;
-            }
-            if (++nkeep == 64u) {
-              mo[keep_p] = keep_m;
-              nkeep = 0;
-            }
-          }
-          np = p + ((m & ZES_TOK_MATCH) ? zes_tok_len(m) : 1u);
+        cb = base;
+        if (!predicted) {  // walking on position by position: the chunk behind
+          nb = base + 64u;
+          nw = __hip_atomic_load(&mo[min(nb + lane, ZES_BLK - 1u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
-      p = np > p ? np : p + 1u;  // (np > p always; the guard only keeps a corrupted table from hanging the wavefront)
+      {
+        // a run of evaluated literals is stepped over at once
+        const uint64_t lit = __ballot(cw == LAZY_EVAL_LIT) >> (p - base);
+        if (lit & 1ull) {
+          const uint32_t run = (~lit) ? (uint32_t)__builtin_ctzll(~lit) : 64u;
+          p += min(run, 64u - (p - base));
+          continue;
+        }
+      }
+      uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)cw, (int)(p - base));
+      if (m == 0u) {  // nobody evaluated this position yet
+        if (p >= tbase) {
+          m = LAZY_EVAL_LIT;  // (cannot happen: phase 0 evaluated the tail; keeps a corrupted table from hanging the wavefront)
+        } else {
+          uint32_t iv = predicted ? q1iv : inv[p];
+          iv = (uint32_t)__builtin_amdgcn_readfirstlane((int)iv);
+          // hand the queue down and request what lies three maximal matches ahead
+          const bool inq = predicted && q2p == p + ZES_MAXMATCH;
+          q1p = inq ? q2p : 0xFFFFFFFFu;
+          q1iv = q2iv;
+          q1w = q2w;
+          q2p = inq ? q3p : 0xFFFFFFFFu;
+          q2iv = q3iv;
+          q2w = q3w;
+          if (!inq) {  // (re)start: the next two as well
+            q1p = min(p + ZES_MAXMATCH, cnt - 1u);
+            q1iv = inv[q1p];
+            q1w = __hip_atomic_load(&mo[min((q1p & ~63u) + lane, ZES_BLK - 1u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            q2p = min(p + 2u * ZES_MAXMATCH, cnt - 1u);
+            q2iv = inv[q2p];
+            q2w = __hip_atomic_load(&mo[min((q2p & ~63u) + lane, ZES_BLK - 1u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          q3p = min(p + 3u * ZES_MAXMATCH, cnt - 1u);
+          q3iv = inv[q3p];
+          q3w = __hip_atomic_load(&mo[min((q3p & ~63u) + lane, ZES_BLK - 1u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          m = lazy_wave_eval(S, iv, sd, p, T, avail);
+          if (lane == nkeep) {
+            keep_p = p;
+            keep_m = m;
+          }
+          if (++nkeep == 64u) {
+            mo[keep_p] = keep_m;
+            nkeep = 0;
+          }
+        }
+      }
+      p += (m & ZES_TOK_MATCH) ? zes_tok_len(m) : 1u;
     }
     if (lane < nkeep) mo[keep_p] = keep_m;
-    LSTAMP(5);
   }
+  LSTAMP(5);
 }
 
 // ------------------------------------------------------------------------------------------

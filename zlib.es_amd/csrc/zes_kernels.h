@@ -100,8 +100,8 @@ void zes_parse_set_dbg(unsigned long long*);
 void zes_lazy_set_dbg(unsigned long long*);
 void zes_huff_set_dbg(unsigned long long*);
 __global__ void k_make_blks(ZesBuf, uint32_t, ZesBuf*, ZesBlk*, uint32_t, unsigned long long*);
-__global__ void k_lz_sort(const uint8_t*, const ZesBuf*, const ZesBlk*, uint32_t*, uint32_t*, uint32_t*);
-__global__ void k_lz_match_lazy(const uint8_t*, const ZesBuf*, const ZesBlk*, const uint32_t*, const uint32_t*, uint32_t*);
+__global__ void k_lz_sort(const uint8_t*, const ZesBuf*, const ZesBlk*, uint32_t*, uint32_t*, uint32_t*, uint16_t*);
+__global__ void k_lz_match_lazy(const uint8_t*, const ZesBuf*, const ZesBlk*, const uint32_t*, const uint32_t*, const uint16_t*, uint32_t*);
 __global__ void k_lz_match(const uint8_t*, const ZesBuf*, const ZesBlk*, const uint32_t*, uint32_t*);
 __global__ void k_lz_parse(const uint8_t*, const ZesBuf*, ZesBlk*, const uint32_t*, uint32_t*, uint32_t*);
 __global__ void k_huff(ZesBlk*, const uint32_t*, uint32_t*, uint32_t*);
