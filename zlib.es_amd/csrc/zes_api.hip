@@ -867,7 +867,7 @@ constexpr uint32_t SEG_GROUP_WORK = 8192;    // work items per segment launch (e
 
 // One group: buffers ids[0..nb) with their sorted candidate lists at cand_sorted + cbase[k], ncand[k] entries.
 int inflate_segments_run(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const uint32_t* ids, const uint32_t* cbase, const uint32_t* ncand,
-                         uint32_t nb, uint32_t* dscratch /* 2 * nb words: chain segments not in the store, failure flags */) {
+                         uint32_t nb, uint32_t* dscratch /* 2 * nb + 1 words: chain segments not in the store, failure flags, far-match counter */) {
   int rc;
   ZesSegJob* hj = (ZesSegJob*)((uint8_t*)g.pinned + PIN_UP);
   uint32_t work = 0;
@@ -899,17 +899,32 @@ int inflate_segments_run(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, cons
   if ((rc = ensure(g.segorder, (size_t)work * 4))) return rc;
   if ((rc = ensure(g.res, sizeof(ZesRes) * nb))) return rc;
   HIPCHK(hipMemcpyAsync(g.segjobs.p, hj, sizeof(ZesSegJob) * nb, hipMemcpyHostToDevice, g.stream));
-  HIPCHK(hipMemsetAsync(dscratch, 0, (size_t)nb * 8, g.stream));
+  HIPCHK(hipMemsetAsync(dscratch, 0, (size_t)nb * 8 + 4, g.stream));
   uint32_t* novf_d = dscratch;
   uint32_t* fail_d = dscratch + nb;
   const uint32_t* cs = (const uint32_t*)g.cand_sorted.p;
   for (uint32_t k = 0; k < nb; k++)
     hipLaunchKernelGGL(k_inf_seg_order, dim3(1), dim3(1024), 0, g.stream, cs + cbase[k], ncand[k], jobs[ids[k]].c,
                        (uint32_t*)g.segorder.p + hj[k].work_first);
+  // The decoders run with the short marker ring first (three per CU instead of two); a match that reaches behind the
+  // ring takes its symbols from the symbol store, so a segment that has outgrown its share of the store and then meets
+  // such a match cannot go on: far_d counts those, and the whole group runs again with the full ring (rare: streams
+  // that inflate by more than the store's symbols per compressed byte).
+  uint32_t* far_d = dscratch + 2 * nb;
   {
     Timed t("k_inf_seg_scan");
-    hipLaunchKernelGGL(k_inf_seg_scan, dim3(work), dim3(64), 0, g.stream, d_in, (const ZesSegJob*)g.segjobs.p, nb, cs, (ZesSegRes*)g.sres.p,
-                       (uint32_t*)g.maps.p, (uint32_t*)g.sym16.p, ratio, (const uint32_t*)g.segorder.p);
+    hipLaunchKernelGGL(k_inf_seg_scan_short, dim3(work), dim3(64), 0, g.stream, d_in, (const ZesSegJob*)g.segjobs.p, nb, cs, (ZesSegRes*)g.sres.p,
+                       (uint32_t*)g.maps.p, (uint32_t*)g.sym16.p, ratio, (const uint32_t*)g.segorder.p, far_d);
+  }
+  {
+    uint32_t* hf = (uint32_t*)g.pinned;
+    HIPCHK(hipMemcpyAsync(hf, far_d, 4, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    if (hf[0] != 0) {
+      Timed t("k_inf_seg_scan");
+      hipLaunchKernelGGL(k_inf_seg_scan, dim3(work), dim3(64), 0, g.stream, d_in, (const ZesSegJob*)g.segjobs.p, nb, cs, (ZesSegRes*)g.sres.p,
+                         (uint32_t*)g.maps.p, (uint32_t*)g.sym16.p, ratio, (const uint32_t*)g.segorder.p, far_d);
+    }
   }
   {
     Timed t("k_inf_seg_chain");
@@ -1007,7 +1022,7 @@ int inflate_segments(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const st
       max_c = std::max(max_c, j.c);
     }
     const uint32_t surv_cap = (uint32_t)std::min<uint64_t>(max_c / 4 + 1024ull, 1ull << 30);
-    const size_t cnt_words = 4 + (size_t)nb + 2 * (size_t)nb + 4;  // scan/verify scratch, counts, run scratch, first-byte sink
+    const size_t cnt_words = 4 + (size_t)nb + 2 * (size_t)nb + 4 + 4;  // scan/verify scratch, counts, run scratch (+ far-match counter), first-byte sink
     if ((rc = ensure(g.ibufs, sizeof(ZesInfBuf) * 2))) return rc;
     if ((rc = ensure(g.surv, (size_t)surv_cap * 8))) return rc;
     if ((rc = ensure(g.cand, (size_t)cands * 4))) return rc;
@@ -1017,7 +1032,7 @@ int inflate_segments(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const st
     uint32_t* counters = (uint32_t*)g.counters.p;
     uint32_t* cnt = counters + 4;
     uint32_t* dscratch = cnt + nb;
-    uint8_t* sink = (uint8_t*)(dscratch + 2 * nb);
+    uint8_t* sink = (uint8_t*)(dscratch + 2 * nb + 4);
     HIPCHK(hipMemsetAsync(counters, 0, cnt_words * 4, g.stream));
     const ZesInfBuf* dbufs = (const ZesInfBuf*)g.ibufs.p;
     for (uint32_t k = 0; k < nb; k++) {

@@ -426,15 +426,24 @@ __global__ __launch_bounds__(1024) void k_inf_ranksort(const ZesInfBuf* __restri
 #define DROOT 9u
 #define RING 65536u
 #define FLUSH 16384u
-#define RING16 33280u  // marker ring (16-bit symbols): window + longest match + slack; not a power of two
+#define RING16 33280u  // marker ring (16-bit symbols), full form: window + longest match + slack; not a power of two
+// The segment-parallel tier also has a short form of the marker ring: three decoders fit a CU instead of two (the ring is
+// what the decoder's LDS goes to), and a match that reaches further back than the ring takes its symbols from the
+// segment's symbol store in global memory — or, in front of the segment's first byte, writes the marker values directly.
+#define RING16_SHORT 20480u
+#define FLUSH_SHORT 4096u  // the short ring flushes to the symbol store this often: everything older than that is in the store
 
 // One wavefront decodes serially; all decoder state is wave-uniform and kept in scalar registers
 // (every value that comes out of LDS goes through readfirstlane), so the per-token work is a few
 // scalar instructions around one or two LDS table reads.  The compressed input sits in two vector
 // registers (lane l = dword l of a 64-dword window and of the next one) and is picked with
 // readlane; a window is re-loaded every 2048 bits, one window ahead of its use.
-struct InfSmem {
-  uint8_t ring[RING16 * 2];  // byte mode uses the first RING bytes
+template <uint32_t R16>
+struct InfSmemT {
+  static constexpr uint32_t kR16 = R16;                                   // symbols of the marker ring
+  static constexpr uint32_t kFlush = R16 >= RING16 ? FLUSH : FLUSH_SHORT;  // marker mode: symbols per flush to the store
+  static constexpr uint32_t kNear = R16 - ZES_MAXMATCH - 64u;              // a match at most this far back is wholly inside the ring
+  uint8_t ring[R16 * 2];  // byte mode uses the first RING bytes (full form only)
   uint32_t lut_l[1u << LROOT];  // wd_entry() words; 0 = code longer than the root, or no code
   uint32_t lut_d[1u << DROOT];
   uint16_t syms_l[288];
@@ -444,6 +453,9 @@ struct InfSmem {
   uint8_t lens[352];  // [0,288) lit/len, [288,320) dist
   uint8_t cl_lut[128];
 };
+using InfSmem = InfSmemT<RING16>;
+using InfSmemShort = InfSmemT<RING16_SHORT>;
+static_assert(sizeof(InfSmemShort) * 3 <= 160 * 1024, "three short-ring decoders per CU");
 
 struct WaveDec {
   // uniform state (identical in all 64 lanes)
@@ -470,7 +482,7 @@ struct WaveDec {
   uint32_t vcur, vnxt;  // input dwords (idx & ~63) + lane (end-of-stream zeros applied) and + 64 + lane (as loaded)
 };
 
-enum { WD_OK = 0, WD_ANOMALY = 1, WD_NEEDS_HISTORY = 2 };
+enum { WD_OK = 0, WD_ANOMALY = 1, WD_NEEDS_HISTORY = 2, WD_FAR_NOSTORE = 3 };  // 3: short marker ring, a far match, and no symbol store to take it from
 
 #define WD_SGPR(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 #ifdef WD_PROFILE
@@ -536,7 +548,8 @@ __device__ __forceinline__ static uint32_t wd_take(WaveDec& d, uint32_t k) {  //
   return v;
 }
 
-__device__ __forceinline__ static void wd_flush_range(InfSmem& S, WaveDec& d, uint64_t from, uint64_t to) {
+template <class SM>
+__device__ __forceinline__ static void wd_flush_range(SM& S, WaveDec& d, uint64_t from, uint64_t to) {
   // ring -> global for output offsets [from, to); from is a multiple of 16
   const uint32_t lane = zes_lane();
   for (uint64_t off = from + (uint64_t)lane * 16; off < to; off += 64 * 16) {
@@ -550,7 +563,8 @@ __device__ __forceinline__ static void wd_flush_range(InfSmem& S, WaveDec& d, ui
   }
   WD_JOIN();
 }
-__device__ __forceinline__ static void wd_produced(InfSmem& S, WaveDec& d, uint32_t n) {  // n bytes were put into the ring
+template <class SM>
+__device__ __forceinline__ static void wd_produced(SM& S, WaveDec& d, uint32_t n) {  // n bytes were put into the ring
   d.o += n;
   d.reach = min(d.reach + n, ZES_WINDOW);
   d.unfl += n;
@@ -601,7 +615,8 @@ __device__ __forceinline__ static uint32_t wd_entry(uint32_t s, uint32_t l, bool
 
 // canonical tables + root LUT for one alphabet; lens in S.lens[base .. base+nsym).
 // Returns false when the length set is over-subscribed.
-__device__ __noinline__ static bool wd_build(InfSmem& S, uint32_t base, uint32_t nsym, uint32_t root, uint32_t* lut, uint16_t* syms,
+template <class SM>
+__device__ __noinline__ static bool wd_build(SM& S, uint32_t base, uint32_t nsym, uint32_t root, uint32_t* lut, uint16_t* syms,
                                              uint32_t* first, uint16_t* cnt, uint16_t* offs) {
   const uint32_t lane = zes_lane();
   const uint8_t* lens = S.lens + base;
@@ -694,19 +709,21 @@ __device__ __forceinline__ static uint32_t wd_mod(uint32_t i, uint32_t dist, flo
 
 // Marker mode keeps the decoded symbols: every FLUSH symbols the ring's unflushed part goes to the segment's
 // region of the symbol store (k_inf_seg_translate turns it into bytes once the windows are known).
-__device__ __forceinline__ static void wd_mark_flush(InfSmem& S, WaveDec& d, uint32_t count) {  // the oldest `count` unflushed symbols
+template <class SM>
+__device__ __forceinline__ static void wd_mark_flush(SM& S, WaveDec& d, uint32_t count) {  // the oldest `count` unflushed symbols
   const uint16_t* r16 = reinterpret_cast<const uint16_t*>(S.ring);
-  const uint64_t first = d.o - d.unfl;  // symbol offset inside the segment; a multiple of FLUSH
+  constexpr uint32_t R = SM::kR16;
+  const uint64_t first = d.o - d.unfl;  // symbol offset inside the segment; a multiple of the flush size
   if (d.sym == nullptr || first + count > d.sym_cap) {
     d.sym_ovf = 1;
   } else {
-    uint32_t base = d.oi + RING16 - d.unfl;  // ring index of the first unflushed symbol
-    if (base >= RING16) base -= RING16;
+    uint32_t base = d.oi + R - d.unfl;  // ring index of the first unflushed symbol
+    if (base >= R) base -= R;
     uint32_t* dst = d.sym + first / 2;
     for (uint32_t i2 = zes_lane(); i2 < (count + 1) / 2; i2 += 64) {
       uint32_t a = base + 2 * i2, b = a + 1;
-      if (a >= RING16) a -= RING16;
-      if (b >= RING16) b -= RING16;
+      if (a >= R) a -= R;
+      if (b >= R) b -= R;
       const uint32_t lo = r16[a], hi = 2 * i2 + 1 < count ? (uint32_t)r16[b] : 0u;
       dst[i2] = lo | (hi << 16);
     }
@@ -714,17 +731,18 @@ __device__ __forceinline__ static void wd_mark_flush(InfSmem& S, WaveDec& d, uin
   }
   d.unfl -= count;
 }
-__device__ __forceinline__ static void wd_mark_produced(InfSmem& S, WaveDec& d, uint32_t n) {  // n symbols entered the ring
+template <class SM>
+__device__ __forceinline__ static void wd_mark_produced(SM& S, WaveDec& d, uint32_t n) {  // n symbols entered the ring
   d.o += n;
-  d.unfl += n;  // never more than FLUSH + 257, so the unflushed symbols are all still in the ring
-  if (WD_UNLIKELY(d.unfl >= FLUSH)) wd_mark_flush(S, d, FLUSH);
+  d.unfl += n;  // never more than the flush size + 257, so the unflushed symbols are all still in the ring
+  if (WD_UNLIKELY(d.unfl >= SM::kFlush)) wd_mark_flush(S, d, SM::kFlush);
 }
 
 // Decodes the symbols of one fixed/dynamic block whose tables are built.  Uniform control flow.
 // MARK: 16-bit symbols in the marker ring (values >= 256 stand for bytes of the unknown window in
 // front of the segment), nothing is stored and every distance is allowed.
-template <bool MARK>
-__device__ __forceinline__ static int wd_symbols(InfSmem& S, WaveDec& d) {
+template <bool MARK, class SM>
+__device__ __forceinline__ static int wd_symbols(SM& S, WaveDec& d) {
   const uint32_t lane = zes_lane();
   const uint64_t limit = d.nbytes * 8;
   // every token refills first, so the reader can run at most 64 bits + one dword ahead of a valid position;
@@ -760,7 +778,7 @@ __device__ __forceinline__ static int wd_symbols(InfSmem& S, WaveDec& d) {
       if (MARK) {
         if (lane == 0) r16[d.oi] = (uint16_t)(e >> 16);
         WD_JOIN();
-        d.oi = d.oi + 1u == RING16 ? 0u : d.oi + 1u;
+        d.oi = d.oi + 1u == SM::kR16 ? 0u : d.oi + 1u;
         wd_mark_produced(S, d, 1);
       } else {
         if (lane == 0) S.ring[d.o & (RING - 1)] = (uint8_t)(e >> 16);
@@ -796,13 +814,36 @@ __device__ __forceinline__ static int wd_symbols(InfSmem& S, WaveDec& d) {
     // lane-parallel copy; overlapping matches read i % dist so every source symbol already exists
     const bool overlap = dist < len;
     if (MARK) {
-      const uint32_t si = d.oi >= dist ? d.oi - dist : d.oi + RING16 - dist;
+      constexpr uint32_t R = SM::kR16;
+      if (R < RING16 && WD_UNLIKELY(dist > SM::kNear)) {
+        // short ring, and the source lies (or may lie) behind it: the symbols come from the segment's store — flushed
+        // long ago: the ring keeps far more than one flush interval — or, in front of the segment's first symbol, are
+        // the marker values themselves (marker 256 + i stands for byte i of the 32 KiB in front of the segment)
+        if (WD_UNLIKELY(d.sym_ovf || d.sym == nullptr)) {
+          const int64_t s0 = (int64_t)d.o - (int64_t)dist;
+          if (s0 + (int64_t)len > 0) return WD_FAR_NOSTORE;  // (all of it in front of the segment needs no store)
+        }
+        for (uint32_t i0 = 0; i0 < len; i0 += 64) {  // (dist > len: no overlap)
+          const uint32_t i = i0 + lane;
+          const int64_t pos = (int64_t)d.o - (int64_t)dist + (int64_t)i;
+          uint32_t v = 256u + (uint32_t)((int64_t)ZES_WINDOW + pos);  // pos < 0
+          if (pos >= 0 && i < len) {
+            const uint32_t w = __hip_atomic_load(&d.sym[(uint64_t)pos >> 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v = (pos & 1) ? w >> 16 : w & 0xffffu;
+          }
+          uint32_t b = d.oi + i;
+          if (b >= R) b -= R;
+          if (i < len) r16[b] = (uint16_t)v;
+          WD_JOIN();
+        }
+      } else {
+      const uint32_t si = d.oi >= dist ? d.oi - dist : d.oi + R - dist;
       if (!overlap) {  // the common case, kept lean: the wave executes about one instruction per five cycles
         for (uint32_t i0 = 0; i0 < len; i0 += 64) {
           const uint32_t i = i0 + lane;
           uint32_t a = si + i, b = d.oi + i;
-          if (a >= RING16) a -= RING16;
-          if (b >= RING16) b -= RING16;
+          if (a >= R) a -= R;
+          if (b >= R) b -= R;
           if (i < len) r16[b] = r16[a];
           WD_JOIN();
         }
@@ -811,14 +852,15 @@ __device__ __forceinline__ static int wd_symbols(InfSmem& S, WaveDec& d) {
         for (uint32_t i0 = 0; i0 < len; i0 += 64) {
           const uint32_t i = i0 + lane;
           uint32_t a = si + wd_mod(i, dist, rcp), b = d.oi + i;
-          if (a >= RING16) a -= RING16;
-          if (b >= RING16) b -= RING16;
+          if (a >= R) a -= R;
+          if (b >= R) b -= R;
           if (i < len) r16[b] = r16[a];
           WD_JOIN();
         }
       }
+      }
       d.oi += len;
-      if (d.oi >= RING16) d.oi -= RING16;
+      if (d.oi >= R) d.oi -= R;
       wd_mark_produced(S, d, len);
       continue;
     }
@@ -847,8 +889,8 @@ __device__ __forceinline__ static int wd_symbols(InfSmem& S, WaveDec& d) {
 }
 
 // One block starting at the reader's position (BFINAL bit).  *bfinal receives the flag.
-template <bool MARK>
-__device__ __forceinline__ static int wd_block(InfSmem& S, WaveDec& d, uint32_t* bfinal) {
+template <bool MARK, class SM>
+__device__ __forceinline__ static int wd_block(SM& S, WaveDec& d, uint32_t* bfinal) {
   const uint32_t lane = zes_lane();
   wd_refill(d);
   *bfinal = wd_take(d, 1);
@@ -871,15 +913,15 @@ __device__ __forceinline__ static int wd_block(InfSmem& S, WaveDec& d, uint32_t*
     if (MARK) {
       uint16_t* r16 = reinterpret_cast<uint16_t*>(S.ring);
       for (uint32_t done = 0; done < LEN;) {
-        const uint32_t n = min(LEN - done, FLUSH - d.unfl);  // unflushed symbols never exceed FLUSH + 258: they stay inside the ring
+        const uint32_t n = min(LEN - done, SM::kFlush - d.unfl);  // unflushed symbols never exceed the flush size + 258: they stay inside the ring
         for (uint32_t i = lane; i < n; i += 64) {
           uint32_t b = d.oi + i;
-          if (b >= RING16) b -= RING16;
+          if (b >= SM::kR16) b -= SM::kR16;
           r16[b] = in8[src + done + i];
         }
         WD_JOIN();
         d.oi += n;
-        if (d.oi >= RING16) d.oi -= RING16;
+        if (d.oi >= SM::kR16) d.oi -= SM::kR16;
         wd_mark_produced(S, d, n);
         done += n;
       }
@@ -1101,7 +1143,7 @@ __global__ __launch_bounds__(256) void k_inf_stored_copy(const uint8_t* __restri
 // exactly on a candidate position, passes a final block, or fails; false candidates make
 // segments nobody chains to.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ static uint32_t seg_ring_idx(uint32_t oi, uint32_t i) {  // ring index of position o - 32768 + i
+__device__ __forceinline__ static uint32_t seg_ring_idx(uint32_t oi, uint32_t i) {  // full ring: index of position o - 32768 + i
   uint32_t a = oi + (RING16 - ZES_WINDOW) + i;
   if (a >= RING16) a -= RING16;
   if (a >= RING16) a -= RING16;
@@ -1182,11 +1224,12 @@ __global__ __launch_bounds__(1024) void k_inf_seg_order(const uint32_t* __restri
   }
 }
 
-__global__ __launch_bounds__(64) void k_inf_seg_scan(const uint8_t* __restrict__ d_in, const ZesSegJob* __restrict__ jobs, uint32_t njobs,
+template <class SM>
+__device__ __forceinline__ static void seg_scan_body(SM& S, const uint8_t* __restrict__ d_in, const ZesSegJob* __restrict__ jobs, uint32_t njobs,
                                                      const uint32_t* __restrict__ cand_all, ZesSegRes* __restrict__ sres_all,
                                                      uint32_t* __restrict__ maps_all, uint32_t* __restrict__ sym16_all, uint32_t sym_ratio,
-                                                     const uint32_t* __restrict__ order) {
-  __shared__ __align__(16) InfSmem S;
+                                                     const uint32_t* __restrict__ order, uint32_t* __restrict__ far_nostore) {
+  constexpr uint32_t R = SM::kR16;
   const uint32_t lane = threadIdx.x;
   // buffer of this work item: the last one whose first work item is <= blockIdx.x
   uint32_t bi = 0;
@@ -1231,7 +1274,7 @@ __global__ __launch_bounds__(64) void k_inf_seg_scan(const uint8_t* __restrict__
   d.ostart = 0;
   d.reach = 0;
   d.unfl = 0;
-  d.oi = ZES_WINDOW;
+  d.oi = R >= RING16 ? ZES_WINDOW : 0u;
   // symbol store: the work item that starts at compressed byte b owns symbols [b * ratio, b' * ratio), b' the start of
   // the next work item (the end of the stream for the last one); a segment that outgrows its share is decoded twice
   {
@@ -1243,7 +1286,11 @@ __global__ __launch_bounds__(64) void k_inf_seg_scan(const uint8_t* __restrict__
     d.sym_ovf = sym_ratio ? 0u : 1u;
   }
   uint16_t* r16 = reinterpret_cast<uint16_t*>(S.ring);
-  for (uint32_t i = lane; i < ZES_WINDOW; i += 64) r16[i] = (uint16_t)(256u + i);  // window byte i of the previous segment
+  if (R >= RING16) {
+    for (uint32_t i = lane; i < ZES_WINDOW; i += 64) r16[i] = (uint16_t)(256u + i);  // window byte i of the previous segment
+  } else {  // short ring: the last R bytes of that window, output position 0 at ring index 0 (= R)
+    for (uint32_t i = lane; i < R; i += 64) r16[i] = (uint16_t)(256u + (ZES_WINDOW - R) + i);
+  }
   wd_seek(d, start);
   uint32_t bfinal = 0;
   int rc;
@@ -1267,20 +1314,69 @@ __global__ __launch_bounds__(64) void k_inf_seg_scan(const uint8_t* __restrict__
     }
   }
   if (rc != WD_OK) {
+    if (rc == WD_FAR_NOSTORE && lane == 0) atomicAdd(far_nostore, 1u);  // the host runs the group again with the full ring
     if (lane == 0) sres[w] = r;
     return;
   }
   // the last 32 Ki symbols of the output so far (for a short segment they start inside the previous window)
   uint32_t* mp = maps + (size_t)w * (ZES_WINDOW / 2);
-  for (uint32_t i2 = lane; i2 < ZES_WINDOW / 2; i2 += 64) {
-    const uint32_t lo16 = r16[seg_ring_idx(d.oi, 2 * i2)], hi16 = r16[seg_ring_idx(d.oi, 2 * i2 + 1)];
-    mp[i2] = lo16 | (hi16 << 16);
+  if (R >= RING16) {
+    for (uint32_t i2 = lane; i2 < ZES_WINDOW / 2; i2 += 64) {
+      const uint32_t lo16 = r16[seg_ring_idx(d.oi, 2 * i2)], hi16 = r16[seg_ring_idx(d.oi, 2 * i2 + 1)];
+      mp[i2] = lo16 | (hi16 << 16);
+    }
+    if (d.unfl) wd_mark_flush(S, d, d.unfl);  // the tail of the symbol store
+  } else {
+    // short ring: the nearest R symbols from the ring, the ones before from the store (everything but the ring's share
+    // has been flushed) or, in front of the segment, the markers themselves
+    if (d.o > (uint64_t)R && (d.sym_ovf || d.sym == nullptr)) {  // (cannot read back what was never stored)
+      if (lane == 0) {
+        atomicAdd(far_nostore, 1u);
+        sres[w] = r;
+      }
+      return;
+    }
+    for (uint32_t i2 = lane; i2 < ZES_WINDOW / 2; i2 += 64) {
+      uint32_t v[2];
+#pragma unroll
+      for (uint32_t h = 0; h < 2; h++) {
+        const uint32_t back = ZES_WINDOW - (2 * i2 + h);  // the symbol `back` positions before the end, 1..32768
+        if (back <= R) {
+          v[h] = r16[d.oi >= back ? d.oi - back : d.oi + R - back];
+        } else {
+          const int64_t pos = (int64_t)d.o - (int64_t)back;
+          if (pos < 0) {
+            v[h] = 256u + (uint32_t)((int64_t)ZES_WINDOW + pos);
+          } else {
+            const uint32_t wd = __hip_atomic_load(&d.sym[(uint64_t)pos >> 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v[h] = (pos & 1) ? wd >> 16 : wd & 0xffffu;
+          }
+        }
+      }
+      mp[i2] = v[0] | (v[1] << 16);
+    }
+    if (d.unfl) wd_mark_flush(S, d, d.unfl);  // the tail of the symbol store
   }
-  if (d.unfl) wd_mark_flush(S, d, d.unfl);  // the tail of the symbol store
   r.end_bit = wd_pos(d);
   r.out_len = d.o;
   r.flags = 1u | (bfinal ? 2u : 0u) | (d.sym_ovf ? 4u : 0u);
   if (lane == 0) sres[w] = r;
+}
+
+__global__ __launch_bounds__(64) void k_inf_seg_scan(const uint8_t* __restrict__ d_in, const ZesSegJob* __restrict__ jobs, uint32_t njobs,
+                                                     const uint32_t* __restrict__ cand_all, ZesSegRes* __restrict__ sres_all,
+                                                     uint32_t* __restrict__ maps_all, uint32_t* __restrict__ sym16_all, uint32_t sym_ratio,
+                                                     const uint32_t* __restrict__ order, uint32_t* __restrict__ far_nostore) {
+  __shared__ __align__(16) InfSmem S;
+  seg_scan_body(S, d_in, jobs, njobs, cand_all, sres_all, maps_all, sym16_all, sym_ratio, order, far_nostore);
+}
+// the same with the short marker ring: three decoders per CU
+__global__ __launch_bounds__(64) void k_inf_seg_scan_short(const uint8_t* __restrict__ d_in, const ZesSegJob* __restrict__ jobs, uint32_t njobs,
+                                                           const uint32_t* __restrict__ cand_all, ZesSegRes* __restrict__ sres_all,
+                                                           uint32_t* __restrict__ maps_all, uint32_t* __restrict__ sym16_all, uint32_t sym_ratio,
+                                                           const uint32_t* __restrict__ order, uint32_t* __restrict__ far_nostore) {
+  __shared__ __align__(16) InfSmemShort S;
+  seg_scan_body(S, d_in, jobs, njobs, cand_all, sres_all, maps_all, sym16_all, sym_ratio, order, far_nostore);
 }
 
 // One workgroup per stream: the chain of segments from work item 0 to the final block.
