@@ -48,6 +48,21 @@ def _worker(rank, world, port, q):
             return e.code, np.zeros(0, dtype=np.uint8)
 
     res = shard.run_sharded(bufs, engine)
+    # the asynchronous form bench.py uses under --gpus N (the transfers of one step in flight during the next): same bytes
+    import torch
+
+    owned = shard.partition([len(b) for b in bufs], world)
+    mine = owned[rank]
+    outs = [engine(bufs[i]) for i in mine]
+    local = torch.cat([torch.from_numpy(d) for _, d in outs]) if outs else torch.empty(0, dtype=torch.uint8)
+    got, works = shard.gather_results(local, mine, [len(d) for _, d in outs], [st for st, _ in outs], owned, len(bufs), async_op=True)
+    for w in works:
+        w.wait()
+    if rank == 0:
+        for i, (st, data) in enumerate(res):
+            assert got.status[i] == st and got.result(i).numpy().tobytes() == data.tobytes()
+    else:
+        assert got is None
     if rank == 0:
         ok = True
         for b, (st, data) in zip(bufs, res):

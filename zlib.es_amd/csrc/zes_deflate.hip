@@ -76,9 +76,11 @@ void zes_sort_set_dbg(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBO
 #define ZES_INV_NONE 0xFFFFFFFFu   // inv entry of a position without a candidate
 #define SORT_HASH_BITS 19u
 #define SORT_OWN 128u  // consecutive positions owned by one thread in the filter phase
-#define SORT_ROUNDS 4u
+#ifndef SORT_ROUNDS
+#define SORT_ROUNDS 8u
+#endif
 #define SORT_TILE (SORT_THREADS * SORT_ROUNDS)
-static_assert(SORT_ROUNDS == 4u, "the arrival wait names four registers");
+static_assert(SORT_ROUNDS == 4u || SORT_ROUNDS == 8u, "the arrival wait names four or eight registers");
 struct SortSmem {
   uint8_t in[ZES_BLK + 16];  // filter phase: the counter table; then the staged block
   uint32_t hist[3][256];     // digit histograms of the kept positions, one per pass
@@ -345,6 +347,9 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
 #pragma unroll
       for (uint32_t r = 0; r < SORT_ROUNDS; r++) p[r] = (dense && pass == 0) ? min(i0 + 64u * r, ns - 1u) : pn[r];  // dense: the list is 0, 1, 2, ...
       asm volatile("" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]));
+#if SORT_ROUNDS == 8u
+      asm volatile("" : "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]));
+#endif
 #pragma unroll
       for (uint32_t r = 0; r < SORT_ROUNDS; r++) d[r] = (i0 + 64u * r < ns) ? S.in[p[r] + off] : 0u;
       __syncthreads();  // (A) counters zeroed
@@ -775,7 +780,8 @@ __device__ static uint32_t lazy_wave_eval(const LazySmem& S, uint32_t iv, const 
 #define LZ_PROBE 1u  // looking at the candidates of p
 #define LZ_DONE 2u   // the match at p is known
 #define LZ_STAND 3u  // the chain stands at p: leave, merge, hop or evaluate
-#define LZ_WAIT 4u   // a position has started: its inv entry is on the way
+#define LZ_WAIT 4u   // (chain-per-lane form) a position has started: its inv entry is on the way
+#define LZ_EVAL 5u   // the row is on a position: rounds of sixteen candidates
 
 // Phases 0-2: one chain per group of 16 lanes (a DPP row), four chains per wavefront, 64 per workgroup.
 // A turn of the loop evaluates one position of every chain: its sixteen nearest candidates at once, lane k the
@@ -803,6 +809,10 @@ __device__ __forceinline__ static uint32_t lazy_chains(LazySmem& S, const uint32
   bool fw = false;                                           // wpend holds this row's next window
   uint32_t sdp = 0, sdp_r = 0;                               // first sixteen distances requested ahead for slot sdp_r
   bool sdp_ok = false;
+  // the position a row is on (rounds of sixteen candidates; a row whose position needs another round does not hold up
+  // the other three: every turn of the loop is one round for each row that has one to do)
+  uint32_t r = 0, maxl = 0, best = 0, bestq = 0, base = 0, lastq = 0, dnext = 0;
+  bool more = false;
   bool drained = false;  // no work items left (uniform)
   uint32_t niter = 0;
 #ifdef LAZY_PROF
@@ -880,7 +890,8 @@ __device__ __forceinline__ static uint32_t lazy_chains(LazySmem& S, const uint32
       mode = (leave || merged || gaveup) ? LZ_IDLE : mode;
     }
     LLAP(0);
-    // ---- the match at p (src/lz77.ts:49-95) ----
+    // ---- a position starts (src/lz77.ts:49-95): its sorted slot, the first sixteen distances ----
+    bool fin = false;  // the match at p is known
     if (__ballot(ev)) {
       // sorted slot of p from the row's two windows of inv entries (sixteen positions each, lane k the k-th); a chain
       // moves on by a few bytes per position, so the window behind the current one was requested turns ago
@@ -904,124 +915,140 @@ __device__ __forceinline__ static uint32_t lazy_chains(LazySmem& S, const uint32
       }
       const uint32_t iv = (uint32_t)__shfl((int)wcur, (int)(g0 + ((ev ? p - wb : 0u) & (LAZY_G - 1u))));
       LLAP(1);
-      const uint32_t r = iv & 0x1FFFFu;  // sorted slot of p: the distance to candidate k is the sum of sd[r], sd[r-1], ... sd[r-k]
-      const uint32_t maxl = min(ZES_MAXMATCH, avail - (ev ? p : 0u));  // = min(258, n - p)
-      uint32_t best = 0, bestq = 0, base = 0, lastq = p;
-      bool more = ev && iv != ZES_INV_NONE;
+      const bool has = ev && iv != ZES_INV_NONE;
+      r = ev ? (iv & 0x1FFFFu) : r;  // sorted slot of p: the distance to candidate k is the sum of sd[r], sd[r-1], ... sd[r-k]
+      maxl = ev ? min(ZES_MAXMATCH, avail - p) : maxl;  // = min(258, n - p)
+      best = ev ? 0u : best;
+      bestq = ev ? 0u : bestq;
+      base = ev ? 0u : base;
+      lastq = ev ? p : lastq;
+      more = ev ? has : more;
+      fin = ev && !has;  // no candidate: a literal
+      mode = has ? LZ_EVAL : mode;
       // the distances of a round are requested one round ahead (round 0: at the end of the turn before, when the chain's
       // next position was known — sdp/sdp_r say for which slot)
-      uint32_t dnext;
       {
-        const bool hit = more && sdp_ok && sdp_r == r;
-        if (__ballot(more && !hit)) {
-          const uint32_t t = sd[(more && sub <= r) ? r - sub : 0u];
-          sdp = hit ? sdp : t;
+        const bool hit = has && sdp_ok && sdp_r == r;
+        if (__ballot(has && !hit)) {
+          const uint32_t t = sd[(has && sub <= r) ? r - sub : 0u];
+          sdp = (has && !hit) ? t : sdp;
         }
-        dnext = sdp;
+        dnext = has ? sdp : dnext;
       }
-      while (__ballot(more)) {
-        const uint32_t k = base + sub;
-        const bool inl = more && k <= r;  // (slot 0 has nobody in front of it: sd[0] is 0)
-        uint32_t d = inl ? dnext : 0u;
-        {
-          const uint32_t k2 = k + LAZY_G;
-          dnext = sd[(more && k2 <= r) ? r - k2 : 0u];  // next round's sixteen, in flight while this round is worked on
-        }
-        LLAP(2);
-        // candidate positions: prefix sum of the distances over the row
-        uint32_t ps = d;
-        ps += row_shr<1>(ps);
-        ps += row_shr<2>(ps);
-        ps += row_shr<4>(ps);
-        ps += row_shr<8>(ps);
-        const uint32_t qk = lastq - ps;
-        // the list ends at the first 0 (another key, or further than 32768 from its neighbour: src/lz77.ts:49 — the
-        // window test on the candidate itself comes on top), and at 128 candidates (:66)
-        const uint32_t zm = (uint32_t)(__ballot(d == 0u || (p - qk) > ZES_WINDOW || k >= 128u) >> g0) & 0xffffu;
-        const uint32_t nv = zm ? (uint32_t)__builtin_ctz(zm) : LAZY_G;  // valid candidates of this round
-        const bool v = more && sub < nv;
-        // common prefix of the strings at qk and p (first three bytes equal by the key), capped at maxl
-        uint32_t L = 3;
-        LLAP(3);
-        {
-          const uint32_t qo = (v ? qk : 0u) + 3u, po = p + 3u;
-          uint32_t qi = qo >> 2, pi = po >> 2;
-          const uint32_t qs = qo & 3u, ps2 = po & 3u;
-          uint32_t qlo = S.in[mswz(qi)], plo = S.in[mswz(pi)];
-          bool run = v;
-          while (__ballot(run && L < maxl)) {  // 8 bytes per step
-            const uint32_t qm = S.in[mswz(qi + 1)], pm = S.in[mswz(pi + 1)];
-            const uint32_t qhi = S.in[mswz(qi + 2)], phi = S.in[mswz(pi + 2)];
-            const uint32_t x1 = __builtin_amdgcn_alignbyte(qm, qlo, qs) ^ __builtin_amdgcn_alignbyte(pm, plo, ps2);
-            const uint32_t x2 = __builtin_amdgcn_alignbyte(qhi, qm, qs) ^ __builtin_amdgcn_alignbyte(phi, pm, ps2);
-            const bool live = run && L < maxl;
-            const uint32_t f1 = ((uint32_t)__ffs((int)x1) - 1u) >> 3, f2 = ((uint32_t)__ffs((int)x2) - 1u) >> 3;
-            const uint32_t add = x1 ? f1 : (x2 ? 4u + f2 : 8u);
-            L += live ? add : 0u;
-            run = run && !(live && (x1 | x2));
-            qi += 2;
-            pi += 2;
-            qlo = qhi;
-            plo = phi;
-#ifdef LAZY_PROF
-            nlcp++;
-#endif
-          }
-        }
-        LLAP(4);
-        L = v ? min(L, maxl) : 0u;
-        // what is in hand before candidate k is looked at: the running maximum over the nearer ones
-        uint32_t incl = L;
-        incl = max(incl, row_shr<1>(incl));
-        incl = max(incl, row_shr<2>(incl));
-        incl = max(incl, row_shr<4>(incl));
-        incl = max(incl, row_shr<8>(incl));
-        const uint32_t excl = max(row_shr<1>(incl), best);
-        // candidate k is looked at unless 8 bytes are in hand after 16 candidates (:66-69) or a full-length match has
-        // ended the scan (:89-91); both tests only ever cut off a tail of the row
-        const bool ex = v && (base == 0u || excl < 8u) && excl < maxl;
-        const uint32_t xm = (uint32_t)(__ballot(ex) >> g0) & 0xffffu;  // a prefix of the valid ones
-        const uint32_t nx = (uint32_t)__popc(xm);
-        const uint32_t top = (uint32_t)__shfl((int)incl, (int)(g0 + (nx ? nx - 1u : 0u)));  // maximum over the candidates looked at
-        const uint32_t gmax = nx ? top : 0u;
-        if (__ballot(more && gmax > best)) {
-          // strictly longer only, and the nearest of the longest: the nearest candidate wins ties (:86-88)
-          const uint32_t who = (uint32_t)(__ballot(ex && L == gmax) >> g0) & 0xffffu;
-          const uint32_t kb = who ? (uint32_t)__builtin_ctz(who) : 0u;
-          const uint32_t qb = (uint32_t)__shfl((int)qk, (int)(g0 + kb));
-          const bool up = more && gmax > best;
-          bestq = up ? qb : bestq;
-          best = up ? gmax : best;
-        }
-        // another round: all sixteen were there and were looked at, fewer than 128 so far, and the rule lets candidate
-        // 16 (32, ...) be looked at: less than 8 bytes in hand, no full-length match
-        const uint32_t lq = (uint32_t)__shfl((int)qk, (int)(g0 + LAZY_G - 1u));
-        lastq = more ? lq : lastq;
-        base += LAZY_G;
-        more = more && nx == LAZY_G && base < 128u && best < 8u && best < maxl;
-#ifdef LAZY_PROF
-        nrnd++;
-#endif
+    }
+    // ---- one round of sixteen candidates for every row that is on a position ----
+    if (__ballot(more)) {
+      const bool was = more;
+      const uint32_t k = base + sub;
+      const bool inl = more && k <= r;  // (slot 0 has nobody in front of it: sd[0] is 0)
+      uint32_t d = inl ? dnext : 0u;
+      {
+        const uint32_t k2 = k + LAZY_G;
+        const uint32_t t = sd[(more && k2 <= r) ? r - k2 : 0u];  // next round's sixteen, in flight while this round is worked on
+        dnext = more ? t : dnext;
       }
+      LLAP(2);
+      // candidate positions: prefix sum of the distances over the row
+      uint32_t ps = d;
+      ps += row_shr<1>(ps);
+      ps += row_shr<2>(ps);
+      ps += row_shr<4>(ps);
+      ps += row_shr<8>(ps);
+      const uint32_t qk = lastq - ps;
+      // the list ends at the first 0 (another key, or further than 32768 from its neighbour: src/lz77.ts:49 — the
+      // window test on the candidate itself comes on top), and at 128 candidates (:66)
+      const uint32_t zm = (uint32_t)(__ballot(d == 0u || (p - qk) > ZES_WINDOW || k >= 128u) >> g0) & 0xffffu;
+      const uint32_t nv = zm ? (uint32_t)__builtin_ctz(zm) : LAZY_G;  // valid candidates of this round
+      const bool v = more && sub < nv;
+      // common prefix of the strings at qk and p (first three bytes equal by the key), capped at maxl
+      uint32_t L = 3;
+      LLAP(3);
+      {
+        const uint32_t qo = (v ? qk : 0u) + 3u, po = p + 3u;
+        uint32_t qi = qo >> 2, pi = po >> 2;
+        const uint32_t qs = qo & 3u, ps2 = po & 3u;
+        uint32_t qlo = S.in[mswz(qi)], plo = S.in[mswz(pi)];
+        bool run = v;
+        while (__ballot(run && L < maxl)) {  // 8 bytes per step
+          const uint32_t qm = S.in[mswz(qi + 1)], pm = S.in[mswz(pi + 1)];
+          const uint32_t qhi = S.in[mswz(qi + 2)], phi = S.in[mswz(pi + 2)];
+          const uint32_t x1 = __builtin_amdgcn_alignbyte(qm, qlo, qs) ^ __builtin_amdgcn_alignbyte(pm, plo, ps2);
+          const uint32_t x2 = __builtin_amdgcn_alignbyte(qhi, qm, qs) ^ __builtin_amdgcn_alignbyte(phi, pm, ps2);
+          const bool live = run && L < maxl;
+          const uint32_t f1 = ((uint32_t)__ffs((int)x1) - 1u) >> 3, f2 = ((uint32_t)__ffs((int)x2) - 1u) >> 3;
+          const uint32_t add = x1 ? f1 : (x2 ? 4u + f2 : 8u);
+          L += live ? add : 0u;
+          run = run && !(live && (x1 | x2));
+          qi += 2;
+          pi += 2;
+          qlo = qhi;
+          plo = phi;
+#ifdef LAZY_PROF
+          nlcp++;
+#endif
+        }
+      }
+      LLAP(4);
+      L = v ? min(L, maxl) : 0u;
+      // what is in hand before candidate k is looked at: the running maximum over the nearer ones
+      uint32_t incl = L;
+      incl = max(incl, row_shr<1>(incl));
+      incl = max(incl, row_shr<2>(incl));
+      incl = max(incl, row_shr<4>(incl));
+      incl = max(incl, row_shr<8>(incl));
+      const uint32_t excl = max(row_shr<1>(incl), best);
+      // candidate k is looked at unless 8 bytes are in hand after 16 candidates (:66-69) or a full-length match has
+      // ended the scan (:89-91); both tests only ever cut off a tail of the row
+      const bool ex = v && (base == 0u || excl < 8u) && excl < maxl;
+      const uint32_t xm = (uint32_t)(__ballot(ex) >> g0) & 0xffffu;  // a prefix of the valid ones
+      const uint32_t nx = (uint32_t)__popc(xm);
+      const uint32_t top = (uint32_t)__shfl((int)incl, (int)(g0 + (nx ? nx - 1u : 0u)));  // maximum over the candidates looked at
+      const uint32_t gmax = nx ? top : 0u;
+      if (__ballot(more && gmax > best)) {
+        // strictly longer only, and the nearest of the longest: the nearest candidate wins ties (:86-88)
+        const uint32_t who = (uint32_t)(__ballot(ex && L == gmax) >> g0) & 0xffffu;
+        const uint32_t kb = who ? (uint32_t)__builtin_ctz(who) : 0u;
+        const uint32_t qb = (uint32_t)__shfl((int)qk, (int)(g0 + kb));
+        const bool up = more && gmax > best;
+        bestq = up ? qb : bestq;
+        best = up ? gmax : best;
+      }
+      // another round: all sixteen were there and were looked at, fewer than 128 so far, and the rule lets candidate
+      // 16 (32, ...) be looked at: less than 8 bytes in hand, no full-length match
+      const uint32_t lq = (uint32_t)__shfl((int)qk, (int)(g0 + LAZY_G - 1u));
+      lastq = more ? lq : lastq;
+      base += more ? LAZY_G : 0u;
+      more = more && nx == LAZY_G && base < 128u && best < 8u && best < maxl;
+      fin = fin || (was && !more);
+#ifdef LAZY_PROF
+      nrnd++;
+#endif
+    }
+    // ---- a finished evaluation moves its chain on ----
+    if (__ballot(fin)) {
       const bool acc = best >= 3u && p + best + 3u <= T;  // src/lz77.ts:95
-      if (ev && sub == 0u) mo[p] = acc ? (ZES_TOK_MATCH | ((best - 3u) << 16) | (p - bestq - 1u)) : LAZY_EVAL_LIT;
+      if (fin && sub == 0u) mo[p] = acc ? (ZES_TOK_MATCH | ((best - 3u) << 16) | (p - bestq - 1u)) : LAZY_EVAL_LIT;
       if (PHASE == 0u) {
-        if (ev && sub == 0u) S.tail[item] = (uint16_t)(acc ? best : 1u);
+        if (fin && sub == 0u) S.tail[item] = (uint16_t)(acc ? best : 1u);
       }
-      p += ev ? (acc ? best : 1u) : 0u;
+      p += fin ? (acc ? best : 1u) : 0u;
+      mode = fin ? LZ_STAND : mode;
       // the first sixteen distances of the position the chain stands on now, for the next turn (when that position
       // is still inside the two windows of inv entries, and if chain control does not move the chain elsewhere)
       {
         const uint32_t off = p - wb;
-        const bool in2 = ev && off < 2u * LAZY_G && p < cnt;
+        const bool in2 = fin && off < 2u * LAZY_G && p < cnt;
         const uint32_t e0 = (uint32_t)__shfl((int)wcur, (int)(g0 + (off & (LAZY_G - 1u))));
         const uint32_t e1 = (uint32_t)__shfl((int)wnxt, (int)(g0 + (off & (LAZY_G - 1u))));
         const uint32_t ivn = off < LAZY_G ? e0 : e1;
         const bool want = in2 && ivn != ZES_INV_NONE && !(fw && off >= LAZY_G);  // (a window still on its way: not this time)
         const uint32_t rn = ivn & 0x1FFFFu;
-        if (__ballot(want)) sdp = sd[(want && sub <= rn) ? rn - sub : 0u];
-        sdp_ok = want;
-        sdp_r = rn;
+        if (__ballot(want)) {
+          const uint32_t t = sd[(want && sub <= rn) ? rn - sub : 0u];
+          sdp = fin ? t : sdp;  // (a row in the middle of its rounds keeps what it has: it is not the one asking)
+        }
+        sdp_ok = fin ? want : sdp_ok;
+        sdp_r = fin ? rn : sdp_r;
       }
     }
     LLAP(5);

@@ -37,7 +37,6 @@
 
 #define RES_W 4096u    // P4: bytes of the image resolved at a time (a multiple of PAR_THREADS and of 8)
 #define RES_REPS 4u    // pointer-jumping steps between two barriers
-#define RES_EXT 258u   // a match that starts in a window can run this far past its end
 #define STAGE_DW ((ZES_BLK + ZES_BLK / 8) / 4)  // compressed bytes staged over the image + bitmap until P3
 struct ParSmem {
   uint8_t out[ZES_BLK];            // P0-P2: first part of the staged compressed block (swizzled dwords)
@@ -57,10 +56,12 @@ struct ParSmem {
   uint8_t wentry[PAR_WAVES];      // entry code of each wave's first segment
   uint32_t hdr_end, status, tail_entry, bfinal, tail_bytes, tail_end;
   uint32_t res_flag[3];       // P4: "a pointer moved in this step"
+  uint32_t res_lastw[RES_W / 32];  // P4: last match start (+1) at or before each 32 positions of the window
+  uint32_t res_strad[4];      // P4: end and distance of the match that runs into the window from the one before; the next one's
   uint32_t f8lo, f8n, f8off;  // 8-bit literal codes: first code value, how many (0 = fast path off), index into syms_l
 };
 
-static_assert(offsetof(ParSmem, cl_lut) - offsetof(ParSmem, lut_l) >= (RES_W + RES_EXT) * 2u, "P4's distance array lies over the decode tables");
+static_assert(offsetof(ParSmem, cl_lut) - offsetof(ParSmem, lut_l) >= RES_W * 2u, "P4's distance array lies over the decode tables");
 static_assert(RES_W % PAR_THREADS == 0 && RES_W % 8u == 0, "P4 lane mapping");
 
 // LUT entry: [3:0] code length (0 = not in the root table), [7:4] extra bits, [9:8] kind
@@ -1306,8 +1307,10 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __
     // below it — and then all bytes of the window are copied at once.  Overlapping copies (distance < length)
     // need no special case: byte p+5 of a run with D = 1 simply has the parent p+4.
     {
-      uint16_t* dist = reinterpret_cast<uint16_t*>(S.lut_l);  // the decode tables are dead: [RES_W + RES_EXT] entries over them
+      uint16_t* dist = reinterpret_cast<uint16_t*>(S.lut_l);  // the decode tables are dead: [RES_W] entries over them
       if (tid < 3u) S.res_flag[tid] = 0u;
+      if (tid < 4u) S.res_strad[tid] = 0u;
+      __syncthreads();
       unsigned long long tacc[4] = {0, 0, 0, 0}, tlast = dbg ? clock64() : 0ull, nrounds = 0;  // ZES_DEBUG_PHASES: cycles of the four steps
 #define P4LAP(i)                                         \
   do {                                                   \
@@ -1317,27 +1320,62 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __
       tlast = now_;                                      \
     }                                                    \
   } while (0)
-      const uint8_t* bm8 = reinterpret_cast<const uint8_t*>(S.bitmap);
       for (uint32_t ws = 0; ws < total; ws += RES_W) {
         const uint32_t wlen = min(RES_W, total - ws);
-        // (a) the part of a match that ran past the previous window's end is carried over; the rest starts at 0
-        uint32_t carry = 0;
-        if (ws != 0u && tid < RES_EXT) carry = dist[RES_W + tid];
-        __syncthreads();
-        for (uint32_t i = tid; i < RES_W + RES_EXT; i += PAR_THREADS) dist[i] = (uint16_t)(i < RES_EXT ? carry : 0u);
+        // (a) per 32 positions of the window: the last match start at or before them (matches do not overlap each
+        // other, so the nearest start in front of a byte is the only match that can cover it)
+        if (tid < RES_W / 32u) {
+          const uint32_t w = S.bitmap[(ws >> 5) + tid];
+          uint32_t hs = w ? 32u * tid + 32u - (uint32_t)__clz(w) : 0u;  // start + 1 (window-relative), 0: none
+#pragma unroll
+          for (int dlt = 1; dlt < 64; dlt <<= 1) {
+            const uint32_t t = __shfl_up(hs, dlt);
+            if ((int)lane >= dlt) hs = max(hs, t);
+          }
+          S.res_lastw[tid] = hs;
+        }
         __syncthreads();
         P4LAP(0);
-        // (b) every match that starts in the window writes its distance over its bytes: one lane per 8 positions
-        // (at most three matches start there: a match is at least 3 bytes long)
-        if (tid < RES_W / 8u && tid * 8u < wlen) {
-          uint32_t bits = bm8[(ws >> 3) + tid];
-          while (bits) {
-            const uint32_t t = (uint32_t)__builtin_ctz(bits);
-            bits &= bits - 1u;
-            const uint32_t rel = tid * 8u + t, p = ws + rel;
-            const uint32_t D = ((uint32_t)S.out[p] | ((uint32_t)S.out[p + 1] << 8)) + 1u;
-            const uint32_t L = (uint32_t)S.out[p + 2] + 3u;
-            for (uint32_t j = 0; j < L; j++) dist[rel + j] = (uint16_t)D;  // rel + j < RES_W + RES_EXT
+        // (b) every byte of the window looks up the match that covers it — the nearest start in its own 32 positions,
+        // else the last one of the words before (a match that began in the window before is in res_strad) — and takes
+        // that match's distance, or 0 for a literal byte.  The lane keeps its four entries in registers.
+        uint32_t d[RES_W / PAR_THREADS];
+        {
+          const uint32_t sEnd = S.res_strad[0], sD = S.res_strad[1];  // absolute end and distance of the match that straddles in
+          const uint32_t* out32 = reinterpret_cast<const uint32_t*>(S.out);
+#pragma unroll
+          for (uint32_t k = 0; k < RES_W / PAR_THREADS; k++) {
+            const uint32_t bpos = tid + k * PAR_THREADS, wi = bpos >> 5;
+            const uint32_t w = S.bitmap[(ws >> 5) + wi] & (0xFFFFFFFFu >> (31u - (bpos & 31u)));  // starts at or before this byte
+            // (the first 64 words' running maxima were made by wave 0, the others by wave 1: take both)
+            uint32_t before = wi ? S.res_lastw[wi - 1u] : 0u;
+            if (wi > 64u) before = max(before, S.res_lastw[63]);
+            const uint32_t sp1 = w ? 32u * wi + 32u - (uint32_t)__clz(w) : before;  // start + 1, 0: no start in this window
+            const uint32_t s = ws + (sp1 ? sp1 - 1u : 0u);
+            const uint32_t lo = out32[s >> 2], hi = out32[(s >> 2) + 1u];
+            const uint32_t rec = __builtin_amdgcn_alignbyte(hi, lo, s & 3u);  // distance - 1 (16 bits), length - 3 (8 bits)
+            const uint32_t D = (rec & 0xffffu) + 1u, L = ((rec >> 16) & 0xffu) + 3u;
+            const uint32_t P = ws + bpos;
+            uint32_t dv = (sp1 && P < s + L) ? D : 0u;
+            dv = (!sp1 && P < sEnd) ? sD : dv;
+            dv = bpos < wlen ? dv : 0u;
+            d[k] = dv;
+            dist[bpos] = (uint16_t)dv;
+          }
+          // the match that runs past this window's end, for the next window
+          if (tid == 0) {
+            const uint32_t sp1 = max(S.res_lastw[63], S.res_lastw[RES_W / 32u - 1u]);
+            uint32_t e = 0, dd = 0;
+            if (sp1) {
+              const uint32_t s = ws + sp1 - 1u;
+              dd = ((uint32_t)S.out[s] | ((uint32_t)S.out[s + 1] << 8)) + 1u;
+              e = s + (uint32_t)S.out[s + 2] + 3u;
+            } else if (sEnd > ws + RES_W) {  // (a straddler longer than a window cannot be: 258 < RES_W)
+              e = sEnd;
+              dd = sD;
+            }
+            S.res_strad[2] = e > ws + RES_W ? e : 0u;
+            S.res_strad[3] = dd;
           }
         }
         __syncthreads();
@@ -1347,14 +1385,9 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __
         // are in place: whatever a lane reads from another byte's entry is the distance to one of that byte's
         // ancestors, at any moment.  RES_REPS steps per barrier (progress travels through LDS without one; the barrier
         // is there to find out that nothing moves any more); a wave whose bytes are settled skips its steps.
-        uint32_t d[RES_W / PAR_THREADS];
         bool live[RES_W / PAR_THREADS];
 #pragma unroll
-        for (uint32_t k = 0; k < RES_W / PAR_THREADS; k++) {
-          const uint32_t b = tid + k * PAR_THREADS;
-          d[k] = b < wlen ? dist[b] : 0u;
-          live[k] = d[k] != 0u && d[k] <= b;  // (d > b: the ancestor lies below the window: final)
-        }
+        for (uint32_t k = 0; k < RES_W / PAR_THREADS; k++) live[k] = d[k] != 0u && d[k] <= tid + k * PAR_THREADS;  // (d > b: the ancestor lies below the window: final)
         for (uint32_t rnd = 0;; rnd++) {
           bool moved = false;
 #pragma unroll
@@ -1391,7 +1424,11 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __
           if (d[k] != 0u) S.out[ws + b] = S.out[ws + b - d[k]];
         }
         P4LAP(3);
-        // (the next round's first barrier separates these reads of dist[] from its rewrite)
+        if (tid == 0) {
+          S.res_strad[0] = S.res_strad[2];
+          S.res_strad[1] = S.res_strad[3];
+        }
+        __syncthreads();  // (also: the copies above have read dist[] and the image before the next window rewrites them)
       }
       if (dbg && tid == 0) {
         unsigned long long* row = dbg + (size_t)blockIdx.x * ZES_PAR_DBG_ROW;
