@@ -811,7 +811,7 @@ __device__ __forceinline__ static uint32_t lazy_chains(LazySmem& S, const uint32
   bool sdp_ok = false;
   // the position a row is on (rounds of sixteen candidates; a row whose position needs another round does not hold up
   // the other three: every turn of the loop is one round for each row that has one to do)
-  uint32_t r = 0, maxl = 0, best = 0, bestq = 0, base = 0, lastq = 0, dnext = 0;
+  uint32_t r = 0, maxl = 0, best = 0, bestq = 0, base = 0, lastq = 0, dnext = 0, litrun = 1;
   bool more = false;
   bool drained = false;  // no work items left (uniform)
   uint32_t niter = 0;
@@ -925,6 +925,17 @@ __device__ __forceinline__ static uint32_t lazy_chains(LazySmem& S, const uint32
       more = ev ? has : more;
       fin = ev && !has;  // no candidate: a literal
       mode = has ? LZ_EVAL : mode;
+      // A literal like that is often one of a run (incompressible stretches, the first period of periodic data): the
+      // positions behind it whose inv entries, in the row's current window, say "no candidate" too are settled with it
+      // — window chains only: a second chain has to test every position it stands on for a merge.
+      litrun = 1u;
+      if (PHASE == 1u) {
+        const uint32_t off = (ev ? p - wb : 0u) & (LAZY_G - 1u);
+        const uint32_t nm = (uint32_t)(__ballot(wcur == ZES_INV_NONE) >> g0) & 0xffffu;  // positions wb + k without a candidate
+        const uint32_t inv_run = (uint32_t)__builtin_ctz(~(nm >> off) | 0x10000u);         // how many from p on (>= 1 when p has none)
+        const uint32_t lim = min(min(wend, cnt), tbase) - p;                                // stay inside the window, the keyed and the not pre-evaluated positions
+        litrun = fin ? max(1u, min(min(inv_run, LAZY_G - off), lim)) : 1u;
+      }
       // the distances of a round are requested one round ahead (round 0: at the end of the turn before, when the chain's
       // next position was known — sdp/sdp_r say for which slot)
       {
@@ -1031,7 +1042,14 @@ __device__ __forceinline__ static uint32_t lazy_chains(LazySmem& S, const uint32
       if (PHASE == 0u) {
         if (fin && sub == 0u) S.tail[item] = (uint16_t)(acc ? best : 1u);
       }
-      p += fin ? (acc ? best : 1u) : 0u;
+      if (PHASE == 1u) {  // a run of literals: their words, and their bits in V1 (the first one's is set already)
+        const bool rl = fin && !acc && litrun > 1u;
+        if (rl && sub >= 1u && sub < litrun) {
+          mo[p + sub] = LAZY_EVAL_LIT;
+          atomicOr(&S.v1[(p + sub) >> 5], 1u << ((p + sub) & 31u));
+        }
+      }
+      p += fin ? (acc ? best : litrun) : 0u;
       mode = fin ? LZ_STAND : mode;
       // the first sixteen distances of the position the chain stands on now, for the next turn (when that position
       // is still inside the two windows of inv entries, and if chain control does not move the chain elsewhere)
@@ -1144,34 +1162,18 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match_lazy(const uint8_t* 
   if (S.unmerged && wave == 0) {
     uint32_t p = 0;
     // The words of the chain's positions come 64 at a time (lane k: the word of position cb + k; the chunk behind is
-    // requested while this one is walked).  Chains of maximal matches move on by exactly 258: when a position has to
-    // be evaluated here, the chunk and the inv entry of p + 3 * 258 are requested — three evaluations ahead of their
-    // use (one trip to memory takes longer than one evaluation) — and handed down a three-deep queue.
+    // requested while this one is walked); runs of evaluated literals are stepped over at once.
     // (Words written by the other waves of this workgroup: read past this CU's L1.)
     uint32_t cb = 0xFFFFFFFFu, cw = 0, nb = 0xFFFFFFFFu, nw = 0;  // current chunk, next sequential chunk
-    uint32_t q1p = 0xFFFFFFFFu, q1iv = 0, q1w = 0, q2p = 0xFFFFFFFFu, q2iv = 0, q2w = 0, q3p = 0xFFFFFFFFu, q3iv = 0, q3w = 0;
-    // results are parked in registers, one per lane, and stored 64 at a time: a store followed by the next load would
-    // make every evaluation wait for the store to complete (loads and stores share one counter)
-    uint32_t keep_p = 0, keep_m = 0, nkeep = 0;
     while (p < cnt) {
       const uint32_t base = p & ~63u;
-      const bool predicted = p == q1p;
       if (base != cb) {
-        if (predicted) {
-          cw = q1w;
-        } else if (base == nb) {
-          cw = nw;
-        } else {
-          cw = __hip_atomic_load(&mo[min(base + lane, ZES_BLK - 1u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        cw = (base == nb) ? nw : __hip_atomic_load(&mo[min(base + lane, ZES_BLK - 1u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         cb = base;
-        if (!predicted) {  // walking on position by position: the chunk behind
-          nb = base + 64u;
-          nw = __hip_atomic_load(&mo[min(nb + lane, ZES_BLK - 1u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        nb = base + 64u;
+        nw = __hip_atomic_load(&mo[min(nb + lane, ZES_BLK - 1u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       {
-        // a run of evaluated literals is stepped over at once
         const uint64_t lit = __ballot(cw == LAZY_EVAL_LIT) >> (p - base);
         if (lit & 1ull) {
           const uint32_t run = (~lit) ? (uint32_t)__builtin_ctzll(~lit) : 64u;
@@ -1184,41 +1186,35 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match_lazy(const uint8_t* 
         if (p >= tbase) {
           m = LAZY_EVAL_LIT;  // (cannot happen: phase 0 evaluated the tail; keeps a corrupted table from hanging the wavefront)
         } else {
-          uint32_t iv = predicted ? q1iv : inv[p];
-          iv = (uint32_t)__builtin_amdgcn_readfirstlane((int)iv);
-          // hand the queue down and request what lies three maximal matches ahead
-          const bool inq = predicted && q2p == p + ZES_MAXMATCH;
-          q1p = inq ? q2p : 0xFFFFFFFFu;
-          q1iv = q2iv;
-          q1w = q2w;
-          q2p = inq ? q3p : 0xFFFFFFFFu;
-          q2iv = q3iv;
-          q2w = q3w;
-          if (!inq) {  // (re)start: the next two as well
-            q1p = min(p + ZES_MAXMATCH, cnt - 1u);
-            q1iv = inv[q1p];
-            q1w = __hip_atomic_load(&mo[min((q1p & ~63u) + lane, ZES_BLK - 1u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            q2p = min(p + 2u * ZES_MAXMATCH, cnt - 1u);
-            q2iv = inv[q2p];
-            q2w = __hip_atomic_load(&mo[min((q2p & ~63u) + lane, ZES_BLK - 1u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-          q3p = min(p + 3u * ZES_MAXMATCH, cnt - 1u);
-          q3iv = inv[q3p];
-          q3w = __hip_atomic_load(&mo[min((q3p & ~63u) + lane, ZES_BLK - 1u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const uint32_t iv = (uint32_t)__builtin_amdgcn_readfirstlane((int)inv[p]);
           m = lazy_wave_eval(S, iv, sd, p, T, avail);
-          if (lane == nkeep) {
-            keep_p = p;
-            keep_m = m;
-          }
-          if (++nkeep == 64u) {
-            mo[keep_p] = keep_m;
-            nkeep = 0;
+          if (lane == 0) mo[p] = m;
+          if ((m & ZES_TOK_MATCH) && zes_tok_len(m) == ZES_MAXMATCH) {
+            // A maximal match: on periodic data the chain goes on like this, 258 bytes at a time.  The next 64 positions
+            // it would stand on are tested side by side, lane j the j-th: does the NEAREST candidate match at full
+            // length?  Then the reference takes it and stops looking (src/lz77.ts:89-91), whatever the other candidates
+            // are, so the positions up to the first lane that fails are settled: their words are written and the chain
+            // moves past all of them at once.
+            const uint32_t pj = p + ZES_MAXMATCH * (lane + 1u);
+            // (not inside the pre-evaluated tail, where a match that reaches the block's last three bytes is dropped: :95)
+            const bool inr = pj < tbase && pj + ZES_MAXMATCH + 3u <= T && pj + ZES_MAXMATCH <= avail;
+            const uint32_t ivj = inv[inr ? pj : 0u];
+            const bool has = inr && ivj != ZES_INV_NONE;
+            const uint32_t dj = (ivj >> 17) + 1u;
+            const uint32_t qj = has ? pj - dj : 0u, pp = has ? pj : 0u;
+            bool full = has;
+            for (uint32_t wv = 0; wv < 64u && __ballot(full); wv++)  // bytes 0..255, four at a time
+              full = full && m_ld32u(S.in, qj + 4u * wv) == m_ld32u(S.in, pp + 4u * wv);
+            full = full && ((m_ld32u(S.in, qj + 256u) ^ m_ld32u(S.in, pp + 256u)) & 0xffffu) == 0u;  // bytes 256, 257
+            const uint64_t okm = __ballot(full);
+            const uint32_t nk = (~okm) ? (uint32_t)__builtin_ctzll(~okm) : 64u;  // leading lanes that are settled
+            if (lane < nk) mo[pj] = ZES_TOK_MATCH | ((ZES_MAXMATCH - 3u) << 16) | (dj - 1u);
+            p += ZES_MAXMATCH * nk;
           }
         }
       }
       p += (m & ZES_TOK_MATCH) ? zes_tok_len(m) : 1u;
     }
-    if (lane < nkeep) mo[keep_p] = keep_m;
   }
   LSTAMP(5);
 }
