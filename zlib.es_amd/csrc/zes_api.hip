@@ -644,7 +644,8 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
     Timed t("k_inf_verify");
     // (measured on 64 MiB: 8192 workgroups 0.33 ms, 2048 0.26 ms, 512 0.36 ms — about one survivor in 256 input bytes,
     // and a lane should get a few of them)
-    const uint32_t nwg = (uint32_t)std::min<uint64_t>(total_c / 32768 + 1, 8192);
+    uint32_t nwg = (uint32_t)std::min<uint64_t>(total_c / 32768 + 1, 8192);
+    if (const char* e = getenv("ZES_VERIFY_DIV")) nwg = (uint32_t)std::min<uint64_t>(total_c / (uint64_t)atoi(e) + 1, 8192);
     hipLaunchKernelGGL(k_inf_verify, dim3(nwg), dim3(64), 0, g.stream, d_in, dbufs, (const unsigned long long*)g.surv.p, surv_cap,
                        counters, (uint32_t*)g.cand.p, cnt, (flags & ZES_F_LOOSE_CANDIDATES) ? 1u : 0u);
   }
