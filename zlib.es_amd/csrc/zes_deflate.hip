@@ -1388,61 +1388,30 @@ __global__ __launch_bounds__(PARSE_THREADS) void k_lz_parse(const uint8_t* __res
   __syncthreads();
 
   PSTAMP(3);
-  // ---- D1: visited lanes of every touched chunk ----
+  // ---- D1: visited lanes of every touched chunk: one lane per chunk walks the chunk's chain from its entry lane
+  // (at most 64 hops, a dozen on text), 64 chunks of the wave's region side by side; the match words come from
+  // global memory, a line of sixteen serving the next hops.  (Round 1 found the visited lanes of one chunk at a
+  // time with all 64 lanes, by binary hop decomposition: a dozen cross-lane shuffles per chunk, 287k cycles per
+  // block on text against the ~40k of this walk.) ----
   unsigned long long mymask[2] = {0ull, 0ull};  // thread t owns chunks 2t, 2t+1 for the scan
-  for (uint32_t cb = c_lo; cb < c_hi; cb += PARSE_BATCH) {
-    uint32_t mw[PARSE_BATCH], en[PARSE_BATCH];
-#pragma unroll
-    for (uint32_t k = 0; k < PARSE_BATCH; k++) {  // match words only of touched chunks that hold a match
-      const uint32_t c = cb + k;
-      const uint32_t p = c * 64u + lane;
-      en[k] = c < c_hi ? (uint32_t)S.centry[c] : PARSE_NOENTRY;
-      const bool need = en[k] != PARSE_NOENTRY && !S.cplain[min(c, PARSE_CHUNKS - 1u)] && p < T;
-      mw[k] = mi[need ? p : lane];  // unconditional: chunks that need no words read the block's first line
+  for (uint32_t cb = c_lo; cb < c_hi; cb += 64u) {
+    const uint32_t c = cb + lane;
+    const bool have = c < c_hi;
+    const uint32_t cc = min(c, PARSE_CHUNKS - 1u);
+    const uint32_t e = have ? (uint32_t)S.centry[cc] : PARSE_NOENTRY;
+    const bool plain = S.cplain[cc] != 0;
+    const uint32_t left = (have && cc * 64u < T) ? min(64u, T - cc * 64u) : 0u;  // positions of the chunk that exist
+    unsigned long long mk = 0ull;
+    if (e != PARSE_NOENTRY && plain)  // no match in the chunk: the chain visits every position from the entry lane on
+      mk = (~0ull << e) & (left >= 64u ? ~0ull : ((1ull << left) - 1ull));
+    uint32_t cur = (e != PARSE_NOENTRY && !plain) ? e : 64u;
+    while (__ballot(cur < left)) {
+      const bool act = cur < left;
+      const uint32_t m = mi[act ? cc * 64u + cur : 0u];  // unconditional (clamped) load
+      mk |= act ? (1ull << cur) : 0ull;
+      cur += act ? ((m & ZES_TOK_MATCH) ? zes_tok_len(m) : 1u) : 0u;
     }
-    PARSE_ARRIVE8(mw);
-#pragma unroll
-    for (uint32_t k = 0; k < PARSE_BATCH; k++) {
-      const uint32_t c = cb + k;
-      if (c >= c_hi) break;
-      const uint32_t e = en[k];
-      unsigned long long mk = 0ull;
-      if (e != PARSE_NOENTRY && S.cplain[c]) {
-        // no match in the chunk: the chain visits every position from the entry lane on
-        const uint32_t left = T - c * 64u;  // > 0: the chunk exists
-        mk = (~0ull << e) & (left >= 64u ? ~0ull : ((1ull << left) - 1ull));
-      } else if (e != PARSE_NOENTRY) {
-        const uint32_t p = c * 64u + lane;
-        const uint32_t m = p < T ? mw[k] : 0u;
-        uint32_t h[6], cnt = 1;
-        h[0] = lane + ((m & ZES_TOK_MATCH) ? zes_tok_len(m) : 1u);
-#pragma unroll
-        for (int r = 0; r < 5; r++) {  // h[r] = landing lane after 2^r hops (>= 64: left the chunk)
-          const uint32_t hv = __shfl(h[r], (int)(h[r] & 63u));
-          const uint32_t cv = __shfl(cnt, (int)(h[r] & 63u));
-          const bool in = h[r] < 64u;
-          h[r + 1] = in ? hv : h[r];
-          cnt = in ? cnt + cv : cnt;
-        }
-        {  // hops from h[5] on are not needed: 32+..; finish the count with one more round
-          const uint32_t cv = __shfl(cnt, (int)(h[5] & 63u));
-          if (h[5] < 64u) cnt += cv;
-        }
-        // lane i is visited iff i >= e and hopping (cnt[e] - cnt[i]) times from e lands on i
-        const uint32_t ce = __shfl(cnt, (int)e);
-        const bool cand = lane >= e && cnt <= ce;
-        const uint32_t kk = cand ? ce - cnt : 0u;
-        uint32_t pos = e;
-#pragma unroll
-        for (int r = 0; r < 6; r++) {
-          const uint32_t nx = __shfl(h[r], (int)(pos & 63u));
-          if ((kk >> r) & 1u) pos = nx;
-        }
-        mk = __ballot(cand && pos == lane && p < T);
-      }
-      // hand the mask to the thread that owns this chunk in the scan
-      if (lane == 0) S.u.d.mask[c] = mk;  // xmap of chunk c is dead: the walk of phase C is over
-    }
+    if (have) S.u.d.mask[c] = mk;  // xmap of chunk c is dead: the walk of phase C is over
   }
   __syncthreads();
   // NOTE: mask[] aliases xmap[]; chunk c's mask (8 B at c*8) overlaps xmap rows c/8 — all reads
