@@ -735,14 +735,14 @@ template <class SM>
 __device__ __forceinline__ static void wd_mark_produced(SM& S, WaveDec& d, uint32_t n) {  // n symbols entered the ring
   d.o += n;
   d.unfl += n;  // never more than the flush size + 257, so the unflushed symbols are all still in the ring
-  if (WD_UNLIKELY(d.unfl >= SM::kFlush)) wd_mark_flush(S, d, SM::kFlush);
+  while (WD_UNLIKELY(d.unfl >= SM::kFlush)) wd_mark_flush(S, d, SM::kFlush);
 }
 
 // Decodes the symbols of one fixed/dynamic block whose tables are built.  Uniform control flow.
 // MARK: 16-bit symbols in the marker ring (values >= 256 stand for bytes of the unknown window in
 // front of the segment), nothing is stored and every distance is allowed.
 template <bool MARK, class SM>
-__device__ __forceinline__ static int wd_symbols(SM& S, WaveDec& d) {
+__device__ __forceinline__ static int wd_symbols_serial(SM& S, WaveDec& d) {
   const uint32_t lane = zes_lane();
   const uint64_t limit = d.nbytes * 8;
   // every token refills first, so the reader can run at most 64 bits + one dword ahead of a valid position;
@@ -886,6 +886,193 @@ __device__ __forceinline__ static int wd_symbols(SM& S, WaveDec& d) {
     WDT(t5);
     WDACC(4, t4, t5);
   }
+}
+
+// Decodes the symbols of one fixed/dynamic block whose tables are built — 64 bit positions at a time.
+// A token's bits are found serially (where it starts is known only when the one before is decoded), but decoding the
+// token that WOULD start at a given bit needs nothing but the bits: every lane decodes the token at its bit of a
+// 64-bit window (root tables in LDS: one gather for the literal/length code, one for the distance code; 48 bits of
+// lookahead from three dwords of the input window, which sits in two vector registers), and the real chain is then
+// followed with lane reads — a few scalar instructions per token where the serial form (wd_symbols_serial, kept for
+// the cycle-stamp build) pays two dependent table lookups and the refill logic per token: ~1000 cycles per token for
+// a lone wave, five tokens per window on text.
+// MARK: 16-bit symbols in the marker ring (values >= 256 stand for bytes of the unknown window in
+// front of the segment), nothing is stored and every distance is allowed.
+template <bool MARK, class SM>
+__device__ __forceinline__ static int wd_symbols(SM& S, WaveDec& d) {
+  const uint32_t lane = zes_lane();
+  const uint64_t limit = d.nbytes * 8;
+  uint16_t* r16 = reinterpret_cast<uint16_t*>(S.ring);
+  uint64_t P = wd_pos(d);  // bit position of the next token (uniform)
+  // input window of its own: dwords [B, B + 64) in vc (zeros beyond the end applied), [B + 64, B + 128) in vn (as loaded)
+  uint64_t B = (P >> 5) & ~63ull;
+  uint32_t vc = wd_fetch_fix(d, wd_fetch_raw(d, B + lane), B + lane), vn = wd_fetch_raw(d, B + 64 + lane);
+  int rc = -1;
+  while (rc < 0) {
+    if (WD_UNLIKELY(P >= limit + 64)) {  // (a reader this far past the data has decoded zeros for a while)
+      rc = WD_ANOMALY;
+      break;
+    }
+    if (WD_UNLIKELY((P >> 5) - B >= 64)) {  // the window moves on: the load issued one window ago is waited for here
+      B += 64;
+      vc = wd_fetch_fix(d, vn, B + lane);
+      vn = wd_fetch_raw(d, B + 64 + lane);
+    }
+    // ---- every lane: the token that would start at bit P + lane ----
+    uint32_t tk, tv, tdist = 0, tb;
+    {
+      const uint64_t bpos = P + lane;
+      const uint32_t rel = (uint32_t)((bpos >> 5) - B), sh = (uint32_t)bpos & 31u;  // rel <= 65
+      uint32_t w[3];
+#pragma unroll
+      for (uint32_t k = 0; k < 3; k++) {
+        const uint32_t q = rel + k;
+        const uint32_t a = (uint32_t)__shfl((int)vc, (int)(q & 63u)), bq = (uint32_t)__shfl((int)vn, (int)(q & 63u));
+        w[k] = q < 64u ? a : wd_fetch_fix(d, bq, B + q);
+      }
+      const uint64_t lo = ((uint64_t)w[1] << 32) | w[0];
+      const uint64_t v = sh ? (lo >> sh) | ((uint64_t)w[2] << (64u - sh)) : lo;  // 64 bits from bit P + lane on
+      uint32_t e = S.lut_l[(uint32_t)v & ((1u << LROOT) - 1u)];
+      if (__ballot((e & 31u) == 0u)) {
+        if ((e & 31u) == 0u) e = wd_long(v, LROOT, S.syms_l, S.first_l, S.cnt_l, S.offs_l, false);  // 0: no code
+        WD_JOIN();
+      }
+      const uint32_t kind = (e >> 9) & 3u, tot = e & 31u, cl = (e >> 5) & 15u;
+      tk = e == 0u ? WE_BAD : kind;
+      tb = tot;
+      tv = e >> 16;  // literal byte, or base of the length
+      if (__ballot(tk == WE_BASE)) {
+        const bool ism = tk == WE_BASE;
+        tv += ((uint32_t)(v >> cl)) & ((1u << (tot - cl)) - 1u);  // (tot == cl for a literal: adds 0)
+        const uint64_t v2 = v >> tot;
+        uint32_t e2 = S.lut_d[(uint32_t)v2 & ((1u << DROOT) - 1u)];
+        if (__ballot(ism && (e2 & 31u) == 0u)) {
+          if (ism && (e2 & 31u) == 0u) e2 = wd_long(v2, DROOT, S.syms_d, S.first_d, S.cnt_d, S.offs_d, true);
+          WD_JOIN();
+        }
+        const uint32_t tot2 = e2 & 31u, cl2 = (e2 >> 5) & 15u;
+        const bool bad2 = e2 == 0u || ((e2 >> 9) & 3u) != WE_BASE;
+        tdist = (e2 >> 16) + (((uint32_t)(v2 >> cl2)) & ((1u << (tot2 - cl2)) - 1u));  // <= 15 + 13 bits
+        tk = (ism && bad2) ? WE_BAD : tk;
+        tb += ism ? tot2 : 0u;
+        WD_JOIN();
+      }
+    }
+    // ---- the real chain through the window ----
+    // (Tried: marking the window's tokens first, then one store for the literals between two matches and the matches in
+    // order, ring bookkeeping once per window — 8.05 ms against 7.30 ms for the token-by-token form below on the
+    // 64 MiB zlib text stream: the lone wave pays for the extra mask arithmetic more than it saves.)
+    uint32_t o = 0;
+    while (o < 64u) {
+      const uint32_t kind = (uint32_t)__builtin_amdgcn_readlane((int)tk, (int)o);
+      const uint32_t bits = (uint32_t)__builtin_amdgcn_readlane((int)tb, (int)o);
+      if (WD_UNLIKELY(kind == WE_BAD || P + o + bits > limit)) {  // no such code, or its bits lie behind the data
+        rc = WD_ANOMALY;
+        break;
+      }
+      const uint32_t val = (uint32_t)__builtin_amdgcn_readlane((int)tv, (int)o);
+      o += bits;
+      if (kind == WE_LIT) {
+        if (MARK) {
+          if (lane == 0) r16[d.oi] = (uint16_t)val;
+          WD_JOIN();
+          d.oi = d.oi + 1u == SM::kR16 ? 0u : d.oi + 1u;
+          wd_mark_produced(S, d, 1);
+        } else {
+          if (lane == 0) S.ring[d.o & (RING - 1)] = (uint8_t)val;
+          WD_JOIN();
+          wd_produced(S, d, 1);
+        }
+        continue;
+      }
+      if (WD_UNLIKELY(kind == WE_EOB)) {
+        rc = WD_OK;
+        break;
+      }
+      const uint32_t len = val;
+      const uint32_t dist = (uint32_t)__builtin_amdgcn_readlane((int)tdist, (int)(o - bits));
+      // lane-parallel copy; overlapping matches read i % dist so every source symbol already exists
+      const bool overlap = dist < len;
+      if (MARK) {
+        constexpr uint32_t R = SM::kR16;
+        if (R < RING16 && WD_UNLIKELY(dist > SM::kNear)) {
+          // short ring, and the source lies (or may lie) behind it: the symbols come from the segment's store — flushed
+          // long ago: the ring keeps far more than one flush interval — or, in front of the segment's first symbol, are
+          // the marker values themselves (marker 256 + i stands for byte i of the 32 KiB in front of the segment)
+          if (WD_UNLIKELY(d.sym_ovf || d.sym == nullptr)) {
+            const int64_t s0 = (int64_t)d.o - (int64_t)dist;
+            if (s0 + (int64_t)len > 0) {  // (all of it in front of the segment needs no store)
+              rc = WD_FAR_NOSTORE;
+              break;
+            }
+          }
+          for (uint32_t i0 = 0; i0 < len; i0 += 64) {  // (dist > len: no overlap)
+            const uint32_t i = i0 + lane;
+            const int64_t pos = (int64_t)d.o - (int64_t)dist + (int64_t)i;
+            uint32_t sv = 256u + (uint32_t)((int64_t)ZES_WINDOW + pos);  // pos < 0
+            if (pos >= 0 && i < len) {
+              const uint32_t wd2 = __hip_atomic_load(&d.sym[(uint64_t)pos >> 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              sv = (pos & 1) ? wd2 >> 16 : wd2 & 0xffffu;
+            }
+            uint32_t bx = d.oi + i;
+            if (bx >= R) bx -= R;
+            if (i < len) r16[bx] = (uint16_t)sv;
+            WD_JOIN();
+          }
+        } else {
+          const uint32_t si = d.oi >= dist ? d.oi - dist : d.oi + R - dist;
+          if (!overlap) {
+            for (uint32_t i0 = 0; i0 < len; i0 += 64) {
+              const uint32_t i = i0 + lane;
+              uint32_t ax = si + i, bx = d.oi + i;
+              if (ax >= R) ax -= R;
+              if (bx >= R) bx -= R;
+              if (i < len) r16[bx] = r16[ax];
+              WD_JOIN();
+            }
+          } else {
+            const float rcp = __builtin_amdgcn_rcpf((float)dist);
+            for (uint32_t i0 = 0; i0 < len; i0 += 64) {
+              const uint32_t i = i0 + lane;
+              uint32_t ax = si + wd_mod(i, dist, rcp), bx = d.oi + i;
+              if (ax >= R) ax -= R;
+              if (bx >= R) bx -= R;
+              if (i < len) r16[bx] = r16[ax];
+              WD_JOIN();
+            }
+          }
+        }
+        d.oi += len;
+        if (d.oi >= R) d.oi -= R;
+        wd_mark_produced(S, d, len);
+        continue;
+      }
+      if (WD_UNLIKELY(dist > d.reach)) {  // behind the first output byte of the stream
+        rc = WD_NEEDS_HISTORY;
+        break;
+      }
+      const uint32_t srcb = (uint32_t)(d.o - dist), dstb = (uint32_t)d.o;
+      if (!overlap) {
+        for (uint32_t i0 = 0; i0 < len; i0 += 64) {
+          const uint32_t i = i0 + lane;
+          if (i < len) S.ring[(dstb + i) & (RING - 1)] = S.ring[(srcb + i) & (RING - 1)];
+          WD_JOIN();
+        }
+      } else {
+        const float rcp = __builtin_amdgcn_rcpf((float)dist);
+        for (uint32_t i0 = 0; i0 < len; i0 += 64) {
+          const uint32_t i = i0 + lane;
+          if (i < len) S.ring[(dstb + i) & (RING - 1)] = S.ring[(srcb + wd_mod(i, dist, rcp)) & (RING - 1)];
+          WD_JOIN();
+        }
+      }
+      wd_produced(S, d, len);
+    }
+    P += o;
+  }
+  // the reader state of the bit-serial code around this loop (block headers, the stored-block path)
+  wd_seek(d, P);
+  return rc;
 }
 
 // One block starting at the reader's position (BFINAL bit).  *bfinal receives the flag.
