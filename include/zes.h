@@ -37,7 +37,8 @@ typedef enum zes_status {
   /* engine-defined errors (no reference counterpart) */
   ZES_E_NOSPACE = -16,      /* caller's output capacity too small; *out_len holds the size needed when known */
   ZES_E_DEVICE = -17,       /* HIP runtime error / no gfx950 device */
-  ZES_E_ARG = -18           /* bad argument (null pointer, size overflow) */
+  ZES_E_ARG = -18,          /* bad argument (null pointer, size overflow) */
+  ZES_E_NOTRANGE = -19      /* zes_inflate_range_dev: the range does not hold a clean chain of reference-made blocks */
 } zes_status;
 
 /* Geometry of the reference format (src/const.ts:7). */
@@ -46,6 +47,8 @@ typedef enum zes_status {
 /* flags for zes_inflate*: */
 #define ZES_F_DEFAULT 0u
 #define ZES_F_NO_FASTPATH 1u   /* force the general (serial, any-stream) decoder: testing aid */
+#define ZES_F_PIECES 4u        /* decode a reference-made stream piece by piece (1 MiB pieces) as streams of 512 MiB and more are
+                                  * (256 MiB pieces): testing aid for that path; same results */
 #define ZES_F_LOOSE_CANDIDATES 2u /* block-start search without the reference's run-length-coding rules: more false
                                   * candidates reach the block decoder (testing aid for that path; same results) */
 
@@ -153,6 +156,23 @@ int zes_deflate_range_dev(const uint8_t* d_in, uint64_t n, uint64_t n_readable, 
                           uint64_t* out_bits, uint32_t* adler);
 int zes_deflate_join_dev(const uint8_t* const* d_piece, const uint64_t* piece_bits, const uint32_t* piece_adler,
                          const uint64_t* piece_len, uint32_t count, uint8_t* d_out, uint64_t cap, uint64_t* out_len);
+
+/* One stream over several GPUs, the other direction, and streams too long for one pass: a
+ * reference-made stream is a chain of independent blocks of exactly 131072 output bytes (the last one shorter), so
+ * any GPU can decode the blocks that START inside a range of the compressed bits once it has found them — the same
+ * block-start search and block decoder as zes_inflate_dev, restricted to the range.
+ *   d_in .. d_in + c     the piece: 16-byte aligned, c < 512 MiB, holding the range, what the range's last block needs
+ *                        behind it (<= 144 KiB) and the header of the block after it
+ *   lo_bit, own_bit      blocks that start at bit lo_bit <= s < own_bit (relative to d_in; lo_bit >= 16) belong to the call
+ *   exact_start          != 0: a block starts exactly at lo_bit (the end bit of the piece before); 0: the first block
+ *                        start found at or behind lo_bit begins the chain (a GPU that takes a middle part of the stream)
+ *   d_out, cap           block k of the range goes to d_out + k * 131072
+ *   *first_bit, *end_bit bit positions (relative to d_in) of the range's first block and behind its last one: consecutive
+ *                        ranges fit when one's end is the next one's first; *nblocks, *final_block (BFINAL seen)
+ * ZES_E_NOTRANGE: not a clean chain (another encoder's stream, a false block start): decode the stream with zes_inflate_dev.
+ * replaces: the block loop of src/inflate.ts:22-37, split at block boundaries. */
+int zes_inflate_range_dev(const uint8_t* d_in, uint64_t c, uint64_t lo_bit, uint64_t own_bit, int exact_start, uint8_t* d_out,
+                          uint64_t cap, uint64_t* out_len, uint64_t* first_bit, uint64_t* end_bit, uint32_t* nblocks, int* final_block);
 
 /* Stage-level entry points (device pointers) used by the kernel parity tests; each mirrors
  * one internal function of the reference. */

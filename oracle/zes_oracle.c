@@ -821,6 +821,35 @@ int zor_inflate_raw(const uint8_t* in, uint64_t c, uint64_t offset, uint8_t** ou
   return ZOR_OK;
 }
 
+/* The same block loop (src/inflate.ts:22-37) as a map of the stream: the bit position of every block's first bit
+ * and the output length behind every block — what the tests of the range decoder (zes_inflate_range_dev) and of
+ * shard.inflate_split hold the engine's block starts against.  Not an interface of the reference. */
+int zor_inflate_blocks(const uint8_t* in, uint64_t c, uint64_t offset, uint64_t* start_bit, uint64_t* out_end, uint32_t max,
+                       uint32_t* count) {
+  zor_out o = {NULL, 0, 0, 0, 0};
+  o.limit = 1032ull * (offset < c ? c - offset : 0) + 65536;
+  zor_br r;
+  br_init(&r, in, c, offset);
+  int bfinal = 0, rc = ZOR_OK;
+  uint32_t k = 0;
+  while (bfinal != 1 && !rc) {
+    if (k < max) start_bit[k] = (uint64_t)(r.idx + 1) * 8 - (uint64_t)r.now_len;
+    bfinal = (int)br_range(&r, 1);
+    int btype = (int)br_range(&r, 2);
+    if (btype == 0) rc = inflate_stored(&r, &o);
+    else if (btype == 1) rc = inflate_fixed(&r, &o);
+    else if (btype == 2) rc = inflate_dynamic(&r, &o);
+    else rc = ZOR_E_BTYPE3;
+    if (!rc && o.runaway) rc = ZOR_E_LACK;
+    if (!rc && k < max) out_end[k] = o.idx;
+    if (!rc) k++;
+    if (!rc && bfinal == 0 && r.is_end) rc = ZOR_E_INSUFFICIENT;
+  }
+  free(o.buf);
+  *count = k;
+  return rc;
+}
+
 /* zlib wrapper — src/zlib.ts:11-23 */
 int zor_inflate(const uint8_t* in, uint64_t c, uint8_t** out, uint64_t* out_len) {
   zor_br r;

@@ -41,6 +41,7 @@ def lib():
         L.zor_inflate_raw.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p), u64p]
         L.zor_deflate_raw.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, u64p]
         L.zor_deflate_range.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, u64p]
+        L.zor_inflate_blocks.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, u32p]
         L.zor_lz77_block.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, u32p]
         L.zor_huff_lengths.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.zor_free.argtypes = [C.c_void_p]
@@ -141,3 +142,15 @@ def deflate_range(data, start, length, final):
     if rc:
         raise OracleError(rc)
     return out[: (bits.value + 7) // 8].copy(), bits.value
+
+
+def inflate_blocks(data, offset=2):
+    """Map of a stream: (start bit of every block, output length behind every block)."""
+    a = _as_u8(data)
+    cap = a.size // 8 + 16
+    sb, oe = np.zeros(cap, dtype=np.uint64), np.zeros(cap, dtype=np.uint64)
+    k = C.c_uint32()
+    rc = lib().zor_inflate_blocks(a.ctypes.data, a.size, offset, sb.ctypes.data, oe.ctypes.data, cap, C.byref(k))
+    if rc:
+        raise OracleError(rc)
+    return [int(x) for x in sb[: k.value]], [int(x) for x in oe[: k.value]]

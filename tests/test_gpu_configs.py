@@ -160,6 +160,129 @@ def test_deflate_split_over_nccl(z, oracle, gpu, nccl_group):
     assert res.cpu().numpy().tobytes() == oracle.deflate(a).tobytes()
 
 
+def test_stream_ranges_decode_to_the_whole(z, oracle, gpu):
+    """zes_inflate_range_dev over 2..4 bit ranges of one stream: the block starts it reports are the oracle's map of
+    the stream, the ranges fit (shard.check_chain) and the outputs concatenate to the input."""
+    import torch
+
+    shard = load_shard()
+    for kind, seed, n, world in (("itext", 61, 9 * 131072 + 999, 4), ("xorshift", 62, 6 * 131072, 3), ("lowent4k", 63, 20 * 131072 + 2, 4),
+                                 ("itext", 64, 131072 * 2, 2), ("itext", 65, 50000, 2)):
+        a = z.gen(kind, seed, n)
+        comp = oracle.deflate(a)
+        starts, ends = oracle.inflate_blocks(comp)
+        t = dev(comp, gpu)
+        table, outs = [], []
+        for r, (lo, own) in enumerate(shard.split_bits(len(comp), world)):
+            out = torch.zeros(n + 131072, dtype=torch.uint8, device=gpu)
+            res = z.inflate_range_tensor(t, lo, own, r == 0, out)
+            assert res is not None, (kind, r)
+            ln, fb, eb, nb, fin = res
+            ks = [k for k, s in enumerate(starts) if max(16, lo) <= s < own]
+            assert nb == len(ks), (kind, r, nb, ks)
+            if ks:
+                assert fb == starts[ks[0]] and fin == (ks[-1] == len(starts) - 1)
+                if not fin:
+                    assert eb == starts[ks[-1] + 1]
+                assert ln == ends[ks[-1]] - (ends[ks[0] - 1] if ks[0] else 0)
+            table.append([1, fb, eb, nb, ln, int(fin)])
+            outs.append(out[:ln])
+        assert shard.check_chain(table), (kind, table)
+        assert torch.cat(outs).cpu().numpy().tobytes() == a.tobytes(), kind
+    # a range of another encoder's stream is refused, not mis-decoded
+    import zlib as pyzlib
+
+    other = np.frombuffer(pyzlib.compress(z.gen("itext", 66, 600000).tobytes(), 6), dtype=np.uint8).copy()
+    t = dev(other, gpu)
+    out = torch.zeros(700000, dtype=torch.uint8, device=gpu)
+    assert z.inflate_range_tensor(t, 16, 8 * len(other), True, out) is None
+
+
+def test_inflate_split_over_nccl(z, oracle, gpu, nccl_group):
+    import torch
+
+    shard = load_shard()
+    n = 7 * 131072 + 31
+    a = z.gen("itext", 71, n)
+    t = dev(oracle.deflate(a), gpu)
+    out = torch.zeros(n + 131072, dtype=torch.uint8, device=gpu)
+
+    def rng(lo, own, exact):
+        res = z.inflate_range_tensor(t, lo, own, exact, out)
+        return None if res is None else (out,) + res
+
+    def whole():
+        return z.inflate_tensor(t, torch.empty(n, dtype=torch.uint8, device=gpu))
+
+    res = shard.inflate_split(t.numel(), rng, whole, group=nccl_group, device=gpu)
+    assert res.cpu().numpy().tobytes() == a.tobytes()
+    # and the fallback leg: a stream that is not reference-made
+    import zlib as pyzlib
+
+    t2 = dev(np.frombuffer(pyzlib.compress(a.tobytes(), 6), dtype=np.uint8).copy(), gpu)
+    res = shard.inflate_split(t2.numel(), lambda lo, own, ex: (lambda r: None if r is None else (out,) + r)(z.inflate_range_tensor(t2, lo, own, ex, out)),
+                              lambda: z.inflate_tensor(t2, torch.empty(n, dtype=torch.uint8, device=gpu)), group=nccl_group, device=gpu)
+    assert res.cpu().numpy().tobytes() == a.tobytes()
+
+
+def test_long_streams_piece_by_piece(z, oracle, gpu):
+    """Streams of 512 MiB and more are decoded by the block-parallel tier in pieces (256 MiB); ZES_F_PIECES runs the
+    same loop with 1 MiB pieces on streams of ordinary length: same bytes, same tier, same errors."""
+    import torch
+
+    for kind, seed, n in (("xorshift", 81, 5 * (1 << 20) + 12345), ("itext", 82, 6 << 20), ("lowent4k", 83, (4 << 20) + 2), ("itext", 84, 3000)):
+        a = z.gen(kind, seed, n)
+        comp = oracle.deflate(a)
+        t = dev(comp, gpu)
+        out = torch.zeros(n, dtype=torch.uint8, device=gpu)
+        got = z.inflate_tensor(t, out, flags=z.ZES_F_PIECES)
+        assert z.last_inflate_tier() == 1, kind
+        assert got.cpu().numpy().tobytes() == a.tobytes(), kind
+        # capacity one byte short: the size needed comes back
+        small = torch.zeros(n - 1 - ((n - 1) % 16), dtype=torch.uint8, device=gpu)
+        with pytest.raises(z.ZlibEsError) as e:
+            z.inflate_tensor(t, small, flags=z.ZES_F_PIECES)
+        assert e.value.code == -16 and e.value.need == n
+    # another encoder's stream falls through to the general tiers with the same bytes
+    import zlib as pyzlib
+
+    a = z.gen("itext", 85, 3 << 20)
+    t = dev(np.frombuffer(pyzlib.compress(a.tobytes(), 6), dtype=np.uint8).copy(), gpu)
+    got = z.inflate_tensor(t, torch.zeros(len(a), dtype=torch.uint8, device=gpu), flags=z.ZES_F_PIECES)
+    assert z.last_inflate_tier() != 1 and got.cpu().numpy().tobytes() == a.tobytes()
+    # a corrupted block in the middle: the reference's error, whatever tier finds it
+    a = z.gen("itext", 86, 4 << 20)
+    comp = oracle.deflate(a).copy()
+    comp[len(comp) // 2: len(comp) // 2 + 64] ^= 0x5A
+    try:
+        want = ("ok", oracle.inflate(comp).tobytes())
+    except oracle.OracleError as e:
+        want = ("err", str(e))
+    try:
+        got = ("ok", z.inflate_tensor(dev(comp, gpu), torch.zeros(len(a) + (1 << 20), dtype=torch.uint8, device=gpu), flags=z.ZES_F_PIECES).cpu().numpy().tobytes())
+    except z.ZlibEsError as e:
+        got = ("err", str(e))
+    assert got == want
+
+
+def test_stream_of_more_than_512_mib(z, gpu):
+    """A compressed stream of 2^29 bytes and more (bit positions beyond 32 bits) stays on the block-parallel tier:
+    three pieces here.  The stream is made by the engine's own deflate (bit-exact with the reference by the tests
+    above); the round trip must give the input back."""
+    import torch
+
+    n = 650 << 20
+    a = z.gen("xorshift", 91, n)
+    t = torch.from_numpy(a).to(gpu)
+    comp = z.deflate_tensor(t)
+    assert comp.numel() >= 1 << 29
+    comp = comp.clone()
+    back = torch.empty(n, dtype=torch.uint8, device=gpu)
+    got = z.inflate_tensor(comp, back)
+    assert z.last_inflate_tier() == 1
+    assert got.numel() == n and torch.equal(got, t)
+
+
 # ---------------------------------------------------------------------------------------------
 # boundary
 # ---------------------------------------------------------------------------------------------

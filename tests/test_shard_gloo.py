@@ -138,6 +138,96 @@ def test_split_one_buffer_over_two_ranks_gloo():
     assert q.get(timeout=5) is True
 
 
+def _oracle_range(_oracle, comp, want):
+    """What zes_inflate_range_dev does, restated with the oracle's map of the stream (test infrastructure)."""
+    starts, ends = _oracle.inflate_blocks(comp)
+
+    def rng(lo_bit, own_bit, exact):
+        ks = [k for k, s in enumerate(starts) if lo_bit <= s < own_bit]
+        if not ks:
+            return np.zeros(0, dtype=np.uint8), 0, lo_bit, lo_bit, 0, False
+        if exact and starts[ks[0]] != max(16, lo_bit):
+            return None
+        a, b = ks[0], ks[-1]
+        o0 = ends[a - 1] if a else 0
+        eb = starts[b + 1] if b + 1 < len(starts) else 0  # (behind the last block: unused by the chain check)
+        return want[o0: ends[b]].copy(), ends[b] - o0, starts[a], eb, len(ks), b == len(starts) - 1
+
+    return rng
+
+
+def _inflate_split_worker(rank, world, port, q):
+    """One stream over the ranks: bit ranges, the six-number exchange, the chain check, the gather —
+    and the fallback when the ranges do not fit."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+
+    import __graft_entry__ as ge
+    import _oracle
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    z = ge.load()
+    shard = _load_shard()
+    ok = True
+    for kind, seed, n in (("itext", 21, 5 * 131072 + 777), ("xorshift", 4, 3 * 131072), ("lowent4k", 8, 131072 * 9 + 5), ("itext", 2, 40000)):
+        data = z.gen(kind, seed, n)
+        comp = _oracle.deflate(data)
+        fell = []
+
+        def fallback():
+            fell.append(1)
+            return torch.from_numpy(_oracle.inflate(comp))
+
+        res = shard.inflate_split(len(comp), _oracle_range(_oracle, comp, data), fallback)
+        if rank == 0:
+            ok = ok and not fell and res.numpy().tobytes() == data.tobytes()
+        else:
+            assert res is None
+        # a rank whose range is not a clean chain: every rank sees it in the table, rank 0 decodes the whole stream
+        inner = _oracle_range(_oracle, comp, data)
+        res = shard.inflate_split(len(comp), (lambda lo, own, ex: None if rank == world - 1 else inner(lo, own, ex)), fallback)
+        if rank == 0:
+            ok = ok and len(fell) == 1 and res.numpy().tobytes() == data.tobytes()
+    if rank == 0:
+        q.put(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_inflate_split_one_stream_over_ranks_gloo(world):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_inflate_split_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert q.get(timeout=5) is True
+
+
+def test_chain_check():
+    shard = _load_shard()
+    B = 131072
+    good = [[1, 16, 5000, 2, 2 * B, 0], [1, 5000, 5000, 0, 0, 0], [1, 5000, 9000, 1, 70, 1]]
+    assert shard.check_chain(good)
+    for r, f, v in ((0, 1, 24), (0, 2, 5001), (0, 4, 2 * B - 1), (0, 5, 1), (2, 5, 0), (2, 4, B + 1), (1, 0, 0)):
+        bad = [list(m) for m in good]
+        bad[r][f] = v
+        assert not shard.check_chain(bad), (r, f, v)
+    assert not shard.check_chain([[1, 16, 16, 0, 0, 0]])
+    assert shard.split_bits(1000, 4) == [(16, 2000), (2000, 4000), (4000, 6000), (6000, 8000)]
+    assert shard.split_bits(3, 4)[0] == (16, 16)
+
+
 def test_adler_combine_and_block_split():
     import zlib as pyzlib
 

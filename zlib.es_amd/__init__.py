@@ -37,6 +37,8 @@ ZES_E_DEVICE = -17
 ZES_E_ARG = -18
 ZES_F_NO_FASTPATH = 1
 ZES_F_LOOSE_CANDIDATES = 2
+ZES_F_PIECES = 4
+ZES_E_NOTRANGE = -19
 
 GEN_KINDS = {"xorshift": 0, "lowent4k": 1, "itext": 2}
 
@@ -99,6 +101,8 @@ def lib():
         L.zes_inflate_batch_dev.argtypes = [C.c_void_p, u64p, u64p, C.c_void_p, u64p, u64p, u64p, i32p, C.c_uint32,
                                             C.c_uint32]
         L.zes_deflate_range_dev.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, u64p, u32p]
+        L.zes_inflate_range_dev.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, u64p, u64p, u64p,
+                                            u32p, i32p]
         L.zes_deflate_join_dev.argtypes = [C.POINTER(C.c_void_p), u64p, u32p, u64p, C.c_uint32, C.c_void_p, C.c_uint64, u64p]
         L.zes_stage_lz77_dev.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, u32p]
         L.zes_stage_huff_lengths_dev.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
@@ -391,6 +395,31 @@ def deflate_join_tensors(pieces, bits, adlers, lens, out=None):
     if rc:
         _raise(rc)
     return out[: n.value]
+
+
+def inflate_range_tensor(t, lo_bit, own_bit, exact, out):
+    """The blocks of a reference-made zlib stream (CUDA tensor ``t``, the whole stream) that start at bits
+    lo_bit <= s < own_bit of it, decoded into ``out`` (block k of the range at k * 131072) -> (out_len, first_bit,
+    end_bit, nblocks, final) with bit positions relative to the stream, or None when the range is not a clean chain
+    of reference-made blocks (zes_inflate_range_dev; one stream split over several GPUs)."""
+    import torch
+
+    assert t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous() and out.is_cuda
+    lo_bit = max(16, int(lo_bit))
+    byte0 = (lo_bit >> 3) & ~15
+    if byte0 >= 16:
+        byte0 -= 16  # (the search starts 16 bits into what it is given)
+    end = min(t.numel(), (int(own_bit) + 7) // 8 + (1 << 20))  # the last block's bytes and the header behind it
+    view = _aligned(t[byte0:end])
+    torch.cuda.current_stream(t.device).synchronize()
+    n, fb, eb, nb, fin = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint32(), C.c_int32()
+    rc = lib().zes_inflate_range_dev(view.data_ptr(), view.numel(), lo_bit - 8 * byte0, int(own_bit) - 8 * byte0, 1 if exact else 0,
+                                     out.data_ptr(), out.numel(), C.byref(n), C.byref(fb), C.byref(eb), C.byref(nb), C.byref(fin))
+    if rc == ZES_E_NOTRANGE:
+        return None
+    if rc:
+        _raise(rc)
+    return n.value, fb.value + 8 * byte0, eb.value + 8 * byte0, nb.value, bool(fin.value)
 
 
 def last_inflate_tier():

@@ -577,7 +577,7 @@ struct InfJob {
   int tier;    // 0 = not decoded yet
 };
 
-bool t1_eligible(const InfJob& j, uint32_t flags) { return !(flags & ZES_F_NO_FASTPATH) && j.c >= 64 && j.c < (1ull << 29); }
+bool t1_eligible(const InfJob& j, uint32_t flags) { return !(flags & (ZES_F_NO_FASTPATH | ZES_F_PIECES)) && j.c >= 64 && j.c < (1ull << 29); }
 
 // T1 over a group of buffers: every launch covers all of them (scan, verify, sort, one decode work
 // item per candidate block, chain check), two host synchronisations for the whole group.  Jobs the
@@ -600,6 +600,10 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
     // sort never sees more than this many (a zlib stream with 250-byte blocks has 250 000 of them)
     b.cand_cap = (uint32_t)std::min<uint64_t>(j.c / 64 + 64, j.cap / ZES_BLK + 65);
     b.work_first = 0;
+    b.start_rel = 0;
+    b.own_rel = 0xFFFFFFFFu;
+    b.range_flags = 0;
+    b.pad = 0;
     chunks += (j.c + INF_SCAN_BYTES - 1) / INF_SCAN_BYTES;
     cands += b.cand_cap;
     total_c += j.c;
@@ -853,6 +857,118 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
     j.out_len = r.out_len;
     j.status = r.out_len > j.cap ? ZES_E_NOSPACE : ZES_OK;
   }
+  return ZES_OK;
+}
+
+// T1 over one PIECE of a reference-made stream: the blocks that start inside bits [lo_bit, own_bit) of the piece at
+// d_in + in_off (c readable bytes: the piece and enough behind it for its last block, <= 144 KiB, and for the header
+// of the block after it).  exact: the first block starts at lo_bit (known from the piece before); else the chain
+// starts at the first block start found at or behind lo_bit.  Block k of the piece goes to d_out + out_off + k * 131072.
+// handled = false: not a clean chain of reference-made blocks (the caller decodes the stream some other way).
+struct RangeRes {
+  bool handled = false;
+  uint64_t out_len = 0, first_bit = 0, end_bit = 0;
+  uint32_t nblocks = 0;
+  bool final_block = false;
+};
+int inflate_t1_range(const uint8_t* d_in, uint64_t in_off, uint64_t c, uint64_t lo_bit, uint64_t own_bit, bool exact, uint8_t* d_out,
+                     uint64_t out_off, uint64_t cap, uint32_t flags, RangeRes* rr) {
+  int rc;
+  *rr = RangeRes();
+  if (c >= (1ull << 29) || lo_bit < 16) return ZES_OK;
+  // a range without a block start (a piece in the middle of one block): nothing to decode, and that is an answer
+  auto nothing_here = [&]() {
+    if (exact) return ZES_OK;
+    rr->handled = true;
+    rr->first_bit = rr->end_bit = lo_bit;
+    return ZES_OK;
+  };
+  if (c * 8 < lo_bit + 64) return nothing_here();
+  ZesInfBuf* hb = (ZesInfBuf*)((uint8_t*)g.pinned + PIN_UP);
+  memset(hb, 0, 2 * sizeof(ZesInfBuf));
+  const uint64_t chunks = (c + INF_SCAN_BYTES - 1) / INF_SCAN_BYTES;
+  hb[0].in_off = in_off;
+  hb[0].c = c;
+  hb[0].out_off = out_off;
+  hb[0].cap = cap;
+  hb[0].cand_cap = (uint32_t)std::min<uint64_t>(c / 64 + 64, 1ull << 23);  // (not from cap: a short output still gets its size)
+  hb[0].start_rel = (uint32_t)(lo_bit - 16);
+  hb[0].own_rel = (uint32_t)std::min<uint64_t>(own_bit >= 16 ? own_bit - 16 : 0, 0xFFFFFFFEull);
+  hb[0].range_flags = exact ? 0u : ZES_START_ANY;
+  hb[1].first_chunk = (uint32_t)chunks;
+  hb[1].cand_base = hb[0].cand_cap;
+  const uint32_t cands = hb[0].cand_cap;
+  const uint32_t surv_cap = (uint32_t)std::min<uint64_t>(c / 4 + 1024ull, 1ull << 30);
+  const size_t cnt_bytes = 16 + 4 + 4;  // counters[4], cnt[1], first byte
+  if ((rc = ensure(g.ibufs, sizeof(ZesInfBuf) * 2))) return rc;
+  if ((rc = ensure(g.surv, (size_t)surv_cap * 8))) return rc;
+  if ((rc = ensure(g.cand, (size_t)cands * 4))) return rc;
+  if ((rc = ensure(g.cand_sorted, (size_t)cands * 4))) return rc;
+  if ((rc = ensure(g.cres, sizeof(ZesCandRes) * cands))) return rc;
+  if ((rc = ensure(g.counters, cnt_bytes))) return rc;
+  if ((rc = ensure(g.res, sizeof(ZesRes) * 2))) return rc;
+  const ZesInfBuf* dbufs = (const ZesInfBuf*)g.ibufs.p;
+  uint32_t* counters = (uint32_t*)g.counters.p;
+  uint32_t* cnt = counters + 4;
+  uint8_t* dfirst = (uint8_t*)(cnt + 1);
+  HIPCHK(hipMemcpyAsync(g.ibufs.p, hb, sizeof(ZesInfBuf) * 2, hipMemcpyHostToDevice, g.stream));
+  HIPCHK(hipMemsetAsync(g.counters.p, 0, cnt_bytes, g.stream));
+  {
+    Timed t("k_inf_scan");
+    // (the scan's rule that a BFINAL position far from the end is no block start uses the end of the piece: a piece in
+    // the middle of a stream merely keeps a few more survivors near its own end)
+    hipLaunchKernelGGL(k_inf_scan, dim3((uint32_t)chunks), dim3(INF_SCAN_THREADS), 0, g.stream, d_in, dbufs, 1u, (unsigned long long*)g.surv.p,
+                       surv_cap, counters, dfirst, (flags & ZES_F_LOOSE_CANDIDATES) ? 1u : 0u, (const uint8_t*)g.kraft.p);
+  }
+  {
+    Timed t("k_inf_verify");
+    const uint32_t nwg = (uint32_t)std::min<uint64_t>(c / 32768 + 1, 8192);
+    hipLaunchKernelGGL(k_inf_verify, dim3(nwg), dim3(64), 0, g.stream, d_in, dbufs, (const unsigned long long*)g.surv.p, surv_cap, counters,
+                       (uint32_t*)g.cand.p, cnt, (flags & ZES_F_LOOSE_CANDIDATES) ? 1u : 0u);
+  }
+  uint32_t* hc = (uint32_t*)g.pinned;
+  HIPCHK(hipMemcpyAsync(hc, g.counters.p, cnt_bytes, hipMemcpyDeviceToHost, g.stream));
+  HIPCHK(hipStreamSynchronize(g.stream));
+  const uint32_t nsurv = hc[0], ncand = hc[4];
+  if (nsurv > surv_cap || ncand > hb[0].cand_cap) return ZES_OK;
+  if (nsurv == 0 || ncand == 0) return nothing_here();
+  hb[1].work_first = ncand;
+  HIPCHK(hipMemcpyAsync(g.ibufs.p, hb, sizeof(ZesInfBuf) * 2, hipMemcpyHostToDevice, g.stream));
+  {
+    Timed t("k_inf_ranksort");
+    hipLaunchKernelGGL(k_inf_ranksort, dim3(1), dim3(1024), 0, g.stream, dbufs, (const uint32_t*)cnt, (const uint32_t*)g.cand.p, (uint32_t*)g.cand_sorted.p);
+  }
+  {
+    Timed t("k_inf_block_par");
+    hipLaunchKernelGGL(k_inf_block_par, dim3(ncand), dim3(PAR_THREADS), 0, g.stream, d_in, d_out, dbufs, 1u, (const uint32_t*)cnt,
+                       (const uint32_t*)g.cand_sorted.p, (const uint32_t*)nullptr, (ZesCandRes*)g.cres.p, (unsigned long long*)nullptr, (const uint32_t*)nullptr);
+  }
+  {
+    Timed t("k_inf_chain");
+    hipLaunchKernelGGL(k_inf_chain_range, dim3(1), dim3(256), 0, g.stream, dbufs, (const uint32_t*)cnt, (const uint32_t*)g.cand_sorted.p,
+                       (const ZesCandRes*)g.cres.p, (ZesRes*)g.res.p);
+  }
+  ZesRes* hres = (ZesRes*)((uint8_t*)g.pinned + 128 * 1024);
+  HIPCHK(hipMemcpyAsync(hres, g.res.p, sizeof(ZesRes) * 2, hipMemcpyDeviceToHost, g.stream));
+  HIPCHK(hipStreamSynchronize(g.stream));
+  if (getenv("ZES_RANGE_DBG")) {
+    std::vector<uint32_t> hcand(ncand);
+    std::vector<ZesCandRes> hcr(ncand);
+    HIPCHK(hipMemcpy(hcand.data(), g.cand_sorted.p, ncand * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hcr.data(), g.cres.p, ncand * sizeof(ZesCandRes), hipMemcpyDeviceToHost));
+    fprintf(stderr, "range: c=%llu lo=%llu own=%llu exact=%d nsurv=%u ncand=%u status=%u\n", (unsigned long long)c, (unsigned long long)lo_bit,
+            (unsigned long long)own_bit, (int)exact, nsurv, ncand, hres[0].status);
+    for (uint32_t k = 0; k < ncand && k < 12; k++)
+      fprintf(stderr, "  cand[%u]=%u flags=%u out_len=%llu end_bit=%llu\n", k, hcand[k], hcr[k].flags, (unsigned long long)hcr[k].out_len,
+              (unsigned long long)hcr[k].end_bit);
+  }
+  if (hres[0].status != 0) return ZES_OK;
+  rr->handled = true;
+  rr->out_len = hres[0].out_len;
+  rr->nblocks = hres[0].aux & 0x7FFFFFFFu;
+  rr->final_block = (hres[0].aux >> 31) != 0;
+  rr->end_bit = hres[1].out_len;
+  rr->first_bit = hres[1].aux;
   return ZES_OK;
 }
 
@@ -1187,6 +1303,40 @@ int inflate_slow(const uint8_t* d_in, uint8_t* d_out, InfJob& j) {
   return ZES_OK;
 }
 
+// A reference-made stream too long for 32-bit bit positions (c >= 512 MiB), or any stream when ZES_F_PIECES asks for it
+// (testing aid): T1 piece by piece.  A piece = the blocks that start inside the next `piece` bytes behind the end of
+// the piece before; it is handed over with enough bytes behind it for its last block and the header behind that.
+constexpr uint64_t T1_PIECE = 256ull << 20;
+constexpr uint64_t T1_PIECE_SLACK = 1ull << 20;
+int inflate_pieces(const uint8_t* d_in, uint8_t* d_out, InfJob& j, uint32_t flags) {
+  uint64_t piece = T1_PIECE;
+  if (flags & ZES_F_PIECES) piece = 1ull << 20;  // testing aid: 1 MiB pieces
+  uint64_t pos_bit = 16, total = 0, blocks = 0;
+  for (uint32_t round = 0; round < (1u << 20); round++) {
+    uint64_t byte0 = (pos_bit >> 3) & ~15ull;
+    if (byte0 >= 16) byte0 -= 16;  // (the block search starts 16 bits into a buffer: keep the piece's first block behind that)
+    const uint64_t rel = pos_bit - 8 * byte0;
+    const uint64_t pc = std::min<uint64_t>(j.c - byte0, piece + T1_PIECE_SLACK);
+    const uint64_t done_bytes = blocks * ZES_BLK;
+    RangeRes rr;
+    int rc = inflate_t1_range(d_in, j.in_off + byte0, pc, rel, rel + piece * 8, true, d_out, j.out_off + std::min(done_bytes, j.cap),
+                              j.cap > done_bytes ? j.cap - done_bytes : 0, flags, &rr);
+    if (rc) return rc;
+    if (!rr.handled || rr.nblocks == 0) return ZES_OK;  // not a clean chain: the other tiers decide
+    blocks += rr.nblocks;
+    total += rr.out_len;
+    pos_bit = 8 * byte0 + rr.end_bit;
+    if (rr.final_block) {
+      j.tier = 1;
+      j.out_len = total;
+      j.status = total > j.cap ? ZES_E_NOSPACE : ZES_OK;
+      return ZES_OK;
+    }
+    if (pos_bit >= j.c * 8) return ZES_OK;
+  }
+  return ZES_OK;
+}
+
 // All jobs of a call: T1 in groups, then the stragglers one by one.  jobs[i].status must be ZES_OK
 // for the buffers to decode (anything else is left untouched).  firsts[i] = first byte of buffer i.
 int inflate_jobs(const uint8_t* d_in, uint8_t* d_out, std::vector<InfJob>& jobs, const uint8_t* firsts, uint32_t flags) {
@@ -1230,6 +1380,24 @@ int inflate_jobs(const uint8_t* d_in, uint8_t* d_out, std::vector<InfJob>& jobs,
   for (size_t g0 = 0; g0 < ids.size(); g0 += INF_GROUP) {
     const uint32_t nb = (uint32_t)std::min<size_t>(INF_GROUP, ids.size() - g0);
     if ((rc = inflate_t1_group(d_in, d_out, jobs.data(), ids.data() + g0, nb, firsts == nullptr, flags))) return rc;
+  }
+  // streams too long for the block-parallel tier's 32-bit bit positions (and ZES_F_PIECES): the same tier, piece by piece
+  for (uint32_t i : todo) {
+    InfJob& j = jobs[i];
+    if (j.tier != 0 || j.status != ZES_OK || (flags & ZES_F_NO_FASTPATH)) continue;
+    if (!(j.c >= (1ull << 29) || ((flags & ZES_F_PIECES) && j.c >= 64))) continue;
+    if (firsts == nullptr) {  // the CM nibble (src/zlib.ts:13-16) was not checked on the way for this one
+      uint8_t fb = 0;
+      HIPCHK(hipMemcpyAsync(g.pinned, d_in + j.in_off, 1, hipMemcpyDeviceToHost, g.stream));
+      HIPCHK(hipStreamSynchronize(g.stream));
+      fb = *(const uint8_t*)g.pinned;
+      if ((fb & 15u) != 8u) {
+        j.status = ZES_E_NOT_DEFLATE;
+        j.tier = -1;
+        continue;
+      }
+    }
+    if ((rc = inflate_pieces(d_in, d_out, j, flags))) return rc;
   }
   // Many streams the block-parallel tier left over (a batch of another encoder's streams): one serial wavefront
   // per stream, all at once — 512 of them run side by side, where the per-buffer tiers would take the streams one
@@ -1321,6 +1489,7 @@ const char* zes_strerror(int status) {
     case ZES_E_NOSPACE: return "zes: output capacity too small";
     case ZES_E_DEVICE: return "zes: HIP device error (no gfx950 device or runtime failure)";
     case ZES_E_ARG: return "zes: bad argument";
+    case ZES_E_NOTRANGE: return "zes: not a clean chain of reference-made blocks in this range";
     default: return "zes: unknown status";
   }
 }
@@ -1691,6 +1860,25 @@ int zes_deflate_join_dev(const uint8_t* const* d_piece, const uint64_t* piece_bi
   HIPCHK(hipStreamSynchronize(g.stream));
   collect_times();
   return ZES_OK;
+}
+
+int zes_inflate_range_dev(const uint8_t* d_in, uint64_t c, uint64_t lo_bit, uint64_t own_bit, int exact_start, uint8_t* d_out, uint64_t cap,
+                          uint64_t* out_len, uint64_t* first_bit, uint64_t* end_bit, uint32_t* nblocks, int* final_block) {
+  if (!d_in || !out_len || !first_bit || !end_bit || !nblocks || !final_block || lo_bit < 16 || own_bit <= lo_bit) return ZES_E_ARG;
+  if ((((uintptr_t)d_in) & 15u) || (((uintptr_t)d_out) & 15u) || c >= (1ull << 29)) return ZES_E_ARG;
+  std::lock_guard<std::mutex> lk(g_mu);
+  int rc = init_locked(-1);
+  if (rc) return rc;
+  RangeRes rr;
+  if ((rc = inflate_t1_range(d_in, 0, c, lo_bit, own_bit, exact_start != 0, d_out, 0, cap, ZES_F_DEFAULT, &rr))) return rc;
+  collect_times();
+  if (!rr.handled) return ZES_E_NOTRANGE;
+  *out_len = rr.out_len;
+  *first_bit = rr.first_bit;
+  *end_bit = rr.end_bit;
+  *nblocks = rr.nblocks;
+  *final_block = rr.final_block ? 1 : 0;
+  return rr.out_len > cap ? ZES_E_NOSPACE : ZES_OK;
 }
 
 int zes_adler32_dev(const uint8_t* d_in, uint64_t n, uint32_t* adler_out) {

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(INF_SCAN_THREADS) void k_inf_scan(const uint8_t* __
       const uint32_t i = (uint32_t)__builtin_ctz(m);
       m &= m - 1u;
       const uint64_t abs_bit = abs_base + i;
-      if (abs_bit < 16 || abs_bit + 17 + 12 > end_bits) continue;
+      if (abs_bit < 16ull + bufs[bi].start_rel || abs_bit + 17 + 12 > end_bits) continue;  // (start_rel: 0 unless the buffer is a piece of a longer stream)
       const uint64_t lo = i ? ((w0 >> i) | (w1 << (64u - i))) : w0;
       const uint64_t hi = w1 >> i;
       const uint32_t ncl = (uint32_t)((lo >> 13) & 15u) + 4u;
@@ -1877,7 +1877,7 @@ __global__ __launch_bounds__(256) void k_inf_chain(const ZesInfBuf* __restrict__
     res->aux = 0;
   }
   __syncthreads();
-  if (ncand == 0 || nwork == 0 || cand[0] != 0 || cnt[blockIdx.x] > bf.cand_cap) return;  // (no work items: the buffer was left out, results would be stale)
+  if (ncand == 0 || nwork == 0 || cand[0] != bf.start_rel || cnt[blockIdx.x] > bf.cand_cap) return;  // (no work items: the buffer was left out, results would be stale)
   if (autow && ncand > nwork) return;  // more candidates than work items were launched: the host falls back
   // Fast check, all work items in parallel: item k is ok, non-final items give exactly one slot
   // and end where item k+1 starts, the first final item closes the chain.
@@ -1939,6 +1939,75 @@ __global__ __launch_bounds__(256) void k_inf_chain(const ZesInfBuf* __restrict__
   res->out_len = total;
   res->aux = k;
   res->status = 2;  // the slots are shifted: decode the chain again in order
+}
+
+// ------------------------------------------------------------------------------------------
+// k_inf_chain_range: the chain check of one PIECE of a reference-made stream (zes_inflate_range_dev): the blocks that
+// start inside [start_rel, own_rel) — every one decoded fine, exactly 131072 bytes unless it is the stream's final
+// block, each ending where the next candidate starts (the candidate behind the last own block included: it is the
+// next piece's first block).  No repair of any kind: anything irregular (a false candidate among them) fails the piece
+// and the caller decodes the stream in one go.
+// res[0]: status 0, out_len = bytes of the own blocks, aux = their number | final << 31;  res[1]: out_len = bit
+// position (relative to the piece) behind the last own block, aux|status = bit position of the first own block.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_inf_chain_range(const ZesInfBuf* __restrict__ bufs, const uint32_t* __restrict__ cnt,
+                                                         const uint32_t* __restrict__ cand_all, const ZesCandRes* __restrict__ cres_all,
+                                                         ZesRes* __restrict__ res) {
+  __shared__ uint32_t s_bad, s_final;
+  __shared__ unsigned long long s_total;
+  const uint32_t tid = threadIdx.x;
+  const ZesInfBuf bf = bufs[0];
+  const uint32_t ncand = min(cnt[0], bf.cand_cap);
+  const uint32_t* cand = cand_all + bf.cand_base;
+  const ZesCandRes* cres = cres_all + bf.cand_base;
+  if (tid == 0) {
+    s_bad = 0;
+    s_final = 0;
+    s_total = 0;
+    res[0].status = 1;
+    res[0].out_len = 0;
+    res[0].aux = 0;
+    res[1].status = 0;
+    res[1].out_len = 0;
+    res[1].aux = 0;
+  }
+  __syncthreads();
+  if (ncand == 0 || cnt[0] > bf.cand_cap) return;
+  if (!(bf.range_flags & ZES_START_ANY) && cand[0] != bf.start_rel) return;
+  // own blocks: candidates below own_rel (the list is sorted)
+  uint32_t lo = 0, hi = ncand;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (cand[mid] < bf.own_rel) lo = mid + 1; else hi = mid;
+  }
+  const uint32_t nown = lo;
+  if (nown == 0) {  // no block starts in this piece (possible for a piece in the middle of one block)
+    if (tid == 0) res[0].status = 0;
+    return;
+  }
+  unsigned long long part = 0;
+  uint32_t bad = 0, fin = 0;
+  for (uint32_t k = tid; k < nown; k += 256) {
+    const ZesCandRes r = cres[k];
+    if (!(r.flags & 1u)) bad = 1;
+    part += r.out_len;
+    if (r.flags & 2u) {  // the stream's final block: must be the last own one
+      if (k + 1 != nown) bad = 1;
+      fin = 1;
+    } else if (r.out_len != ZES_BLK || k + 1 >= ncand || (uint64_t)cand[k + 1] + 16 != r.end_bit) {
+      bad = 1;  // (k + 1 == nown: the candidate behind the last own block is the next piece's first block)
+    }
+  }
+  if (bad) atomicOr(&s_bad, 1u);
+  if (fin) atomicOr(&s_final, 1u);
+  atomicAdd(&s_total, part);
+  __syncthreads();
+  if (s_bad || tid != 0) return;
+  res[0].status = 0;
+  res[0].out_len = s_total;
+  res[0].aux = nown | (s_final << 31);
+  res[1].out_len = cres[nown - 1].end_bit;
+  res[1].aux = cand[0] + 16u;
 }
 
 // ------------------------------------------------------------------------------------------

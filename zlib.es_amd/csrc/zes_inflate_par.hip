@@ -1052,7 +1052,7 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __
   const uint32_t* map = map_all ? map_all + bufs[bi].cand_base : nullptr;
   // the first block of a reference-made stream starts at bit 16 and passes the candidate rules: if the sorted
   // list does not begin there, k_inf_chain rejects the buffer whatever is decoded here (another encoder's stream)
-  if (!map_all && !redo && (cand[0] != 0 || cnt[bi] > bufs[bi].cand_cap)) return;  // (or more candidates than the output has blocks)
+  if (!map_all && !redo && ((cand[0] != bufs[bi].start_rel && !(bufs[bi].range_flags & ZES_START_ANY)) || cnt[bi] > bufs[bi].cand_cap)) return;  // (or more candidates than the output has blocks)
   ZesCandRes* cres = cres_all + bufs[bi].cand_base;
   const uint64_t c = bufs[bi].c;
   const uint32_t lastdw = (uint32_t)((c - 1) >> 2);

@@ -24,7 +24,15 @@ struct ZesInfBuf {
   uint32_t cand_base;    // start of the buffer's region in cand[] / cand_sorted[] / cres[] / map[]
   uint32_t cand_cap;     // entries in that region
   uint32_t work_first;   // k_inf_block_par: first work item of this buffer
+  // range form (zes_inflate_range_dev: one piece of a longer stream): the chain of blocks starts at candidate value
+  // start_rel (bit position - 16; 0 = right behind the zlib header) or, with ZES_START_ANY, at the first candidate at
+  // or behind it; candidates at or behind own_rel only serve as end estimates and are left to the next piece
+  uint32_t start_rel;
+  uint32_t own_rel;      // 0xFFFFFFFF: the whole buffer
+  uint32_t range_flags;  // ZES_START_ANY
+  uint32_t pad;
 };
+#define ZES_START_ANY 1u
 
 // work_first of the table's sentinel entry in one-buffer calls: the decode kernels take the number of work
 // items from the candidate counter on the device (the sentinel's cand_cap holds the launch bound)
@@ -92,6 +100,7 @@ __global__ void k_inf_block_par(const uint8_t*, uint8_t*, const ZesInfBuf*, uint
                                 ZesCandRes*, unsigned long long*, const uint32_t*);
 __global__ void k_inf_move_slots(uint8_t*, const uint8_t*, const uint32_t*, const uint32_t*, uint32_t);
 __global__ void k_inf_chain(const ZesInfBuf*, const uint32_t*, const uint32_t*, const ZesCandRes*, const uint32_t*, uint32_t*, ZesRes*);
+__global__ void k_inf_chain_range(const ZesInfBuf*, const uint32_t*, const uint32_t*, const ZesCandRes*, ZesRes*);
 __global__ void k_inf_exact(const uint8_t*, uint64_t, uint64_t, uint8_t*, uint64_t, uint64_t, const uint64_t*, ZesRes*);
 // deflate direction (zes_deflate.hip)
 void zes_sort_set_dbg(unsigned long long*);

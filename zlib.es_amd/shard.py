@@ -282,3 +282,72 @@ def deflate_split(n: int, deflate_range: Callable[[int, int, bool], Tuple[object
         host = g.arena.cpu().numpy()
         pieces = [host[g.offset[r]: g.offset[r] + g.length[r]] for r in range(world)]
     return join(pieces, [mh[3 * r] for r in range(world)], [mh[3 * r + 1] for r in range(world)], [mh[3 * r + 2] for r in range(world)])
+
+
+def split_bits(c: int, world: int) -> List[Tuple[int, int]]:
+    """Ranges [lo_bit, own_bit) of a c-byte zlib stream per rank: equal byte shares, the first one behind the 2-byte
+    header (src/zlib.ts:21).  A rank decodes the blocks that START inside its range."""
+    cuts = [max(2, (c * r) // world) for r in range(world)] + [c]
+    return [(8 * cuts[r], 8 * max(cuts[r], cuts[r + 1])) for r in range(world)]
+
+
+def check_chain(meta: Sequence[Sequence[int]]) -> bool:
+    """Do the per-rank results (ok, first_bit, end_bit, nblocks, out_len, final) make one stream?  The first block at
+    bit 16, every range's end the next one's first, full 131072-byte blocks everywhere but at the very end, BFINAL
+    on the last block and nowhere else (src/inflate.ts:22-37 stops at the first BFINAL)."""
+    if not all(m[0] for m in meta):
+        return False
+    have = [m for m in meta if m[3] > 0]
+    if not have or have[0][1] != 16:
+        return False
+    for a, b in zip(have, have[1:]):
+        if a[2] != b[1] or a[5] or a[4] != a[3] * BLOCK:
+            return False
+    last = have[-1]
+    return bool(last[5]) and (last[3] - 1) * BLOCK <= last[4] <= last[3] * BLOCK
+
+
+def inflate_split(c: int, inflate_range: Callable[[int, int, bool], Optional[Tuple[object, int, int, int, int, bool]]],
+                  fallback: Callable[[], object], group=None, dst: int = 0, device=None):
+    """inflate() of ONE c-byte zlib stream by all ranks of the group: the same bytes as the
+    single-GPU result.
+
+    A reference-made stream is a chain of blocks of exactly 131072 output bytes (src/deflate.ts:20-37), so the blocks
+    can be decoded anywhere once their first bits are known — and the engine's block-start search finds them in
+    any part of the stream.  Rank r searches split_bits(c, world)[r] and decodes the blocks that start there:
+    `inflate_range(lo_bit, own_bit, exact)` returns (bytes, out_len, first_bit, end_bit, nblocks, final) — bit
+    positions relative to the stream — or None when its range is not a clean chain (z.inflate_range_tensor →
+    zes_inflate_range_dev on a GPU).  The exchange: one all_reduce of those six numbers per rank; every rank then
+    runs check_chain on the same table.  If the ranges fit, the outputs are gathered on `dst` in rank order (device
+    to device under "nccl") and their concatenation is the result; if they do not (another encoder's stream, a rank
+    that started on a false block start), `dst` returns `fallback()` — the single-GPU inflate of the whole stream,
+    with the reference's error behaviour.  Returns the result on `dst`, None elsewhere.
+    """
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = device if device is not None else torch.device("cpu")
+    lo, own = split_bits(c, world)[rank]
+    res = inflate_range(lo, own, rank == 0) if own > lo else (np.zeros(0, dtype=np.uint8), 0, lo, lo, 0, False)
+    if res is None:
+        piece, my = np.zeros(0, dtype=np.uint8), (0, 0, 0, 0, 0, 0)
+    else:
+        piece, n, fb, eb, nb, fin = res
+        my = (1, int(fb), int(eb), int(nb), int(n), int(bool(fin)))
+    meta = torch.zeros(6 * world, dtype=torch.int64, device=dev)
+    meta[6 * rank: 6 * rank + 6] = torch.tensor(my, dtype=torch.int64, device=dev)
+    dist.all_reduce(meta, op=dist.ReduceOp.SUM, group=group)
+    mh = [int(x) for x in meta.cpu().numpy()]
+    table = [mh[6 * r: 6 * r + 6] for r in range(world)]
+    if not check_chain(table):
+        return fallback() if rank == dst else None
+    t = piece if isinstance(piece, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(piece, dtype=np.uint8))
+    t = t.to(dev)[: my[4]]
+    g = gather_results(t, [rank], [int(t.numel())], [0], [[r] for r in range(world)], world, group=group, dst=dst)
+    if g is None:
+        return None
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+    return g.arena[: sum(g.length)]  # (the arena holds the ranks' outputs back to back, in rank order)
