@@ -39,7 +39,7 @@ struct Ctx {
   // deflate scratch
   DevBuf bufs, blks, idx_a, idx_b, inv, sdelta, hists, codes, hdrs, adler, res;
   // inflate scratch
-  DevBuf surv, cand, cand_sorted, counters, cres, map, resume, dbg, ibufs, ibufs2, mvlist, scratch, sres, maps, seglist, segprefix, wins, sym16, segorder, segjobs, pw16, gwins;
+  DevBuf surv, vlong, cand, cand_sorted, counters, cres, map, resume, dbg, ibufs, ibufs2, mvlist, scratch, sres, maps, seglist, segprefix, wins, sym16, segorder, segjobs, pw16, gwins;
   // staging for the host-pointer API
   DevBuf st_in, st_out;
   DevBuf kraft;  // k_inf_scan's table: Kraft contribution of four 3-bit code-length fields at once
@@ -579,6 +579,41 @@ struct InfJob {
 
 bool t1_eligible(const InfJob& j, uint32_t flags) { return !(flags & (ZES_F_NO_FASTPATH | ZES_F_PIECES)) && j.c >= 64 && j.c < (1ull << 29); }
 
+// The header test of the block-start search, two launches: k_inf_verify (a lane per survivor, the first VERIFY_STEPS
+// code-length symbols: nearly all survivors end there) and k_inf_verify_long (a wave per survivor still alive: the
+// real headers, ~300 symbols each).  `total_c`: compressed bytes behind the survivors (sizes the grids).
+int launch_verify(const uint8_t* d_in, const ZesInfBuf* dbufs, uint32_t surv_cap, uint32_t* counters, uint32_t* cnt, uint32_t loose,
+                  uint64_t total_c, uint32_t div) {
+  int rc;
+  (void)div;
+  // the list of the long pass: one survivor in ~350 bytes of stream, one in eight of them listed; ten times that
+  const uint32_t vlong_cap = (uint32_t)std::min<uint64_t>(total_c / 256 + 4096, surv_cap);
+  if ((rc = ensure(g.vlong, (size_t)vlong_cap * 24))) return rc;
+  // one lane per survivor: waves for all of them at once (the loop in the kernel takes what is beyond)
+  uint32_t nwg = (uint32_t)std::min<uint64_t>(total_c / 16384 + 1, 8192);
+  if (const char* e = getenv("ZES_VERIFY_DIV")) nwg = (uint32_t)std::min<uint64_t>(total_c / (uint64_t)atoi(e) + 1, 8192);
+  {
+    Timed t("k_inf_verify");
+    hipLaunchKernelGGL(k_inf_verify, dim3(nwg), dim3(64), 0, g.stream, d_in, dbufs, (const unsigned long long*)g.surv.p, surv_cap, counters,
+                       (uint32_t*)g.cand.p, cnt, loose, (uint32_t*)g.vlong.p, vlong_cap,
+                       getenv("ZES_VERIFY_STEPS") ? (uint32_t)atoi(getenv("ZES_VERIFY_STEPS")) : 32u);
+  }
+  {
+    Timed t("k_inf_verify_long");
+    // one wave per listed survivor (about one in 2800 bytes of stream)
+    const uint32_t nlong = (uint32_t)std::min<uint64_t>(total_c / 2048 + 1, 8192);
+    hipLaunchKernelGGL(k_inf_verify_long, dim3(nlong), dim3(64), 0, g.stream, d_in, dbufs, (const unsigned long long*)g.surv.p, surv_cap,
+                       counters, (uint32_t*)g.cand.p, cnt, loose, (const uint32_t*)g.vlong.p, vlong_cap);
+  }
+  if (getenv("ZES_VERIFY_DBG")) {
+    uint32_t hc[4];
+    HIPCHK(hipStreamSynchronize(g.stream));
+    HIPCHK(hipMemcpy(hc, counters, 16, hipMemcpyDeviceToHost));
+    fprintf(stderr, "verify: survivors %u, handed to the wave form %u\n", hc[0], hc[1]);
+  }
+  return ZES_OK;
+}
+
 // T1 over a group of buffers: every launch covers all of them (scan, verify, sort, one decode work
 // item per candidate block, chain check), two host synchronisations for the whole group.  Jobs the
 // tier settles get tier = 1; the others are left for the per-buffer tiers.
@@ -643,16 +678,9 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
                        (unsigned long long*)g.surv.p, surv_cap, counters, dfirst, (flags & ZES_F_LOOSE_CANDIDATES) ? 1u : 0u,
                        (const uint8_t*)g.kraft.p);
   }
-  {
-    // persistent lanes pulling survivors from a counter: the grid only has to be large enough to fill the chip
-    Timed t("k_inf_verify");
-    // (measured on 64 MiB: 8192 workgroups 0.33 ms, 2048 0.26 ms, 512 0.36 ms — about one survivor in 256 input bytes,
-    // and a lane should get a few of them)
-    uint32_t nwg = (uint32_t)std::min<uint64_t>(total_c / 32768 + 1, 8192);
-    if (const char* e = getenv("ZES_VERIFY_DIV")) nwg = (uint32_t)std::min<uint64_t>(total_c / (uint64_t)atoi(e) + 1, 8192);
-    hipLaunchKernelGGL(k_inf_verify, dim3(nwg), dim3(64), 0, g.stream, d_in, dbufs, (const unsigned long long*)g.surv.p, surv_cap,
-                       counters, (uint32_t*)g.cand.p, cnt, (flags & ZES_F_LOOSE_CANDIDATES) ? 1u : 0u);
-  }
+  // (k_inf_verify, measured on 64 MiB: 8192 workgroups 0.33 ms, 2048 0.26 ms, 512 0.36 ms — about one survivor in 256 input
+  // bytes, and a lane should get a few of them)
+  if ((rc = launch_verify(d_in, dbufs, surv_cap, counters, cnt, (flags & ZES_F_LOOSE_CANDIDATES) ? 1u : 0u, total_c, 32768))) return rc;
   // One buffer: nothing has to come back before the decode is launched.  The grid is sized for the most
   // blocks the caller's capacity can hold (plus room for false candidates); the kernels take the real
   // candidate count from device memory (table sentinel ZES_WORK_AUTO) and the host reads counters and
@@ -920,12 +948,7 @@ int inflate_t1_range(const uint8_t* d_in, uint64_t in_off, uint64_t c, uint64_t 
     hipLaunchKernelGGL(k_inf_scan, dim3((uint32_t)chunks), dim3(INF_SCAN_THREADS), 0, g.stream, d_in, dbufs, 1u, (unsigned long long*)g.surv.p,
                        surv_cap, counters, dfirst, (flags & ZES_F_LOOSE_CANDIDATES) ? 1u : 0u, (const uint8_t*)g.kraft.p);
   }
-  {
-    Timed t("k_inf_verify");
-    const uint32_t nwg = (uint32_t)std::min<uint64_t>(c / 32768 + 1, 8192);
-    hipLaunchKernelGGL(k_inf_verify, dim3(nwg), dim3(64), 0, g.stream, d_in, dbufs, (const unsigned long long*)g.surv.p, surv_cap, counters,
-                       (uint32_t*)g.cand.p, cnt, (flags & ZES_F_LOOSE_CANDIDATES) ? 1u : 0u);
-  }
+  if ((rc = launch_verify(d_in, dbufs, surv_cap, counters, cnt, (flags & ZES_F_LOOSE_CANDIDATES) ? 1u : 0u, c, 32768))) return rc;
   uint32_t* hc = (uint32_t*)g.pinned;
   HIPCHK(hipMemcpyAsync(hc, g.counters.p, cnt_bytes, hipMemcpyDeviceToHost, g.stream));
   HIPCHK(hipStreamSynchronize(g.stream));
@@ -1172,13 +1195,8 @@ int inflate_segments(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const st
         hipLaunchKernelGGL(k_inf_scan, dim3(chunks), dim3(INF_SCAN_THREADS), 0, g.stream, d_in, dbufs, 1u, (unsigned long long*)g.surv.p,
                            surv_cap, counters, sink, 0u, (const uint8_t*)g.kraft.p);
       }
-      {
-        // other encoders do not follow the reference's run-length rules for code lengths: loose candidates
-        Timed t("k_inf_verify");
-        const uint32_t nwg = (uint32_t)std::min<uint64_t>(j.c / 16384 + 1, 8192);
-        hipLaunchKernelGGL(k_inf_verify, dim3(nwg), dim3(64), 0, g.stream, d_in, dbufs, (const unsigned long long*)g.surv.p, surv_cap,
-                           counters, (uint32_t*)g.cand.p, cnt + k, 1u);
-      }
+      // other encoders do not follow the reference's run-length rules for code lengths: loose candidates
+      if ((rc = launch_verify(d_in, dbufs, surv_cap, counters, cnt + k, 1u, j.c, 16384))) return rc;
       {
         // one candidate per bucket of the stream, in order (at most SEG_BUCKETS segments whatever the block size)
         Timed t("k_inf_cand_thin");
@@ -1504,7 +1522,7 @@ int zes_shutdown(void) {
   if (!g.ready) return ZES_OK;
   (void)hipSetDevice(g.device);
   (void)hipStreamSynchronize(g.stream);
-  DevBuf* all[] = {&g.bufs, &g.blks, &g.idx_a, &g.idx_b, &g.inv, &g.sdelta, &g.hists, &g.codes, &g.hdrs, &g.adler, &g.res, &g.surv, &g.cand,
+  DevBuf* all[] = {&g.bufs, &g.blks, &g.idx_a, &g.idx_b, &g.inv, &g.sdelta, &g.hists, &g.codes, &g.hdrs, &g.adler, &g.res, &g.surv, &g.vlong, &g.cand,
                    &g.cand_sorted, &g.counters, &g.cres, &g.map, &g.resume, &g.dbg, &g.ibufs, &g.ibufs2, &g.mvlist, &g.scratch, &g.st_in, &g.st_out,
                    &g.sres, &g.maps, &g.seglist, &g.segprefix, &g.wins, &g.sym16, &g.segorder, &g.segjobs, &g.kraft, &g.pw16, &g.gwins};
   for (DevBuf* b : all) {

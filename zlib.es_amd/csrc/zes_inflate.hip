@@ -49,6 +49,7 @@ __device__ static inline uint64_t g_load64_le(const uint8_t* p, uint64_t byte, u
 // ------------------------------------------------------------------------------------------
 #define SCAN_BYTES INF_SCAN_BYTES  // bytes of the stream per workgroup
 #define RANK_LDS 8192u  // candidates k_inf_ranksort keeps in LDS
+#define VERIFY_STEPS 32u  // code-length symbols a lane of k_inf_verify decodes before it hands its survivor to a whole wave
 #define SCAN_LIST 4096u             // survivors a workgroup can stage (expected: ~0.2 % of 65536 positions)
 // Copies whole 128 KiB slots: item i moves slot src_slot[i] of src to slot dst_slot[i] of dst (32 workgroups
 // per item, 16 bytes per lane and step).  Used to close the gaps false candidates leave in the output.
@@ -189,199 +190,421 @@ __global__ __launch_bounds__(INF_SCAN_THREADS) void k_inf_scan(const uint8_t* __
 }
 
 // ------------------------------------------------------------------------------------------
-// k_inf_verify: one thread per survivor; decodes the code-length sequence and checks that the
-// lit/len code is complete with an end-of-block code and the distance code is complete, a
-// single 1-bit code, or absent.
+// k_inf_verify / k_inf_verify_long: the header test of the block-start search.  A survivor of the scan has its
+// code-length sequence decoded and the codes checked: lit/len complete with an end-of-block code; distances complete,
+// a single 1-bit code, or absent.  Two launches:
+//   k_inf_verify       one LANE per survivor, the first VERIFY_STEPS code-length symbols.  Seven in eight are rejected
+//                      by then (a code over-subscribes, or the sequence breaks the reference's run-length rules); the
+//                      others go on a list with their state.
+//   k_inf_verify_long  one WAVE per listed survivor, to the end: the real headers (~300 symbols) and under-subscribed
+//                      garbage.  A lone lane needs ~110 instructions per symbol, 4 cycles each whatever the other 63
+//                      lanes do: 300 symbols held its wave for ~90 us.  The wave form decodes the symbol at each of
+//                      128 bit offsets at once, walks the chain through them (one lane read per symbol), compacts the
+//                      ~22 symbols on the chain into lanes and runs the sequence logic on all of them with wave scans.
+// Lane form: the stream bits a lane needs (18 dwords: 32 symbols of at most 14 bits) are copied to LDS in one batch of
+// loads when it starts, so a step has no global load in it, and the step has no branch in it.  Per-lane decode table of
+// the code-length code in LDS: 128 bytes indexed by the next 7 stream bits read MSB-first (bit-reversed window),
+// entry = symbol | length << 5.  In that index space a canonical code is a run of consecutive entries, so the table is
+// filled front to back in (length, symbol) order.  Dword j of lane l lives at [j][l].
 // ------------------------------------------------------------------------------------------
+#define VERIFY_WIN 18u  // dwords per lane: VERIFY_STEPS symbols of at most 14 bits + alignment + read-ahead
+static_assert(VERIFY_STEPS * 14u + 31u + 64u <= VERIFY_WIN * 32u, "the capped pass does not reload its window");
+#define VSTATE_WORDS 6u  // per listed survivor: index in surv[], bit position, k, kl, kd, (psym | prev << 5 | eob << 9 | dmaxlen << 10 | nd << 14)
+
+// the reference's run-length coding of the code lengths (src/deflate.ts:100-139) never produces these (another
+// encoder's stream that does is decoded by T2):
+//  - "repeat previous" (16) directly after anything but a plain non-zero length, or with count 6: a run is cut into
+//    chunks of at most 6, the chunk's first length is written out, 16 repeats the other 3..5
+//  - a zero run (17) of 3: three zeros are written as three plain zeros
+//  - 17 closes its zero run (it codes the remainder 4..10), so a non-zero plain length follows; plain zeros (a
+//    remainder below 4) close their run as well, so no 17/18 follows them
+__device__ __forceinline__ uint32_t verify_rule_break(uint32_t psym, uint32_t sy, uint32_t xv, uint32_t is16, uint32_t is17, uint32_t is18) {
+  const uint32_t p_plain_nz = (uint32_t)(psym - 1u < 15u), s_plain_nz = (uint32_t)(sy - 1u < 15u);
+  return (is16 & ((p_plain_nz ^ 1u) | (uint32_t)(xv == 3u))) | (is17 & (uint32_t)(xv == 0u)) | ((uint32_t)(psym == 17u) & (s_plain_nz ^ 1u)) |
+         ((uint32_t)(psym == 0u) & (is17 | is18));
+}
+
 __global__ __launch_bounds__(64) void k_inf_verify(const uint8_t* __restrict__ d_in, const ZesInfBuf* __restrict__ bufs,
                                                    const unsigned long long* __restrict__ surv, uint32_t surv_cap,
                                                    uint32_t* __restrict__ counters, uint32_t* __restrict__ cand,
-                                                   uint32_t* __restrict__ cnt, uint32_t loose) {
-  // Persistent lanes: most survivors are rejected within ~15 code-length symbols (their codes
-  // over-subscribe at once), a few need all ~300, so a lane that is done pulls the next survivor
-  // from a shared counter (counters[2]) instead of idling until the wave's slowest lane ends.
-  //
-  // Per-lane decode table of the code-length code in LDS: 128 bytes indexed by the next 7 stream
-  // bits read MSB-first (bit-reversed window), entry = symbol | length << 5.  In that index space
-  // a canonical code is a run of consecutive entries, so the table is filled front to back in
-  // (length, symbol) order.  Dword j of lane l lives at [j][l]: conflict-free for equal j.
+                                                   uint32_t* __restrict__ cnt, uint32_t loose, uint32_t* __restrict__ vstate,
+                                                   uint32_t vlong_cap, uint32_t vsteps) {
+  constexpr uint32_t WIN = VERIFY_WIN;
   __shared__ uint32_t s_lut[32][64];
+  __shared__ uint32_t s_win[WIN][64];
   const uint32_t lane = threadIdx.x;
-  uint32_t ns = counters[0];
-  if (ns > surv_cap) ns = surv_cap;
-  // per-lane view of the buffer the lane's current survivor lives in
-  const uint32_t* in32 = reinterpret_cast<const uint32_t*>(d_in);
-  uint32_t lastdw = 0, mybuf = 0;
-  uint32_t limit = 0;
   uint8_t* lut8 = reinterpret_cast<uint8_t*>(&s_lut[0][0]);
-
-  bool have = false, exhausted = false;
-  // survivors are handed to a wave in chunks (same-address atomics serialise in the L2) sized so
-  // that every wave of the grid still gets about two
-  const uint32_t chunk = min(1024u, max(64u, ((ns / (2u * gridDim.x)) + 63u) & ~63u));
-  uint32_t wnext = 0, wend = 0;
-  uint64_t bb = 0;
-  uint32_t pos = 0, pos0 = 0, nb = 0, nw = 0, nwi = 0;
-  uint32_t HLIT = 0, total = 0, k = 0, kl = 0, kd = 0, nd = 0, dmaxlen = 0, prev = 0, psym = 31;
-  bool has_eob = false;
+  const uint32_t n = min(counters[0], surv_cap);
+  vsteps = min(max(vsteps, 1u), VERIFY_STEPS);
   constexpr uint64_t M0 = 0x0049249249249249ull;  // bit 0 of each of the 19 three-bit fields
-
-  for (;;) {
-    const uint64_t idle = __ballot(!have);
-    const uint32_t nidle = (uint32_t)__popcll(idle);
-    if (!exhausted && (nidle >= 32u || nidle == 64u)) {  // (16: 0.255 ms, 32: 0.242, 48: 0.244 on random64)
-      if (wnext >= wend) {  // the wave's chunk is used up: one atomic on the shared counter per chunk
-        uint32_t basei = 0;
-        if (lane == 0) basei = atomicAdd(&counters[2], chunk);
-        basei = (uint32_t)__builtin_amdgcn_readfirstlane((int)basei);
-        wnext = basei;
-        wend = min(basei + chunk, ns);
-        if (basei >= ns) {
-          exhausted = true;
-          wend = wnext;
-        }
-      }
-      const uint32_t myi = wnext + (uint32_t)__popcll(idle & zes_lanemask_lt());
-      const uint32_t wlim = wend;
-      wnext = min(wnext + nidle, wend);
-      if (!have && myi < wlim) {
-        // ---- set up one survivor: fixed header fields, code-length code ----
-        const unsigned long long sv = surv[myi];
-        mybuf = (uint32_t)(sv >> 32);
-        in32 = reinterpret_cast<const uint32_t*>(d_in + bufs[mybuf].in_off);
-        lastdw = (uint32_t)((bufs[mybuf].c - 1) >> 2);
-        limit = (uint32_t)(bufs[mybuf].c * 8);
-        pos0 = (uint32_t)sv + 16u;
-        uint64_t clb;
-        {
-          // 17 header bits + up to 57 bits of code-length-code lengths, from four dwords
-          const uint32_t di = pos0 >> 5, sh = pos0 & 31u;
-          const uint64_t w0 = (uint64_t)in32[min(di, lastdw)] | ((uint64_t)in32[min(di + 1, lastdw)] << 32);
-          const uint64_t w1 = (uint64_t)in32[min(di + 2, lastdw)] | ((uint64_t)in32[min(di + 3, lastdw)] << 32);
-          const uint64_t lo = sh ? ((w0 >> sh) | (w1 << (64u - sh))) : w0;
-          const uint64_t hi = w1 >> sh;
-          HLIT = ((uint32_t)(lo >> 3) & 31u) + 257u;
-          const uint32_t HDIST = ((uint32_t)(lo >> 8) & 31u) + 1u, HCLEN = ((uint32_t)(lo >> 13) & 15u) + 4u;
-          total = HLIT + HDIST;
-          clb = ((lo >> 17) | (hi << 47)) & ((1ull << (3u * HCLEN)) - 1ull);
-          pos = pos0 + 17u + 3u * HCLEN;
-        }
-        {
-          const uint32_t di = pos >> 5, sh = pos & 31u;
-          const uint64_t w = (uint64_t)in32[min(di, lastdw)] | ((uint64_t)in32[min(di + 1, lastdw)] << 32);
-          bb = w >> sh;
-          nb = 64u - sh;
-          nwi = di + 2u;  // the dword behind the bit buffer is kept loaded: a refill never waits for memory,
-          nw = in32[min(nwi, lastdw)];  // which matters for the few lanes that decode a real header (~300 symbols)
-        }
-        // lengths from transmission order into symbol order (3 bits per symbol)
-        uint64_t sl = 0;
-#pragma unroll
-        for (uint32_t q = 0; q < 19; q++) {
-          constexpr uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};  // src/const.ts:31-35
-          sl |= ((clb >> (3u * q)) & 7ull) << (3u * order[q]);
-        }
-        // fill the table: lengths ascending, symbols ascending (the scan kernel has already checked
-        // that the lengths form a complete code, so exactly 128 entries get written)
-        uint32_t fill = 0;
 #pragma unroll 1
-        for (uint32_t L = 1; L <= 7; L++) {
-          const uint64_t x = sl ^ (M0 * L);
-          uint64_t z = ~(x | (x >> 1) | (x >> 2)) & M0;  // fields equal to L
-          while (z) {
-            const uint32_t t = (uint32_t)__builtin_ctzll(z);
-            z &= z - 1ull;
-            const uint32_t e = ((t * 11u) >> 5) | (L << 5);  // t / 3 for t <= 54
-            const uint32_t n = 128u >> L;
-            if (fill + n <= 128u) {
-              if (n >= 4u) {
-                const uint32_t v = e * 0x01010101u;
-                for (uint32_t j = 0; j < (n >> 2); j++) s_lut[(fill >> 2) + j][lane] = v;
-              } else {
-                for (uint32_t j = 0; j < n; j++) lut8[(((fill + j) >> 2) * 64u + lane) * 4u + ((fill + j) & 3u)] = (uint8_t)e;
-              }
+  for (uint32_t base = blockIdx.x * 64u; base < n; base += gridDim.x * 64u) {
+    const uint32_t item = base + lane;
+    bool have = item < n;
+    const uint32_t si = have ? item : base;
+    const unsigned long long sv = surv[si];
+    const uint32_t mybuf = (uint32_t)(sv >> 32);
+    const uint32_t* in32 = reinterpret_cast<const uint32_t*>(d_in + bufs[mybuf].in_off);
+    const uint32_t lastdw = (uint32_t)((bufs[mybuf].c - 1) >> 2);
+    const uint32_t limit = (uint32_t)(bufs[mybuf].c * 8);
+    const uint32_t pos0 = (uint32_t)sv + 16u;
+    uint32_t HLIT, total, pos;
+    uint64_t clb;
+    {
+      // 17 header bits + up to 57 bits of code-length-code lengths, from four dwords
+      const uint32_t di = pos0 >> 5, sh = pos0 & 31u;
+      const uint64_t w0 = (uint64_t)in32[min(di, lastdw)] | ((uint64_t)in32[min(di + 1, lastdw)] << 32);
+      const uint64_t w1 = (uint64_t)in32[min(di + 2, lastdw)] | ((uint64_t)in32[min(di + 3, lastdw)] << 32);
+      const uint64_t lo = sh ? ((w0 >> sh) | (w1 << (64u - sh))) : w0;
+      const uint64_t hi = w1 >> sh;
+      HLIT = ((uint32_t)(lo >> 3) & 31u) + 257u;
+      const uint32_t HDIST = ((uint32_t)(lo >> 8) & 31u) + 1u, HCLEN = ((uint32_t)(lo >> 13) & 15u) + 4u;
+      total = HLIT + HDIST;
+      clb = ((lo >> 17) | (hi << 47)) & ((1ull << (3u * HCLEN)) - 1ull);
+      pos = pos0 + 17u + 3u * HCLEN;
+    }
+    // the lane's window of the stream, from the dword of the first code-length symbol
+    uint32_t wd0 = pos >> 5;
+#pragma unroll
+    for (uint32_t j0 = 0; j0 < WIN; j0 += 16u) {
+      uint32_t t[16];
+#pragma unroll
+      for (uint32_t j = 0; j < 16u; j++)
+        if (j0 + j < WIN) t[j] = in32[min(wd0 + j0 + j, lastdw)];
+#pragma unroll
+      for (uint32_t j = 0; j < 16u; j++)
+        if (j0 + j < WIN) s_win[j0 + j][lane] = t[j];
+    }
+    // lengths from transmission order into symbol order (3 bits per symbol)
+    uint64_t sl = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < 19; q++) {
+      constexpr uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};  // src/const.ts:31-35
+      sl |= ((clb >> (3u * q)) & 7ull) << (3u * order[q]);
+    }
+    // fill the table: lengths ascending, symbols ascending (the scan kernel has already checked that the lengths
+    // form a complete code, so exactly 128 entries get written)
+    uint32_t fill = 0;
+    if (have) {
+#pragma unroll 1
+      for (uint32_t L = 1; L <= 7; L++) {
+        const uint64_t x = sl ^ (M0 * L);
+        uint64_t z = ~(x | (x >> 1) | (x >> 2)) & M0;  // fields equal to L
+        while (z) {
+          const uint32_t t = (uint32_t)__builtin_ctzll(z);
+          z &= z - 1ull;
+          const uint32_t e = ((t * 11u) >> 5) | (L << 5);  // t / 3 for t <= 54
+          const uint32_t nn = 128u >> L;
+          if (fill + nn <= 128u) {
+            if (nn >= 4u) {
+              const uint32_t v = e * 0x01010101u;
+              for (uint32_t j = 0; j < (nn >> 2); j++) s_lut[(fill >> 2) + j][lane] = v;
+            } else {
+              for (uint32_t j = 0; j < nn; j++) lut8[(((fill + j) >> 2) * 64u + lane) * 4u + ((fill + j) & 3u)] = (uint8_t)e;
             }
-            fill += n;
           }
+          fill += nn;
         }
-        k = kl = kd = nd = dmaxlen = prev = 0;
-        psym = 31;  // no previous symbol
-        has_eob = false;
-        have = fill == 128u;  // anything else cannot come from the scan kernel; dropped, not decoded
       }
     }
-    if (!__ballot(have)) break;  // nothing running and nothing left to fetch
-    // ---- one code-length symbol for every running lane ----
-    if (have) {
-      bool ok = pos + 14u <= limit;
-      if (nb <= 32u) {
-        bb |= (uint64_t)nw << nb;
-        nb += 32u;
-        nwi++;
-        nw = in32[min(nwi, lastdw)];
+    have = have && fill == 128u;  // anything else cannot come from the scan kernel; dropped, not decoded
+    uint64_t bb;
+    uint32_t nb, wi = 2;
+    {
+      const uint32_t sh = pos & 31u;
+      bb = ((uint64_t)s_win[0][lane] | ((uint64_t)s_win[1][lane] << 32)) >> sh;
+      nb = 64u - sh;
+    }
+    uint32_t k = 0, kl = 0, kd = 0, nd = 0, dmaxlen = 0, prev = 0, psym = 31;  // psym 31: no previous symbol
+    uint32_t has_eob = 0;
+    uint32_t step = 0;
+    const uint32_t strict = loose ? 0u : 1u;  // (ZES_F_LOOSE_CANDIDATES switches the rules off to exercise the false-candidate path)
+#pragma unroll 1
+    while (__ballot(have)) {
+      if (have) {
+        // ---- one code-length symbol; no branch in it: a step of a lone lane is a dependent chain, and every exec-mask
+        // region the compiler builds for an `if` adds to it (the branchy form took ~1400 cycles per step) ----
+        uint32_t ok = (uint32_t)(pos + 14u <= limit);
+        {
+          const uint32_t need = (uint32_t)(nb <= 32u);
+          if (__ballot(need && wi == WIN)) {  // only a lane that found no room on the list gets here: the next window
+            if (need && wi == WIN) {
+              wd0 += WIN;
+              for (uint32_t j = 0; j < WIN; j++) s_win[j][lane] = in32[min(wd0 + j, lastdw)];
+              wi = 0;
+            }
+          }
+          const uint32_t wv = s_win[min(wi, WIN - 1u)][lane];  // (read whether needed or not: no branch)
+          const uint32_t w = need ? wv : 0u;
+          bb |= (uint64_t)w << (nb & 63u);
+          nb += need << 5;
+          wi += need;
+        }
+        const uint32_t lo = (uint32_t)bb;
+        const uint32_t ix = __brev(lo) >> 25;
+        const uint32_t ent = lut8[((ix >> 2) * 64u + lane) * 4u + (ix & 3u)];
+        const uint32_t sy = ent & 31u, len = ent >> 5;
+        const uint32_t is16 = (uint32_t)(sy == 16u), is17 = (uint32_t)(sy == 17u), is18 = (uint32_t)(sy == 18u);
+        const uint32_t run = is16 | is17 | is18;
+        const uint32_t xb = is16 * 2u + is17 * 3u + is18 * 7u;
+        const uint32_t xv = __builtin_amdgcn_ubfe(lo, len, xb);  // (width 0 gives 0)
+        const uint32_t rep = (run ? (is18 ? 11u : 3u) : 1u) + xv;
+        const uint32_t val = run ? (is16 ? prev : 0u) : sy;
+        ok &= (uint32_t)!(is16 & (uint32_t)(k == 0u));
+        ok &= (verify_rule_break(psym, sy, xv, is16, is17, is18) & strict) ^ 1u;
+        psym = sy;
+        const uint32_t adv = len + xb;
+        bb >>= adv;
+        nb -= adv;
+        pos += adv;
+        ok &= (uint32_t)(k + rep <= total);
+        {
+          // rep entries of length val starting at index k: split at the lit/len | distance border (val = 0 adds nothing)
+          const uint32_t c = val ? (32768u >> val) : 0u;
+          const uint32_t nl = min(rep, max(HLIT, k) - k);
+          const uint32_t ndd = rep - nl;
+          kl += nl * c;
+          kd += ndd * c;
+          const uint32_t dd = val ? ndd : 0u;
+          nd += dd;
+          dmaxlen = max(dmaxlen, dd ? val : 0u);
+          has_eob |= (uint32_t)(val != 0u) & (uint32_t)(k <= 256u) & (uint32_t)(256u < k + nl);
+          // garbage headers over-subscribe a code within a few symbols: stop right there
+          ok &= (uint32_t)(kl <= 32768u) & (uint32_t)(kd <= 32768u);
+        }
+        prev = val;
+        k += rep;
+        const uint32_t fin = (uint32_t)(k >= total);
+        const uint32_t good = ok & fin & has_eob & (uint32_t)(kl == 32768u) &
+                              ((uint32_t)(kd == 32768u) | (uint32_t)(nd == 0u) | ((uint32_t)(nd == 1u) & (uint32_t)(dmaxlen == 1u)));
+        if (__ballot(good)) {  // rare: about one per block of the stream
+          if (good) {
+            const uint32_t slot = atomicAdd(&cnt[mybuf], 1u);
+            if (slot < bufs[mybuf].cand_cap) cand[bufs[mybuf].cand_base + slot] = pos0 - 16u;
+          }
+        }
+        have = (ok & (fin ^ 1u)) != 0u;
       }
-      const uint32_t ix = __brev((uint32_t)bb) >> 25;
-      const uint32_t ent = lut8[((ix >> 2) * 64u + lane) * 4u + (ix & 3u)];
-      const uint32_t sy = ent & 31u, len = ent >> 5;
-      uint32_t rep = 1, val = sy, xb = 0;
-      if (sy == 16) {
-        ok = ok && k != 0;
-        xb = 2;
-        val = prev;
-      } else if (sy == 17) {
-        xb = 3;
-        val = 0;
-      } else if (sy == 18) {
-        xb = 7;
-        val = 0;
-      }
-      const uint32_t xv = ((uint32_t)(bb >> len)) & ((1u << xb) - 1u);
-      if (sy == 16 || sy == 17) rep = 3 + xv;
-      if (sy == 18) rep = 11 + xv;
-      // T1 looks for blocks the reference wrote, and its run-length coding of the code lengths
-      // (src/deflate.ts:100-139) never produces these (another encoder's stream that does is decoded by T2):
-      //  - "repeat previous" (16) directly after anything but a plain non-zero length, or with count 6: a run
-      //    is cut into chunks of at most 6, the chunk's first length is written out, 16 repeats the other 3..5
-      //  - a zero run (17) of 3: three zeros are written as three plain zeros
-      //  - 17 closes its zero run (it codes the remainder 4..10), so a non-zero plain length follows;
-      //    plain zeros (a remainder below 4) close their run as well, so no 17/18 follows them
-      if (!loose) {  // (ZES_F_LOOSE_CANDIDATES switches the rules off to exercise the false-candidate path)
-        const bool plain_nz = psym >= 1u && psym <= 15u;
-        ok = ok && !(sy == 16u && (!plain_nz || xv == 3u));
-        ok = ok && !(sy == 17u && xv == 0u);
-        ok = ok && !(psym == 17u && !(sy >= 1u && sy <= 15u));
-        ok = ok && !(psym == 0u && (sy == 17u || sy == 18u));
-      }
-      psym = sy;
-      const uint32_t adv = len + xb;
-      bb >>= adv;
-      nb -= adv;
-      pos += adv;
-      ok = ok && (k + rep <= total);
-      if (ok && val) {
-        // rep entries of length val starting at index k: split at the lit/len | distance border
-        const uint32_t nl = k < HLIT ? min(rep, HLIT - k) : 0u;
-        const uint32_t ndd = rep - nl;
-        kl += nl * (32768u >> val);
-        kd += ndd * (32768u >> val);
-        nd += ndd;
-        if (ndd) dmaxlen = max(dmaxlen, val);
-        if (k <= 256u && 256u < k + nl) has_eob = true;
-        // garbage headers over-subscribe a code within a few symbols: stop right there
-        ok = kl <= 32768u && kd <= 32768u;
-      }
-      prev = val;
-      k += rep;
-      if (!ok) {
-        have = false;
-      } else if (k >= total) {
-        have = false;
-        const bool good = has_eob && kl == 32768u && (kd == 32768u || nd == 0 || (nd == 1 && dmaxlen == 1));
-        if (good) {
-          const uint32_t slot = atomicAdd(&cnt[mybuf], 1u);  // rare: about one per block of the stream
-          if (slot < bufs[mybuf].cand_cap) cand[bufs[mybuf].cand_base + slot] = pos0 - 16u;
+      if (++step == vsteps) {
+        // still alive: onto the list of the long pass, with the state reached (one atomic per wave)
+        const uint64_t alive = __ballot(have);
+        if (alive) {
+          uint32_t slot0 = 0;
+          if (lane == 0) slot0 = atomicAdd(&counters[1], (uint32_t)__popcll(alive));
+          slot0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot0);
+          const uint32_t slot = slot0 + (uint32_t)__popcll(alive & zes_lanemask_lt());
+          if (have && slot < vlong_cap) {  // (no room — ten times the usual share of long runners: the lane carries on by itself)
+            uint32_t* st = vstate + (size_t)slot * VSTATE_WORDS;
+            st[0] = si;
+            st[1] = pos;
+            st[2] = k;
+            st[3] = kl;
+            st[4] = kd;
+            st[5] = psym | (prev << 5) | (has_eob << 9) | (dmaxlen << 10) | (nd << 14);
+            have = false;
+          }
         }
       }
+    }
+  }
+}
+
+// wave scans over 64 lanes (inclusive), DPP: four steps inside each row of 16, then the row totals carried over
+template <int CTRL, int ROWS>
+__device__ __forceinline__ uint32_t vdpp(uint32_t old, uint32_t x) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)x, CTRL, ROWS, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t x) {
+  x += vdpp<0x111, 0xf>(0u, x);
+  x += vdpp<0x112, 0xf>(0u, x);
+  x += vdpp<0x114, 0xf>(0u, x);
+  x += vdpp<0x118, 0xf>(0u, x);
+  x += vdpp<0x142, 0xa>(0u, x);  // row_bcast:15 into rows 1 and 3
+  x += vdpp<0x143, 0xc>(0u, x);  // row_bcast:31 into rows 2 and 3
+  return x;
+}
+__device__ __forceinline__ uint32_t wave_scan_max(uint32_t x) {
+  x = max(x, vdpp<0x111, 0xf>(0u, x));
+  x = max(x, vdpp<0x112, 0xf>(0u, x));
+  x = max(x, vdpp<0x114, 0xf>(0u, x));
+  x = max(x, vdpp<0x118, 0xf>(0u, x));
+  x = max(x, vdpp<0x142, 0xa>(0u, x));
+  x = max(x, vdpp<0x143, 0xc>(0u, x));
+  return x;
+}
+
+__global__ __launch_bounds__(64) void k_inf_verify_long(const uint8_t* __restrict__ d_in, const ZesInfBuf* __restrict__ bufs,
+                                                        const unsigned long long* __restrict__ surv, uint32_t surv_cap,
+                                                        uint32_t* __restrict__ counters, uint32_t* __restrict__ cand,
+                                                        uint32_t* __restrict__ cnt, uint32_t loose, const uint32_t* __restrict__ vstate,
+                                                        uint32_t vlong_cap) {
+  __shared__ uint8_t s_lut[128];   // 7 stream bits read MSB-first -> symbol | length << 5
+  __shared__ uint32_t s_sym[64];   // the symbols on the chain, in order
+  const uint32_t lane = threadIdx.x;
+  const uint32_t n = min(counters[1], vlong_cap);
+  const uint32_t strict = loose ? 0u : 1u;
+  constexpr uint64_t M0 = 0x0049249249249249ull;
+  auto rl = [](uint32_t v, uint32_t i) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)i); };
+#pragma unroll 1
+  for (uint32_t it = blockIdx.x; it < n; it += gridDim.x) {
+    const uint32_t* st = vstate + (size_t)it * VSTATE_WORDS;
+    const uint32_t si = (uint32_t)__builtin_amdgcn_readfirstlane((int)st[0]);
+    uint32_t P = (uint32_t)__builtin_amdgcn_readfirstlane((int)st[1]);
+    uint32_t c_k = (uint32_t)__builtin_amdgcn_readfirstlane((int)st[2]), c_kl = (uint32_t)__builtin_amdgcn_readfirstlane((int)st[3]);
+    uint32_t c_kd = (uint32_t)__builtin_amdgcn_readfirstlane((int)st[4]);
+    const uint32_t pk = (uint32_t)__builtin_amdgcn_readfirstlane((int)st[5]);
+    uint32_t c_psym = pk & 31u, c_prev = (pk >> 5) & 15u, c_eob = (pk >> 9) & 1u, c_dmax = (pk >> 10) & 15u, c_nd = pk >> 14;
+    const unsigned long long sv0 = surv[si];
+    const uint32_t mybuf = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(sv0 >> 32));
+    const uint32_t pos0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sv0) + 16u;
+    const uint32_t* in32 = reinterpret_cast<const uint32_t*>(d_in + bufs[mybuf].in_off);
+    const uint32_t lastdw = (uint32_t)((bufs[mybuf].c - 1) >> 2);
+    const uint32_t limit = (uint32_t)(bufs[mybuf].c * 8);
+    uint32_t d0 = pos0 >> 5;  // first dword of the 64-dword window: lane l holds dword d0 + l
+    uint32_t W = in32[min(d0 + lane, lastdw)];
+    uint32_t HLIT, total;
+    uint64_t sl = 0;
+    {
+      const uint32_t sh = pos0 & 31u;
+      const uint64_t w0 = (uint64_t)rl(W, 0) | ((uint64_t)rl(W, 1) << 32);
+      const uint64_t w1 = (uint64_t)rl(W, 2) | ((uint64_t)rl(W, 3) << 32);
+      const uint64_t lo = sh ? ((w0 >> sh) | (w1 << (64u - sh))) : w0;
+      const uint64_t hi = w1 >> sh;
+      HLIT = ((uint32_t)(lo >> 3) & 31u) + 257u;
+      const uint32_t HDIST = ((uint32_t)(lo >> 8) & 31u) + 1u, HCLEN = ((uint32_t)(lo >> 13) & 15u) + 4u;
+      total = HLIT + HDIST;
+      const uint64_t clb = ((lo >> 17) | (hi << 47)) & ((1ull << (3u * HCLEN)) - 1ull);
+#pragma unroll
+      for (uint32_t q = 0; q < 19; q++) {
+        constexpr uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};  // src/const.ts:31-35
+        sl |= ((clb >> (3u * q)) & 7ull) << (3u * order[q]);
+      }
+    }
+    // the table, two entries per lane: codes in (length, symbol) order are consecutive runs of entries
+    uint32_t e_lo = 0, e_hi = 0, fill = 0;
+#pragma unroll 1
+    for (uint32_t L = 1; L <= 7; L++) {
+      const uint64_t x = sl ^ (M0 * L);
+      uint64_t z = ~(x | (x >> 1) | (x >> 2)) & M0;
+      while (z) {
+        const uint32_t t = (uint32_t)__builtin_ctzll(z);
+        z &= z - 1ull;
+        const uint32_t e = ((t * 11u) >> 5) | (L << 5);
+        const uint32_t nn = 128u >> L;
+        if (lane >= fill && lane < fill + nn) e_lo = e;
+        if (lane + 64u >= fill && lane + 64u < fill + nn) e_hi = e;
+        fill += nn;
+      }
+    }
+    __syncthreads();  // (the item before has finished with the table)
+    s_lut[lane] = (uint8_t)e_lo;
+    s_lut[lane + 64u] = (uint8_t)e_hi;
+    __syncthreads();
+    bool running = fill == 128u, good = false;
+#pragma unroll 1
+    while (running) {
+      uint32_t i0 = (P >> 5) - d0;
+      if (i0 + 5u > 63u) {  // the window is used up: the next one starts at P's dword
+        d0 = P >> 5;
+        W = in32[min(d0 + lane, lastdw)];
+        i0 = 0;
+      }
+      // the symbol that would start at bit P + lane and the one at P + 64 + lane
+      uint32_t p0, p1;
+      {
+        const uint32_t a = rl(W, i0), b = rl(W, i0 + 1u), c = rl(W, i0 + 2u), d = rl(W, i0 + 3u), e = rl(W, i0 + 4u), f = rl(W, i0 + 5u);
+        const uint32_t sh = (P & 31u) + lane;  // 0 .. 94
+        const bool s32 = sh < 32u, s64 = sh < 64u;
+        const uint32_t x0 = s32 ? a : s64 ? b : c, x1 = s32 ? b : s64 ? c : d;
+        const uint32_t y0 = s32 ? c : s64 ? d : e, y1 = s32 ? d : s64 ? e : f;
+        const uint32_t v0 = __builtin_amdgcn_alignbit(x1, x0, sh & 31u) & 0x3FFFu;  // the 14 bits at P + lane
+        const uint32_t v1 = __builtin_amdgcn_alignbit(y1, y0, sh & 31u) & 0x3FFFu;  // ... at P + 64 + lane
+        auto dec = [&](uint32_t v, uint32_t off) {
+          const uint32_t ent = s_lut[__brev(v) >> 25];
+          const uint32_t sy = ent & 31u, len = ent >> 5;
+          const uint32_t xb = (uint32_t)(sy == 16u) * 2u + (uint32_t)(sy == 17u) * 3u + (uint32_t)(sy == 18u) * 7u;
+          const uint32_t xv = __builtin_amdgcn_ubfe(v, len, xb);
+          return sy | (xv << 5) | ((len + xb) << 12) | (off << 16);
+        };
+        p0 = dec(v0, lane);
+        p1 = dec(v1, lane + 64u);
+      }
+      // the chain through the 128 offsets (at most 64 symbols a round)
+      uint64_t m0 = 0, m1 = 0;
+      uint32_t cur = 0, nsym = 0;
+#pragma unroll 1
+      while (cur < 64u) {
+        m0 |= 1ull << cur;
+        cur += (rl(p0, cur) >> 12) & 15u;
+        nsym++;
+      }
+#pragma unroll 1
+      while (cur < 128u && nsym < 64u) {
+        m1 |= 1ull << (cur - 64u);
+        cur += (rl(p1, cur - 64u) >> 12) & 15u;
+        nsym++;
+      }
+      // into lanes 0 .. nsym-1, in order
+      {
+        const uint64_t lt = zes_lanemask_lt();
+        const uint32_t r0 = (uint32_t)__popcll(m0 & lt), r1 = (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1 & lt);
+        __syncthreads();
+        if ((m0 >> lane) & 1ull) s_sym[r0] = p0;
+        if ((m1 >> lane) & 1ull) s_sym[r1] = p1;
+        __syncthreads();
+      }
+      const uint32_t t = s_sym[lane];
+      const bool valid = lane < nsym;
+      const uint32_t sy = valid ? (t & 31u) : 0u, xv = valid ? ((t >> 5) & 127u) : 0u, off = (t >> 16) & 127u;
+      const uint32_t is16 = (uint32_t)(sy == 16u), is17 = (uint32_t)(sy == 17u), is18 = (uint32_t)(sy == 18u);
+      const uint32_t run = is16 | is17 | is18;
+      const uint32_t rep = (run ? (is18 ? 11u : 3u) : 1u) + xv;
+      const uint32_t valraw = run ? 0u : sy;
+      // "repeat previous" takes the value of the last symbol that is not one (in front of the round: the carry)
+      const uint32_t src = wave_scan_max(is16 ? 0u : lane + 1u);
+      const uint32_t vsrc = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((src ? src - 1u : 0u) << 2), (int)valraw);
+      const uint32_t val = src ? vsrc : c_prev;
+      const uint32_t psym = vdpp<0x138, 0xf>(c_psym, sy);  // wave_shr:1, lane 0 keeps the carry
+      const uint32_t kin = wave_scan_add(rep);
+      const uint32_t k = c_k + kin - rep;
+      const uint32_t c = val ? (32768u >> val) : 0u;
+      const uint32_t nl = min(rep, max(HLIT, k) - k);
+      const uint32_t ndd = rep - nl;
+      const uint32_t kl = c_kl + wave_scan_add(nl * c), kd = c_kd + wave_scan_add(ndd * c);
+      const uint32_t dd = val ? ndd : 0u;
+      uint32_t ok = (uint32_t)(P + off + 14u <= limit);
+      ok &= (uint32_t)!(is16 & (uint32_t)(k == 0u));
+      ok &= (verify_rule_break(psym, sy, xv, is16, is17, is18) & strict) ^ 1u;
+      ok &= (uint32_t)(k + rep <= total) & (uint32_t)(kl <= 32768u) & (uint32_t)(kd <= 32768u);
+      const uint64_t notok = __ballot(valid && !ok), finm = __ballot(valid && k + rep >= total);
+      const uint32_t e = notok ? (uint32_t)__builtin_ctzll(notok) : 64u, f = finm ? (uint32_t)__builtin_ctzll(finm) : 64u;
+      if (e <= f && e < 64u) {
+        running = false;  // rejected (a symbol that breaks a rule at or before the one that completes the sequence)
+      } else {
+        const uint32_t cut = f < 64u ? f : nsym - 1u;
+        const uint32_t nd = c_nd + rl(wave_scan_add(dd), cut);
+        const uint32_t dmax = max(c_dmax, rl(wave_scan_max(dd ? val : 0u), cut));
+        const uint32_t eob = c_eob | (uint32_t)(__ballot(lane <= cut && val != 0u && k <= 256u && 256u < k + nl) != 0ull);
+        const uint32_t kl_c = rl(kl, cut), kd_c = rl(kd, cut);
+        if (f < 64u) {
+          good = eob && kl_c == 32768u && (kd_c == 32768u || nd == 0u || (nd == 1u && dmax == 1u));
+          running = false;
+        } else {
+          c_k = rl(k + rep, cut);
+          c_kl = kl_c;
+          c_kd = kd_c;
+          c_nd = nd;
+          c_dmax = dmax;
+          c_eob = eob;
+          c_prev = rl(val, cut);
+          c_psym = rl(sy, cut);
+          P += cur;
+        }
+      }
+    }
+    if (good && lane == 0) {
+      const uint32_t slot = atomicAdd(&cnt[mybuf], 1u);
+      if (slot < bufs[mybuf].cand_cap) cand[bufs[mybuf].cand_base + slot] = pos0 - 16u;
     }
   }
 }
