@@ -353,6 +353,53 @@ def test_pinned_host_memory_and_large_host_calls(z, oracle, gpu):
         z.host_free(pin)
 
 
+def test_pipelined_host_calls(z, oracle, gpu):
+    """Host calls on large buffers run in pieces (upload, kernels and download side by side): the same bytes as the
+    one-pass path (ZES_NO_PIPELINE=1), which the tests above hold against the oracle and the reference's goldens."""
+    import zlib as pyzlib
+
+    L = z.lib()
+    for kind, n, pinned in (("xorshift", (70 << 20) + 12345, False), ("itext", (96 << 20) + 131073 + 5, True), ("lowent4k", 64 << 20, False)):
+        src = z.gen(kind, 4242, n)
+        cap = z.deflate_bound(n)
+        if pinned:
+            a, comp, comp1, back = z.host_alloc(n), z.host_alloc(cap), z.host_alloc(cap), z.host_alloc(n)
+            a[:] = src
+        else:
+            a, comp, comp1, back = src, np.zeros(cap, dtype=np.uint8), np.zeros(cap, dtype=np.uint8), np.zeros(n, dtype=np.uint8)
+        clen, clen1, blen = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        assert L.zes_deflate(a.ctypes.data, n, comp.ctypes.data, cap, C.byref(clen)) == 0
+        os.environ["ZES_NO_PIPELINE"] = "1"
+        try:
+            assert L.zes_deflate(a.ctypes.data, n, comp1.ctypes.data, cap, C.byref(clen1)) == 0
+        finally:
+            del os.environ["ZES_NO_PIPELINE"]
+        assert clen.value == clen1.value and sha(comp[: clen.value]) == sha(comp1[: clen1.value]), kind
+        assert pyzlib.adler32(src.tobytes()) == int.from_bytes(comp[clen.value - 4: clen.value].tobytes(), "big")
+        # a capacity that holds the result but not the bound: still the same bytes; one byte short: the size needed
+        tight = np.zeros(clen.value, dtype=np.uint8)
+        t = C.c_uint64()
+        assert L.zes_deflate(a.ctypes.data, n, tight.ctypes.data, tight.size, C.byref(t)) == 0 and sha(tight) == sha(comp[: clen.value])
+        assert L.zes_deflate(a.ctypes.data, n, tight.ctypes.data, tight.size - 1, C.byref(t)) == -16 and t.value == clen.value
+        # and back, in pieces
+        assert L.zes_inflate(comp.ctypes.data, clen.value, back.ctypes.data, n, C.byref(blen), 0) == 0
+        assert blen.value == n and z.last_inflate_tier() == 1 and sha(back) == sha(src), kind
+        assert L.zes_inflate(comp.ctypes.data, clen.value, back.ctypes.data, n - 1, C.byref(blen), 0) == -16 and blen.value == n
+        got = z.inflate(comp[: clen.value])  # (the form that allocates once the size is known)
+        assert sha(got) == sha(src)
+        # bytes behind the end of the stream are ignored (src/inflate.ts:22-37 stops at BFINAL)
+        longer = np.concatenate([comp[: clen.value], np.frombuffer(os.urandom(3 << 20), dtype=np.uint8)])
+        assert sha(z.inflate(longer)) == sha(src)
+        if pinned:
+            for x in (a, comp, comp1, back):
+                z.host_free(x)
+    # another encoder's long stream: the pieces do not chain, the one-pass path decodes it
+    src = z.gen("xorshift", 77, 24 << 20)
+    other = np.frombuffer(pyzlib.compress(src.tobytes(), 1), dtype=np.uint8).copy()
+    assert len(other) >= 8 << 20
+    assert sha(z.inflate(other)) == sha(src) and z.last_inflate_tier() != 1
+
+
 def test_unaligned_device_views_are_staged(z, oracle, gpu):
     import torch
 

@@ -12,6 +12,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
+#include <functional>
+#include <future>
 #include <map>
 #include <mutex>
 #include <string>
@@ -36,6 +39,8 @@ struct Ctx {
   bool ready = false;
   int device = -1;
   hipStream_t stream = nullptr;
+  hipStream_t cs_in = nullptr, cs_out = nullptr;  // copy streams of the pipelined host calls (H2D / D2H beside the kernels)
+  hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_k = nullptr;
   // deflate scratch
   DevBuf bufs, blks, idx_a, idx_b, inv, sdelta, hists, codes, hdrs, adler, res;
   // inflate scratch
@@ -102,6 +107,10 @@ int init_locked(int device) {
   g.cus = prop.multiProcessorCount;
   g.hbm = prop.totalGlobalMem;
   HIPCHK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&g.cs_in, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&g.cs_out, hipStreamNonBlocking));
+  for (int k = 0; k < 2; k++) HIPCHK(hipEventCreateWithFlags(&g.ev_up[k], hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&g.ev_k, hipEventDisableTiming));
   g.pinned_cap = 1 << 20;
   HIPCHK(hipHostMalloc(&g.pinned, g.pinned_cap, hipHostMallocDefault));
   {
@@ -127,7 +136,7 @@ int init_locked(int device) {
 // chunk k runs (and the other way round on the way back), so the trip costs max(memcpy, DMA) instead of their sum
 // and the memcpy is spread over several cores.  A buffer that already is pinned (zes_host_alloc) is handed to the
 // DMA engine as it is.
-constexpr size_t STAGE_CHUNK = 4u << 20;
+constexpr size_t STAGE_CHUNK = 8u << 20;
 constexpr int STAGE_RING = 4;
 constexpr size_t STAGE_DIRECT_MAX = 256u << 10;  // below this one plain copy call is quicker than the ring
 
@@ -170,7 +179,7 @@ struct CopyPool {
   void start() {
     if (!threads.empty()) return;
     const unsigned hw = std::thread::hardware_concurrency();
-    const unsigned nt = std::max(1u, std::min(6u, hw ? hw / 2 : 2u));
+    const unsigned nt = std::max(1u, std::min(7u, hw ? hw / 2 : 2u));  // (two pools + two side threads: 16, a one-GPU box's share)
     for (unsigned i = 0; i + 1 < nt; i++) threads.emplace_back([this] { worker(); });
   }
   // memcpy spread over the pool (the caller takes parts too); plain memcpy when it is short
@@ -211,19 +220,77 @@ struct CopyPool {
   ~CopyPool() { shutdown(); }
 };
 
-CopyPool g_pool;
-uint8_t* g_stage[STAGE_RING] = {nullptr};
-hipEvent_t g_stage_ev[STAGE_RING] = {nullptr};
-
-int stage_ready() {
-  if (g_stage[0]) return ZES_OK;
-  for (int k = 0; k < STAGE_RING; k++) {
-    HIPCHK(hipHostMalloc((void**)&g_stage[k], STAGE_CHUNK, hipHostMallocDefault));
-    HIPCHK(hipEventCreateWithFlags(&g_stage_ev[k], hipEventDisableTiming));
+// One direction's staging: a ring of pinned chunks, their events, the copy helpers.  Two of them, so that an upload
+// and a download of a pipelined call run side by side (each on its own copy stream and its own thread).
+struct Stager {
+  CopyPool pool;
+  uint8_t* buf[STAGE_RING] = {nullptr};
+  hipEvent_t ev[STAGE_RING] = {nullptr};
+  int ready() {
+    if (buf[0]) return ZES_OK;
+    for (int k = 0; k < STAGE_RING; k++) {
+      HIPCHK(hipHostMalloc((void**)&buf[k], STAGE_CHUNK, hipHostMallocDefault));
+      HIPCHK(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+    }
+    pool.start();
+    return ZES_OK;
   }
-  g_pool.start();
-  return ZES_OK;
-}
+  void release() {
+    pool.shutdown();
+    for (int k = 0; k < STAGE_RING; k++) {
+      if (buf[k]) (void)hipHostFree(buf[k]);
+      if (ev[k]) (void)hipEventDestroy(ev[k]);
+      buf[k] = nullptr;
+      ev[k] = nullptr;
+    }
+  }
+};
+Stager g_up, g_down;
+
+// A thread that runs the side legs of a pipelined host call (one for uploads, one for downloads): submit() hands it
+// a task, the returned future gives the task's status.
+struct SideThread {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<std::packaged_task<int()>> q;
+  bool stop = false;
+  void loop() {
+    if (g.device >= 0) (void)hipSetDevice(g.device);  // HIP's current device is per thread
+    std::unique_lock<std::mutex> lk(mu);
+    for (;;) {
+      cv.wait(lk, [&] { return stop || !q.empty(); });
+      if (q.empty()) return;
+      std::packaged_task<int()> t = std::move(q.front());
+      q.erase(q.begin());
+      lk.unlock();
+      t();
+      lk.lock();
+    }
+  }
+  std::future<int> submit(std::function<int()> fn) {
+    std::packaged_task<int()> t(std::move(fn));
+    std::future<int> f = t.get_future();
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      if (!th.joinable()) th = std::thread([this] { loop(); });
+      q.push_back(std::move(t));
+    }
+    cv.notify_one();
+    return f;
+  }
+  void shutdown() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      stop = true;
+    }
+    cv.notify_all();
+    if (th.joinable()) th.join();
+    stop = false;
+  }
+  ~SideThread() { shutdown(); }
+};
+SideThread g_side_up, g_side_down;
 
 bool is_pinned(const void* p) {
   hipPointerAttribute_t a;
@@ -234,53 +301,123 @@ bool is_pinned(const void* p) {
   return a.type == hipMemoryTypeHost;
 }
 
-// host -> device on the library's stream; returns once the caller's memory has been read
-int upload(uint8_t* d_dst, const uint8_t* src, uint64_t n) {
+// A caller's large pageable buffer is page-locked in place for the duration of the call (hipHostRegister: ~0.25 ms per
+// 64 MiB on the MI355X host, tools/gpu_hostregister_probe.py) and the DMA engines read and write it directly — the
+// staging ring costs a memcpy of every byte (~1 ms per 32 MiB with seven helper threads).  The ring remains for memory
+// that cannot be registered (a read-only file mapping) and for short buffers.  Registered ranges are kept until the
+// entry point returns (RegScope): pieces of one buffer register what is not covered yet.
+constexpr uint64_t REG_MIN = 8ull << 20;  // (below: the ring; a registration has a fixed cost too)
+struct RegList {
+  std::mutex mu;
+  std::vector<std::pair<uintptr_t, uintptr_t>> iv;  // page-aligned [lo, hi) registered by this call
+  bool cover(const void* p, uint64_t n) {
+    if (n < REG_MIN || getenv("ZES_NO_REGISTER")) return false;
+    const uintptr_t pg = 4096;
+    uintptr_t lo = (uintptr_t)p & ~(pg - 1), hi = ((uintptr_t)p + n + pg - 1) & ~(pg - 1);
+    std::lock_guard<std::mutex> lk(mu);
+    for (const auto& r : iv) {  // what earlier pieces of the same buffer have registered
+      if (r.first <= lo && lo < r.second) lo = r.second;
+      if (r.first < hi && hi <= r.second) hi = r.first;
+    }
+    if (lo >= hi) return true;
+    for (const auto& r : iv)
+      if (r.first < hi && lo < r.second) return false;  // an interval in the middle: leave it to the ring
+    if (hipHostRegister((void*)lo, hi - lo, hipHostRegisterDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      return false;
+    }
+    iv.emplace_back(lo, hi);
+    return true;
+  }
+  // the pieces of [p, p + n) by registration: one copy may not span two of them (the runtime refuses it)
+  std::vector<std::pair<uint64_t, uint64_t>> split(const void* p, uint64_t n) {
+    std::vector<std::pair<uint64_t, uint64_t>> out;  // (offset, length)
+    const uintptr_t a = (uintptr_t)p, b = a + n;
+    std::lock_guard<std::mutex> lk(mu);
+    std::vector<std::pair<uintptr_t, uintptr_t>> v(iv);
+    std::sort(v.begin(), v.end());
+    uintptr_t at = a;
+    for (const auto& r : v) {
+      if (r.second <= at || r.first >= b) continue;
+      const uintptr_t e = std::min(b, r.second);
+      out.emplace_back(at - a, e - at);
+      at = e;
+    }
+    if (at < b) out.emplace_back(at - a, b - at);  // (not registered by this call: pinned by the caller)
+    return out;
+  }
+  void release() {
+    std::lock_guard<std::mutex> lk(mu);
+    for (const auto& r : iv) (void)hipHostUnregister((void*)r.first);
+    iv.clear();
+  }
+};
+RegList g_reg;
+// at the end of a host entry point: every copy of the call has landed, the caller's memory is unpinned again
+struct RegScope {
+  ~RegScope() {
+    if (g_reg.iv.empty()) return;
+    if (g.stream) (void)hipStreamSynchronize(g.stream);
+    if (g.cs_in) (void)hipStreamSynchronize(g.cs_in);
+    if (g.cs_out) (void)hipStreamSynchronize(g.cs_out);
+    g_reg.release();
+  }
+};
+
+// host -> device on `stream` (the library's stream by default); returns once the caller's memory has been read
+int upload(uint8_t* d_dst, const uint8_t* src, uint64_t n, hipStream_t stream = nullptr) {
+  if (!stream) stream = g.stream;
   if (!n) return ZES_OK;
-  if (n <= STAGE_DIRECT_MAX || is_pinned(src)) {
-    HIPCHK(hipMemcpyAsync(d_dst, src, n, hipMemcpyHostToDevice, g.stream));
+  if (n <= STAGE_DIRECT_MAX || is_pinned(src) || g_reg.cover(src, n)) {
+    for (const auto& pc : g_reg.split(src, n)) HIPCHK(hipMemcpyAsync(d_dst + pc.first, src + pc.first, pc.second, hipMemcpyHostToDevice, stream));
     return ZES_OK;
   }
-  int rc = stage_ready();
+  Stager& S = g_up;
+  int rc = S.ready();
   if (rc) return rc;
   uint64_t off = 0;
   for (uint32_t k = 0; off < n; k++, off += STAGE_CHUNK) {
     const int slot = (int)(k % STAGE_RING);
     const size_t len = (size_t)std::min<uint64_t>(STAGE_CHUNK, n - off);
-    if (k >= STAGE_RING) HIPCHK(hipEventSynchronize(g_stage_ev[slot]));  // its previous DMA has read the pinned buffer
-    g_pool.copy(g_stage[slot], src + off, len);
-    HIPCHK(hipMemcpyAsync(d_dst + off, g_stage[slot], len, hipMemcpyHostToDevice, g.stream));
-    HIPCHK(hipEventRecord(g_stage_ev[slot], g.stream));
+    if (k >= STAGE_RING) HIPCHK(hipEventSynchronize(S.ev[slot]));  // its previous DMA has read the pinned buffer
+    S.pool.copy(S.buf[slot], src + off, len);
+    HIPCHK(hipMemcpyAsync(d_dst + off, S.buf[slot], len, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipEventRecord(S.ev[slot], stream));
   }
   // the pinned ring is reused by the next call: its DMAs must have left it (the caller's memory was read above)
-  for (int k = 0; k < STAGE_RING; k++) HIPCHK(hipEventSynchronize(g_stage_ev[k]));
+  for (int k = 0; k < STAGE_RING; k++) HIPCHK(hipEventSynchronize(S.ev[k]));
   return ZES_OK;
 }
 
 // device -> host, complete on return
-int download(uint8_t* dst, const uint8_t* d_src, uint64_t n) {
-  if (n && (n <= STAGE_DIRECT_MAX || is_pinned(dst))) HIPCHK(hipMemcpyAsync(dst, d_src, n, hipMemcpyDeviceToHost, g.stream));
-  if (n <= STAGE_DIRECT_MAX || is_pinned(dst)) {
-    HIPCHK(hipStreamSynchronize(g.stream));
+// (`wait`: with a pinned destination, return with the copy in flight on `stream`; the caller synchronises)
+int download(uint8_t* dst, const uint8_t* d_src, uint64_t n, hipStream_t stream = nullptr, bool wait = true) {
+  if (!stream) stream = g.stream;
+  const bool direct = n <= STAGE_DIRECT_MAX || is_pinned(dst) || g_reg.cover(dst, n);
+  if (n && direct)
+    for (const auto& pc : g_reg.split(dst, n)) HIPCHK(hipMemcpyAsync(dst + pc.first, d_src + pc.first, pc.second, hipMemcpyDeviceToHost, stream));
+  if (direct) {
+    if (wait) HIPCHK(hipStreamSynchronize(stream));
     return ZES_OK;
   }
-  int rc = stage_ready();
+  Stager& S = g_down;
+  int rc = S.ready();
   if (rc) return rc;
   const uint32_t chunks = (uint32_t)((n + STAGE_CHUNK - 1) / STAGE_CHUNK);
   auto issue = [&](uint32_t k) -> int {
     const uint64_t off = (uint64_t)k * STAGE_CHUNK;
     const size_t len = (size_t)std::min<uint64_t>(STAGE_CHUNK, n - off);
-    HIPCHK(hipMemcpyAsync(g_stage[k % STAGE_RING], d_src + off, len, hipMemcpyDeviceToHost, g.stream));
-    HIPCHK(hipEventRecord(g_stage_ev[k % STAGE_RING], g.stream));
+    HIPCHK(hipMemcpyAsync(S.buf[k % STAGE_RING], d_src + off, len, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipEventRecord(S.ev[k % STAGE_RING], stream));
     return ZES_OK;
   };
   for (uint32_t k = 0; k < chunks && k < (uint32_t)STAGE_RING - 1; k++)
     if ((rc = issue(k))) return rc;
   for (uint32_t k = 0; k < chunks; k++) {
     if (k + STAGE_RING - 1 < chunks && (rc = issue(k + STAGE_RING - 1))) return rc;  // its slot was emptied in the round before
-    HIPCHK(hipEventSynchronize(g_stage_ev[k % STAGE_RING]));
+    HIPCHK(hipEventSynchronize(S.ev[k % STAGE_RING]));
     const uint64_t off = (uint64_t)k * STAGE_CHUNK;
-    g_pool.copy(dst + off, g_stage[k % STAGE_RING], (size_t)std::min<uint64_t>(STAGE_CHUNK, n - off));
+    S.pool.copy(dst + off, S.buf[k % STAGE_RING], (size_t)std::min<uint64_t>(STAGE_CHUNK, n - off));
   }
   return ZES_OK;
 }
@@ -343,7 +480,8 @@ uint64_t deflate_bound(uint64_t n) { return ((n < ZES_BLK / 2) ? (uint64_t)ZES_B
 // rejected on the host (throw cases, capacity) and are skipped by the device pass.
 int deflate_batch_core(const uint8_t* d_in, const uint64_t* in_off, const uint64_t* in_len, uint8_t* d_out,
                        const uint64_t* out_off, const uint64_t* out_cap, uint64_t* out_len, int32_t* status,
-                       uint32_t count, const uint64_t* in_read = nullptr, const uint32_t* bflags = nullptr, uint32_t* adler_out = nullptr) {
+                       uint32_t count, const uint64_t* in_read = nullptr, const uint32_t* bflags = nullptr, uint32_t* adler_out = nullptr,
+                       const uint32_t* start_bits = nullptr, bool defer = false) {
   std::vector<ZesBuf> hb;
   uint64_t nblk_total = 0;
   std::vector<uint32_t> live;
@@ -373,7 +511,7 @@ int deflate_batch_core(const uint8_t* d_in, const uint64_t* in_off, const uint64
     b.nblk = (uint32_t)((in_len[i] + ZES_BLK - 1) / ZES_BLK);
     b.n_read = in_read ? std::max(in_read[i], in_len[i]) : in_len[i];
     b.flags = bflags ? bflags[i] : 0u;
-    b.pad = 0;
+    b.start_bit = start_bits ? start_bits[i] : 0u;
     nblk_total += b.nblk;
     hb.push_back(b);
     live.push_back(i);
@@ -549,6 +687,7 @@ int deflate_batch_core(const uint8_t* d_in, const uint64_t* in_off, const uint64
     HIPCHK(hipHostMalloc(&g.pinned, g.pinned_cap, hipHostMallocDefault));
   }
   HIPCHK(hipMemcpyAsync(g.pinned, g.res.p, sizeof(ZesRes) * nbuf, hipMemcpyDeviceToHost, g.stream));
+  if (defer) return ZES_OK;  // (one buffer: the caller reads g.pinned after its own synchronisation, deflate_piece_finish)
   HIPCHK(hipStreamSynchronize(g.stream));
   collect_times();
   const ZesRes* r = (const ZesRes*)g.pinned;
@@ -1514,11 +1653,13 @@ const char* zes_strerror(int status) {
 
 int zes_init(int device) {
   std::lock_guard<std::mutex> lk(g_mu);
+  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   return init_locked(device);
 }
 
 int zes_shutdown(void) {
   std::lock_guard<std::mutex> lk(g_mu);
+  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   if (!g.ready) return ZES_OK;
   (void)hipSetDevice(g.device);
   (void)hipStreamSynchronize(g.stream);
@@ -1532,17 +1673,18 @@ int zes_shutdown(void) {
   }
   if (g.pinned) (void)hipHostFree(g.pinned);
   g.pinned = nullptr;
-  g_pool.shutdown();
-  for (int k = 0; k < STAGE_RING; k++) {
-    if (g_stage[k]) (void)hipHostFree(g_stage[k]);
-    if (g_stage_ev[k]) (void)hipEventDestroy(g_stage_ev[k]);
-    g_stage[k] = nullptr;
-    g_stage_ev[k] = nullptr;
-  }
+  g_side_up.shutdown();
+  g_side_down.shutdown();
+  g_up.release();
+  g_down.release();
   for (hipEvent_t e : g.event_pool) (void)hipEventDestroy(e);
   g.event_pool.clear();
   (void)hipStreamDestroy(g.stream);
-  g.stream = nullptr;
+  (void)hipStreamDestroy(g.cs_in);
+  (void)hipStreamDestroy(g.cs_out);
+  for (int k = 0; k < 2; k++) (void)hipEventDestroy(g.ev_up[k]);
+  (void)hipEventDestroy(g.ev_k);
+  g.stream = g.cs_in = g.cs_out = nullptr;
   g.ready = false;
   return ZES_OK;
 }
@@ -1551,6 +1693,7 @@ int zes_host_alloc(uint64_t n, void** p) {
   if (!p) return ZES_E_ARG;
   *p = nullptr;
   std::lock_guard<std::mutex> lk(g_mu);
+  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   int rc = init_locked(-1);
   if (rc) return rc;
   HIPCHK(hipHostMalloc(p, n ? n : 1, hipHostMallocDefault));
@@ -1560,6 +1703,7 @@ int zes_host_alloc(uint64_t n, void** p) {
 int zes_host_free(void* p) {
   if (!p) return ZES_OK;
   std::lock_guard<std::mutex> lk(g_mu);
+  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   if (!g.ready) return ZES_E_ARG;
   (void)hipSetDevice(g.device);
   HIPCHK(hipStreamSynchronize(g.stream));
@@ -1569,6 +1713,7 @@ int zes_host_free(void* p) {
 
 int zes_device_info(char* name, int cap, int* cus, uint64_t* hbm_bytes) {
   std::lock_guard<std::mutex> lk(g_mu);
+  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   int rc = init_locked(-1);
   if (rc) return rc;
   if (name && cap > 0) snprintf(name, (size_t)cap, "%s", g.arch);
@@ -1587,6 +1732,7 @@ int zes_deflate_batch_dev(const uint8_t* d_in, const uint64_t* in_off, const uin
                           const uint64_t* out_off, const uint64_t* out_cap, uint64_t* out_len, int32_t* status, uint32_t count) {
   if (!in_off || !in_len || !out_off || !out_cap || !out_len || !status) return ZES_E_ARG;
   std::lock_guard<std::mutex> lk(g_mu);
+  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   int rc = init_locked(-1);
   if (rc) return rc;
   return deflate_batch_core(d_in, in_off, in_len, d_out, out_off, out_cap, out_len, status, count);
@@ -1600,6 +1746,122 @@ int zes_deflate_dev(const uint8_t* d_in, uint64_t n, uint8_t* d_out, uint64_t ca
   return rc ? rc : st;
 }
 
+// Host deflate of a large buffer in pieces of 256 blocks (one workgroup per CU), so that the three legs overlap: while
+// the kernels work on piece k, piece k+1 crosses PCIe on one copy stream and the finished bytes of piece k-1 go back
+// on another.  A piece is a block range (the machinery of zes_deflate_range_dev): it is emitted straight at its place
+// in the output stream — bit offset = all bits before it, known when the piece before has finished — and continues
+// the last dword of the piece before (ZES_BUF_CONT).  78 9C and the Adler-32 of the whole input (combined from the
+// pieces': src/adler32.ts:1-10 is associative) are put into the caller's buffer by the host.  Same bytes as the
+// one-pass path (tests/test_gpu_configs.py::test_pipelined_host_calls).
+struct SettleGuard {  // no side task may outlive the frame whose variables it uses
+  std::future<int>&a, &b;
+  ~SettleGuard() {
+    if (a.valid()) a.wait();
+    if (b.valid()) b.wait();
+  }
+};
+constexpr uint64_t PIPE_PIECE = 256ull * ZES_BLK;  // 32 MiB
+constexpr uint64_t PIPE_MIN = PIPE_PIECE + PIPE_PIECE / 2;
+constexpr uint64_t PIPE_HALO = 4096;  // a piece's match finder reads up to 258 bytes behind it: uploads are cut this far behind the piece ends
+static int deflate_host_pipelined(const uint8_t* in, uint64_t n, uint8_t* out, uint64_t cap, uint64_t* out_len) {
+  int rc;
+  const uint64_t bound = deflate_bound(n);
+  if ((rc = ensure(g.st_in, n + 64))) return rc;
+  if ((rc = ensure(g.st_out, bound + 64))) return rc;
+  const uint8_t* d_in = (const uint8_t*)g.st_in.p;
+  uint8_t* d_out = (uint8_t*)g.st_out.p;
+  const uint32_t np = (uint32_t)((n + PIPE_PIECE - 1) / PIPE_PIECE);
+  auto cut = [&](uint32_t k) { return k == 0 ? 0ull : k >= np ? n : std::min<uint64_t>(n, (uint64_t)k * PIPE_PIECE + PIPE_HALO); };
+  auto up = [&](uint32_t k) -> int {  // upload k: bytes [cut(k), cut(k+1))
+    int r = upload((uint8_t*)g.st_in.p + cut(k), in + cut(k), cut(k + 1) - cut(k), g.cs_in);
+    if (r) return r;
+    HIPCHK(hipEventRecord(g.ev_up[k & 1], g.cs_in));
+    return ZES_OK;
+  };
+  const bool pdbg = getenv("ZES_PIPE_DBG") != nullptr;
+  const auto t00 = std::chrono::steady_clock::now();
+  auto stamp = [&](const char* what, uint32_t k) {
+    if (pdbg) fprintf(stderr, "  pipe %-14s %u  %.3f ms\n", what, k, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t00).count());
+  };
+  if ((rc = up(0))) return rc;
+  stamp("up done", 0);
+  uint64_t pos = 16;       // bit position of the next piece in the output stream (behind 78 9C)
+  uint64_t sent = 0;       // bytes of the output already on their way to the caller
+  uint64_t s1 = 1, s2 = 0;  // Adler-32 of the pieces so far
+  const bool out_fits = cap >= bound;  // (else: count first, the caller gets the size needed)
+  uint64_t pend_lo = 0, pend_hi = 0;   // bytes of the output finished by the piece before, not yet sent
+  std::future<int> f_up, f_down;
+  SettleGuard guard{f_up, f_down};
+  auto settle = [&](std::future<int>& f) { return f.valid() ? f.get() : (int)ZES_OK; };
+  for (uint32_t k = 0; k < np; k++) {
+    const uint64_t lo = (uint64_t)k * PIPE_PIECE, len = std::min<uint64_t>(PIPE_PIECE, n - lo);
+    const uint64_t readable = std::min<uint64_t>(n - lo, len + 258);
+    const uint64_t o_off = (pos >> 7) << 4;  // 16-byte aligned byte offset; the piece starts start_bit bits into it
+    const uint32_t sbit = (uint32_t)(pos - o_off * 8);
+    const uint64_t o_cap = bound + 64 - o_off;
+    const uint32_t fl = ZES_BUF_RANGE | (k + 1 < np ? ZES_BUF_NOTFINAL : 0u) | (k ? ZES_BUF_CONT : 0u);
+    uint64_t bits = 0, in_off = lo;
+    int32_t st = 0;
+    uint32_t ad = 1;
+    if ((rc = settle(f_up))) {  // (piece k is up, or on its way with its event recorded)
+      (void)settle(f_down);
+      return rc;
+    }
+    HIPCHK(hipStreamWaitEvent(g.stream, g.ev_up[k & 1], 0));
+    rc = deflate_batch_core(d_in, &in_off, &len, d_out, &o_off, &o_cap, &bits, &st, 1, &readable, &fl, &ad, &sbit, true);
+    if (rc || st) {
+      (void)settle(f_down);
+      return rc ? rc : st;
+    }
+    // beside the kernels: the next piece up, the bytes the piece before finished down
+    stamp("launched", k);
+    if (k + 1 < np) f_up = g_side_up.submit([&up, &stamp, k] { int r = up(k + 1); stamp("up done", k + 1); return r; });
+    if (out_fits && pend_hi > pend_lo) {
+      if ((rc = settle(f_down))) return rc;
+      const uint64_t a = pend_lo, b = pend_hi;
+      f_down = g_side_down.submit([=, &stamp] { int r = download(out + a, d_out + a, b - a, g.cs_out, false); stamp("down issued", k); return r; });
+      sent = pend_hi;
+    }
+    if (hipStreamSynchronize(g.stream) != hipSuccess) {
+      (void)settle(f_up);
+      (void)settle(f_down);
+      return ZES_E_DEVICE;
+    }
+    collect_times();
+    stamp("kernels done", k);
+    const ZesRes* r = (const ZesRes*)g.pinned;
+    if (r[0].status) {
+      (void)settle(f_up);
+      (void)settle(f_down);
+      return r[0].status;
+    }
+    bits = r[0].out_len;
+    ad = r[0].aux;
+    pos += bits;
+    const uint64_t a1 = ad & 0xFFFFu, a2 = ad >> 16;
+    s2 = (s2 + a2 + (len % 65521u) * ((s1 + 65520u) % 65521u)) % 65521u;
+    s1 = (s1 + a1 + 65520u) % 65521u;
+    pend_lo = sent;
+    pend_hi = (k + 1 < np) ? (pos >> 3) : ((pos + 7) >> 3);  // whole bytes; the last piece's padded end
+  }
+  if ((rc = settle(f_down))) return rc;
+  const uint64_t raw_end = (pos + 7) >> 3, total = raw_end + 4;
+  *out_len = total;
+  if (total > cap) return ZES_E_NOSPACE;
+  if (!out_fits) {  // a capacity below the bound that still holds the result: one copy now
+    if ((rc = download(out, d_out, raw_end, g.cs_out, true))) return rc;
+  } else {
+    if (pend_hi > pend_lo && (rc = download(out + pend_lo, d_out + pend_lo, pend_hi - pend_lo, g.cs_out, false))) return rc;
+    HIPCHK(hipStreamSynchronize(g.cs_out));
+  }
+  stamp("all down", np);
+  out[0] = 0x78;  // src/zlib.ts:29-34
+  out[1] = 0x9C;
+  const uint32_t adl = (uint32_t)((s2 << 16) | s1);
+  for (int k = 0; k < 4; k++) out[raw_end + k] = (uint8_t)(adl >> (24 - 8 * k));  // big-endian trailer (src/zlib.ts:37-40)
+  return ZES_OK;
+}
+
 int zes_deflate(const uint8_t* in, uint64_t n, uint8_t* out, uint64_t cap, uint64_t* out_len) {
   if (!out_len || (!in && n) || !out) return ZES_E_ARG;
   *out_len = 0;
@@ -1607,8 +1869,10 @@ int zes_deflate(const uint8_t* in, uint64_t n, uint8_t* out, uint64_t cap, uint6
   const uint64_t bound = deflate_bound(n);
   {
     std::lock_guard<std::mutex> lk(g_mu);
+    RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
     int rc = init_locked(-1);
     if (rc) return rc;
+    if (n >= PIPE_MIN && !getenv("ZES_NO_PIPELINE")) return deflate_host_pipelined(in, n, out, cap, out_len);
     if ((rc = ensure(g.st_in, n + 64))) return rc;
     if ((rc = ensure(g.st_out, bound + 64))) return rc;
     if ((rc = upload((uint8_t*)g.st_in.p, in, n))) return rc;
@@ -1627,6 +1891,7 @@ int zes_inflate_dev(const uint8_t* d_in, uint64_t c, uint8_t* d_out, uint64_t ca
   if (!out_len) return ZES_E_ARG;
   if ((((uintptr_t)d_in) & 15u) || (((uintptr_t)d_out) & 15u)) return ZES_E_ARG;
   std::lock_guard<std::mutex> lk(g_mu);
+  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   int rc = init_locked(-1);
   if (rc) return rc;
   return inflate_one(d_in, 0, c, d_out, 0, cap, out_len, flags, -1);
@@ -1638,6 +1903,7 @@ int zes_inflate_batch_dev(const uint8_t* d_in, const uint64_t* in_off, const uin
   if (!in_off || !in_len || !out_off || !out_cap || !out_len || !status) return ZES_E_ARG;
   if ((((uintptr_t)d_in) & 15u) || (((uintptr_t)d_out) & 15u)) return ZES_E_ARG;
   std::lock_guard<std::mutex> lk(g_mu);
+  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   int rc = init_locked(-1);
   if (rc) return rc;
   for (uint32_t i = 0; i < count; i++) status[i] = ((in_off[i] & 15u) || (out_off[i] & 15u)) ? ZES_E_ARG : ZES_OK;
@@ -1652,14 +1918,110 @@ int zes_inflate_batch_dev(const uint8_t* d_in, const uint64_t* in_off, const uin
   return ZES_OK;
 }
 
+// Host inflate of a long reference-made stream in pieces, so that the three legs overlap: the stream is cut into equal
+// bit ranges (as shard.inflate_split cuts it over GPUs); while the block-parallel tier decodes the blocks that start in
+// range k (inflate_t1_range), a helper thread sends range k+1 up on one copy stream and the output of range k-1 down on
+// another.  The ranges must chain (each one's first block where the one before ended, full blocks everywhere but at
+// the end, BFINAL last); anything else — another encoder's stream, a false block start — and the call starts over on
+// the one-pass path below, which has every tier.  *done = false then.
+constexpr uint64_t PIPE_IN_MIN = 8ull << 20;
+static int inflate_host_pipelined(const uint8_t* in, uint64_t c, uint8_t* out, uint64_t cap, uint64_t* out_len, uint32_t flags,
+                                  zes_alloc_fn alloc, void* user, bool* done) {
+  *done = false;
+  int rc;
+  const uint64_t pb = std::min<uint64_t>(32ull << 20, std::max<uint64_t>(4ull << 20, ((c / 2 + 65535) >> 16) << 16));
+  const uint32_t np = (uint32_t)((c + pb - 1) / pb);
+  if (np < 2) return ZES_OK;
+  const uint64_t dcap = std::max<uint64_t>(alloc ? 0 : cap, std::max<uint64_t>(c * 4, 1 << 20));
+  if ((rc = ensure(g.st_in, c + 64))) return rc;
+  if ((rc = ensure(g.st_out, dcap + 64))) return rc;
+  const uint8_t* d_in = (const uint8_t*)g.st_in.p;
+  uint8_t* d_out = (uint8_t*)g.st_out.p;
+  auto cut = [&](uint32_t k) { return k == 0 ? 0ull : k >= np ? c : std::min<uint64_t>(c, (uint64_t)k * pb + T1_PIECE_SLACK); };
+  auto up = [&](uint32_t k) -> int {
+    int r = upload((uint8_t*)g.st_in.p + cut(k), in + cut(k), cut(k + 1) - cut(k), g.cs_in);
+    if (r) return r;
+    HIPCHK(hipEventRecord(g.ev_up[k & 1], g.cs_in));
+    return ZES_OK;
+  };
+  if ((rc = up(0))) return rc;
+  uint64_t blocks = 0, total = 0, prev_end = 16, pend_lo = 0, pend_hi = 0;
+  bool final_seen = false, chain = true;
+  std::future<int> f_up, f_down;
+  SettleGuard guard{f_up, f_down};
+  auto settle = [&](std::future<int>& f) { return f.valid() ? f.get() : (int)ZES_OK; };
+  for (uint32_t k = 0; k < np && chain && !final_seen; k++) {
+    if ((rc = settle(f_up))) return rc;  // (range k is up, or on its way with its event recorded)
+    HIPCHK(hipStreamWaitEvent(g.stream, g.ev_up[k & 1], 0));
+    if (k + 1 < np) f_up = g_side_up.submit([&up, k] { return up(k + 1); });
+    if (out && !alloc && pend_hi > pend_lo) {
+      if ((rc = settle(f_down))) return rc;
+      const uint64_t a = pend_lo, b = pend_hi;
+      f_down = g_side_down.submit([=] { return download(out + a, d_out + a, b - a, g.cs_out, false); });
+    }
+    const uint64_t lo_bit = k == 0 ? 16 : (uint64_t)k * pb * 8, own_bit = std::min<uint64_t>((uint64_t)(k + 1) * pb, c) * 8;
+    uint64_t byte0 = (lo_bit >> 3) & ~15ull;
+    if (byte0 >= 16) byte0 -= 16;
+    const uint64_t pc = std::min<uint64_t>(c - byte0, (own_bit >> 3) - byte0 + T1_PIECE_SLACK);
+    const uint64_t o_off = std::min<uint64_t>(blocks * ZES_BLK, dcap);
+    RangeRes rr;
+    if ((rc = inflate_t1_range(d_in, byte0, pc, lo_bit - 8 * byte0, own_bit - 8 * byte0, k == 0, d_out, o_off, dcap - o_off, flags, &rr))) return rc;
+    pend_lo = pend_hi = 0;
+    if (!rr.handled) {
+      chain = false;
+    } else if (rr.nblocks) {
+      if (rr.first_bit + 8 * byte0 != prev_end || total != blocks * ZES_BLK) {
+        chain = false;
+      } else {
+        prev_end = rr.end_bit + 8 * byte0;
+        pend_lo = std::min(total, cap);
+        total += rr.out_len;
+        pend_hi = std::min(total, cap);
+        blocks += rr.nblocks;
+        final_seen = rr.final_block;
+      }
+    }
+  }
+  if ((rc = settle(f_up))) return rc;
+  if ((rc = settle(f_down))) return rc;
+  HIPCHK(hipStreamSynchronize(g.cs_in));
+  if (!chain || !final_seen || total > dcap) {
+    HIPCHK(hipStreamSynchronize(g.cs_out));
+    return ZES_OK;  // not this way: the one-pass path decides
+  }
+  *done = true;
+  g.last_tier = 1;
+  *out_len = total;
+  if (alloc) {  // the caller allocates the exact result now that its size is known
+    out = alloc(user, 0, total);
+    if (!out) return ZES_E_ARG;
+    return download(out, d_out, total, g.cs_out, true);
+  }
+  if (total > cap) {
+    HIPCHK(hipStreamSynchronize(g.cs_out));
+    return ZES_E_NOSPACE;
+  }
+  if (pend_hi > pend_lo && (rc = download(out + pend_lo, d_out + pend_lo, pend_hi - pend_lo, g.cs_out, false))) return rc;
+  HIPCHK(hipStreamSynchronize(g.cs_out));
+  return ZES_OK;
+}
+
 static int inflate_host(const uint8_t* in, uint64_t c, uint8_t* out, uint64_t cap, uint64_t* out_len, uint32_t flags,
                         bool size_only, zes_alloc_fn alloc, void* user) {
   if (!out_len || (!in && c)) return ZES_E_ARG;
   *out_len = 0;
   if (c == 0 || (in[0] & 15u) != 8u) return ZES_E_NOT_DEFLATE;  // src/zlib.ts:13-16, decided before the device is touched
   std::lock_guard<std::mutex> lk(g_mu);
+  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   int rc = init_locked(-1);
   if (rc) return rc;
+  if (c >= PIPE_IN_MIN && c < (1ull << 29) && !size_only && (out || alloc) && !(flags & (ZES_F_NO_FASTPATH | ZES_F_PIECES)) &&
+      !getenv("ZES_NO_PIPELINE")) {
+    bool done = false;
+    rc = inflate_host_pipelined(in, c, out, cap, out_len, flags, alloc, user, &done);
+    if (rc || done) return rc;
+    *out_len = 0;
+  }
   if ((rc = ensure(g.st_in, c + 64))) return rc;
   if ((rc = upload((uint8_t*)g.st_in.p, in, c))) return rc;
   // decode into pooled device memory: grow-and-retry like the reference's Uint8WriteStream
@@ -1702,6 +2064,7 @@ int zes_deflate_batch(const uint8_t* const* in, const uint64_t* in_len, uint8_t*
                       uint64_t* out_len, int32_t* status, uint32_t count) {
   if (!in || !in_len || !out || !out_cap || !out_len || !status) return ZES_E_ARG;
   std::lock_guard<std::mutex> lk(g_mu);
+  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   int rc = init_locked(-1);
   if (rc) return rc;
   std::vector<uint64_t> in_off(count), o_off(count), o_cap(count), dl(count);
@@ -1736,6 +2099,7 @@ int zes_inflate_batch_alloc(const uint8_t* const* in, const uint64_t* in_len, ze
                             int32_t* status, uint32_t count, uint32_t flags) {
   if (!in || !in_len || !alloc || !out_len || !status) return ZES_E_ARG;
   std::lock_guard<std::mutex> lk(g_mu);
+  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   int rc = init_locked(-1);
   if (rc) return rc;
   std::vector<uint64_t> in_off(count), o_off(count), o_cap(count);
@@ -1821,6 +2185,7 @@ int zes_deflate_range_dev(const uint8_t* d_in, uint64_t n, uint64_t n_readable, 
   if ((n % ZES_BLK) == 1) return ZES_E_CORRUPT;         // the reference throws on a 1-byte last block
   if ((((uintptr_t)d_in) & 15u) || (((uintptr_t)d_out) & 15u)) return ZES_E_ARG;
   std::lock_guard<std::mutex> lk(g_mu);
+  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   int rc = init_locked(-1);
   if (rc) return rc;
   uint64_t zero = 0, bits = 0;
@@ -1855,6 +2220,7 @@ int zes_deflate_join_dev(const uint8_t* const* d_piece, const uint64_t* piece_bi
   *out_len = total;
   if (total > cap) return ZES_E_NOSPACE;
   std::lock_guard<std::mutex> lk(g_mu);
+  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   int rc = init_locked(-1);
   if (rc) return rc;
   HIPCHK(hipMemsetAsync(d_out, 0, (total + 3) & ~3ull, g.stream));  // (cap of a deflate result always has the slack: zes_deflate_bound)
@@ -1885,6 +2251,7 @@ int zes_inflate_range_dev(const uint8_t* d_in, uint64_t c, uint64_t lo_bit, uint
   if (!d_in || !out_len || !first_bit || !end_bit || !nblocks || !final_block || lo_bit < 16 || own_bit <= lo_bit) return ZES_E_ARG;
   if ((((uintptr_t)d_in) & 15u) || (((uintptr_t)d_out) & 15u) || c >= (1ull << 29)) return ZES_E_ARG;
   std::lock_guard<std::mutex> lk(g_mu);
+  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   int rc = init_locked(-1);
   if (rc) return rc;
   RangeRes rr;
@@ -1902,6 +2269,7 @@ int zes_inflate_range_dev(const uint8_t* d_in, uint64_t c, uint64_t lo_bit, uint
 int zes_adler32_dev(const uint8_t* d_in, uint64_t n, uint32_t* adler_out) {
   if (!adler_out) return ZES_E_ARG;
   std::lock_guard<std::mutex> lk(g_mu);
+  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   int rc = init_locked(-1);
   if (rc) return rc;
   return adler32_locked(d_in, n, adler_out);
@@ -1921,6 +2289,7 @@ int zes_inflate_raw_dev(const uint8_t* d_in, uint64_t c, uint64_t offset, uint8_
   if (!out_len || (!d_in && c)) return ZES_E_ARG;
   if ((((uintptr_t)d_out) & 15u)) return ZES_E_ARG;
   std::lock_guard<std::mutex> lk(g_mu);
+  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   int rc = init_locked(-1);
   if (rc) return rc;
   const uint64_t n = offset < c ? c - offset : 0;
@@ -1933,6 +2302,7 @@ int zes_inflate_raw(const uint8_t* in, uint64_t c, uint64_t offset, uint8_t* out
   if (!out_len || (!in && c)) return ZES_E_ARG;
   *out_len = 0;
   std::lock_guard<std::mutex> lk(g_mu);
+  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   int rc = init_locked(-1);
   if (rc) return rc;
   const uint64_t n = offset < c ? c - offset : 0;
@@ -1974,6 +2344,7 @@ int zes_deflate_raw_dev(const uint8_t* d_in, uint64_t n, uint8_t* d_out, uint64_
   *out_len = 0;
   if (deflate_throws(n)) return ZES_E_CORRUPT;
   std::lock_guard<std::mutex> lk(g_mu);
+  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   int rc = init_locked(-1);
   if (rc) return rc;
   uint64_t rl = 0;
@@ -1990,6 +2361,7 @@ int zes_deflate_raw(const uint8_t* in, uint64_t n, uint8_t* out, uint64_t cap, u
   *out_len = 0;
   if (deflate_throws(n)) return ZES_E_CORRUPT;
   std::lock_guard<std::mutex> lk(g_mu);
+  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   int rc = init_locked(-1);
   if (rc) return rc;
   if ((rc = ensure(g.st_in, n + 64))) return rc;
@@ -2003,7 +2375,8 @@ int zes_deflate_raw(const uint8_t* in, uint64_t n, uint8_t* out, uint64_t cap, u
 
 int zes_adler32(const uint8_t* in, uint64_t n, uint32_t* adler_out) {
   if (!adler_out || (!in && n)) return ZES_E_ARG;
-  std::lock_guard<std::mutex> lk(g_mu);  // staging and kernel under one lock: nobody else's call can replace st_in in between
+  std::lock_guard<std::mutex> lk(g_mu);
+  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)  // staging and kernel under one lock: nobody else's call can replace st_in in between
   int rc = init_locked(-1);
   if (rc) return rc;
   if ((rc = ensure(g.st_in, n + 64))) return rc;
@@ -2014,6 +2387,7 @@ int zes_adler32(const uint8_t* in, uint64_t n, uint32_t* adler_out) {
 int zes_stage_lz77_dev(const uint8_t* d_in, uint64_t n, uint64_t start, uint32_t len, uint32_t* h_tokens, uint32_t* ntokens) {
   if (!h_tokens || !ntokens || len < 2 || len > ZES_BLK || start + len > n || (start % ZES_BLK)) return ZES_E_ARG;
   std::lock_guard<std::mutex> lk(g_mu);
+  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   int rc = init_locked(-1);
   if (rc) return rc;
   ZesBuf b;
@@ -2055,6 +2429,7 @@ int zes_stage_lz77_dev(const uint8_t* d_in, uint64_t n, uint64_t start, uint32_t
 int zes_stage_huff_lengths_dev(const uint32_t* h_hist, uint32_t nsym, uint32_t maxlen, uint8_t* h_lens) {
   if (!h_hist || !h_lens || nsym == 0 || nsym > 288 || maxlen == 0 || maxlen > 15) return ZES_E_ARG;
   std::lock_guard<std::mutex> lk(g_mu);
+  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   int rc = init_locked(-1);
   if (rc) return rc;
   if ((rc = ensure(g.hists, 320 * 4))) return rc;
@@ -2070,17 +2445,20 @@ int zes_stage_huff_lengths_dev(const uint32_t* h_hist, uint32_t nsym, uint32_t m
 
 int zes_last_inflate_tier(void) {
   std::lock_guard<std::mutex> lk(g_mu);
+  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   return g.last_tier;
 }
 
 int zes_set_profiling(int on) {
   std::lock_guard<std::mutex> lk(g_mu);
+  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   g.profiling = on != 0;
   return ZES_OK;
 }
 
 int zes_last_kernel_times(zes_ktime* out, int cap) {
   std::lock_guard<std::mutex> lk(g_mu);
+  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   int n = 0;
   g.name_pool.clear();
   for (auto& e : g.last_times) g.name_pool.push_back(e.first);

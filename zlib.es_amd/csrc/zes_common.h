@@ -24,9 +24,10 @@ struct ZesBuf {
   uint64_t n_read;    // bytes readable from in_off (>= n): the match finder compares up to 258 bytes past a block's end
                       // (SURVEY A.3); larger than n only when the buffer is a block range of a longer input
   uint32_t flags;     // ZES_BUF_*
-  uint32_t pad;
+  uint32_t start_bit;  // ZES_BUF_RANGE: bit of out_off's first byte at which the range's stream starts (0 .. 127)
 };
 #define ZES_BUF_RANGE 1u     // raw bit stream of a block range: starts at bit 0, no zlib header / trailer; res.out_len = bits
+#define ZES_BUF_CONT 4u      // the range continues another one's stream inside the same dword: that dword is not cleared
 #define ZES_BUF_NOTFINAL 2u  // the range's last block is not the input's last one: BFINAL stays 0
 
 // Result per buffer, written by the device, read back by the host.

@@ -2024,7 +2024,7 @@ __global__ __launch_bounds__(256) void k_layout(uint8_t* __restrict__ d_out, con
     s_part[tid] = sum;
     __syncthreads();
     if (tid == 0) {
-      uint64_t off = (bf.flags & ZES_BUF_RANGE) ? 0 : 16;  // after the two zlib header bytes
+      uint64_t off = (bf.flags & ZES_BUF_RANGE) ? bf.start_bit : 16;  // after the two zlib header bytes
       for (uint32_t t = 0; t < 256; t++) {
         const uint64_t v = s_part[t];
         s_part[t] = off;
@@ -2048,7 +2048,8 @@ __global__ __launch_bounds__(256) void k_layout(uint8_t* __restrict__ d_out, con
   // block's final dword through the trailer
   for (uint32_t i = tid; i < bf.nblk; i += 256) {
     const uint64_t s = bk[i].bit_off, e = s + bk[i].bits - 1;
-    out32[s >> 5] = 0;
+    // (a range that continues another one's stream inside a dword leaves that dword's bits alone)
+    if (!(i == 0 && (bf.flags & ZES_BUF_CONT) && (s & 31u))) out32[s >> 5] = 0;
     out32[e >> 5] = 0;
   }
   __syncthreads();
@@ -2070,7 +2071,7 @@ __global__ __launch_bounds__(256) void k_layout(uint8_t* __restrict__ d_out, con
         atomicOr(&out32[pos >> 2], byte << (8 * (pos & 3)));
       }
     }
-    res[b].out_len = range ? tot : out_len;  // a range reports bits: its seam with the next range is a bit position
+    res[b].out_len = range ? tot - bf.start_bit : out_len;  // a range reports bits: its seam with the next range is a bit position
     res[b].status = 0;
     res[b].aux = ad;
   }
