@@ -44,7 +44,7 @@ struct Ctx {
   // deflate scratch
   DevBuf bufs, blks, idx_a, idx_b, inv, sdelta, hists, codes, hdrs, adler, res;
   // inflate scratch
-  DevBuf surv, vlong, cand, cand_sorted, counters, cres, map, resume, dbg, ibufs, ibufs2, mvlist, scratch, sres, maps, seglist, segprefix, wins, sym16, segorder, segjobs, pw16, gwins;
+  DevBuf surv, vlong, segfail, cand, cand_sorted, counters, cres, map, resume, dbg, ibufs, ibufs2, mvlist, scratch, sres, maps, seglist, segprefix, wins, sym16, segorder, segjobs, pw16, gwins;
   // staging for the host-pointer API
   DevBuf st_in, st_out;
   DevBuf kraft;  // k_inf_scan's table: Kraft contribution of four 3-bit code-length fields at once
@@ -1190,19 +1190,36 @@ int inflate_segments_run(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, cons
   // such a match cannot go on: far_d counts those, and the whole group runs again with the full ring (rare: streams
   // that inflate by more than the store's symbols per compressed byte).
   uint32_t* far_d = dscratch + 2 * nb;
+  // One buffer: every work item first goes to the block decoder of the block-parallel tier in its any-encoder form
+  // (k_inf_seg_block_par: a workgroup per block, 1024 lanes decoding 1024 bit segments of it) — a wave that decodes a
+  // block token by token gets through ~13 MB/s.  What it declines (an item whose block is stored or fixed, is followed
+  // by a block that is not on the list, or is longer than 128 KiB) is listed, and the wave decoder runs for the list.
+  const bool blockpar = nb == 1 && ratio != 0 && !getenv("ZES_NO_SEG_PAR");
+  uint32_t* fail_list = nullptr;
+  if (blockpar) {
+    if ((rc = ensure(g.segfail, ((size_t)work + 1) * 4))) return rc;
+    fail_list = (uint32_t*)g.segfail.p;
+    HIPCHK(hipMemsetAsync(fail_list, 0, 4, g.stream));
+    Timed t("k_inf_seg_block_par");
+    hipLaunchKernelGGL(k_inf_seg_block_par, dim3(work), dim3(PAR_THREADS), 0, g.stream, d_in, (const ZesSegJob*)g.segjobs.p, cs, (ZesSegRes*)g.sres.p,
+                       (uint32_t*)g.maps.p, (uint32_t*)g.sym16.p, ratio, fail_list);
+  }
   {
     Timed t("k_inf_seg_scan");
     hipLaunchKernelGGL(k_inf_seg_scan_short, dim3(work), dim3(64), 0, g.stream, d_in, (const ZesSegJob*)g.segjobs.p, nb, cs, (ZesSegRes*)g.sres.p,
-                       (uint32_t*)g.maps.p, (uint32_t*)g.sym16.p, ratio, (const uint32_t*)g.segorder.p, far_d);
+                       (uint32_t*)g.maps.p, (uint32_t*)g.sym16.p, ratio, blockpar ? (const uint32_t*)fail_list + 1 : (const uint32_t*)g.segorder.p, far_d,
+                       (const uint32_t*)fail_list);
   }
   {
     uint32_t* hf = (uint32_t*)g.pinned;
     HIPCHK(hipMemcpyAsync(hf, far_d, 4, hipMemcpyDeviceToHost, g.stream));
+    if (blockpar) HIPCHK(hipMemcpyAsync(hf + 1, fail_list, 4, hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
+    if (blockpar && getenv("ZES_DEBUG")) fprintf(stderr, "zes T2: %u work items, %u left to the wave decoder\n", work, hf[1]);
     if (hf[0] != 0) {
       Timed t("k_inf_seg_scan");
       hipLaunchKernelGGL(k_inf_seg_scan, dim3(work), dim3(64), 0, g.stream, d_in, (const ZesSegJob*)g.segjobs.p, nb, cs, (ZesSegRes*)g.sres.p,
-                         (uint32_t*)g.maps.p, (uint32_t*)g.sym16.p, ratio, (const uint32_t*)g.segorder.p, far_d);
+                         (uint32_t*)g.maps.p, (uint32_t*)g.sym16.p, ratio, (const uint32_t*)g.segorder.p, far_d, (const uint32_t*)nullptr);
     }
   }
   {
@@ -1663,7 +1680,7 @@ int zes_shutdown(void) {
   if (!g.ready) return ZES_OK;
   (void)hipSetDevice(g.device);
   (void)hipStreamSynchronize(g.stream);
-  DevBuf* all[] = {&g.bufs, &g.blks, &g.idx_a, &g.idx_b, &g.inv, &g.sdelta, &g.hists, &g.codes, &g.hdrs, &g.adler, &g.res, &g.surv, &g.vlong, &g.cand,
+  DevBuf* all[] = {&g.bufs, &g.blks, &g.idx_a, &g.idx_b, &g.inv, &g.sdelta, &g.hists, &g.codes, &g.hdrs, &g.adler, &g.res, &g.surv, &g.vlong, &g.segfail, &g.cand,
                    &g.cand_sorted, &g.counters, &g.cres, &g.map, &g.resume, &g.dbg, &g.ibufs, &g.ibufs2, &g.mvlist, &g.scratch, &g.st_in, &g.st_out,
                    &g.sres, &g.maps, &g.seglist, &g.segprefix, &g.wins, &g.sym16, &g.segorder, &g.segjobs, &g.kraft, &g.pw16, &g.gwins};
   for (DevBuf* b : all) {

@@ -653,7 +653,9 @@ __global__ __launch_bounds__(1024) void k_inf_ranksort(const ZesInfBuf* __restri
 // The segment-parallel tier also has a short form of the marker ring: three decoders fit a CU instead of two (the ring is
 // what the decoder's LDS goes to), and a match that reaches further back than the ring takes its symbols from the
 // segment's symbol store in global memory — or, in front of the segment's first byte, writes the marker values directly.
+#ifndef RING16_SHORT
 #define RING16_SHORT 20480u
+#endif
 #define FLUSH_SHORT 4096u  // the short ring flushes to the symbol store this often: everything older than that is in the store
 
 // One wavefront decodes serially; all decoder state is wave-uniform and kept in scalar registers
@@ -678,7 +680,7 @@ struct InfSmemT {
 };
 using InfSmem = InfSmemT<RING16>;
 using InfSmemShort = InfSmemT<RING16_SHORT>;
-static_assert(sizeof(InfSmemShort) * 3 <= 160 * 1024, "three short-ring decoders per CU");
+static_assert(sizeof(InfSmemShort) * 3 <= 160 * 1024, "at least three short-ring decoders per CU");
 
 struct WaveDec {
   // uniform state (identical in all 64 lanes)
@@ -1638,9 +1640,12 @@ template <class SM>
 __device__ __forceinline__ static void seg_scan_body(SM& S, const uint8_t* __restrict__ d_in, const ZesSegJob* __restrict__ jobs, uint32_t njobs,
                                                      const uint32_t* __restrict__ cand_all, ZesSegRes* __restrict__ sres_all,
                                                      uint32_t* __restrict__ maps_all, uint32_t* __restrict__ sym16_all, uint32_t sym_ratio,
-                                                     const uint32_t* __restrict__ order, uint32_t* __restrict__ far_nostore) {
+                                                     const uint32_t* __restrict__ order, uint32_t* __restrict__ far_nostore,
+                                                     const uint32_t* __restrict__ nlive) {
   constexpr uint32_t R = SM::kR16;
   const uint32_t lane = threadIdx.x;
+  // (one-buffer launch behind k_inf_seg_block_par: order[] lists the items that kernel left, *nlive is how many)
+  if (nlive && blockIdx.x >= *nlive) return;
   // buffer of this work item: the last one whose first work item is <= blockIdx.x
   uint32_t bi = 0;
   {
@@ -1776,17 +1781,19 @@ __device__ __forceinline__ static void seg_scan_body(SM& S, const uint8_t* __res
 __global__ __launch_bounds__(64) void k_inf_seg_scan(const uint8_t* __restrict__ d_in, const ZesSegJob* __restrict__ jobs, uint32_t njobs,
                                                      const uint32_t* __restrict__ cand_all, ZesSegRes* __restrict__ sres_all,
                                                      uint32_t* __restrict__ maps_all, uint32_t* __restrict__ sym16_all, uint32_t sym_ratio,
-                                                     const uint32_t* __restrict__ order, uint32_t* __restrict__ far_nostore) {
+                                                     const uint32_t* __restrict__ order, uint32_t* __restrict__ far_nostore,
+                                                     const uint32_t* __restrict__ nlive) {
   __shared__ __align__(16) InfSmem S;
-  seg_scan_body(S, d_in, jobs, njobs, cand_all, sres_all, maps_all, sym16_all, sym_ratio, order, far_nostore);
+  seg_scan_body(S, d_in, jobs, njobs, cand_all, sres_all, maps_all, sym16_all, sym_ratio, order, far_nostore, nlive);
 }
 // the same with the short marker ring: three decoders per CU
 __global__ __launch_bounds__(64) void k_inf_seg_scan_short(const uint8_t* __restrict__ d_in, const ZesSegJob* __restrict__ jobs, uint32_t njobs,
                                                            const uint32_t* __restrict__ cand_all, ZesSegRes* __restrict__ sres_all,
                                                            uint32_t* __restrict__ maps_all, uint32_t* __restrict__ sym16_all, uint32_t sym_ratio,
-                                                           const uint32_t* __restrict__ order, uint32_t* __restrict__ far_nostore) {
+                                                           const uint32_t* __restrict__ order, uint32_t* __restrict__ far_nostore,
+                                                           const uint32_t* __restrict__ nlive) {
   __shared__ __align__(16) InfSmemShort S;
-  seg_scan_body(S, d_in, jobs, njobs, cand_all, sres_all, maps_all, sym16_all, sym_ratio, order, far_nostore);
+  seg_scan_body(S, d_in, jobs, njobs, cand_all, sres_all, maps_all, sym16_all, sym_ratio, order, far_nostore, nlive);
 }
 
 // One workgroup per stream: the chain of segments from work item 0 to the final block.

@@ -673,7 +673,7 @@ __device__ __forceinline__ static void seg_table(ParSmem& S, const BitSrc& src, 
 }
 
 // Decodes tokens from bit `entry` while the token start is below `stop`.
-template <bool EMIT, bool LDS>
+template <bool EMIT, bool LDS, bool HIST = false>
 __device__ __forceinline__ static void seg_decode(ParSmem& S, const BitSrc& src, uint32_t limit, uint32_t entry, uint32_t stop,
                                                   uint32_t out_off, uint32_t& exit_pos, uint32_t& outbytes, uint32_t& flags) {
   LaneBits b;
@@ -696,7 +696,7 @@ __device__ __forceinline__ static void seg_decode(ParSmem& S, const BitSrc& src,
     } else {
       if (EMIT) {
         const uint32_t p = out_off + ob;
-        if (dist > p) {
+        if (!HIST && dist > p) {
           fl |= F_HIST;  // looks behind the block start: not a reference-made block
         } else {
           S.out[p] = (uint8_t)(dist - 1u);
@@ -719,7 +719,7 @@ __device__ __forceinline__ static void seg_decode(ParSmem& S, const BitSrc& src,
 
 // Predicated form of seg_decode for the count (P2) and emit (P3) passes: one loop for the whole
 // wave, lanes drop out by clearing `act`; the rarely needed distance lookup sits behind a ballot.
-template <bool EMIT, bool LDS>
+template <bool EMIT, bool LDS, bool HIST = false>
 __device__ __forceinline__ static void seg_run(ParSmem& S, const BitSrc& src, uint32_t limit, uint32_t entry, uint32_t stop, bool live,
                                                const Lit8& f8, uint32_t out_off, uint32_t& exit_pos, uint32_t& outbytes,
                                                uint32_t& flags) {
@@ -800,7 +800,7 @@ __device__ __forceinline__ static void seg_run(ParSmem& S, const BitSrc& src, ui
       } else {
         if (EMIT) {
           const uint32_t p = out_off + ob;
-          if (dist > p) {
+          if (!HIST && dist > p) {
             fl |= F_HIST;  // looks behind the block start: not a reference-made block
           } else {
             S.out[p] = (uint8_t)(dist - 1u);
@@ -1019,48 +1019,62 @@ __device__ __forceinline__ static bool par_header(ParSmem& S, const BitSrc& src,
   return true;
 }
 
-__global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __restrict__ d_in, uint8_t* __restrict__ d_out,
-                                                               const ZesInfBuf* __restrict__ bufs, uint32_t nbuf,
-                                                               const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ cand_all,
-                                                               const uint32_t* __restrict__ map_all, ZesCandRes* __restrict__ cres_all,
-                                                               unsigned long long* __restrict__ dbg, const uint32_t* __restrict__ redo) {
-  __shared__ __align__(16) ParSmem S;
+// What a work item is and where its results go.  T1 (k_inf_block_par): candidate ci of a reference-made stream, output
+// slot w of 131072 bytes, a ZesCandRes.  T2 (k_inf_seg_block_par, FOREIGN): one block of any encoder's stream — a
+// block may copy from the 32 KiB in front of it and has any length up to the LDS image — whose output is 16-bit
+// symbols in the segment-parallel tier's symbol store (a byte, or 256 + index into the window in front of the block),
+// the map of its last 32 Ki symbols and a ZesSegRes: the same products as the wave decoder's (k_inf_seg_scan), which
+// still takes what this kernel declines (stored and fixed blocks, blocks behind an unlisted start, > 128 KiB).
+struct ParItem {
+  const uint32_t* g32;  // the buffer as dwords
+  uint32_t lastdw, limit, start;
+  uint32_t de_est, de_est2;  // end estimates: the next listed block start, the one after it (0: none)
+  // T1
+  ZesCandRes* cres;  // this item's result
+  uint8_t* dst;      // its output slot
+  uint64_t room;     // bytes that may be stored there
+  // T2
+  ZesSegRes* sres;
+  uint32_t* sym;      // the item's share of the symbol store (two symbols per dword)
+  uint64_t sym_cap;   // symbols it holds
+  uint32_t* map;      // [ZES_WINDOW / 2]
+  const uint32_t* cand;
+  uint32_t ncand;
+  uint32_t* fail_list;  // items left to the wave decoder: [0] = count, then the items
+  uint32_t w;
+};
+
+template <bool FOREIGN>
+__device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, unsigned long long* dbg) {
 #define STAMP(i)                                                     \
   do {                                                               \
     if (dbg && threadIdx.x == 0) dbg[(size_t)blockIdx.x * ZES_PAR_DBG_ROW + (i)] = (unsigned long long)clock64(); \
   } while (0)
+  // the item could not be decoded here: T1 reports it (the chain check decides), T2 hands it to the wave decoder
+#define PAR_DECLINE(END_BIT, TOTAL)                                   \
+  do {                                                                \
+    if (threadIdx.x == 0) {                                           \
+      if (FOREIGN) {                                                  \
+        ZesSegRes r_;                                                 \
+        r_.end_bit = 0;                                               \
+        r_.out_len = 0;                                               \
+        r_.flags = 0;                                                 \
+        r_.next = 0;                                                  \
+        *it.sres = r_;                                                \
+        it.fail_list[1u + atomicAdd(&it.fail_list[0], 1u)] = it.w;    \
+      } else {                                                        \
+        ZesCandRes r_;                                                \
+        r_.end_bit = (END_BIT);                                       \
+        r_.out_len = (TOTAL);                                         \
+        r_.flags = 0;                                                 \
+        *it.cres = r_;                                                \
+      }                                                               \
+    }                                                                 \
+  } while (0)
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  // buffer of this work item: the last entry whose first work item is <= blockIdx.x
-  uint32_t bi = 0;
-  {
-    uint32_t lo = 0, hi = nbuf;
-    while (hi - lo > 1) {
-      const uint32_t mid = (lo + hi) >> 1;
-      if (bufs[mid].work_first <= blockIdx.x) lo = mid; else hi = mid;
-    }
-    bi = lo;
-  }
-  // work item inside the buffer = output slot (a one-buffer launch may name the slots to decode again: redo[])
-  const uint32_t w = redo ? redo[blockIdx.x] : blockIdx.x - bufs[bi].work_first;
-  const uint32_t ncand = min(cnt[bi], bufs[bi].cand_cap);
-  uint32_t nwork = bufs[bi + 1].work_first - bufs[bi].work_first;
-  if (bufs[nbuf].work_first == ZES_WORK_AUTO) {  // one buffer, launched before the host saw the candidate count
-    nwork = min(ncand, bufs[nbuf].cand_cap);
-    if (blockIdx.x >= nwork) return;
-  }
-  const uint32_t* cand = cand_all + bufs[bi].cand_base;
-  const uint32_t* map = map_all ? map_all + bufs[bi].cand_base : nullptr;
-  // the first block of a reference-made stream starts at bit 16 and passes the candidate rules: if the sorted
-  // list does not begin there, k_inf_chain rejects the buffer whatever is decoded here (another encoder's stream)
-  if (!map_all && !redo && ((cand[0] != bufs[bi].start_rel && !(bufs[bi].range_flags & ZES_START_ANY)) || cnt[bi] > bufs[bi].cand_cap)) return;  // (or more candidates than the output has blocks)
-  ZesCandRes* cres = cres_all + bufs[bi].cand_base;
-  const uint64_t c = bufs[bi].c;
-  const uint32_t lastdw = (uint32_t)((c - 1) >> 2);
-  const uint32_t limit = (uint32_t)(c * 8);
-  const uint32_t ci = map ? map[w] : w;
-  const uint32_t start = cand[ci] + 16u;
+  const uint32_t lastdw = it.lastdw, limit = it.limit, start = it.start;
   BitSrc src;
-  src.g32 = reinterpret_cast<const uint32_t*>(d_in + bufs[bi].in_off);
+  src.g32 = it.g32;
   src.lastdw = lastdw;
   src.s32 = reinterpret_cast<const uint32_t*>(S.out);
   src.s_first = start >> 5;
@@ -1174,31 +1188,18 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __
     return 0u;
   };
   // estimate of the block's end: the next candidate on the list (exact on a clean chain)
-  uint32_t de_est = limit;
-  if (map) {
-    if (w + 1 < nwork) de_est = cand[map[w + 1]] + 16u;
-  } else if (ci + 1u < ncand) {
-    de_est = cand[ci + 1u] + 16u;
-  }
-  uint32_t bad = stage_and_tables(de_est);
+  uint32_t bad = stage_and_tables(it.de_est);
   // The chain is still alive after the last segment: the estimate was a false candidate inside
   // this block.  Take the candidate after it as the estimate and decode once more in parallel (a
   // serial tail from here can cost ~10 ms); a second false candidate in the same block falls to
   // the serial tail below.  Written as a second straight-line copy, not a loop: a back edge makes
   // the compiler hoist invariants across the whole decoder and spill.
-  if (!bad && tail_code < 48u && !map && ci + 1u < ncand) {
+  if (!bad && tail_code < 48u && it.de_est2) {
     __syncthreads();
-    de_est = ci + 2u < ncand ? cand[ci + 2u] + 16u : limit;
-    bad = stage_and_tables(de_est);
+    bad = stage_and_tables(it.de_est2);
   }
   if (bad) {
-    if (tid == 0) {
-      ZesCandRes r;
-      r.end_bit = start;
-      r.out_len = 0;
-      r.flags = 0;
-      cres[w] = r;
-    }
+    PAR_DECLINE(start, 0u);
     return;
   }
   STAMP(3);
@@ -1257,15 +1258,9 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __
     total += S.tail_bytes;
     const uint32_t st = S.status;
     const uint32_t end_bit = (tail_code < 48u) ? S.tail_end : S.hdr_end;
-    const bool good = (st & 4u) && !(st & 2u) && total <= ZES_BLK;
+    const bool good = (st & 4u) && !(st & 2u) && total <= ZES_BLK && (!FOREIGN || (uint64_t)total <= it.sym_cap);
     if (!good) {
-      if (tid == 0) {
-        ZesCandRes r;
-        r.end_bit = end_bit;
-        r.out_len = total;
-        r.flags = 0;
-        cres[w] = r;
-      }
+      PAR_DECLINE(end_bit, total);
       return;
     }
     const uint32_t my_off = wbase + incl - outbytes;
@@ -1275,23 +1270,17 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __
     uint32_t f2 = 0;
     {
       uint32_t ex2, ob2;
-      seg_run<true, false>(S, src, limit, entry, stop, !(flags & F_VOID) && entry < stop, f8, my_off, ex2, ob2, f2);
+      seg_run<true, false, FOREIGN>(S, src, limit, entry, stop, !(flags & F_VOID) && entry < stop, f8, my_off, ex2, ob2, f2);
     }
     if (tid == 0 && tail_code < 48u) {
       uint32_t ex2, ob2, f3 = 0;
-      seg_decode<true, false>(S, src, limit, tail_start, 0xFFFFFF00u, seg_total, ex2, ob2, f3);
+      seg_decode<true, false, FOREIGN>(S, src, limit, tail_start, 0xFFFFFF00u, seg_total, ex2, ob2, f3);
       f2 |= f3;
     }
     if (f2 & F_HIST) atomicOr(&S.status, 8u);
     __syncthreads();
     if (S.status & 8u) {
-      if (tid == 0) {
-        ZesCandRes r;
-        r.end_bit = end_bit;
-        r.out_len = total;
-        r.flags = 0;
-        cres[w] = r;
-      }
+      PAR_DECLINE(end_bit, total);
       return;
     }
 
@@ -1418,10 +1407,48 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __
         }
         P4LAP(2);
         // (d) every match byte of the window takes its value from its final ancestor
+        if (!FOREIGN) {
 #pragma unroll
-        for (uint32_t k = 0; k < RES_W / PAR_THREADS; k++) {
-          const uint32_t b = tid + k * PAR_THREADS;
-          if (d[k] != 0u) S.out[ws + b] = S.out[ws + b - d[k]];
+          for (uint32_t k = 0; k < RES_W / PAR_THREADS; k++) {
+            const uint32_t b = tid + k * PAR_THREADS;
+            if (d[k] != 0u) S.out[ws + b] = S.out[ws + b - d[k]];
+          }
+        } else {
+          // T2: the ancestor may lie in front of the block — the byte is then a marker, 256 + its index in the 32 KiB
+          // window before the block — or be such a marker byte of a window resolved earlier: its symbol is read back
+          // from the store (this workgroup wrote it; the bitmap words of resolved windows hold "is a marker").  All
+          // symbols of the window go to the symbol store, two bytes each.
+          uint16_t* sym16 = reinterpret_cast<uint16_t*>(it.sym);
+          uint32_t sy[RES_W / PAR_THREADS];
+#pragma unroll
+          for (uint32_t k = 0; k < RES_W / PAR_THREADS; k++) {
+            const uint32_t b = tid + k * PAR_THREADS, P = ws + b;
+            const int32_t a = (int32_t)P - (int32_t)d[k];
+            const uint32_t ai = a < 0 ? 0u : (uint32_t)a;
+            const bool hist = a < 0;
+            const bool mk = !hist && ai < ws && ((S.bitmap[ai >> 5] >> (ai & 31u)) & 1u);
+            uint32_t v = S.out[ai];
+            if (mk) {
+              const uint32_t wd = __hip_atomic_load(&it.sym[ai >> 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              v = (ai & 1u) ? wd >> 16 : wd & 0xffffu;
+            }
+            v = hist ? (uint32_t)(256 + (int32_t)ZES_WINDOW + a) : v;
+            sy[k] = v;
+          }
+#pragma unroll
+          for (uint32_t k = 0; k < RES_W / PAR_THREADS; k++) {
+            const uint32_t b = tid + k * PAR_THREADS;
+            if (b < wlen) {
+              S.out[ws + b] = (uint8_t)sy[k];
+              sym16[ws + b] = (uint16_t)sy[k];
+            }
+            // marker flags over this window's (dead) match bits: lanes tid .. tid + 63 of a wave are 64 consecutive bytes
+            const uint64_t mm = __ballot(b < wlen && sy[k] >= 256u);
+            if (lane == 0) {
+              S.bitmap[((ws + b) >> 5)] = (uint32_t)mm;
+              S.bitmap[((ws + b) >> 5) + 1u] = (uint32_t)(mm >> 32);
+            }
+          }
         }
         P4LAP(3);
         if (tid == 0) {
@@ -1440,23 +1467,180 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __
     __syncthreads();
 
     STAMP(6);
-    // ---- P5: flush ----
-    const uint64_t slot_off = (uint64_t)w * ZES_BLK;
-    uint8_t* dst = d_out + bufs[bi].out_off + slot_off;
-    const uint64_t cap = bufs[bi].cap;
-    const uint64_t room = cap > slot_off ? cap - slot_off : 0;
-    const uint32_t nstore = (uint32_t)min((uint64_t)total, room);
-    const uint32_t full = nstore >> 4;
-    for (uint32_t i = tid; i < full; i += PAR_THREADS)
-      reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(S.out)[i];
-    for (uint32_t i = (full << 4) + tid; i < nstore; i += PAR_THREADS) dst[i] = S.out[i];
-    if (tid == 0) {
-      ZesCandRes r;
-      r.end_bit = end_bit;
-      r.out_len = total;
-      r.flags = 1u | (S.bfinal ? 2u : 0u);
-      cres[w] = r;
+    if (!FOREIGN) {
+      // ---- P5: flush ----
+      uint8_t* dst = it.dst;
+      const uint32_t nstore = (uint32_t)min((uint64_t)total, it.room);
+      const uint32_t full = nstore >> 4;
+      for (uint32_t i = tid; i < full; i += PAR_THREADS)
+        reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(S.out)[i];
+      for (uint32_t i = (full << 4) + tid; i < nstore; i += PAR_THREADS) dst[i] = S.out[i];
+      if (tid == 0) {
+        ZesCandRes r;
+        r.end_bit = end_bit;
+        r.out_len = total;
+        r.flags = 1u | (S.bfinal ? 2u : 0u);
+        *it.cres = r;
+      }
+    } else {
+      // ---- T2: the map of the last 32 Ki symbols (in front of a shorter block: the markers themselves), the result ----
+      // the work item that starts where this block ends (uniform binary search); none, and not the final block: the
+      // next block is not on the list (a stored or fixed block, a start the search missed) — the wave decoder's case
+      uint32_t next = 0;
+      const bool fin = S.bfinal != 0u;
+      if (!fin) {
+        const uint32_t want = end_bit - 16u;
+        uint32_t lo = 0, hi = it.ncand;
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (it.cand[mid] < want) lo = mid + 1; else hi = mid;
+        }
+        if (lo < it.ncand && it.cand[lo] == want) next = lo + 1u;
+        if (next == 0u || end_bit >= limit) {
+          PAR_DECLINE(end_bit, total);
+          return;
+        }
+      }
+      for (uint32_t i2 = tid; i2 < ZES_WINDOW / 2; i2 += PAR_THREADS) {
+        uint32_t v[2];
+#pragma unroll
+        for (uint32_t h = 0; h < 2; h++) {
+          const int32_t pos = (int32_t)total - (int32_t)(ZES_WINDOW - (2u * i2 + h));
+          if (pos < 0) {
+            v[h] = (uint32_t)(256 + (int32_t)ZES_WINDOW + pos);
+          } else {
+            const uint32_t wd = __hip_atomic_load(&it.sym[(uint32_t)pos >> 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v[h] = (pos & 1) ? wd >> 16 : wd & 0xffffu;
+          }
+        }
+        it.map[i2] = v[0] | (v[1] << 16);
+      }
+      if (tid == 0) {
+        ZesSegRes r;
+        r.end_bit = end_bit;
+        r.out_len = total;
+        r.flags = 1u | (fin ? 2u : 0u);
+        r.next = next;
+        *it.sres = r;
+      }
     }
     STAMP(7);
   }
+}
+
+#undef PAR_DECLINE
+#undef STAMP
+
+__global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __restrict__ d_in, uint8_t* __restrict__ d_out,
+                                                               const ZesInfBuf* __restrict__ bufs, uint32_t nbuf,
+                                                               const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ cand_all,
+                                                               const uint32_t* __restrict__ map_all, ZesCandRes* __restrict__ cres_all,
+                                                               unsigned long long* __restrict__ dbg, const uint32_t* __restrict__ redo) {
+  __shared__ __align__(16) ParSmem S;
+  // buffer of this work item: the last entry whose first work item is <= blockIdx.x
+  uint32_t bi = 0;
+  {
+    uint32_t lo = 0, hi = nbuf;
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (bufs[mid].work_first <= blockIdx.x) lo = mid; else hi = mid;
+    }
+    bi = lo;
+  }
+  // work item inside the buffer = output slot (a one-buffer launch may name the slots to decode again: redo[])
+  const uint32_t w = redo ? redo[blockIdx.x] : blockIdx.x - bufs[bi].work_first;
+  const uint32_t ncand = min(cnt[bi], bufs[bi].cand_cap);
+  uint32_t nwork = bufs[bi + 1].work_first - bufs[bi].work_first;
+  if (bufs[nbuf].work_first == ZES_WORK_AUTO) {  // one buffer, launched before the host saw the candidate count
+    nwork = min(ncand, bufs[nbuf].cand_cap);
+    if (blockIdx.x >= nwork) return;
+  }
+  const uint32_t* cand = cand_all + bufs[bi].cand_base;
+  const uint32_t* map = map_all ? map_all + bufs[bi].cand_base : nullptr;
+  // the first block of a reference-made stream starts at bit 16 and passes the candidate rules: if the sorted
+  // list does not begin there, k_inf_chain rejects the buffer whatever is decoded here (another encoder's stream)
+  if (!map_all && !redo && ((cand[0] != bufs[bi].start_rel && !(bufs[bi].range_flags & ZES_START_ANY)) || cnt[bi] > bufs[bi].cand_cap)) return;  // (or more candidates than the output has blocks)
+  const uint64_t c = bufs[bi].c;
+  const uint32_t ci = map ? map[w] : w;
+  ParItem it;
+  it.g32 = reinterpret_cast<const uint32_t*>(d_in + bufs[bi].in_off);
+  it.lastdw = (uint32_t)((c - 1) >> 2);
+  it.limit = (uint32_t)(c * 8);
+  it.start = cand[ci] + 16u;
+  it.de_est = it.limit;
+  it.de_est2 = 0;
+  if (map) {
+    if (w + 1 < nwork) it.de_est = cand[map[w + 1]] + 16u;
+  } else if (ci + 1u < ncand) {
+    it.de_est = cand[ci + 1u] + 16u;
+    it.de_est2 = ci + 2u < ncand ? cand[ci + 2u] + 16u : it.limit;
+  }
+  it.cres = cres_all + bufs[bi].cand_base + w;
+  const uint64_t slot_off = (uint64_t)w * ZES_BLK;
+  it.dst = d_out + bufs[bi].out_off + slot_off;
+  it.room = bufs[bi].cap > slot_off ? bufs[bi].cap - slot_off : 0;
+  it.sres = nullptr;
+  it.sym = nullptr;
+  it.sym_cap = 0;
+  it.map = nullptr;
+  it.cand = nullptr;
+  it.ncand = 0;
+  it.fail_list = nullptr;
+  it.w = w;
+  par_body<false>(S, it, dbg);
+}
+
+// T2: one workgroup per block of another encoder's stream (work items as in k_inf_seg_scan: item 0 starts at bit 16,
+// item w at candidate w - 1).  One buffer per launch.
+__global__ __launch_bounds__(PAR_THREADS) void k_inf_seg_block_par(const uint8_t* __restrict__ d_in, const ZesSegJob* __restrict__ jobs,
+                                                                   const uint32_t* __restrict__ cand_all, ZesSegRes* __restrict__ sres_all,
+                                                                   uint32_t* __restrict__ maps_all, uint32_t* __restrict__ sym16_all,
+                                                                   uint32_t sym_ratio, uint32_t* __restrict__ fail_list) {
+  __shared__ __align__(16) ParSmem S;
+  const ZesSegJob jb = jobs[0];
+  const uint32_t w = blockIdx.x;
+  const uint32_t ncand = jb.ncand;
+  const uint32_t* cand = cand_all + jb.cand_base;
+  ZesSegRes* sres = sres_all + jb.work_first;
+  const uint64_t c = jb.c;
+  uint64_t start = 16;
+  if (w > 0) {
+    const uint32_t c0 = cand[w - 1];
+    if (c0 == 0) {  // the stream start is work item 0 already
+      if (threadIdx.x == 0) {
+        ZesSegRes r;
+        r.end_bit = 0;
+        r.out_len = 0;
+        r.flags = 0;
+        r.next = 0;
+        sres[w] = r;
+      }
+      return;
+    }
+    start = (uint64_t)c0 + 16;
+  }
+  uint32_t nx = w;  // candidate that starts the next work item (candidate 0 at bit 16 duplicates work item 0)
+  if (w == 0 && ncand > 0 && cand[0] == 0) nx = 1;
+  ParItem it;
+  it.g32 = reinterpret_cast<const uint32_t*>(d_in + jb.in_off);
+  it.lastdw = (uint32_t)((c - 1) >> 2);
+  it.limit = (uint32_t)(c * 8);
+  it.start = (uint32_t)start;
+  it.de_est = nx < ncand ? cand[nx] + 16u : it.limit;
+  it.de_est2 = nx < ncand ? (nx + 1u < ncand ? cand[nx + 1u] + 16u : it.limit) : 0u;
+  it.cres = nullptr;
+  it.dst = nullptr;
+  it.room = 0;
+  it.sres = sres + w;
+  // symbol store: the work item that starts at compressed byte b owns symbols [b * ratio, b' * ratio), b' the start of
+  // the next work item (the end of the stream for the last one)
+  const uint64_t b0 = (start - 16) / 8, b1 = nx < ncand ? (uint64_t)cand[nx] / 8 : c;
+  it.sym = sym16_all + jb.sym_base + b0 * sym_ratio / 2;
+  it.sym_cap = (b1 - b0) * sym_ratio;
+  it.map = maps_all + (size_t)jb.work_first * (ZES_WINDOW / 2) + (size_t)w * (ZES_WINDOW / 2);
+  it.cand = cand;
+  it.ncand = ncand;
+  it.fail_list = fail_list;
+  it.w = w;
+  par_body<true>(S, it, nullptr);
 }
