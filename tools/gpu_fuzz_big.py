@@ -46,6 +46,10 @@ while time.time() < t_end:
             parts.append(co.flush(int(rng.choice([pz.Z_SYNC_FLUSH, pz.Z_FULL_FLUSH]))))
     parts.append(co.flush())
     fz = np.frombuffer(b"".join(parts), dtype=np.uint8)
+    if os.environ.get("ZES_FUZZ_TRACE"):  # the input of the call that is about to run, should the GPU fault in it
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        open(os.path.join(ROOT, "gpurun_out", "fuzzbig_last.bin"), "wb").write(fz.tobytes())
+        print("case %d: n=%d c=%d level=%d mem=%d wb=%d strat=%d" % (n_cases, n, len(fz), level, mem, wb, strat), flush=True)
     got = gpu_inflate(fz)
     t = z.last_inflate_tier(); tiers[t] = tiers.get(t, 0) + 1
     assert got == ("out", a.tobytes()), ("foreign", n, level, mem, wb, strat, t)
@@ -55,6 +59,9 @@ while time.time() < t_end:
     bad[pos] ^= np.uint8(1 << int(rng.integers(8)))
     if rng.integers(3) == 0:
         bad = bad[:int(rng.integers(2, len(bad)))]
+    if os.environ.get("ZES_FUZZ_TRACE"):
+        open(os.path.join(ROOT, "gpurun_out", "fuzzbig_last.bin"), "wb").write(bad.tobytes())
+        print("case %d: damaged, c=%d" % (n_cases, len(bad)), flush=True)
     got, exp = gpu_inflate(bad), ref_inflate(bad)
     if got != exp:
         name = os.path.join(ROOT, "gpurun_out", "fuzzbig_fail_%d.bin" % n_cases)

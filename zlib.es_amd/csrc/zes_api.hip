@@ -301,75 +301,26 @@ bool is_pinned(const void* p) {
   return a.type == hipMemoryTypeHost;
 }
 
-// A caller's large pageable buffer is page-locked in place for the duration of the call (hipHostRegister: ~0.25 ms per
-// 64 MiB on the MI355X host, tools/gpu_hostregister_probe.py) and the DMA engines read and write it directly — the
-// staging ring costs a memcpy of every byte (~1 ms per 32 MiB with seven helper threads).  The ring remains for memory
-// that cannot be registered (a read-only file mapping) and for short buffers.  Registered ranges are kept until the
-// entry point returns (RegScope): pieces of one buffer register what is not covered yet.
-constexpr uint64_t REG_MIN = 8ull << 20;  // (below: the ring; a registration has a fixed cost too)
-struct RegList {
-  std::mutex mu;
-  std::vector<std::pair<uintptr_t, uintptr_t>> iv;  // page-aligned [lo, hi) registered by this call
-  bool cover(const void* p, uint64_t n) {
-    if (n < REG_MIN || getenv("ZES_NO_REGISTER")) return false;
-    const uintptr_t pg = 4096;
-    uintptr_t lo = (uintptr_t)p & ~(pg - 1), hi = ((uintptr_t)p + n + pg - 1) & ~(pg - 1);
-    std::lock_guard<std::mutex> lk(mu);
-    for (const auto& r : iv) {  // what earlier pieces of the same buffer have registered
-      if (r.first <= lo && lo < r.second) lo = r.second;
-      if (r.first < hi && hi <= r.second) hi = r.first;
-    }
-    if (lo >= hi) return true;
-    for (const auto& r : iv)
-      if (r.first < hi && lo < r.second) return false;  // an interval in the middle: leave it to the ring
-    if (hipHostRegister((void*)lo, hi - lo, hipHostRegisterDefault) != hipSuccess) {
-      (void)hipGetLastError();
-      return false;
-    }
-    iv.emplace_back(lo, hi);
-    return true;
-  }
-  // the pieces of [p, p + n) by registration: one copy may not span two of them (the runtime refuses it)
-  std::vector<std::pair<uint64_t, uint64_t>> split(const void* p, uint64_t n) {
-    std::vector<std::pair<uint64_t, uint64_t>> out;  // (offset, length)
-    const uintptr_t a = (uintptr_t)p, b = a + n;
-    std::lock_guard<std::mutex> lk(mu);
-    std::vector<std::pair<uintptr_t, uintptr_t>> v(iv);
-    std::sort(v.begin(), v.end());
-    uintptr_t at = a;
-    for (const auto& r : v) {
-      if (r.second <= at || r.first >= b) continue;
-      const uintptr_t e = std::min(b, r.second);
-      out.emplace_back(at - a, e - at);
-      at = e;
-    }
-    if (at < b) out.emplace_back(at - a, b - at);  // (not registered by this call: pinned by the caller)
-    return out;
-  }
-  void release() {
-    std::lock_guard<std::mutex> lk(mu);
-    for (const auto& r : iv) (void)hipHostUnregister((void*)r.first);
-    iv.clear();
-  }
-};
-RegList g_reg;
-// at the end of a host entry point: every copy of the call has landed, the caller's memory is unpinned again
-struct RegScope {
-  ~RegScope() {
-    if (g_reg.iv.empty()) return;
-    if (g.stream) (void)hipStreamSynchronize(g.stream);
-    if (g.cs_in) (void)hipStreamSynchronize(g.cs_in);
-    if (g.cs_out) (void)hipStreamSynchronize(g.cs_out);
-    g_reg.release();
-  }
-};
+// A caller's large pageable buffer goes through the runtime's own copy call: on the MI355X host hipMemcpy reads and
+// writes pageable memory at the rate of pinned memory (1.2 ms per 64 MiB either way, tools/gpu_hostregister_probe.py:
+// it page-locks the range for the copy itself), where the staging ring below costs a memcpy of every byte (~1 ms per
+// 32 MiB with seven helper threads).  The copy is complete when upload()/download() return; in the pipelined calls
+// they run on the side threads.  (Page-locking the caller's buffer in place with hipHostRegister for the whole call
+// was tried: as fast, but a GPU memory fault on a host address turned up in a long fuzz run; the runtime's path it is.)
+// The ring remains for buffers of 256 KiB to 4 MiB: the per-call cost of the runtime's path shows there.
+constexpr uint64_t RUNTIME_COPY_MIN = 4ull << 20;
 
 // host -> device on `stream` (the library's stream by default); returns once the caller's memory has been read
 int upload(uint8_t* d_dst, const uint8_t* src, uint64_t n, hipStream_t stream = nullptr) {
   if (!stream) stream = g.stream;
   if (!n) return ZES_OK;
-  if (n <= STAGE_DIRECT_MAX || is_pinned(src) || g_reg.cover(src, n)) {
-    for (const auto& pc : g_reg.split(src, n)) HIPCHK(hipMemcpyAsync(d_dst + pc.first, src + pc.first, pc.second, hipMemcpyHostToDevice, stream));
+  if (n <= STAGE_DIRECT_MAX || is_pinned(src)) {
+    HIPCHK(hipMemcpyAsync(d_dst, src, n, hipMemcpyHostToDevice, stream));
+    return ZES_OK;
+  }
+  if (n >= RUNTIME_COPY_MIN && !getenv("ZES_STAGE_RING")) {
+    HIPCHK(hipMemcpyAsync(d_dst, src, n, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipStreamSynchronize(stream));  // the caller's memory has been read
     return ZES_OK;
   }
   Stager& S = g_up;
@@ -393,11 +344,15 @@ int upload(uint8_t* d_dst, const uint8_t* src, uint64_t n, hipStream_t stream = 
 // (`wait`: with a pinned destination, return with the copy in flight on `stream`; the caller synchronises)
 int download(uint8_t* dst, const uint8_t* d_src, uint64_t n, hipStream_t stream = nullptr, bool wait = true) {
   if (!stream) stream = g.stream;
-  const bool direct = n <= STAGE_DIRECT_MAX || is_pinned(dst) || g_reg.cover(dst, n);
-  if (n && direct)
-    for (const auto& pc : g_reg.split(dst, n)) HIPCHK(hipMemcpyAsync(dst + pc.first, d_src + pc.first, pc.second, hipMemcpyDeviceToHost, stream));
+  const bool direct = n <= STAGE_DIRECT_MAX || is_pinned(dst);
+  if (n && direct) HIPCHK(hipMemcpyAsync(dst, d_src, n, hipMemcpyDeviceToHost, stream));
   if (direct) {
     if (wait) HIPCHK(hipStreamSynchronize(stream));
+    return ZES_OK;
+  }
+  if (n >= RUNTIME_COPY_MIN && !getenv("ZES_STAGE_RING")) {
+    HIPCHK(hipMemcpyAsync(dst, d_src, n, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
     return ZES_OK;
   }
   Stager& S = g_down;
@@ -1670,13 +1625,11 @@ const char* zes_strerror(int status) {
 
 int zes_init(int device) {
   std::lock_guard<std::mutex> lk(g_mu);
-  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   return init_locked(device);
 }
 
 int zes_shutdown(void) {
   std::lock_guard<std::mutex> lk(g_mu);
-  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   if (!g.ready) return ZES_OK;
   (void)hipSetDevice(g.device);
   (void)hipStreamSynchronize(g.stream);
@@ -1710,7 +1663,6 @@ int zes_host_alloc(uint64_t n, void** p) {
   if (!p) return ZES_E_ARG;
   *p = nullptr;
   std::lock_guard<std::mutex> lk(g_mu);
-  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   int rc = init_locked(-1);
   if (rc) return rc;
   HIPCHK(hipHostMalloc(p, n ? n : 1, hipHostMallocDefault));
@@ -1720,7 +1672,6 @@ int zes_host_alloc(uint64_t n, void** p) {
 int zes_host_free(void* p) {
   if (!p) return ZES_OK;
   std::lock_guard<std::mutex> lk(g_mu);
-  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   if (!g.ready) return ZES_E_ARG;
   (void)hipSetDevice(g.device);
   HIPCHK(hipStreamSynchronize(g.stream));
@@ -1730,7 +1681,6 @@ int zes_host_free(void* p) {
 
 int zes_device_info(char* name, int cap, int* cus, uint64_t* hbm_bytes) {
   std::lock_guard<std::mutex> lk(g_mu);
-  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   int rc = init_locked(-1);
   if (rc) return rc;
   if (name && cap > 0) snprintf(name, (size_t)cap, "%s", g.arch);
@@ -1749,7 +1699,6 @@ int zes_deflate_batch_dev(const uint8_t* d_in, const uint64_t* in_off, const uin
                           const uint64_t* out_off, const uint64_t* out_cap, uint64_t* out_len, int32_t* status, uint32_t count) {
   if (!in_off || !in_len || !out_off || !out_cap || !out_len || !status) return ZES_E_ARG;
   std::lock_guard<std::mutex> lk(g_mu);
-  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   int rc = init_locked(-1);
   if (rc) return rc;
   return deflate_batch_core(d_in, in_off, in_len, d_out, out_off, out_cap, out_len, status, count);
@@ -1886,7 +1835,6 @@ int zes_deflate(const uint8_t* in, uint64_t n, uint8_t* out, uint64_t cap, uint6
   const uint64_t bound = deflate_bound(n);
   {
     std::lock_guard<std::mutex> lk(g_mu);
-    RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
     int rc = init_locked(-1);
     if (rc) return rc;
     if (n >= PIPE_MIN && !getenv("ZES_NO_PIPELINE")) return deflate_host_pipelined(in, n, out, cap, out_len);
@@ -1908,7 +1856,6 @@ int zes_inflate_dev(const uint8_t* d_in, uint64_t c, uint8_t* d_out, uint64_t ca
   if (!out_len) return ZES_E_ARG;
   if ((((uintptr_t)d_in) & 15u) || (((uintptr_t)d_out) & 15u)) return ZES_E_ARG;
   std::lock_guard<std::mutex> lk(g_mu);
-  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   int rc = init_locked(-1);
   if (rc) return rc;
   return inflate_one(d_in, 0, c, d_out, 0, cap, out_len, flags, -1);
@@ -1920,7 +1867,6 @@ int zes_inflate_batch_dev(const uint8_t* d_in, const uint64_t* in_off, const uin
   if (!in_off || !in_len || !out_off || !out_cap || !out_len || !status) return ZES_E_ARG;
   if ((((uintptr_t)d_in) & 15u) || (((uintptr_t)d_out) & 15u)) return ZES_E_ARG;
   std::lock_guard<std::mutex> lk(g_mu);
-  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   int rc = init_locked(-1);
   if (rc) return rc;
   for (uint32_t i = 0; i < count; i++) status[i] = ((in_off[i] & 15u) || (out_off[i] & 15u)) ? ZES_E_ARG : ZES_OK;
@@ -2029,7 +1975,6 @@ static int inflate_host(const uint8_t* in, uint64_t c, uint8_t* out, uint64_t ca
   *out_len = 0;
   if (c == 0 || (in[0] & 15u) != 8u) return ZES_E_NOT_DEFLATE;  // src/zlib.ts:13-16, decided before the device is touched
   std::lock_guard<std::mutex> lk(g_mu);
-  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   int rc = init_locked(-1);
   if (rc) return rc;
   if (c >= PIPE_IN_MIN && c < (1ull << 29) && !size_only && (out || alloc) && !(flags & (ZES_F_NO_FASTPATH | ZES_F_PIECES)) &&
@@ -2081,7 +2026,6 @@ int zes_deflate_batch(const uint8_t* const* in, const uint64_t* in_len, uint8_t*
                       uint64_t* out_len, int32_t* status, uint32_t count) {
   if (!in || !in_len || !out || !out_cap || !out_len || !status) return ZES_E_ARG;
   std::lock_guard<std::mutex> lk(g_mu);
-  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   int rc = init_locked(-1);
   if (rc) return rc;
   std::vector<uint64_t> in_off(count), o_off(count), o_cap(count), dl(count);
@@ -2116,7 +2060,6 @@ int zes_inflate_batch_alloc(const uint8_t* const* in, const uint64_t* in_len, ze
                             int32_t* status, uint32_t count, uint32_t flags) {
   if (!in || !in_len || !alloc || !out_len || !status) return ZES_E_ARG;
   std::lock_guard<std::mutex> lk(g_mu);
-  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   int rc = init_locked(-1);
   if (rc) return rc;
   std::vector<uint64_t> in_off(count), o_off(count), o_cap(count);
@@ -2202,7 +2145,6 @@ int zes_deflate_range_dev(const uint8_t* d_in, uint64_t n, uint64_t n_readable, 
   if ((n % ZES_BLK) == 1) return ZES_E_CORRUPT;         // the reference throws on a 1-byte last block
   if ((((uintptr_t)d_in) & 15u) || (((uintptr_t)d_out) & 15u)) return ZES_E_ARG;
   std::lock_guard<std::mutex> lk(g_mu);
-  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   int rc = init_locked(-1);
   if (rc) return rc;
   uint64_t zero = 0, bits = 0;
@@ -2237,7 +2179,6 @@ int zes_deflate_join_dev(const uint8_t* const* d_piece, const uint64_t* piece_bi
   *out_len = total;
   if (total > cap) return ZES_E_NOSPACE;
   std::lock_guard<std::mutex> lk(g_mu);
-  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   int rc = init_locked(-1);
   if (rc) return rc;
   HIPCHK(hipMemsetAsync(d_out, 0, (total + 3) & ~3ull, g.stream));  // (cap of a deflate result always has the slack: zes_deflate_bound)
@@ -2268,7 +2209,6 @@ int zes_inflate_range_dev(const uint8_t* d_in, uint64_t c, uint64_t lo_bit, uint
   if (!d_in || !out_len || !first_bit || !end_bit || !nblocks || !final_block || lo_bit < 16 || own_bit <= lo_bit) return ZES_E_ARG;
   if ((((uintptr_t)d_in) & 15u) || (((uintptr_t)d_out) & 15u) || c >= (1ull << 29)) return ZES_E_ARG;
   std::lock_guard<std::mutex> lk(g_mu);
-  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   int rc = init_locked(-1);
   if (rc) return rc;
   RangeRes rr;
@@ -2286,7 +2226,6 @@ int zes_inflate_range_dev(const uint8_t* d_in, uint64_t c, uint64_t lo_bit, uint
 int zes_adler32_dev(const uint8_t* d_in, uint64_t n, uint32_t* adler_out) {
   if (!adler_out) return ZES_E_ARG;
   std::lock_guard<std::mutex> lk(g_mu);
-  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   int rc = init_locked(-1);
   if (rc) return rc;
   return adler32_locked(d_in, n, adler_out);
@@ -2306,7 +2245,6 @@ int zes_inflate_raw_dev(const uint8_t* d_in, uint64_t c, uint64_t offset, uint8_
   if (!out_len || (!d_in && c)) return ZES_E_ARG;
   if ((((uintptr_t)d_out) & 15u)) return ZES_E_ARG;
   std::lock_guard<std::mutex> lk(g_mu);
-  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   int rc = init_locked(-1);
   if (rc) return rc;
   const uint64_t n = offset < c ? c - offset : 0;
@@ -2319,7 +2257,6 @@ int zes_inflate_raw(const uint8_t* in, uint64_t c, uint64_t offset, uint8_t* out
   if (!out_len || (!in && c)) return ZES_E_ARG;
   *out_len = 0;
   std::lock_guard<std::mutex> lk(g_mu);
-  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   int rc = init_locked(-1);
   if (rc) return rc;
   const uint64_t n = offset < c ? c - offset : 0;
@@ -2361,7 +2298,6 @@ int zes_deflate_raw_dev(const uint8_t* d_in, uint64_t n, uint8_t* d_out, uint64_
   *out_len = 0;
   if (deflate_throws(n)) return ZES_E_CORRUPT;
   std::lock_guard<std::mutex> lk(g_mu);
-  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   int rc = init_locked(-1);
   if (rc) return rc;
   uint64_t rl = 0;
@@ -2378,7 +2314,6 @@ int zes_deflate_raw(const uint8_t* in, uint64_t n, uint8_t* out, uint64_t cap, u
   *out_len = 0;
   if (deflate_throws(n)) return ZES_E_CORRUPT;
   std::lock_guard<std::mutex> lk(g_mu);
-  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   int rc = init_locked(-1);
   if (rc) return rc;
   if ((rc = ensure(g.st_in, n + 64))) return rc;
@@ -2392,8 +2327,7 @@ int zes_deflate_raw(const uint8_t* in, uint64_t n, uint8_t* out, uint64_t cap, u
 
 int zes_adler32(const uint8_t* in, uint64_t n, uint32_t* adler_out) {
   if (!adler_out || (!in && n)) return ZES_E_ARG;
-  std::lock_guard<std::mutex> lk(g_mu);
-  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)  // staging and kernel under one lock: nobody else's call can replace st_in in between
+  std::lock_guard<std::mutex> lk(g_mu);  // staging and kernel under one lock: nobody else's call can replace st_in in between
   int rc = init_locked(-1);
   if (rc) return rc;
   if ((rc = ensure(g.st_in, n + 64))) return rc;
@@ -2404,7 +2338,6 @@ int zes_adler32(const uint8_t* in, uint64_t n, uint32_t* adler_out) {
 int zes_stage_lz77_dev(const uint8_t* d_in, uint64_t n, uint64_t start, uint32_t len, uint32_t* h_tokens, uint32_t* ntokens) {
   if (!h_tokens || !ntokens || len < 2 || len > ZES_BLK || start + len > n || (start % ZES_BLK)) return ZES_E_ARG;
   std::lock_guard<std::mutex> lk(g_mu);
-  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   int rc = init_locked(-1);
   if (rc) return rc;
   ZesBuf b;
@@ -2446,7 +2379,6 @@ int zes_stage_lz77_dev(const uint8_t* d_in, uint64_t n, uint64_t start, uint32_t
 int zes_stage_huff_lengths_dev(const uint32_t* h_hist, uint32_t nsym, uint32_t maxlen, uint8_t* h_lens) {
   if (!h_hist || !h_lens || nsym == 0 || nsym > 288 || maxlen == 0 || maxlen > 15) return ZES_E_ARG;
   std::lock_guard<std::mutex> lk(g_mu);
-  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   int rc = init_locked(-1);
   if (rc) return rc;
   if ((rc = ensure(g.hists, 320 * 4))) return rc;
@@ -2462,20 +2394,17 @@ int zes_stage_huff_lengths_dev(const uint32_t* h_hist, uint32_t nsym, uint32_t m
 
 int zes_last_inflate_tier(void) {
   std::lock_guard<std::mutex> lk(g_mu);
-  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   return g.last_tier;
 }
 
 int zes_set_profiling(int on) {
   std::lock_guard<std::mutex> lk(g_mu);
-  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   g.profiling = on != 0;
   return ZES_OK;
 }
 
 int zes_last_kernel_times(zes_ktime* out, int cap) {
   std::lock_guard<std::mutex> lk(g_mu);
-  RegScope reg_scope;  // (unpins what the call page-locked of the caller's memory)
   int n = 0;
   g.name_pool.clear();
   for (auto& e : g.last_times) g.name_pool.push_back(e.first);
