@@ -444,6 +444,59 @@ def test_inflate_foreign_stream_sweep(z, gpu):
     assert not slow, slow
 
 
+def test_segment_tier_block_decoder_and_wave_decoder_agree(z, gpu):
+    """The segment-parallel tier sends every work item to the block decoder first (k_inf_seg_block_par) and the items
+    it declines — stored and fixed blocks, blocks behind a start that is not on the list, blocks of more than
+    128 KiB — to the wave decoder; ZES_NO_SEG_PAR=1 sends everything to the wave decoder.  Same bytes either way,
+    and the input back."""
+    import zlib as pz
+
+    text = z.gen("itext", 91, 5 << 20)
+    low = z.gen("lowent4k", 92, 6 << 20)
+    rnd = z.gen("xorshift", 93, 1 << 20)
+    mixed = np.concatenate([text[:1500000], low[:2000000], rnd[:300000], text[1500000:3000000], low[2000000:2300000]])
+    cases = []
+    for name, data in (("text", text), ("pattern", low), ("mixed", mixed)):
+        for level, mem, strat, flush in ((6, 8, pz.Z_DEFAULT_STRATEGY, None), (9, 9, pz.Z_DEFAULT_STRATEGY, pz.Z_SYNC_FLUSH),
+                                         (1, 8, pz.Z_DEFAULT_STRATEGY, pz.Z_FULL_FLUSH), (6, 8, pz.Z_FIXED, None),
+                                         (4, 3, pz.Z_DEFAULT_STRATEGY, pz.Z_SYNC_FLUSH)):
+            co = pz.compressobj(level, pz.DEFLATED, 15, mem, strat)
+            parts, b, step = [], data.tobytes(), len(data) // 5 + 1
+            for o in range(0, len(b), step):
+                parts.append(co.compress(b[o:o + step]))
+                if flush is not None:
+                    parts.append(co.flush(flush))
+            parts.append(co.flush())
+            cases.append(("%s level %d mem %d strategy %d flush %s" % (name, level, mem, strat, flush), np.frombuffer(b"".join(parts), dtype=np.uint8).copy(), data))
+    for name, comp, data in cases:
+        a = z.inflate(comp)
+        ta = z.last_inflate_tier()
+        os.environ["ZES_NO_SEG_PAR"] = "1"
+        try:
+            b = z.inflate(comp)
+        finally:
+            del os.environ["ZES_NO_SEG_PAR"]
+        assert a.tobytes() == data.tobytes() and b.tobytes() == data.tobytes(), name
+        assert ta == z.last_inflate_tier(), (name, ta, z.last_inflate_tier())
+        # damaged in the middle: the same result (bytes or the reference's error) both ways
+        bad = comp.copy()
+        bad[len(bad) // 2] ^= 0x10
+
+        def run():
+            try:
+                return ("out", z.inflate(bad).tobytes())
+            except z.ZlibEsError as e:
+                return ("err", str(e))
+
+        ra = run()
+        os.environ["ZES_NO_SEG_PAR"] = "1"
+        try:
+            rb = run()
+        finally:
+            del os.environ["ZES_NO_SEG_PAR"]
+        assert ra == rb, name
+
+
 def test_inflate_reports_needed_size(z, oracle, gpu):
     import torch
 
