@@ -37,6 +37,9 @@
 
 #define RES_W 4096u    // P4: bytes of the image resolved at a time (a multiple of PAR_THREADS and of 8)
 #define RES_REPS 4u    // pointer-jumping steps between two barriers
+#define PAR_CHUNK (ZES_BLK - 3u * RES_W)  // T2: bytes of a block's output resolved per pass over the image; behind them: room for a match record at the chunk's last byte and P4's distance array (the decode tables stay alive for the next chunk)
+#define PAR_DIST_OFF (PAR_CHUNK + 64u)
+#define PAR_MAX_OUT (1u << 27)      // T2: longest block taken (output bytes)
 #define STAGE_DW ((ZES_BLK + ZES_BLK / 8) / 4)  // compressed bytes staged over the image + bitmap until P3
 struct ParSmem {
   uint8_t out[ZES_BLK];            // P0-P2: first part of the staged compressed block (swizzled dwords)
@@ -675,7 +678,9 @@ __device__ __forceinline__ static void seg_table(ParSmem& S, const BitSrc& src, 
 // Decodes tokens from bit `entry` while the token start is below `stop`.
 template <bool EMIT, bool LDS, bool HIST = false>
 __device__ __forceinline__ static void seg_decode(ParSmem& S, const BitSrc& src, uint32_t limit, uint32_t entry, uint32_t stop,
-                                                  uint32_t out_off, uint32_t& exit_pos, uint32_t& outbytes, uint32_t& flags) {
+                                                  uint32_t out_off, uint32_t& exit_pos, uint32_t& outbytes, uint32_t& flags,
+                                                  uint32_t clo = 0) {
+  // (HIST, the any-encoder form: output positions are clipped to the chunk [clo, clo + PAR_CHUNK) of the image)
   LaneBits b;
   lb_seek<LDS>(b, src, entry);
   uint32_t ob = 0, fl = 0;
@@ -691,23 +696,29 @@ __device__ __forceinline__ static void seg_decode(ParSmem& S, const BitSrc& src,
       break;
     }
     if (kind == T_LIT) {
-      if (EMIT) S.out[out_off + ob] = (uint8_t)v;
+      if (EMIT) {
+        const uint32_t q = out_off + ob - clo;
+        if (!HIST || q < PAR_CHUNK) S.out[q] = (uint8_t)v;
+      }
       ob++;
     } else {
       if (EMIT) {
-        const uint32_t p = out_off + ob;
+        const uint32_t p = out_off + ob, q = p - clo;
         if (!HIST && dist > p) {
           fl |= F_HIST;  // looks behind the block start: not a reference-made block
-        } else {
-          S.out[p] = (uint8_t)(dist - 1u);
-          S.out[p + 1] = (uint8_t)((dist - 1u) >> 8);
-          S.out[p + 2] = (uint8_t)(len - 3u);
-          atomicOr(&S.bitmap[p >> 5], 1u << (p & 31u));
+        } else if (!HIST || q < PAR_CHUNK) {
+          S.out[q] = (uint8_t)(dist - 1u);
+          S.out[q + 1] = (uint8_t)((dist - 1u) >> 8);
+          S.out[q + 2] = (uint8_t)(len - 3u);
+          atomicOr(&S.bitmap[q >> 5], 1u << (q & 31u));
+        } else if (p < clo && p + len > clo) {  // the match that runs into the chunk from the one before
+          S.res_strad[0] = p + len - clo;
+          S.res_strad[1] = dist;
         }
       }
       ob += len;
     }
-    if (ob > ZES_BLK) {  // more than a slot: not a reference-made block
+    if (ob > (HIST ? PAR_MAX_OUT : ZES_BLK)) {  // more than a slot: not a reference-made block
       fl |= F_FAIL;
       break;
     }
@@ -722,7 +733,7 @@ __device__ __forceinline__ static void seg_decode(ParSmem& S, const BitSrc& src,
 template <bool EMIT, bool LDS, bool HIST = false>
 __device__ __forceinline__ static void seg_run(ParSmem& S, const BitSrc& src, uint32_t limit, uint32_t entry, uint32_t stop, bool live,
                                                const Lit8& f8, uint32_t out_off, uint32_t& exit_pos, uint32_t& outbytes,
-                                               uint32_t& flags) {
+                                               uint32_t& flags, uint32_t clo = 0) {
   LaneBits b;
   lb_seek<LDS>(b, src, live ? entry : 0u);
   uint32_t ob = 0, fl = 0;
@@ -733,7 +744,7 @@ __device__ __forceinline__ static void seg_run(ParSmem& S, const BitSrc& src, ui
       for (int rep = 0; rep < 3; rep++) {
         lb_refill<LDS>(b, src);
         const uint32_t w = (uint32_t)b.bb;
-        const bool fast = act && b.pos + 32u <= stop && b.pos + 32u <= limit && ob + 4u <= ZES_BLK;
+        const bool fast = act && b.pos + 32u <= stop && b.pos + 32u <= limit && ob + 4u <= (HIST ? PAR_MAX_OUT : ZES_BLK);
         const uint32_t nlit = fast ? lead_lit8(w, f8) : 0u;
         if (EMIT && nlit) {
           // symbols of all four candidates are looked up (clamped into the table), the stores are per byte:
@@ -795,23 +806,29 @@ __device__ __forceinline__ static void seg_run(ParSmem& S, const BitSrc& src, ui
     }
     if (act) {
       if (kind == 0u) {
-        if (EMIT) S.out[out_off + ob] = (uint8_t)(e >> 16);
+        if (EMIT) {
+          const uint32_t q = out_off + ob - clo;
+          if (!HIST || q < PAR_CHUNK) S.out[q] = (uint8_t)(e >> 16);
+        }
         ob += 1u;
       } else {
         if (EMIT) {
-          const uint32_t p = out_off + ob;
+          const uint32_t p = out_off + ob, q = p - clo;
           if (!HIST && dist > p) {
             fl |= F_HIST;  // looks behind the block start: not a reference-made block
-          } else {
-            S.out[p] = (uint8_t)(dist - 1u);
-            S.out[p + 1] = (uint8_t)((dist - 1u) >> 8);
-            S.out[p + 2] = (uint8_t)(len - 3u);
-            atomicOr(&S.bitmap[p >> 5], 1u << (p & 31u));
+          } else if (!HIST || q < PAR_CHUNK) {
+            S.out[q] = (uint8_t)(dist - 1u);
+            S.out[q + 1] = (uint8_t)((dist - 1u) >> 8);
+            S.out[q + 2] = (uint8_t)(len - 3u);
+            atomicOr(&S.bitmap[q >> 5], 1u << (q & 31u));
+          } else if (p < clo && p + len > clo) {  // the match that runs into the chunk from the one before
+            S.res_strad[0] = p + len - clo;
+            S.res_strad[1] = dist;
           }
         }
         ob += len;
       }
-      if (ob > ZES_BLK) {  // more than a slot: not a reference-made block
+      if (ob > (HIST ? PAR_MAX_OUT : ZES_BLK)) {  // more than a slot: not a reference-made block
         fl |= F_FAIL;
         act = false;
       }
@@ -1206,7 +1223,7 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
 
   // ---- P2: count pass from the true entries, totals, end bit, output offsets ----
   uint32_t entry = base + ecode, exit_pos = 0, outbytes = 0, flags = 0;
-  seg_run<false, true>(S, src, limit, entry, stop, ecode < 48u, f8, 0, exit_pos, outbytes, flags);
+  seg_run<false, true, FOREIGN>(S, src, limit, entry, stop, ecode < 48u, f8, 0, exit_pos, outbytes, flags);
   if (ecode >= 48u) flags = F_VOID;
   if (tid == 0) {
     S.tail_bytes = 0;
@@ -1222,7 +1239,7 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
     tail_start = (uint32_t)(last_stop + tail_code);
     if (tid == 0) {
       uint32_t ex, ob, fl;
-      seg_decode<false, false>(S, src, limit, tail_start, 0xFFFFFF00u, 0, ex, ob, fl);
+      seg_decode<false, false, FOREIGN>(S, src, limit, tail_start, 0xFFFFFF00u, 0, ex, ob, fl);
       S.tail_bytes = ob;
       S.tail_end = ex;
       if (!(fl & F_EOB) || (fl & F_FAIL)) atomicOr(&S.status, 2u);
@@ -1258,7 +1275,7 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
     total += S.tail_bytes;
     const uint32_t st = S.status;
     const uint32_t end_bit = (tail_code < 48u) ? S.tail_end : S.hdr_end;
-    const bool good = (st & 4u) && !(st & 2u) && total <= ZES_BLK && (!FOREIGN || (uint64_t)total <= it.sym_cap);
+    const bool good = (st & 4u) && !(st & 2u) && total <= (FOREIGN ? PAR_MAX_OUT : ZES_BLK) && (!FOREIGN || (uint64_t)total <= it.sym_cap);
     if (!good) {
       PAR_DECLINE(end_bit, total);
       return;
@@ -1266,15 +1283,31 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
     const uint32_t my_off = wbase + incl - outbytes;
     STAMP(4);
 
+    // T2: a block longer than the image is emitted and resolved chunk by chunk (clo = first byte of the chunk); T1 and
+    // blocks of up to PAR_CHUNK bytes make one pass.  (A jump back instead of a loop: T1 gets no back edge.)
+    uint32_t clo = 0;
+    static_assert(PAR_CHUNK % RES_W == 0 && PAR_DIST_OFF + 2u * RES_W <= ZES_BLK, "T2: the distance array lies behind the chunk");
+  next_chunk:
+    const uint32_t clen = FOREIGN ? min(PAR_CHUNK, total - clo) : total;
+    if (FOREIGN) {
+      if (tid < 4u) S.res_strad[tid] = 0u;  // (the emit pass sets the match that runs in from the chunk before)
+      if (clo) {
+        for (uint32_t i = tid; i < ZES_BLK / 32; i += PAR_THREADS) S.bitmap[i] = 0;
+      }
+      __syncthreads();
+    }
     // ---- P3: emit (compressed bits from global memory: the LDS now holds the output image) ----
     uint32_t f2 = 0;
     {
       uint32_t ex2, ob2;
-      seg_run<true, false, FOREIGN>(S, src, limit, entry, stop, !(flags & F_VOID) && entry < stop, f8, my_off, ex2, ob2, f2);
+      const Lit8 f8e = (FOREIGN && total > PAR_CHUNK) ? Lit8{0, 0, 0} : f8;  // (the four-literal store is not clipped to a chunk)
+      // T2: a lane whose output lies outside the chunk has nothing to emit
+      const bool inchunk = !FOREIGN || (my_off < clo + PAR_CHUNK && my_off + outbytes > clo);
+      seg_run<true, false, FOREIGN>(S, src, limit, entry, stop, !(flags & F_VOID) && entry < stop && inchunk, f8e, my_off, ex2, ob2, f2, clo);
     }
     if (tid == 0 && tail_code < 48u) {
       uint32_t ex2, ob2, f3 = 0;
-      seg_decode<true, false, FOREIGN>(S, src, limit, tail_start, 0xFFFFFF00u, seg_total, ex2, ob2, f3);
+      seg_decode<true, false, FOREIGN>(S, src, limit, tail_start, 0xFFFFFF00u, seg_total, ex2, ob2, f3, clo);
       f2 |= f3;
     }
     if (f2 & F_HIST) atomicOr(&S.status, 8u);
@@ -1296,9 +1329,10 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
     // below it — and then all bytes of the window are copied at once.  Overlapping copies (distance < length)
     // need no special case: byte p+5 of a run with D = 1 simply has the parent p+4.
     {
-      uint16_t* dist = reinterpret_cast<uint16_t*>(S.lut_l);  // the decode tables are dead: [RES_W] entries over them
+      // T1: the decode tables are dead, [RES_W] entries over them; T2: behind the chunk (the tables serve the next one)
+      uint16_t* dist = FOREIGN ? reinterpret_cast<uint16_t*>(S.out + PAR_DIST_OFF) : reinterpret_cast<uint16_t*>(S.lut_l);
       if (tid < 3u) S.res_flag[tid] = 0u;
-      if (tid < 4u) S.res_strad[tid] = 0u;
+      if (!FOREIGN && tid < 4u) S.res_strad[tid] = 0u;
       __syncthreads();
       unsigned long long tacc[4] = {0, 0, 0, 0}, tlast = dbg ? clock64() : 0ull, nrounds = 0;  // ZES_DEBUG_PHASES: cycles of the four steps
 #define P4LAP(i)                                         \
@@ -1309,8 +1343,8 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
       tlast = now_;                                      \
     }                                                    \
   } while (0)
-      for (uint32_t ws = 0; ws < total; ws += RES_W) {
-        const uint32_t wlen = min(RES_W, total - ws);
+      for (uint32_t ws = 0; ws < clen; ws += RES_W) {
+        const uint32_t wlen = min(RES_W, clen - ws);
         // (a) per 32 positions of the window: the last match start at or before them (matches do not overlap each
         // other, so the nearest start in front of a byte is the only match that can cover it)
         if (tid < RES_W / 32u) {
@@ -1422,17 +1456,20 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
           uint32_t sy[RES_W / PAR_THREADS];
 #pragma unroll
           for (uint32_t k = 0; k < RES_W / PAR_THREADS; k++) {
-            const uint32_t b = tid + k * PAR_THREADS, P = ws + b;
-            const int32_t a = (int32_t)P - (int32_t)d[k];
+            const uint32_t b = tid + k * PAR_THREADS, P = ws + b;  // (positions inside the chunk)
+            const int32_t a = (int32_t)P - (int32_t)d[k];           // the ancestor, chunk-relative
+            const int32_t ab = a + (int32_t)clo;                    // ... block-relative
             const uint32_t ai = a < 0 ? 0u : (uint32_t)a;
-            const bool hist = a < 0;
-            const bool mk = !hist && ai < ws && ((S.bitmap[ai >> 5] >> (ai & 31u)) & 1u);
+            const bool hist = ab < 0;                               // in front of the block: a marker
+            const bool prior = !hist && a < 0;                      // in a chunk resolved before: its symbol is in the store
+            const bool mk = a >= 0 && ai < ws && ((S.bitmap[ai >> 5] >> (ai & 31u)) & 1u);
             uint32_t v = S.out[ai];
-            if (mk) {
-              const uint32_t wd = __hip_atomic_load(&it.sym[ai >> 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              v = (ai & 1u) ? wd >> 16 : wd & 0xffffu;
+            if (mk || prior) {
+              const uint32_t gi = (uint32_t)ab;
+              const uint32_t wd = __hip_atomic_load(&it.sym[gi >> 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              v = (gi & 1u) ? wd >> 16 : wd & 0xffffu;
             }
-            v = hist ? (uint32_t)(256 + (int32_t)ZES_WINDOW + a) : v;
+            v = hist ? (uint32_t)(256 + (int32_t)ZES_WINDOW + ab) : v;
             sy[k] = v;
           }
 #pragma unroll
@@ -1440,7 +1477,7 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
             const uint32_t b = tid + k * PAR_THREADS;
             if (b < wlen) {
               S.out[ws + b] = (uint8_t)sy[k];
-              sym16[ws + b] = (uint16_t)sy[k];
+              sym16[clo + ws + b] = (uint16_t)sy[k];
             }
             // marker flags over this window's (dead) match bits: lanes tid .. tid + 63 of a wave are 64 consecutive bytes
             const uint64_t mm = __ballot(b < wlen && sy[k] >= 256u);
@@ -1449,6 +1486,8 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
               S.bitmap[((ws + b) >> 5) + 1u] = (uint32_t)(mm >> 32);
             }
           }
+          // (read back later by this workgroup only, past a barrier, with loads that go to the L2: same-CU accesses stay in
+          // order, no device-wide fence — which would write the whole L2 back: measured 4.7x slower)
         }
         P4LAP(3);
         if (tid == 0) {
@@ -1465,6 +1504,10 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
 #undef P4LAP
     }
     __syncthreads();
+    if (FOREIGN) {
+      clo += PAR_CHUNK;
+      if (clo < total) goto next_chunk;
+    }
 
     STAMP(6);
     if (!FOREIGN) {
