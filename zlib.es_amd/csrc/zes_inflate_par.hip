@@ -36,6 +36,8 @@
 #define F_HIST 8u
 
 #define RES_W 4096u    // P4: bytes of the image resolved at a time (a multiple of PAR_THREADS and of 8)
+#define P4_SPARSE_DEP_MAX 32u  // ... of which at most this many copy from another match's bytes
+#define P4_SPARSE_MAX 1024u  // P4 (T1): a block with at most this many matches is copied match by match
 #define RES_REPS 4u    // pointer-jumping steps between two barriers
 #define PAR_CHUNK (ZES_BLK - 3u * RES_W)  // T2: bytes of a block's output resolved per pass over the image; behind them: room for a match record at the chunk's last byte and P4's distance array (the decode tables stay alive for the next chunk)
 #define PAR_DIST_OFF (PAR_CHUNK + 64u)
@@ -62,6 +64,7 @@ struct ParSmem {
   uint32_t res_lastw[RES_W / 32];  // P4: last match start (+1) at or before each 32 positions of the window
   uint32_t res_strad[4];      // P4: end and distance of the match that runs into the window from the one before; the next one's
   uint32_t f8lo, f8n, f8off;  // 8-bit literal codes: first code value, how many (0 = fast path off), index into syms_l
+  uint32_t sp_n;  // P4, few matches: how many
 };
 
 static_assert(offsetof(ParSmem, cl_lut) - offsetof(ParSmem, lut_l) >= RES_W * 2u, "P4's distance array lies over the decode tables");
@@ -1343,7 +1346,115 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
       tlast = now_;                                      \
     }                                                    \
   } while (0)
-      for (uint32_t ws = 0; ws < clen; ws += RES_W) {
+      // T1, few matches in the whole block (incompressible data: ~260 of 3-4 bytes among 131072 literals): the windows
+      // below cost ~4.5k cycles each whatever is in them — 140k cycles a block.  Instead: list the matches (positions
+      // ascending), find the ones whose source bytes are all literals — nearly all: they copy from final bytes, side by
+      // side, one wave per match — and let one wave do the others in order.  Byte j of a match is byte (j mod D) of the
+      // D bytes in front of it, overlapping or not (src/inflate.ts:287-290 copies byte by byte).
+      bool sparse_done = false;
+      if (!FOREIGN) {
+        static_assert(sizeof(S.lut_l) >= P4_SPARSE_MAX * 4u && sizeof(S.lut_d) >= P4_SPARSE_MAX, "the lists lie over the dead decode tables");
+        uint32_t* sp_list = S.lut_l;
+        uint8_t* sp_dep = reinterpret_cast<uint8_t*>(S.lut_d);
+        uint32_t bw[ZES_BLK / 32 / PAR_THREADS], cnt4 = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < ZES_BLK / 32 / PAR_THREADS; k++) {
+          bw[k] = S.bitmap[tid * (ZES_BLK / 32 / PAR_THREADS) + k];
+          cnt4 += (uint32_t)__popc(bw[k]);
+        }
+        uint32_t incl = cnt4;
+#pragma unroll
+        for (int dlt = 1; dlt < 64; dlt <<= 1) {
+          const uint32_t t = __shfl_up(incl, dlt);
+          if ((int)lane >= dlt) incl += t;
+        }
+        __syncthreads();  // (wave_sum is read by the phases before)
+        if (lane == 63) S.wave_sum[wave] = incl;
+        __syncthreads();
+        uint32_t wbase2 = 0, nm = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < PAR_WAVES; k++) {
+          const uint32_t sm = S.wave_sum[k];
+          if (k < wave) wbase2 += sm;
+          nm += sm;
+        }
+        auto rec_of = [&](uint32_t P, uint32_t& D, uint32_t& L) {
+          D = ((uint32_t)S.out[P] | ((uint32_t)S.out[P + 1u] << 8)) + 1u;
+          L = (uint32_t)S.out[P + 2u] + 3u;
+        };
+        if (tid == 0) S.sp_n = 0;
+        if (nm <= P4_SPARSE_MAX) {  // (uniform)
+          uint32_t kk = wbase2 + incl - cnt4;
+#pragma unroll
+          for (uint32_t k = 0; k < ZES_BLK / 32 / PAR_THREADS; k++) {
+            uint32_t w = bw[k];
+            while (w) {
+              const uint32_t bit = (uint32_t)__builtin_ctz(w);
+              w &= w - 1u;
+              sp_list[kk++] = 32u * (tid * (ZES_BLK / 32 / PAR_THREADS) + k) + bit;
+            }
+          }
+          __syncthreads();
+          // which matches copy bytes that another match produces?  (the list is sorted: lower bound, then a short walk)
+          if (tid < nm) {
+            uint32_t P = sp_list[tid], D, L;
+            rec_of(P, D, L);
+            const uint32_t a = P - D, b = a + min(D, L);  // source bytes [a, b)   (D <= P in this tier: checked at emit)
+            const uint32_t from = a > (ZES_MAXMATCH - 1u) ? a - (ZES_MAXMATCH - 1u) : 0u;
+            uint32_t lo = 0, hi = nm;
+            while (lo < hi) {
+              const uint32_t mid = (lo + hi) >> 1;
+              if (sp_list[mid] < from) lo = mid + 1u; else hi = mid;
+            }
+            uint32_t dep = 0;
+            for (; lo < nm; lo++) {
+              const uint32_t Q = sp_list[lo];
+              if (Q >= b) break;
+              if (Q + (uint32_t)S.out[Q + 2u] + 3u > a) {
+                dep = 1;
+                break;
+              }
+            }
+            sp_dep[tid] = (uint8_t)dep;
+            if (dep) atomicAdd(&S.sp_n, 1u);
+          }
+          __syncthreads();
+          // many of them (the 4 KiB pattern: every match copies what the match 4096 bytes earlier produced): one wave doing
+          // them in order would be slower than the windows below (measured 561k cycles against 230k)
+          sparse_done = S.sp_n <= P4_SPARSE_DEP_MAX;
+        }
+        if (sparse_done) {
+          auto copy_match = [&](uint32_t P, uint32_t L, uint32_t D) {
+            // byte j <- byte (j mod D) of the D bytes in front of P; j / D by a 32-bit reciprocal (j < 512: exact)
+            const uint32_t rcp = (D > 1u && D < L) ? 0xFFFFFFFFu / D + 1u : 0u;
+            for (uint32_t j = lane; j < L; j += 64u) {
+              const uint32_t q = D >= L ? 0u : (D > 1u ? __umulhi(j, rcp) : j);
+              S.out[P + j] = S.out[P - D + (j - q * D)];
+            }
+          };
+          for (uint32_t i = wave; i < nm; i += PAR_WAVES) {
+            if (sp_dep[i]) continue;
+            uint32_t P = sp_list[i], D, L;
+            rec_of(P, D, L);
+            copy_match(P, L, D);
+          }
+          __syncthreads();
+          if (wave == 0u) {
+            for (uint32_t base = 0; base < nm; base += 64u) {
+              uint64_t m = __ballot(base + lane < nm && sp_dep[base + lane] != 0u);
+              while (m) {
+                const uint32_t i = base + (uint32_t)__builtin_ctzll(m);
+                m &= m - 1ull;
+                uint32_t P = sp_list[i], D, L;
+                rec_of(P, D, L);
+                copy_match(P, L, D);
+              }
+            }
+          }
+          __syncthreads();
+        }
+      }
+      for (uint32_t ws = 0; ws < (sparse_done ? 0u : clen); ws += RES_W) {
         const uint32_t wlen = min(RES_W, clen - ws);
         // (a) per 32 positions of the window: the last match start at or before them (matches do not overlap each
         // other, so the nearest start in front of a byte is the only match that can cover it)
