@@ -44,7 +44,7 @@ struct Ctx {
   // deflate scratch
   DevBuf bufs, blks, idx_a, idx_b, inv, sdelta, hists, codes, hdrs, adler, res;
   // inflate scratch
-  DevBuf surv, vlong, segfail, cand, cand_sorted, counters, cres, map, resume, dbg, ibufs, ibufs2, mvlist, scratch, sres, maps, seglist, segprefix, wins, sym16, segorder, segjobs, pw16, gwins;
+  DevBuf surv, vlong, segfail, symoff, cand, cand_sorted, counters, cres, map, resume, dbg, ibufs, ibufs2, mvlist, scratch, sres, maps, seglist, segprefix, wins, sym16, segorder, segjobs, pw16, gwins;
   // staging for the host-pointer API
   DevBuf st_in, st_out;
   DevBuf kraft;  // k_inf_scan's table: Kraft contribution of four 3-bit code-length fields at once
@@ -1111,7 +1111,11 @@ int inflate_segments_run(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, cons
   // as many as a 2 GiB store holds, up to DEFLATE's own limit of 1032 bytes per compressed byte
   uint32_t ratio = (uint32_t)std::min<uint64_t>(1032, (2ull << 30) / (2 * csum)) & ~1u;
   if (ratio < 4) ratio = 0;
-  if (ratio && ensure(g.sym16, (size_t)csum * ratio * 2)) ratio = 0;  // no memory for it: two decodes
+  // behind the shares: a common area of a quarter of their size (at least 64 MiB), handed out by need to blocks whose
+  // share is too small for them (a false candidate inside the block has cut it short, or the block inflates further)
+  const uint64_t share_syms = (uint64_t)csum * ratio;
+  const uint64_t bump_syms = ratio ? std::max<uint64_t>(share_syms / 4, 32ull << 20) & ~7ull : 0;
+  if (ratio && ensure(g.sym16, (size_t)(share_syms + bump_syms) * 2 + 64)) ratio = 0;  // no memory for it: two decodes
   uint64_t sym_base = 0;
   for (uint32_t k = 0; k < nb; k++) {
     const InfJob& j = jobs[ids[k]];
@@ -1131,6 +1135,7 @@ int inflate_segments_run(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, cons
   if ((rc = ensure(g.seglist, (size_t)work * 4))) return rc;
   if ((rc = ensure(g.segprefix, (size_t)work * 8))) return rc;
   if ((rc = ensure(g.segorder, (size_t)work * 4))) return rc;
+  if ((rc = ensure(g.symoff, (size_t)work * 8 + 8))) return rc;  // per work item: where its symbols are; behind them: the common area's fill
   if ((rc = ensure(g.res, sizeof(ZesRes) * nb))) return rc;
   HIPCHK(hipMemcpyAsync(g.segjobs.p, hj, sizeof(ZesSegJob) * nb, hipMemcpyHostToDevice, g.stream));
   HIPCHK(hipMemsetAsync(dscratch, 0, (size_t)nb * 8 + 4, g.stream));
@@ -1145,25 +1150,27 @@ int inflate_segments_run(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, cons
   // such a match cannot go on: far_d counts those, and the whole group runs again with the full ring (rare: streams
   // that inflate by more than the store's symbols per compressed byte).
   uint32_t* far_d = dscratch + 2 * nb;
-  // One buffer: every work item first goes to the block decoder of the block-parallel tier in its any-encoder form
+  // Every work item first goes to the block decoder of the block-parallel tier in its any-encoder form
   // (k_inf_seg_block_par: a workgroup per block, 1024 lanes decoding 1024 bit segments of it) — a wave that decodes a
   // block token by token gets through ~13 MB/s.  What it declines (an item whose block is stored or fixed, is followed
   // by a block that is not on the list, or is longer than 128 KiB) is listed, and the wave decoder runs for the list.
-  const bool blockpar = nb == 1 && ratio != 0 && !getenv("ZES_NO_SEG_PAR");
+  const bool blockpar = ratio != 0 && !getenv("ZES_NO_SEG_PAR");
   uint32_t* fail_list = nullptr;
   if (blockpar) {
     if ((rc = ensure(g.segfail, ((size_t)work + 1) * 4))) return rc;
     fail_list = (uint32_t*)g.segfail.p;
     HIPCHK(hipMemsetAsync(fail_list, 0, 4, g.stream));
+    HIPCHK(hipMemsetAsync((uint64_t*)g.symoff.p + work, 0, 8, g.stream));
     Timed t("k_inf_seg_block_par");
-    hipLaunchKernelGGL(k_inf_seg_block_par, dim3(work), dim3(PAR_THREADS), 0, g.stream, d_in, (const ZesSegJob*)g.segjobs.p, cs, (ZesSegRes*)g.sres.p,
-                       (uint32_t*)g.maps.p, (uint32_t*)g.sym16.p, ratio, fail_list);
+    hipLaunchKernelGGL(k_inf_seg_block_par, dim3(work), dim3(PAR_THREADS), 0, g.stream, d_in, (const ZesSegJob*)g.segjobs.p, nb, cs, (ZesSegRes*)g.sres.p,
+                       (uint32_t*)g.maps.p, (uint32_t*)g.sym16.p, ratio, fail_list, (unsigned long long*)((uint64_t*)g.symoff.p + work),
+                       (uint64_t)((share_syms / 2 + 3) & ~3ull), bump_syms, (uint64_t*)g.symoff.p);
   }
   {
     Timed t("k_inf_seg_scan");
     hipLaunchKernelGGL(k_inf_seg_scan_short, dim3(work), dim3(64), 0, g.stream, d_in, (const ZesSegJob*)g.segjobs.p, nb, cs, (ZesSegRes*)g.sres.p,
                        (uint32_t*)g.maps.p, (uint32_t*)g.sym16.p, ratio, blockpar ? (const uint32_t*)fail_list + 1 : (const uint32_t*)g.segorder.p, far_d,
-                       (const uint32_t*)fail_list);
+                       (const uint32_t*)fail_list, (uint64_t*)g.symoff.p);
   }
   {
     uint32_t* hf = (uint32_t*)g.pinned;
@@ -1174,7 +1181,8 @@ int inflate_segments_run(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, cons
     if (hf[0] != 0) {
       Timed t("k_inf_seg_scan");
       hipLaunchKernelGGL(k_inf_seg_scan, dim3(work), dim3(64), 0, g.stream, d_in, (const ZesSegJob*)g.segjobs.p, nb, cs, (ZesSegRes*)g.sres.p,
-                         (uint32_t*)g.maps.p, (uint32_t*)g.sym16.p, ratio, (const uint32_t*)g.segorder.p, far_d, (const uint32_t*)nullptr);
+                         (uint32_t*)g.maps.p, (uint32_t*)g.sym16.p, ratio, (const uint32_t*)g.segorder.p, far_d, (const uint32_t*)nullptr,
+                         (uint64_t*)g.symoff.p);
     }
   }
   {
@@ -1236,7 +1244,7 @@ int inflate_segments_run(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, cons
       const uint32_t ny = std::max(1u, std::min(16u, 2048u / nseg));  // few long segments: split each over several workgroups
       hipLaunchKernelGGL(k_inf_seg_translate, dim3(nseg, ny), dim3(256), 0, g.stream, d_out, j.out_off, j.cap, cs + cbase[k],
                          (const ZesSegRes*)g.sres.p + wf, (const uint32_t*)g.seglist.p + wf, (const uint64_t*)g.segprefix.p + wf,
-                         (const uint8_t*)g.wins.p + (size_t)wf * ZES_WINDOW, (const uint32_t*)g.sym16.p + hj[k].sym_base, ratio, fail_d + k);
+                         (const uint8_t*)g.wins.p + (size_t)wf * ZES_WINDOW, (const uint32_t*)g.sym16.p, (const uint64_t*)g.symoff.p + wf, fail_d + k);
     }
     if (novf[k] > 0) {
       Timed t("k_inf_seg_decode");
@@ -1323,6 +1331,15 @@ int inflate_segments(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const st
     HIPCHK(hipMemcpyAsync(hc, cnt, (size_t)nb * 4, hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
     std::vector<uint32_t> nc(hc, hc + nb);
+    if (getenv("ZES_T2_DBG")) {  // the candidate lists, for a comparison with a map of the stream (tools/gpu_t2_candidates.py)
+      for (uint32_t k = 0; k < nb; k++) {
+        std::vector<uint32_t> hcand(std::min<uint32_t>(nc[k], SEG_BUCKETS));
+        if (!hcand.empty()) HIPCHK(hipMemcpy(hcand.data(), (const uint32_t*)g.cand_sorted.p + cbase[k], hcand.size() * 4, hipMemcpyDeviceToHost));
+        fprintf(stderr, "zes T2 candidates buf %u (%zu):", k, hcand.size());
+        for (uint32_t v : hcand) fprintf(stderr, " %u", v + 16u);
+        fprintf(stderr, "\n");
+      }
+    }
     // ---- segment runs: as many buffers as fit the work-item budget at a time ----
     std::vector<uint32_t> rid, rbase, rn;
     uint32_t work = 0;
@@ -1633,7 +1650,7 @@ int zes_shutdown(void) {
   if (!g.ready) return ZES_OK;
   (void)hipSetDevice(g.device);
   (void)hipStreamSynchronize(g.stream);
-  DevBuf* all[] = {&g.bufs, &g.blks, &g.idx_a, &g.idx_b, &g.inv, &g.sdelta, &g.hists, &g.codes, &g.hdrs, &g.adler, &g.res, &g.surv, &g.vlong, &g.segfail, &g.cand,
+  DevBuf* all[] = {&g.bufs, &g.blks, &g.idx_a, &g.idx_b, &g.inv, &g.sdelta, &g.hists, &g.codes, &g.hdrs, &g.adler, &g.res, &g.surv, &g.vlong, &g.segfail, &g.symoff, &g.cand,
                    &g.cand_sorted, &g.counters, &g.cres, &g.map, &g.resume, &g.dbg, &g.ibufs, &g.ibufs2, &g.mvlist, &g.scratch, &g.st_in, &g.st_out,
                    &g.sres, &g.maps, &g.seglist, &g.segprefix, &g.wins, &g.sym16, &g.segorder, &g.segjobs, &g.kraft, &g.pw16, &g.gwins};
   for (DevBuf* b : all) {

@@ -1641,18 +1641,20 @@ __device__ __forceinline__ static void seg_scan_body(SM& S, const uint8_t* __res
                                                      const uint32_t* __restrict__ cand_all, ZesSegRes* __restrict__ sres_all,
                                                      uint32_t* __restrict__ maps_all, uint32_t* __restrict__ sym16_all, uint32_t sym_ratio,
                                                      const uint32_t* __restrict__ order, uint32_t* __restrict__ far_nostore,
-                                                     const uint32_t* __restrict__ nlive) {
+                                                     const uint32_t* __restrict__ nlive, uint64_t* __restrict__ symoff_all) {
   constexpr uint32_t R = SM::kR16;
   const uint32_t lane = threadIdx.x;
-  // (one-buffer launch behind k_inf_seg_block_par: order[] lists the items that kernel left, *nlive is how many)
+  // (launch behind k_inf_seg_block_par: order[] lists the items that kernel left — numbered over the whole group —
+  // and *nlive is how many)
   if (nlive && blockIdx.x >= *nlive) return;
-  // buffer of this work item: the last one whose first work item is <= blockIdx.x
+  const uint32_t gid = nlive ? order[blockIdx.x] : blockIdx.x;
+  // buffer of this work item: the last one whose first work item is <= gid
   uint32_t bi = 0;
   {
     uint32_t lo = 0, hi = njobs;
     while (hi - lo > 1) {
       const uint32_t mid = (lo + hi) >> 1;
-      if (jobs[mid].work_first <= blockIdx.x) lo = mid; else hi = mid;
+      if (jobs[mid].work_first <= gid) lo = mid; else hi = mid;
     }
     bi = lo;
   }
@@ -1663,7 +1665,7 @@ __device__ __forceinline__ static void seg_scan_body(SM& S, const uint8_t* __res
   ZesSegRes* sres = sres_all + jb.work_first;
   uint32_t* maps = maps_all + (size_t)jb.work_first * (ZES_WINDOW / 2);
   uint32_t* sym16 = sym16_all + jb.sym_base;
-  const uint32_t w = order[blockIdx.x];  // (a buffer's part of order[] holds its own work items) longest compressed span first
+  const uint32_t w = nlive ? gid - jb.work_first : order[blockIdx.x];  // (a buffer's part of order[] holds its own work items) longest compressed span first
   ZesSegRes r;
   r.end_bit = 0;
   r.out_len = 0;
@@ -1697,6 +1699,7 @@ __device__ __forceinline__ static void seg_scan_body(SM& S, const uint8_t* __res
     if (w == 0 && ncand > 0 && cand[0] == 0) nx = 1;
     const uint64_t b0 = (start - 16) / 8, b1 = nx < ncand ? (uint64_t)cand[nx] / 8 : c;
     d.sym = sym_ratio ? sym16 + b0 * sym_ratio / 2 : nullptr;
+    if (lane == 0) symoff_all[jb.work_first + w] = jb.sym_base + b0 * sym_ratio / 2;  // (where k_inf_seg_translate finds the symbols)
     d.sym_cap = (b1 - b0) * sym_ratio;
     d.sym_ovf = sym_ratio ? 0u : 1u;
   }
@@ -1782,18 +1785,18 @@ __global__ __launch_bounds__(64) void k_inf_seg_scan(const uint8_t* __restrict__
                                                      const uint32_t* __restrict__ cand_all, ZesSegRes* __restrict__ sres_all,
                                                      uint32_t* __restrict__ maps_all, uint32_t* __restrict__ sym16_all, uint32_t sym_ratio,
                                                      const uint32_t* __restrict__ order, uint32_t* __restrict__ far_nostore,
-                                                     const uint32_t* __restrict__ nlive) {
+                                                     const uint32_t* __restrict__ nlive, uint64_t* __restrict__ symoff_all) {
   __shared__ __align__(16) InfSmem S;
-  seg_scan_body(S, d_in, jobs, njobs, cand_all, sres_all, maps_all, sym16_all, sym_ratio, order, far_nostore, nlive);
+  seg_scan_body(S, d_in, jobs, njobs, cand_all, sres_all, maps_all, sym16_all, sym_ratio, order, far_nostore, nlive, symoff_all);
 }
 // the same with the short marker ring: three decoders per CU
 __global__ __launch_bounds__(64) void k_inf_seg_scan_short(const uint8_t* __restrict__ d_in, const ZesSegJob* __restrict__ jobs, uint32_t njobs,
                                                            const uint32_t* __restrict__ cand_all, ZesSegRes* __restrict__ sres_all,
                                                            uint32_t* __restrict__ maps_all, uint32_t* __restrict__ sym16_all, uint32_t sym_ratio,
                                                            const uint32_t* __restrict__ order, uint32_t* __restrict__ far_nostore,
-                                                           const uint32_t* __restrict__ nlive) {
+                                                           const uint32_t* __restrict__ nlive, uint64_t* __restrict__ symoff_all) {
   __shared__ __align__(16) InfSmemShort S;
-  seg_scan_body(S, d_in, jobs, njobs, cand_all, sres_all, maps_all, sym16_all, sym_ratio, order, far_nostore, nlive);
+  seg_scan_body(S, d_in, jobs, njobs, cand_all, sres_all, maps_all, sym16_all, sym_ratio, order, far_nostore, nlive, symoff_all);
 }
 
 // One workgroup per stream: the chain of segments from work item 0 to the final block.
@@ -1982,8 +1985,8 @@ __global__ __launch_bounds__(1024) void k_inf_seg_win_fin(const uint32_t* __rest
 __global__ __launch_bounds__(256) void k_inf_seg_translate(uint8_t* __restrict__ d_out, uint64_t out_off, uint64_t cap,
                                                            const uint32_t* __restrict__ cand, const ZesSegRes* __restrict__ sres,
                                                            const uint32_t* __restrict__ seg, const uint64_t* __restrict__ prefix,
-                                                           const uint8_t* __restrict__ wins, const uint32_t* __restrict__ sym16,
-                                                           uint32_t sym_ratio, uint32_t* __restrict__ fail) {
+                                                           const uint8_t* __restrict__ wins, const uint32_t* __restrict__ sym16_all,
+                                                           const uint64_t* __restrict__ symoff, uint32_t* __restrict__ fail) {
   __shared__ __align__(16) uint8_t W[ZES_WINDOW];
   const uint32_t k = blockIdx.x, tid = threadIdx.x;
   const uint32_t w = seg[k];
@@ -1996,8 +1999,7 @@ __global__ __launch_bounds__(256) void k_inf_seg_translate(uint8_t* __restrict__
   }
   __syncthreads();
   const uint32_t first_ok = pre >= ZES_WINDOW ? 0u : ZES_WINDOW - (uint32_t)pre;  // window positions below this do not exist
-  const uint64_t b0 = w ? (uint64_t)cand[w - 1] / 8 : 0;
-  const uint16_t* sy = reinterpret_cast<const uint16_t*>(sym16 + b0 * sym_ratio / 2);
+  const uint16_t* sy = reinterpret_cast<const uint16_t*>(sym16_all + symoff[w]);  // (the buffer's part of symoff[])
   uint8_t* dst = d_out + out_off;
   const uint64_t end = min(pre + r.out_len, cap);
   uint32_t bad = 0;

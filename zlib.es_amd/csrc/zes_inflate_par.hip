@@ -1057,6 +1057,10 @@ struct ParItem {
   ZesSegRes* sres;
   uint32_t* sym;      // the item's share of the symbol store (two symbols per dword)
   uint64_t sym_cap;   // symbols it holds
+  uint32_t* sym_all;  // the store; behind the shares: a common area handed out by need (a block whose share a false
+  unsigned long long* bump;  // candidate has cut short, or that inflates further than its share)
+  uint64_t bump_base, bump_cap;  // first dword of that area, symbols it holds
+  uint64_t* symoff;   // out: where the item's symbols are (dword offset into the store)
   uint32_t* map;      // [ZES_WINDOW / 2]
   const uint32_t* cand;
   uint32_t ncand;
@@ -1278,13 +1282,32 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
     total += S.tail_bytes;
     const uint32_t st = S.status;
     const uint32_t end_bit = (tail_code < 48u) ? S.tail_end : S.hdr_end;
-    const bool good = (st & 4u) && !(st & 2u) && total <= (FOREIGN ? PAR_MAX_OUT : ZES_BLK) && (!FOREIGN || (uint64_t)total <= it.sym_cap);
+    const bool good = (st & 4u) && !(st & 2u) && total <= (FOREIGN ? PAR_MAX_OUT : ZES_BLK);
     if (!good) {
       PAR_DECLINE(end_bit, total);
       return;
     }
     const uint32_t my_off = wbase + incl - outbytes;
     STAMP(4);
+    // T2: where the symbols go — the item's share of the store, or, when that is too small, a piece of the common area
+    uint32_t* symp = it.sym;
+    if (FOREIGN) {
+      if ((uint64_t)total > it.sym_cap) {
+        if (tid == 0) {
+          const unsigned long long o = atomicAdd(it.bump, (unsigned long long)((total + 7u) & ~7u));
+          S.sp_n = (o + total <= it.bump_cap) ? (uint32_t)(o >> 3) : 0xFFFFFFFFu;  // (units of 8 symbols)
+        }
+        __syncthreads();
+        const uint32_t o8 = S.sp_n;
+        __syncthreads();
+        if (o8 == 0xFFFFFFFFu) {
+          PAR_DECLINE(end_bit, total);
+          return;
+        }
+        symp = it.sym_all + it.bump_base + (uint64_t)o8 * 4u;
+      }
+      if (tid == 0) *it.symoff = (uint64_t)(symp - it.sym_all);
+    }
 
     // T2: a block longer than the image is emitted and resolved chunk by chunk (clo = first byte of the chunk); T1 and
     // blocks of up to PAR_CHUNK bytes make one pass.  (A jump back instead of a loop: T1 gets no back edge.)
@@ -1563,7 +1586,7 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
           // window before the block — or be such a marker byte of a window resolved earlier: its symbol is read back
           // from the store (this workgroup wrote it; the bitmap words of resolved windows hold "is a marker").  All
           // symbols of the window go to the symbol store, two bytes each.
-          uint16_t* sym16 = reinterpret_cast<uint16_t*>(it.sym);
+          uint16_t* sym16 = reinterpret_cast<uint16_t*>(symp);
           uint32_t sy[RES_W / PAR_THREADS];
 #pragma unroll
           for (uint32_t k = 0; k < RES_W / PAR_THREADS; k++) {
@@ -1577,7 +1600,7 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
             uint32_t v = S.out[ai];
             if (mk || prior) {
               const uint32_t gi = (uint32_t)ab;
-              const uint32_t wd = __hip_atomic_load(&it.sym[gi >> 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              const uint32_t wd = __hip_atomic_load(&symp[gi >> 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               v = (gi & 1u) ? wd >> 16 : wd & 0xffffu;
             }
             v = hist ? (uint32_t)(256 + (int32_t)ZES_WINDOW + ab) : v;
@@ -1663,7 +1686,7 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
           if (pos < 0) {
             v[h] = (uint32_t)(256 + (int32_t)ZES_WINDOW + pos);
           } else {
-            const uint32_t wd = __hip_atomic_load(&it.sym[(uint32_t)pos >> 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t wd = __hip_atomic_load(&symp[(uint32_t)pos >> 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             v[h] = (pos & 1) ? wd >> 16 : wd & 0xffffu;
           }
         }
@@ -1736,6 +1759,10 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __
   it.sres = nullptr;
   it.sym = nullptr;
   it.sym_cap = 0;
+  it.sym_all = nullptr;
+  it.bump = nullptr;
+  it.bump_base = it.bump_cap = 0;
+  it.symoff = nullptr;
   it.map = nullptr;
   it.cand = nullptr;
   it.ncand = 0;
@@ -1744,15 +1771,27 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __
   par_body<false>(S, it, dbg);
 }
 
-// T2: one workgroup per block of another encoder's stream (work items as in k_inf_seg_scan: item 0 starts at bit 16,
-// item w at candidate w - 1).  One buffer per launch.
+// T2: one workgroup per block of another encoder's stream (work items as in k_inf_seg_scan: a buffer's item 0 starts at
+// bit 16, its item w at candidate w - 1).
 __global__ __launch_bounds__(PAR_THREADS) void k_inf_seg_block_par(const uint8_t* __restrict__ d_in, const ZesSegJob* __restrict__ jobs,
-                                                                   const uint32_t* __restrict__ cand_all, ZesSegRes* __restrict__ sres_all,
-                                                                   uint32_t* __restrict__ maps_all, uint32_t* __restrict__ sym16_all,
-                                                                   uint32_t sym_ratio, uint32_t* __restrict__ fail_list) {
+                                                                   uint32_t njobs, const uint32_t* __restrict__ cand_all,
+                                                                   ZesSegRes* __restrict__ sres_all, uint32_t* __restrict__ maps_all,
+                                                                   uint32_t* __restrict__ sym16_all, uint32_t sym_ratio,
+                                                                   uint32_t* __restrict__ fail_list, unsigned long long* __restrict__ bump,
+                                                                   uint64_t bump_base, uint64_t bump_cap, uint64_t* __restrict__ symoff) {
   __shared__ __align__(16) ParSmem S;
-  const ZesSegJob jb = jobs[0];
-  const uint32_t w = blockIdx.x;
+  // buffer of this work item: the last one whose first work item is <= blockIdx.x
+  uint32_t bi = 0;
+  {
+    uint32_t lo = 0, hi = njobs;
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (jobs[mid].work_first <= blockIdx.x) lo = mid; else hi = mid;
+    }
+    bi = lo;
+  }
+  const ZesSegJob jb = jobs[bi];
+  const uint32_t w = blockIdx.x - jb.work_first;
   const uint32_t ncand = jb.ncand;
   const uint32_t* cand = cand_all + jb.cand_base;
   ZesSegRes* sres = sres_all + jb.work_first;
@@ -1791,10 +1830,15 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_seg_block_par(const uint8_t
   const uint64_t b0 = (start - 16) / 8, b1 = nx < ncand ? (uint64_t)cand[nx] / 8 : c;
   it.sym = sym16_all + jb.sym_base + b0 * sym_ratio / 2;
   it.sym_cap = (b1 - b0) * sym_ratio;
+  it.sym_all = sym16_all;
+  it.bump = bump;
+  it.bump_base = bump_base;
+  it.bump_cap = bump_cap;
+  it.symoff = symoff + blockIdx.x;
   it.map = maps_all + (size_t)jb.work_first * (ZES_WINDOW / 2) + (size_t)w * (ZES_WINDOW / 2);
   it.cand = cand;
   it.ncand = ncand;
   it.fail_list = fail_list;
-  it.w = w;
+  it.w = blockIdx.x;  // (the list numbers items over the whole group)
   par_body<true>(S, it, nullptr);
 }

@@ -85,13 +85,14 @@ __global__ void k_inf_cand_bucket(const uint32_t*, const uint32_t*, uint32_t, ui
 __global__ void k_inf_cand_compact(const uint32_t*, uint32_t*, uint32_t*);
 __global__ void k_inf_seg_order(const uint32_t*, uint32_t, uint64_t, uint32_t*);
 __global__ void k_inf_seg_scan(const uint8_t*, const ZesSegJob*, uint32_t, const uint32_t*, ZesSegRes*, uint32_t*, uint32_t*, uint32_t,
-                               const uint32_t*, uint32_t*, const uint32_t*);
+                               const uint32_t*, uint32_t*, const uint32_t*, uint64_t*);
 __global__ void k_inf_seg_scan_short(const uint8_t*, const ZesSegJob*, uint32_t, const uint32_t*, ZesSegRes*, uint32_t*, uint32_t*, uint32_t,
-                                     const uint32_t*, uint32_t*, const uint32_t*);
-__global__ void k_inf_seg_block_par(const uint8_t*, const ZesSegJob*, const uint32_t*, ZesSegRes*, uint32_t*, uint32_t*, uint32_t, uint32_t*);
+                                     const uint32_t*, uint32_t*, const uint32_t*, uint64_t*);
+__global__ void k_inf_seg_block_par(const uint8_t*, const ZesSegJob*, uint32_t, const uint32_t*, ZesSegRes*, uint32_t*, uint32_t*, uint32_t, uint32_t*,
+                                    unsigned long long*, uint64_t, uint64_t, uint64_t*);
 __global__ void k_inf_seg_chain(const ZesSegRes*, uint32_t, uint32_t*, uint64_t*, ZesRes*, uint32_t*);
 __global__ void k_inf_seg_translate(uint8_t*, uint64_t, uint64_t, const uint32_t*, const ZesSegRes*, const uint32_t*, const uint64_t*,
-                                    const uint8_t*, const uint32_t*, uint32_t, uint32_t*);
+                                    const uint8_t*, const uint32_t*, const uint64_t*, uint32_t*);
 #define SEGWIN_GROUP 32u
 __global__ void k_inf_seg_win_group(const uint32_t*, const uint32_t*, const ZesSegJob*, uint32_t*);
 __global__ void k_inf_seg_win_top(const uint32_t*, const ZesSegJob*, uint8_t*);
