@@ -818,7 +818,7 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
   {
     Timed t("k_inf_ranksort");
     hipLaunchKernelGGL(k_inf_ranksort, dim3(nbuf), dim3(nbuf == 1 ? 1024 : 256), 0, g.stream, dbufs, (const uint32_t*)cnt, (const uint32_t*)g.cand.p,
-                       (uint32_t*)g.cand_sorted.p);
+                       (uint32_t*)g.cand_sorted.p, 0xFFFFFFFFu);
   }
   {
     Timed t("k_inf_block_par");
@@ -1053,7 +1053,7 @@ int inflate_t1_range(const uint8_t* d_in, uint64_t in_off, uint64_t c, uint64_t 
   HIPCHK(hipMemcpyAsync(g.ibufs.p, hb, sizeof(ZesInfBuf) * 2, hipMemcpyHostToDevice, g.stream));
   {
     Timed t("k_inf_ranksort");
-    hipLaunchKernelGGL(k_inf_ranksort, dim3(1), dim3(1024), 0, g.stream, dbufs, (const uint32_t*)cnt, (const uint32_t*)g.cand.p, (uint32_t*)g.cand_sorted.p);
+    hipLaunchKernelGGL(k_inf_ranksort, dim3(1), dim3(1024), 0, g.stream, dbufs, (const uint32_t*)cnt, (const uint32_t*)g.cand.p, (uint32_t*)g.cand_sorted.p, 0xFFFFFFFFu);
   }
   {
     Timed t("k_inf_block_par");
@@ -1095,7 +1095,7 @@ int inflate_t1_range(const uint8_t* d_in, uint64_t in_off, uint64_t c, uint64_t 
 // stream is not a clean chain of blocks keeps tier 0: the serial tiers then reproduce the reference's result.
 constexpr uint64_t SEG_MIN_C = 32768;  // shorter streams go straight to the serial wavefront
 constexpr size_t SERIAL_BATCH_MIN_JOBS = 16;        // this many left-over streams of a call: one serial wavefront each, side by side
-constexpr uint64_t SERIAL_BATCH_MAX_C = 16ull << 20;  // (longer ones are worth their own segment-parallel run)
+constexpr uint64_t SERIAL_BATCH_MAX_C = 128ull << 10;  // (longer ones go to the segment-parallel tier: its block decoder is ~15 times a lone wave)
 constexpr uint32_t SEG_GROUP_BUFS = 64;      // buffers whose candidates are searched before the first read-back
 constexpr uint32_t SEG_GROUP_WORK = 8192;    // work items per segment launch (each owns a 64 KiB map)
 
@@ -1281,7 +1281,7 @@ int inflate_segments(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const st
       max_c = std::max(max_c, j.c);
     }
     const uint32_t surv_cap = (uint32_t)std::min<uint64_t>(max_c / 4 + 1024ull, 1ull << 30);
-    const size_t cnt_words = 4 + (size_t)nb + 2 * (size_t)nb + 4 + 4;  // scan/verify scratch, counts, run scratch (+ far-match counter), first-byte sink
+    const size_t cnt_words = 4 + (size_t)nb + 2 * (size_t)nb + 4 + 4 + ((size_t)nb + 3) / 4;  // scan/verify scratch, counts, run scratch (+ far-match counter), first-byte sink (a byte per buffer)
     if ((rc = ensure(g.ibufs, sizeof(ZesInfBuf) * 2))) return rc;
     if ((rc = ensure(g.surv, (size_t)surv_cap * 8))) return rc;
     if ((rc = ensure(g.cand, (size_t)cands * 4))) return rc;
@@ -1294,7 +1294,57 @@ int inflate_segments(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const st
     uint8_t* sink = (uint8_t*)(dscratch + 2 * nb + 4);
     HIPCHK(hipMemsetAsync(counters, 0, cnt_words * 4, g.stream));
     const ZesInfBuf* dbufs = (const ZesInfBuf*)g.ibufs.p;
+    // Several buffers (a batch of another encoder's streams): one scan and one header test over all of them, the lists
+    // sorted by one launch; only a buffer with more candidates than a segment run takes (tiny blocks) is thinned, by
+    // itself, afterwards.  (256 streams of 1 MiB: the searches one after the other were 36 ms of launches.)
+    std::vector<char> searched(nb, 0);
+    if (nb > 1) {
+      ZesInfBuf* hb = (ZesInfBuf*)((uint8_t*)g.pinned + PIN_UP);
+      memset(hb, 0, sizeof(ZesInfBuf) * (nb + 1));
+      uint64_t chunks = 0, total_c = 0;
+      for (uint32_t k = 0; k < nb; k++) {
+        const InfJob& j = jobs[ids[k]];
+        hb[k].in_off = j.in_off;
+        hb[k].c = j.c;
+        hb[k].out_off = j.out_off;
+        hb[k].cap = j.cap;
+        hb[k].first_chunk = (uint32_t)chunks;
+        hb[k].cand_base = cbase[k];
+        hb[k].cand_cap = ccap[k];
+        chunks += (j.c + INF_SCAN_BYTES - 1) / INF_SCAN_BYTES;
+        total_c += j.c;
+      }
+      hb[nb].first_chunk = (uint32_t)chunks;
+      const uint32_t surv_all = (uint32_t)std::min<uint64_t>(total_c / 4 + 1024ull * nb, 1ull << 30);
+      if ((rc = ensure(g.ibufs, sizeof(ZesInfBuf) * (nb + 1)))) return rc;
+      if ((rc = ensure(g.surv, (size_t)surv_all * 8))) return rc;
+      dbufs = (const ZesInfBuf*)g.ibufs.p;
+      HIPCHK(hipMemcpyAsync(g.ibufs.p, hb, sizeof(ZesInfBuf) * (nb + 1), hipMemcpyHostToDevice, g.stream));
+      {
+        Timed t("k_inf_scan");
+        hipLaunchKernelGGL(k_inf_scan, dim3((uint32_t)chunks), dim3(INF_SCAN_THREADS), 0, g.stream, d_in, dbufs, nb, (unsigned long long*)g.surv.p,
+                           surv_all, counters, sink, 0u, (const uint8_t*)g.kraft.p);
+      }
+      if ((rc = launch_verify(d_in, dbufs, surv_all, counters, cnt, 1u, total_c, 16384))) return rc;
+      {
+        Timed t("k_inf_ranksort");
+        hipLaunchKernelGGL(k_inf_ranksort, dim3(nb), dim3(1024), 0, g.stream, dbufs, (const uint32_t*)cnt, (const uint32_t*)g.cand.p,
+                           (uint32_t*)g.cand_sorted.p, SEG_BUCKETS);
+      }
+      uint32_t* hc0 = (uint32_t*)g.pinned;
+      HIPCHK(hipMemcpyAsync(hc0, cnt, (size_t)nb * 4, hipMemcpyDeviceToHost, g.stream));
+      HIPCHK(hipStreamSynchronize(g.stream));
+      for (uint32_t k = 0; k < nb; k++) searched[k] = hc0[k] <= SEG_BUCKETS;  // (the others: thinned below, from a search of their own)
+      bool redo = false;
+      for (uint32_t k = 0; k < nb; k++) redo = redo || !searched[k];
+      if (redo) {
+        if ((rc = ensure(g.ibufs2, sizeof(ZesInfBuf) * 2))) return rc;
+        dbufs = (const ZesInfBuf*)g.ibufs2.p;
+      }
+    }
     for (uint32_t k = 0; k < nb; k++) {
+      if (searched[k]) continue;
+      HIPCHK(hipMemsetAsync(cnt + k, 0, 4, g.stream));
       const InfJob& j = jobs[ids[k]];
       ZesInfBuf b0, b1;
       memset(&b0, 0, sizeof b0);
@@ -1307,7 +1357,7 @@ int inflate_segments(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const st
       b0.cand_cap = ccap[k];
       const uint32_t chunks = (uint32_t)((j.c + INF_SCAN_BYTES - 1) / INF_SCAN_BYTES);
       b1.first_chunk = chunks;
-      hipLaunchKernelGGL(k_inf_set_table1, dim3(1), dim3(64), 0, g.stream, b0, b1, (ZesInfBuf*)g.ibufs.p, counters, 4u);
+      hipLaunchKernelGGL(k_inf_set_table1, dim3(1), dim3(64), 0, g.stream, b0, b1, const_cast<ZesInfBuf*>(dbufs), counters, 4u);
       {
         Timed t("k_inf_scan");
         // (the BFINAL rule of the scan holds for every encoder's streams: it stays on; only the verify rules are the reference's own)

@@ -611,10 +611,11 @@ __global__ __launch_bounds__(64) void k_inf_verify_long(const uint8_t* __restric
 
 // rank sort of each buffer's candidate list (a few to a few thousand entries); one workgroup per buffer
 __global__ __launch_bounds__(1024) void k_inf_ranksort(const ZesInfBuf* __restrict__ bufs, const uint32_t* __restrict__ cnt,
-                                                      const uint32_t* __restrict__ cand, uint32_t* __restrict__ out) {
+                                                      const uint32_t* __restrict__ cand, uint32_t* __restrict__ out, uint32_t max_n) {
   __shared__ uint32_t s_c[RANK_LDS];  // the list itself when it fits (it does: one entry per block of the stream)
   const ZesInfBuf bf = bufs[blockIdx.x];
   const uint32_t n = min(cnt[blockIdx.x], bf.cand_cap);
+  if (n > max_n) return;  // (a list this long is thinned instead: the segment-parallel tier's group search)
   const uint32_t* in = cand + bf.cand_base;
   uint32_t* o = out + bf.cand_base;
   const bool lds = n <= RANK_LDS;

@@ -77,7 +77,7 @@ __global__ void k_inf_scan(const uint8_t*, const ZesInfBuf*, uint32_t, unsigned 
 __global__ void k_inf_set_table1(ZesInfBuf, ZesInfBuf, ZesInfBuf*, uint32_t*, uint32_t);
 __global__ void k_inf_verify(const uint8_t*, const ZesInfBuf*, const unsigned long long*, uint32_t, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t*, uint32_t, uint32_t);
 __global__ void k_inf_verify_long(const uint8_t*, const ZesInfBuf*, const unsigned long long*, uint32_t, uint32_t*, uint32_t*, uint32_t*, uint32_t, const uint32_t*, uint32_t);
-__global__ void k_inf_ranksort(const ZesInfBuf*, const uint32_t*, const uint32_t*, uint32_t*);
+__global__ void k_inf_ranksort(const ZesInfBuf*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t);
 __global__ void k_inf_decode(const uint8_t*, uint8_t*, const ZesInfBuf*, ZesRes*, uint64_t*);
 __global__ void k_inf_stored_walk(const uint8_t*, uint64_t, uint64_t, uint64_t, ZesStoredBlk*, ZesRes*);
 __global__ void k_inf_stored_copy(const uint8_t*, uint64_t, uint8_t*, uint64_t, const ZesStoredBlk*);
