@@ -180,6 +180,27 @@ __device__ __forceinline__ static void tab_set(SegTab& t, uint32_t o, uint32_t c
   t.g |= (wi == 6u) ? v : 0ull;
   t.h |= (wi == 7u) ? v : 0ull;
 }
+__device__ __forceinline__ static void tab_put(SegTab& t, uint32_t o, uint32_t code, bool doit) {  // replaces an entry
+  const uint32_t wi = o >> 3, sh = (o & 7u) * 8u;
+  const uint64_t m = doit ? (0xffull << sh) : 0ull, v = doit ? ((uint64_t)code << sh) : 0ull;
+  t.a = (wi == 0u) ? ((t.a & ~m) | v) : t.a;
+  t.b = (wi == 1u) ? ((t.b & ~m) | v) : t.b;
+  t.c = (wi == 2u) ? ((t.c & ~m) | v) : t.c;
+  t.d = (wi == 3u) ? ((t.d & ~m) | v) : t.d;
+  t.e = (wi == 4u) ? ((t.e & ~m) | v) : t.e;
+  t.f = (wi == 5u) ? ((t.f & ~m) | v) : t.f;
+  t.g = (wi == 6u) ? ((t.g & ~m) | v) : t.g;
+  t.h = (wi == 7u) ? ((t.h & ~m) | v) : t.h;
+}
+// bit o: entry o is not 0
+__device__ __forceinline__ static uint64_t tab_nzmask(const SegTab& t) {
+  auto nz8 = [](uint64_t w) -> uint64_t {
+    const uint64_t k7 = 0x7f7f7f7f7f7f7f7full;
+    const uint64_t y = (((w & k7) + k7) | w) & ~k7;             // bit 7 of every byte that is not 0
+    return ((y >> 7) * 0x0102040810204080ull) >> 56;            // ... gathered into one byte
+  };
+  return nz8(t.a) | (nz8(t.b) << 8) | (nz8(t.c) << 16) | (nz8(t.d) << 24) | (nz8(t.e) << 32) | (nz8(t.f) << 40) | (nz8(t.g) << 48) | (nz8(t.h) << 56);
+}
 __device__ __forceinline__ static uint64_t bcast64(uint64_t v, uint32_t srclane) {  // srclane uniform
   const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)srclane);
   const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)srclane);
@@ -540,7 +561,7 @@ __device__ __forceinline__ static bool seg_table_f8(ParSmem& S, const BitSrc& sr
   return ok;
 }
 
-template <bool LDS>
+template <bool LDS, bool TWO>
 __device__ __forceinline__ static void seg_table(ParSmem& S, const BitSrc& src, uint32_t limit, uint32_t base, uint32_t stop,
                                                  const Lit8& f8, SegTab& tab, unsigned long long* dp) {
   // uniform: most literals have 8-bit codes, and the segments are long enough for literal runs to matter
@@ -595,27 +616,75 @@ __device__ __forceinline__ static void seg_table(ParSmem& S, const BitSrc& src, 
   }
 
   TSTAMP(0);
+  // ---- (a2) long segments: a second window.  Of its 64 offsets only those are decoded that a token of the first
+  //      window lands on, or a token of the second window that starts on such an offset, and so on: about 30.  The
+  //      trajectories of (b) then start 128 bits into the segment, where the 48 entry offsets have merged into ~7
+  //      token chains instead of ~12 — and every one of them costs the wave the longest lane's walk to the end. ----
+  const bool two = TWO && LDS && !__ballot(stop - base < 176u);  // (uniform: the segments of a block have one length)
+  SegTab nx2 = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t Lmask2 = 0;
+  if (two) {
+    uint32_t b0, b1, b2, b3, b4;
+    {
+      const uint32_t d0 = (base + 64u) >> 5, bo = (base + 64u) & 31u;
+      const uint32_t w0 = src_ldw<LDS>(src, d0), w1 = src_ldw<LDS>(src, d0 + 1), w2 = src_ldw<LDS>(src, d0 + 2),
+                     w3 = src_ldw<LDS>(src, d0 + 3), w4 = src_ldw<LDS>(src, d0 + 4), w5 = src_ldw<LDS>(src, d0 + 5);
+      b0 = __builtin_amdgcn_alignbit(w1, w0, bo);
+      b1 = __builtin_amdgcn_alignbit(w2, w1, bo);
+      b2 = __builtin_amdgcn_alignbit(w3, w2, bo);
+      b3 = __builtin_amdgcn_alignbit(w4, w3, bo);
+      b4 = __builtin_amdgcn_alignbit(w5, w4, bo);
+    }
+    const uint32_t room2 = room > 64u ? room - 64u : 0u;
+    uint64_t todo = Lmask;  // offsets of the second window still to decode (bit r: position base + 64 + r), lowest first
+#pragma unroll 1
+    while (__ballot(todo != 0ull)) {
+      const bool hv = todo != 0ull;
+      const uint32_t r = hv ? (uint32_t)__builtin_ctzll(todo) : 0u;
+      todo &= todo - 1ull;  // (0 stays 0)
+      const uint32_t e = lut_l_entry(S, win_bits(b0, b1, b2, b3, b4, r));
+      const uint32_t kind = (e >> 8) & 3u;
+      uint32_t v = r + (e & 15u) + ((e >> 4) & 15u);
+      if (__ballot(hv && kind == 2u)) {
+        const uint32_t ed = lut_d_entry(S, win_bits(b0, b1, b2, b3, b4, v & 127u));
+        const uint32_t v2 = v + (ed & 15u) + ((ed >> 4) & 15u);
+        const bool dbad = (((ed >> 8) & 3u) != 2u) || (ed & 15u) == 0u;
+        v = (kind == 2u) ? (dbad ? NX_FAIL : v2) : v;
+      }
+      v = (kind == 1u) ? NX_EOB : v;
+      v = (kind == 3u || (e & 15u) == 0u) ? NX_FAIL : v;
+      v = (v < 128u && v > room2) ? NX_FAIL : v;
+      v = (r >= room2) ? NX_FAIL : v;
+      if (hv) {
+        todo |= (v < 64u) ? (1ull << v) : 0ull;  // (v > r: still ahead)
+        Lmask2 |= (v >= 64u && v < 128u) ? (1ull << (v - 64u)) : 0ull;
+        tab_set(nx2, r, v);
+      }
+    }
+  }
+  const uint32_t ZO = two ? 128u : 64u;  // where the landing window of the trajectories starts
+  const uint64_t Lm = two ? Lmask2 : Lmask;
   // ---- (b) full trajectories from the landing offsets, highest first ----
-  SegTab lt = {0, 0, 0, 0, 0, 0, 0, 0};  // exit code of landing offset 64+i at entry i
+  SegTab lt = {0, 0, 0, 0, 0, 0, 0, 0};  // exit code of landing offset ZO+i at entry i
   uint64_t Ldone = 0;
   for (;;) {
-    const uint64_t pend = Lmask & ~Ldone;
+    const uint64_t pend = Lm & ~Ldone;
     const bool have = pend != 0ull;
     if (!__ballot(have)) break;
     const uint32_t L = have ? 63u - (uint32_t)__builtin_clzll(pend) : 0u;
     LaneBits b;
-    lb_seek<LDS>(b, src, base + 64u + L);
+    lb_seek<LDS>(b, src, base + ZO + L);
     uint32_t code = C_FAIL;
-    bool act = have && (base + 64u + L) < limit;
+    bool act = have && (base + ZO + L) < limit;
     // (the landing-window check only matters while a trajectory is still inside that window)
     while (__ballot(act)) {
       // up to twelve 8-bit literals at once, past the landing window and inside the segment (skipped
       // as a whole while every lane is still in its landing window: most trajectories end there)
-      if (f8.n && __ballot(act && (b.pos - base) >= 112u)) {
+      if (f8.n && __ballot(act && (b.pos - base) >= ZO + 48u)) {
 #pragma unroll
         for (int rep = 0; rep < 3; rep++) {
           lb_refill_bf(b, src);
-          const bool fast = act && (b.pos - base) >= 112u && b.pos + 32u <= stop && b.pos + 32u <= limit;
+          const bool fast = act && (b.pos - base) >= ZO + 48u && b.pos + 32u <= stop && b.pos + 32u <= limit;
           const uint32_t adv = fast ? 8u * lead_lit8((uint32_t)b.bb, f8) : 0u;
           b.bb >>= adv;
           b.nb -= adv;
@@ -626,7 +695,7 @@ __device__ __forceinline__ static void seg_table(ParSmem& S, const BitSrc& src, 
         code = b.pos - stop;  // 0..47
         act = false;
       }
-      const uint32_t rel = b.pos - base - 64u;  // landing-window offset
+      const uint32_t rel = b.pos - base - ZO;  // landing-window offset
       const bool inwin = act && rel < 48u;
       if (__ballot(inwin)) {
         const bool hit = inwin && ((Ldone >> rel) & 1ull);
@@ -660,6 +729,24 @@ __device__ __forceinline__ static void seg_table(ParSmem& S, const BitSrc& src, 
   }
 
   TSTAMP(1);
+  // ---- (c2) the decoded offsets of the second window, highest first, in place: successor -> exit code ----
+  if (two) {
+    uint64_t m = tab_nzmask(nx2);  // the decoded offsets (a successor is never 0)
+#pragma unroll 1
+    while (__ballot(m != 0ull)) {
+      const bool hv = m != 0ull;
+      const uint32_t r = hv ? 63u - (uint32_t)__builtin_clzll(m) : 0u;
+      m &= ~(hv ? (1ull << r) : 0ull);
+      const uint32_t v = tab_get(nx2, r);
+      const uint32_t in = tab_get(nx2, v & 63u);  // (v > r: converted already)
+      const uint32_t la = tab_get(lt, (v - 64u) & 63u);
+      uint32_t c = (v < 64u) ? in : la;
+      c = (v == NX_EOB) ? C_EOB : c;
+      c = (v == NX_FAIL) ? C_FAIL : c;
+      tab_put(nx2, r, c, hv);
+    }
+    lt = nx2;  // what a token of the first window lands on
+  }
   // ---- (c) table[o] from offset 63 down: successor inside the window -> its entry; landing ->
   //          the landing's code ----
   SegTab t = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1068,7 +1155,10 @@ struct ParItem {
   uint32_t w;
 };
 
-template <bool FOREIGN>
+// TWO: the transfer tables are built over two windows (compressible data: long segments whose trajectories merge
+// behind the first window); incompressible data takes the 8-bit-literal construction either way and runs ~4 %
+// faster in the smaller kernel, so the host picks the variant by the stream's size against its output's.
+template <bool FOREIGN, bool TWO>
 __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, unsigned long long* dbg) {
 #define STAMP(i)                                                     \
   do {                                                               \
@@ -1141,7 +1231,7 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
     base = (uint32_t)(b_me64 < 0xFFFFFF00ull ? b_me64 : 0xFFFFFF00ull);
     stop = (uint32_t)((b_me64 + seglen) < 0xFFFFFF00ull ? (b_me64 + seglen) : 0xFFFFFF00ull);
     SegTab tab = {0, 0, 0, 0, 0, 0, 0, 0};
-    seg_table<true>(S, src, limit, base, stop, f8, tab, dbg ? dbg + (size_t)blockIdx.x * ZES_PAR_DBG_ROW : nullptr);
+    seg_table<true, TWO>(S, src, limit, base, stop, f8, tab, dbg ? dbg + (size_t)blockIdx.x * ZES_PAR_DBG_ROW : nullptr);
     STAMP(2);
     // Composition.  With room behind the staged block (compressible data: the block's bytes fill a third of the
     // staging area) every lane parks its table in LDS, 52 bytes apart, and a step of the walks below is one byte
@@ -1708,12 +1798,12 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
 #undef PAR_DECLINE
 #undef STAMP
 
-__global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __restrict__ d_in, uint8_t* __restrict__ d_out,
-                                                               const ZesInfBuf* __restrict__ bufs, uint32_t nbuf,
-                                                               const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ cand_all,
-                                                               const uint32_t* __restrict__ map_all, ZesCandRes* __restrict__ cres_all,
-                                                               unsigned long long* __restrict__ dbg, const uint32_t* __restrict__ redo) {
-  __shared__ __align__(16) ParSmem S;
+template <bool TWO>
+__device__ __forceinline__ static void block_par_t1(ParSmem& S, const uint8_t* __restrict__ d_in, uint8_t* __restrict__ d_out,
+                                                    const ZesInfBuf* __restrict__ bufs, uint32_t nbuf, const uint32_t* __restrict__ cnt,
+                                                    const uint32_t* __restrict__ cand_all, const uint32_t* __restrict__ map_all,
+                                                    ZesCandRes* __restrict__ cres_all, unsigned long long* __restrict__ dbg,
+                                                    const uint32_t* __restrict__ redo) {
   // buffer of this work item: the last entry whose first work item is <= blockIdx.x
   uint32_t bi = 0;
   {
@@ -1768,7 +1858,25 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __
   it.ncand = 0;
   it.fail_list = nullptr;
   it.w = w;
-  par_body<false>(S, it, dbg);
+  par_body<false, TWO>(S, it, dbg);
+}
+
+__global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __restrict__ d_in, uint8_t* __restrict__ d_out,
+                                                               const ZesInfBuf* __restrict__ bufs, uint32_t nbuf,
+                                                               const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ cand_all,
+                                                               const uint32_t* __restrict__ map_all, ZesCandRes* __restrict__ cres_all,
+                                                               unsigned long long* __restrict__ dbg, const uint32_t* __restrict__ redo) {
+  __shared__ __align__(16) ParSmem S;
+  block_par_t1<false>(S, d_in, d_out, bufs, nbuf, cnt, cand_all, map_all, cres_all, dbg, redo);
+}
+// the same for compressible data (the launch's streams are shorter than 0.7 of their outputs' capacity)
+__global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par2(const uint8_t* __restrict__ d_in, uint8_t* __restrict__ d_out,
+                                                                const ZesInfBuf* __restrict__ bufs, uint32_t nbuf,
+                                                                const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ cand_all,
+                                                                const uint32_t* __restrict__ map_all, ZesCandRes* __restrict__ cres_all,
+                                                                unsigned long long* __restrict__ dbg, const uint32_t* __restrict__ redo) {
+  __shared__ __align__(16) ParSmem S;
+  block_par_t1<true>(S, d_in, d_out, bufs, nbuf, cnt, cand_all, map_all, cres_all, dbg, redo);
 }
 
 // T2: one workgroup per block of another encoder's stream (work items as in k_inf_seg_scan: a buffer's item 0 starts at
@@ -1840,5 +1948,5 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_seg_block_par(const uint8_t
   it.ncand = ncand;
   it.fail_list = fail_list;
   it.w = blockIdx.x;  // (the list numbers items over the whole group)
-  par_body<true>(S, it, nullptr);
+  par_body<true, true>(S, it, nullptr);
 }
