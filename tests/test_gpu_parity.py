@@ -549,9 +549,9 @@ def test_inflate_false_candidate_inside_a_block_stays_block_parallel(z, oracle, 
     assert tier == 1
     # the false candidate was really there: blocks behind it are moved into place (k_inf_move_slots) and the one
     # whose slot the capacity cut off is decoded again (second k_inf_block_par launch)
-    assert launches.get("k_inf_block_par") == 2
+    assert launches.get("k_inf_block_par", 0) + launches.get("k_inf_block_par2", 0) == 2  # (par2: the variant for compressible data)
     assert back2.numel() == len(a) and (back2.cpu().numpy() == a).all()
-    assert z.last_inflate_tier() == 1 and launches2.get("k_inf_block_par") == 1 and "k_inf_move_slots" not in launches2
+    assert z.last_inflate_tier() == 1 and launches2.get("k_inf_block_par", 0) + launches2.get("k_inf_block_par2", 0) == 1 and "k_inf_move_slots" not in launches2
 
 
 def test_inflate_mostly_8bit_codes_with_other_tokens_mixed_in(z, oracle, gpu):
@@ -595,7 +595,7 @@ def test_64mib_false_candidate_moves_hundreds_of_blocks(z, gpu):
     finally:
         z.set_profiling(False)
     assert back.numel() == n and bool((back == t).all()) and z.last_inflate_tier() == 1
-    assert launches.get("k_inf_move_slots") == 1 and launches.get("k_inf_block_par") == 2
+    assert launches.get("k_inf_move_slots") == 1 and launches.get("k_inf_block_par", 0) + launches.get("k_inf_block_par2", 0) == 2
     back = z.inflate_tensor(comp, out)
     assert back.numel() == n and bool((back == t).all()) and z.last_inflate_tier() == 1
 

@@ -821,12 +821,13 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
                        (uint32_t*)g.cand_sorted.p, 0xFFFFFFFFu);
   }
   {
-    Timed t("k_inf_block_par");
     // compressible data (the streams are shorter than 0.7 of the room for their outputs): the variant whose transfer
     // tables look at two windows; incompressible data runs ~4 % faster in the smaller kernel
     uint64_t total_cap = 0;
     for (uint32_t i = 0; i < nbuf; i++) total_cap += jobs[ids[i]].cap;
-    auto kern = (total_c * 10 < total_cap * 7) ? k_inf_block_par2 : k_inf_block_par;
+    const bool two = total_c * 10 < total_cap * 7;
+    Timed t(two ? "k_inf_block_par2" : "k_inf_block_par");
+    auto kern = two ? k_inf_block_par2 : k_inf_block_par;
     hipLaunchKernelGGL(kern, dim3((uint32_t)work), dim3(PAR_THREADS), 0, g.stream, d_in, d_out, dbufs, nbuf,
                        (const uint32_t*)cnt, (const uint32_t*)g.cand_sorted.p, (const uint32_t*)nullptr, (ZesCandRes*)g.cres.p, dbg, (const uint32_t*)nullptr);
   }
