@@ -66,7 +66,8 @@ int zes_shutdown(void);
 int zes_device_info(char* name, int cap, int* cus, uint64_t* hbm_bytes);
 
 /* Page-locked host memory the DMA engines can read and write directly.  The host-pointer entry points accept any
- * memory; buffers from here skip the library's pinned staging ring (one pass less over the bytes on each side).
+ * memory (pageable buffers of 4 MiB and more are copied by the runtime's own call, shorter ones through a ring of pinned
+ * chunks); buffers from here are handed to the DMA engines as they are, whatever their size.
  * A binding exposes it as an allocator for its callers' arrays (`allocPinned`).  Free before
  * zes_shutdown.  replaces: nothing (the reference works on ordinary Uint8Arrays). */
 int zes_host_alloc(uint64_t n, void** p);
