@@ -731,7 +731,11 @@ struct LazySmem {
   uint16_t tail[LAZY_TAIL];                       // hop (1 or match length) of the block's last LAZY_TAIL keyed positions
   uint32_t wq;                                    // next work item to hand out
   uint32_t unmerged;                              // a second chain gave up: the true chain may hold unevaluated positions
+  uint32_t mp[LAZY_NWIN];                         // where the second chain from window w's exit met a window chain (LAZY_NOMERGE: it ran to the block's end)
+  uint32_t tfrom[LAZY_NWIN];                      // true chain: the first position of window w's own chain that is on it (LAZY_NOMERGE: none)
+  uint8_t titem[LAZY_NWIN];                       // true chain: it leaves window w at that window's exit
 };
+#define LAZY_NOMERGE 0xFFFFFFFFu
 
 // Match at position p by the whole wavefront (p uniform): the candidates one after the other, every compare
 // shared by the 64 lanes (four bytes each).  Candidate order, early exits and tie rule of src/lz77.ts:49-95.
@@ -872,6 +876,8 @@ __device__ __forceinline__ static uint32_t lazy_chains(LazySmem& S, const uint32
         merged = st && !leave && vb != 0u;  // from here on it is a window's own chain
         gaveup = st && !leave && !merged && p - cstart >= LAZY_MERGE_CAP;
         if (gaveup && sub == 0u) S.unmerged = 1u;
+        if (merged && sub == 0u) S.mp[item] = p;
+        if (leave && sub == 0u) S.mp[item] = LAZY_NOMERGE;
       }
       const bool go = st && !leave && !merged && !gaveup;
       if (PHASE == 1u) {
@@ -1083,7 +1089,7 @@ __device__ __forceinline__ static uint32_t lazy_chains(LazySmem& S, const uint32
 __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match_lazy(const uint8_t* __restrict__ d_in, const ZesBuf* __restrict__ bufs,
                                                                  const ZesBlk* __restrict__ blks, const uint32_t* __restrict__ idx_a,
                                                                  const uint32_t* __restrict__ inv_all, const uint16_t* __restrict__ sd_all,
-                                                                 uint32_t* __restrict__ match_out) {
+                                                                 uint32_t* __restrict__ match_out, uint32_t* __restrict__ tmask_all) {
   __shared__ __align__(16) LazySmem S;
   const uint32_t g = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   if (!(idx_a[(uint64_t)g * ZES_BLK + ZES_BLK - 1] & ZES_SORT_LAZY)) return;  // this block belongs to k_lz_match
@@ -1157,6 +1163,51 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match_lazy(const uint8_t* 
     __syncthreads();
     LSTAMP(4);
   }
+  // ---- the positions of the true chain as a bit mask, for k_lz_parse (which otherwise finds them again: exit maps
+  // of all 2048 chunks, region tables, a walk per chunk — 343k of its 480k cycles per block on text).  The chain is
+  // window 0's own chain up to its exit, the second chain from there up to where it met a window chain, that window's
+  // chain from there to its exit, and so on: the windows' parts are in V1 already. ----
+  uint32_t* tm = tmask_all + (uint64_t)g * ZES_TMASK_WORDS;
+  if (!S.unmerged) {
+    for (uint32_t i = tid; i < LAZY_NWIN; i += MATCH_THREADS) {
+      S.tfrom[i] = LAZY_NOMERGE;
+      S.titem[i] = 0;
+    }
+    __syncthreads();
+    if (tid == 0) {  // (at most one step per window)
+      uint32_t w = 0, from = 0;
+      for (uint32_t guard = 0; guard < LAZY_NWIN && w < nwin; guard++) {
+        S.tfrom[w] = from;
+        const uint32_t e = w * LAZY_WIN + S.xw[w];
+        if (e >= T) break;  // the chain ended with the block
+        S.titem[w] = 1;
+        const uint32_t m = S.mp[w];
+        if (m == LAZY_NOMERGE || m / LAZY_WIN <= w) break;  // (ran to the block's end; the second test cannot fail: a chain moves forward)
+        w = m / LAZY_WIN;
+        from = m;
+      }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < ZES_BLK / 32; i += MATCH_THREADS) {  // a window's chain in front of the meeting point, and windows the chain skips: not on it
+      const uint32_t f = S.tfrom[(32u * i) / LAZY_WIN];
+      uint32_t keep = 0u;
+      if (f != LAZY_NOMERGE) keep = f <= 32u * i ? ~0u : (f >= 32u * i + 32u ? 0u : (~0u << (f - 32u * i)));
+      S.v1[i] &= keep;
+    }
+    __syncthreads();
+    if (tid < nwin && S.titem[tid]) {  // the second chains of the true chain: walked again, along the words they left
+      uint32_t p = tid * LAZY_WIN + S.xw[tid];
+      const uint32_t end = min(S.mp[tid], T);
+      while (p < end) {
+        atomicOr(&S.v1[p >> 5], 1u << (p & 31u));
+        const uint32_t m = __hip_atomic_load(&mo[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (written by another wave of this workgroup)
+        p += (m & ZES_TOK_MATCH) ? zes_tok_len(m) : 1u;
+      }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < ZES_BLK / 32; i += MATCH_THREADS) tm[4u + i] = S.v1[i];
+  }
+  if (tid == 0) tm[0] = S.unmerged ? 0u : 1u;
 
   // ---- phase 3 (periodic data only): the true chain, by one wavefront ----
   if (S.unmerged && wave == 0) {
@@ -1277,7 +1328,8 @@ __device__ static uint32_t parse_follow(const uint32_t* mi, uint32_t T, uint32_t
 
 __global__ __launch_bounds__(PARSE_THREADS) void k_lz_parse(const uint8_t* __restrict__ d_in, const ZesBuf* __restrict__ bufs,
                                                             ZesBlk* __restrict__ blks, const uint32_t* __restrict__ match_in,
-                                                            uint32_t* __restrict__ tok_out, uint32_t* __restrict__ hists) {
+                                                            uint32_t* __restrict__ tok_out, uint32_t* __restrict__ hists,
+                                                            const uint32_t* __restrict__ tmask_all) {
   __shared__ __align__(16) ParseSmem S;
   const uint32_t g = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const ZesBlk bk = blks[g];
@@ -1292,9 +1344,22 @@ __global__ __launch_bounds__(PARSE_THREADS) void k_lz_parse(const uint8_t* __res
   if (tid < 32) S.dh[tid] = 0;
   for (uint32_t i = tid; i < PARSE_CHUNKS; i += PARSE_THREADS) S.centry[i] = PARSE_NOENTRY;
 
+  // k_lz_match_lazy's blocks come with the positions of the chain as a bit mask (unless its chains did not merge):
+  // phases A to D1, which find those positions, are skipped.  (The sort's flag word sits where the last token would
+  // go: read before anything is written there.)
+  const uint32_t* tmk = tmask_all + (uint64_t)g * ZES_TMASK_WORDS;
+  const bool havemask = (to[ZES_BLK - 1] & ZES_SORT_LAZY) != 0u && tmk[0] == 1u;  // (uniform)
   PSTAMP(0);
   // ---- A: exit map of every chunk ----
   const uint32_t c_lo = wave * PARSE_REGION, c_hi = min(nchunks, c_lo + PARSE_REGION);
+  if (havemask) {
+    const unsigned long long* t64 = reinterpret_cast<const unsigned long long*>(tmk + 4);
+    for (uint32_t c = tid; c < PARSE_CHUNKS; c += PARSE_THREADS) {
+      S.u.d.mask[c] = c < nchunks ? t64[c] : 0ull;
+      S.cplain[c] = 0;
+    }
+    __syncthreads();
+  } else {
   // Batches of PARSE_BATCH chunks: all their match words are requested before the first is used (one
   // memory latency per batch instead of per chunk).  A chunk without any match (nearly all of them on
   // incompressible input) needs no pointer doubling: every lane leaves at offset 0.
@@ -1393,7 +1458,6 @@ __global__ __launch_bounds__(PARSE_THREADS) void k_lz_parse(const uint8_t* __res
   // global memory, a line of sixteen serving the next hops.  (Round 1 found the visited lanes of one chunk at a
   // time with all 64 lanes, by binary hop decomposition: a dozen cross-lane shuffles per chunk, 287k cycles per
   // block on text against the ~40k of this walk.) ----
-  unsigned long long mymask[2] = {0ull, 0ull};  // thread t owns chunks 2t, 2t+1 for the scan
   for (uint32_t cb = c_lo; cb < c_hi; cb += 64u) {
     const uint32_t c = cb + lane;
     const bool have = c < c_hi;
@@ -1418,6 +1482,8 @@ __global__ __launch_bounds__(PARSE_THREADS) void k_lz_parse(const uint8_t* __res
   // of xmap finished at the barrier above phase D1 only for the walk; D1 itself does not read xmap.
 
   PSTAMP(4);
+  }  // (!havemask)
+  unsigned long long mymask[2] = {0ull, 0ull};  // thread t owns chunks 2t, 2t+1 for the scan
   // ---- D2: token offsets = exclusive scan of the per-chunk counts ----
   uint32_t cnt2[2];
 #pragma unroll
