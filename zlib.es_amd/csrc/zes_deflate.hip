@@ -1209,8 +1209,15 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match_lazy(const uint8_t* 
   }
   if (tid == 0) tm[0] = S.unmerged ? 0u : 1u;
 
-  // ---- phase 3 (periodic data only): the true chain, by one wavefront ----
-  if (S.unmerged && wave == 0) {
+  // ---- phase 3 (periodic data only): the true chain, by one wavefront (which also notes the chain's positions
+  // for k_lz_parse: V1 starts over) ----
+  const bool walk3 = S.unmerged != 0u;  // (uniform)
+  if (walk3) {
+    __syncthreads();
+    for (uint32_t i = tid; i < ZES_BLK / 32; i += MATCH_THREADS) S.v1[i] = 0;
+    __syncthreads();
+  }
+  if (walk3 && wave == 0) {
     uint32_t p = 0;
     // The words of the chain's positions come 64 at a time (lane k: the word of position cb + k; the chunk behind is
     // requested while this one is walked); runs of evaluated literals are stepped over at once.
@@ -1228,11 +1235,14 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match_lazy(const uint8_t* 
         const uint64_t lit = __ballot(cw == LAZY_EVAL_LIT) >> (p - base);
         if (lit & 1ull) {
           const uint32_t run = (~lit) ? (uint32_t)__builtin_ctzll(~lit) : 64u;
-          p += min(run, 64u - (p - base));
+          const uint32_t step = min(min(run, 64u - (p - base)), cnt - p);
+          if (lane < step) atomicOr(&S.v1[(p + lane) >> 5], 1u << ((p + lane) & 31u));
+          p += step;
           continue;
         }
       }
       uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)cw, (int)(p - base));
+      if (lane == 0) atomicOr(&S.v1[p >> 5], 1u << (p & 31u));
       if (m == 0u) {  // nobody evaluated this position yet
         if (p >= tbase) {
           m = LAZY_EVAL_LIT;  // (cannot happen: phase 0 evaluated the tail; keeps a corrupted table from hanging the wavefront)
@@ -1259,13 +1269,24 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match_lazy(const uint8_t* 
             full = full && ((m_ld32u(S.in, qj + 256u) ^ m_ld32u(S.in, pp + 256u)) & 0xffffu) == 0u;  // bytes 256, 257
             const uint64_t okm = __ballot(full);
             const uint32_t nk = (~okm) ? (uint32_t)__builtin_ctzll(~okm) : 64u;  // leading lanes that are settled
-            if (lane < nk) mo[pj] = ZES_TOK_MATCH | ((ZES_MAXMATCH - 3u) << 16) | (dj - 1u);
+            if (lane < nk) {
+              mo[pj] = ZES_TOK_MATCH | ((ZES_MAXMATCH - 3u) << 16) | (dj - 1u);
+              atomicOr(&S.v1[pj >> 5], 1u << (pj & 31u));
+            }
             p += ZES_MAXMATCH * nk;
           }
         }
       }
       p += (m & ZES_TOK_MATCH) ? zes_tok_len(m) : 1u;
     }
+    // the block's last two bytes are always literals (src/lz77.ts:116-117): the chain ends on them
+    if (lane < 2u && cnt + lane < T && cnt + lane >= p) atomicOr(&S.v1[(cnt + lane) >> 5], 1u << ((cnt + lane) & 31u));
+  }
+  if (walk3) {
+    __syncthreads();
+    for (uint32_t i = tid; i < ZES_BLK / 32; i += MATCH_THREADS) tm[4u + i] = S.v1[i];
+    __syncthreads();
+    if (tid == 0) tm[0] = 1u;
   }
   LSTAMP(5);
 }
