@@ -42,7 +42,7 @@ struct Ctx {
   hipStream_t cs_in = nullptr, cs_out = nullptr;  // copy streams of the pipelined host calls (H2D / D2H beside the kernels)
   hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_k = nullptr;
   // deflate scratch
-  DevBuf bufs, blks, idx_a, idx_b, inv, sdelta, tmask, hists, codes, hdrs, adler, res;
+  DevBuf bufs, blks, idx_a, idx_b, inv, sdelta, tmask, mlist, hists, codes, hdrs, adler, res;
   // inflate scratch
   DevBuf surv, vlong, segfail, symoff, cand, cand_sorted, counters, cres, map, resume, dbg, ibufs, ibufs2, mvlist, scratch, sres, maps, seglist, segprefix, wins, sym16, segorder, segjobs, pw16, gwins;
   // staging for the host-pointer API
@@ -482,6 +482,7 @@ int deflate_batch_core(const uint8_t* d_in, const uint64_t* in_off, const uint64
   if ((rc = ensure(g.inv, (size_t)nblk * ZES_BLK * 4))) return rc;
   if ((rc = ensure(g.sdelta, (size_t)nblk * ZES_BLK * 2 + 64))) return rc;
   if ((rc = ensure(g.tmask, (size_t)nblk * ZES_TMASK_WORDS * 4))) return rc;  // k_lz_match_lazy -> k_lz_parse: the chain's positions
+  if ((rc = ensure(g.mlist, (size_t)nblk * ZES_MLIST_WORDS * 4))) return rc;  // k_lz_match -> k_lz_parse: the matches of a match-poor block
   if ((rc = ensure(g.hists, (size_t)nblk * 320 * 4))) return rc;
   if ((rc = ensure(g.codes, (size_t)nblk * 320 * 4))) return rc;
   if ((rc = ensure(g.hdrs, (size_t)nblk * ZES_HDR_WORDS * 4))) return rc;
@@ -546,7 +547,7 @@ int deflate_batch_core(const uint8_t* d_in, const uint64_t* in_off, const uint64
   }
   {
     Timed t("k_lz_match");  // match words go to idx_b (free after the sort)
-    hipLaunchKernelGGL(k_lz_match, dim3(nblk), dim3(MATCH_THREADS), 0, g.stream, d_in, dbufs, dblks, idx_a, idx_b);
+    hipLaunchKernelGGL(k_lz_match, dim3(nblk), dim3(MATCH_THREADS), 0, g.stream, d_in, dbufs, dblks, idx_a, idx_b, (uint32_t*)g.mlist.p);
   }
   if (sort_dbg) {
     HIPCHK(hipMemsetAsync(g.dbg.p, 0, (size_t)nblk * 64, g.stream));
@@ -584,7 +585,7 @@ int deflate_batch_core(const uint8_t* d_in, const uint64_t* in_off, const uint64
   {
     Timed t("k_lz_parse");  // tokens go to idx_a (free after the match pass)
     hipLaunchKernelGGL(k_lz_parse, dim3(nblk), dim3(PARSE_THREADS), 0, g.stream, d_in, dbufs, dblks, idx_b, idx_a, (uint32_t*)g.hists.p,
-                       (const uint32_t*)g.tmask.p);
+                       (const uint32_t*)g.tmask.p, (const uint32_t*)g.mlist.p);
   }
   if (sort_dbg) {  // average shader-clock cycles per phase of k_lz_parse
     HIPCHK(hipStreamSynchronize(g.stream));
@@ -1708,7 +1709,7 @@ int zes_shutdown(void) {
   if (!g.ready) return ZES_OK;
   (void)hipSetDevice(g.device);
   (void)hipStreamSynchronize(g.stream);
-  DevBuf* all[] = {&g.bufs, &g.blks, &g.idx_a, &g.idx_b, &g.inv, &g.sdelta, &g.tmask, &g.hists, &g.codes, &g.hdrs, &g.adler, &g.res, &g.surv, &g.vlong, &g.segfail, &g.symoff, &g.cand,
+  DevBuf* all[] = {&g.bufs, &g.blks, &g.idx_a, &g.idx_b, &g.inv, &g.sdelta, &g.tmask, &g.mlist, &g.hists, &g.codes, &g.hdrs, &g.adler, &g.res, &g.surv, &g.vlong, &g.segfail, &g.symoff, &g.cand,
                    &g.cand_sorted, &g.counters, &g.cres, &g.map, &g.resume, &g.dbg, &g.ibufs, &g.ibufs2, &g.mvlist, &g.scratch, &g.st_in, &g.st_out,
                    &g.sres, &g.maps, &g.seglist, &g.segprefix, &g.wins, &g.sym16, &g.segorder, &g.segjobs, &g.kraft, &g.pw16, &g.gwins};
   for (DevBuf* b : all) {
@@ -2434,17 +2435,18 @@ int zes_stage_lz77_dev(const uint8_t* d_in, uint64_t n, uint64_t start, uint32_t
   if ((rc = ensure(g.sdelta, (size_t)ZES_BLK * 2 + 64))) return rc;
   if ((rc = ensure(g.hists, 320 * 4))) return rc;
   if ((rc = ensure(g.tmask, ZES_TMASK_WORDS * 4))) return rc;
+  if ((rc = ensure(g.mlist, ZES_MLIST_WORDS * 4))) return rc;
   HIPCHK(hipMemcpyAsync(g.bufs.p, &b, sizeof b, hipMemcpyHostToDevice, g.stream));
   HIPCHK(hipMemcpyAsync(g.blks.p, &z, sizeof z, hipMemcpyHostToDevice, g.stream));
   hipLaunchKernelGGL(k_lz_sort, dim3(1), dim3(SORT_THREADS), 0, g.stream, d_in, (const ZesBuf*)g.bufs.p, (const ZesBlk*)g.blks.p,
                      (uint32_t*)g.idx_a.p, (uint32_t*)g.idx_b.p, (uint32_t*)g.inv.p, (uint16_t*)g.sdelta.p);
   hipLaunchKernelGGL(k_lz_match, dim3(1), dim3(MATCH_THREADS), 0, g.stream, d_in, (const ZesBuf*)g.bufs.p,
-                     (const ZesBlk*)g.blks.p, (const uint32_t*)g.idx_a.p, (uint32_t*)g.idx_b.p);
+                     (const ZesBlk*)g.blks.p, (const uint32_t*)g.idx_a.p, (uint32_t*)g.idx_b.p, (uint32_t*)g.mlist.p);
   hipLaunchKernelGGL(k_lz_match_lazy, dim3(1), dim3(MATCH_THREADS), 0, g.stream, d_in, (const ZesBuf*)g.bufs.p,
                      (const ZesBlk*)g.blks.p, (const uint32_t*)g.idx_a.p, (const uint32_t*)g.inv.p, (const uint16_t*)g.sdelta.p, (uint32_t*)g.idx_b.p,
                      (uint32_t*)g.tmask.p);
   hipLaunchKernelGGL(k_lz_parse, dim3(1), dim3(PARSE_THREADS), 0, g.stream, d_in, (const ZesBuf*)g.bufs.p, (ZesBlk*)g.blks.p,
-                     (const uint32_t*)g.idx_b.p, (uint32_t*)g.idx_a.p, (uint32_t*)g.hists.p, (const uint32_t*)g.tmask.p);
+                     (const uint32_t*)g.idx_b.p, (uint32_t*)g.idx_a.p, (uint32_t*)g.hists.p, (const uint32_t*)g.tmask.p, (const uint32_t*)g.mlist.p);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(&z, g.blks.p, sizeof z, hipMemcpyDeviceToHost, g.stream));
   HIPCHK(hipStreamSynchronize(g.stream));

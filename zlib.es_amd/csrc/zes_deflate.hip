@@ -488,6 +488,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
 struct MatchSmem {
   uint32_t in[(MATCH_IN_DWORDS + 31) / 32 * 32];  // whole 32-dword rows: the swizzle permutes inside a row
   uint32_t ring[MATCH_WAVES][MATCH_RING];         // position | same-key-as-previous-slot flag (bit 31)
+  uint32_t ml[ZES_MLIST_WORDS];                   // the block's matches as a list (count first), for k_lz_parse
 };
 
 __device__ __forceinline__ static uint32_t mswz(uint32_t i) { return i ^ ((i >> 5) & 31u) ^ ((i >> 10) & 31u); }
@@ -503,7 +504,7 @@ __device__ __forceinline__ static uint32_t m_ld32u(const uint32_t* w, uint32_t o
 // keeps the index entries it needs in its own LDS ring.
 __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match(const uint8_t* __restrict__ d_in, const ZesBuf* __restrict__ bufs,
                                                             const ZesBlk* __restrict__ blks, const uint32_t* __restrict__ idx_a,
-                                                            uint32_t* __restrict__ match_out) {
+                                                            uint32_t* __restrict__ match_out, uint32_t* __restrict__ mlist_all) {
   __shared__ __align__(16) MatchSmem S;
   const uint32_t g = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const ZesBlk bk = blks[g];
@@ -554,11 +555,15 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match(const uint8_t* __res
     const uint32_t n4 = (T + 3u) >> 2;
     for (uint32_t i = tid; i < n4; i += MATCH_THREADS) mo4[i] = make_uint4(0, 0, 0, 0);
   }
-  __syncthreads();  // the only workgroup barrier: from here on every wave works alone
+  // the matches are also listed (the first few hundred: incompressible data has ~260 a block): k_lz_parse builds the
+  // greedy chain of such a block from the list instead of searching all 131072 result words for it
+  uint32_t* ml = S.ml;  // (collected in LDS: a global atomic per match cost 0.02 ms on random64)
+  if (tid == 0) ml[0] = 0;
+  __syncthreads();  // from here on every wave works alone, up to the flush of the list at the very end
 
   const uint32_t R = ((cnt + MATCH_WAVES * 64u - 1) / (MATCH_WAVES * 64u)) * 64u;
   const uint32_t r0 = min(cnt, wave * R), r1 = min(cnt, r0 + R);
-  if (r0 >= r1) return;
+  if (r0 < r1) {  // (a wave without slots goes straight to the flush below)
   uint32_t* ring = S.ring[wave];
   const uint32_t rb = r0 >= 128u ? r0 - 128u : 0u;  // first slot kept in the ring (multiple of 64)
 
@@ -679,10 +684,20 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match(const uint8_t* __res
       mode = (pr && (stop0 || far)) ? 3u : ((cand && !skip) ? 2u : mode);
     }
     if (mode == 3u) {
-      if (best >= 3u && p + best + 3u <= T)  // nowIndex + len <= endIndex = start + T - 3 (src/lz77.ts:95)
+      if (best >= 3u && p + best + 3u <= T) {  // nowIndex + len <= endIndex = start + T - 3 (src/lz77.ts:95)
         mo[p] = ZES_TOK_MATCH | ((best - 3u) << 16) | (p - bestq - 1u);
+        const uint32_t slot = atomicAdd(&ml[0], 1u);
+        if (slot < ZES_MLIST_CAP) ml[1u + slot] = p | ((best - 3u) << 17);
+      }
       mode = 0u;
     }
+  }
+  }
+  __syncthreads();
+  {
+    uint32_t* gl = mlist_all + (uint64_t)g * ZES_MLIST_WORDS;
+    const uint32_t n = min(S.ml[0], ZES_MLIST_CAP) + 1u;
+    for (uint32_t i = tid; i < n; i += MATCH_THREADS) gl[i] = S.ml[i];
   }
 }
 
@@ -1350,7 +1365,7 @@ __device__ static uint32_t parse_follow(const uint32_t* mi, uint32_t T, uint32_t
 __global__ __launch_bounds__(PARSE_THREADS) void k_lz_parse(const uint8_t* __restrict__ d_in, const ZesBuf* __restrict__ bufs,
                                                             ZesBlk* __restrict__ blks, const uint32_t* __restrict__ match_in,
                                                             uint32_t* __restrict__ tok_out, uint32_t* __restrict__ hists,
-                                                            const uint32_t* __restrict__ tmask_all) {
+                                                            const uint32_t* __restrict__ tmask_all, const uint32_t* __restrict__ mlist_all) {
   __shared__ __align__(16) ParseSmem S;
   const uint32_t g = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const ZesBlk bk = blks[g];
@@ -1373,11 +1388,58 @@ __global__ __launch_bounds__(PARSE_THREADS) void k_lz_parse(const uint8_t* __res
   PSTAMP(0);
   // ---- A: exit map of every chunk ----
   const uint32_t c_lo = wave * PARSE_REGION, c_hi = min(nchunks, c_lo + PARSE_REGION);
+  // k_lz_match's blocks with few matches (incompressible data: ~260): the chain is every position except the insides
+  // of the matches the greedy parse takes — a listed match is taken iff it starts at or behind the end of the last
+  // one taken (src/lz77.ts:39-47,95): sorted, then one pass in order.  (Phases A to D1 cost 213k cycles a block there.)
+  const uint32_t* ml = mlist_all + (uint64_t)g * ZES_MLIST_WORDS;
+  const bool lazyblk = (to[ZES_BLK - 1] & ZES_SORT_LAZY) != 0u;
+  const uint32_t nml = lazyblk ? 0xFFFFFFFFu : ml[0];
+  const bool fewmatches = !lazyblk && nml <= ZES_MLIST_CAP;  // (uniform)
   if (havemask) {
     const unsigned long long* t64 = reinterpret_cast<const unsigned long long*>(tmk + 4);
     for (uint32_t c = tid; c < PARSE_CHUNKS; c += PARSE_THREADS) {
       S.u.d.mask[c] = c < nchunks ? t64[c] : 0ull;
       S.cplain[c] = 0;
+    }
+    __syncthreads();
+  } else if (fewmatches) {
+    // scratch behind the masks and prefixes (the exit maps' area is free): the list as it came, sorted, "taken" flags
+    uint32_t* raw = reinterpret_cast<uint32_t*>(&S.u.xmap[512][0]);     // byte offset 32 KiB
+    uint32_t* srt = raw + ZES_MLIST_WORDS;
+    uint8_t* acc = reinterpret_cast<uint8_t*>(srt + ZES_MLIST_WORDS);
+    if (tid < nml) raw[tid] = ml[1u + tid];
+    for (uint32_t c = tid; c < PARSE_CHUNKS; c += PARSE_THREADS) {
+      const uint32_t lo = c * 64u;
+      S.u.d.mask[c] = lo + 64u <= T ? ~0ull : (lo < T ? ((1ull << (T - lo)) - 1ull) : 0ull);  // every position, so far
+      S.cplain[c] = 1;
+    }
+    __syncthreads();
+    if (tid < nml) {  // rank sort by position (positions are distinct)
+      const uint32_t e = raw[tid], pe = e & 0x1FFFFu;
+      uint32_t r = 0;
+      for (uint32_t j = 0; j < nml; j++) r += (raw[j] & 0x1FFFFu) < pe ? 1u : 0u;
+      srt[r] = e;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t cur = 0;
+      for (uint32_t i = 0; i < nml; i++) {
+        const uint32_t e = srt[i], p = e & 0x1FFFFu, L = (e >> 17) + 3u;
+        const bool take = p >= cur;
+        acc[i] = take ? 1 : 0;
+        cur = take ? p + L : cur;
+      }
+    }
+    __syncthreads();
+    if (tid < nml && acc[tid]) {  // the positions inside a taken match are not on the chain
+      const uint32_t e = srt[tid], p = e & 0x1FFFFu, L = (e >> 17) + 3u;
+      S.cplain[p >> 6] = 0;
+      for (uint32_t q = p + 1u; q < p + L;) {
+        const uint32_t w = q >> 6, b0 = q & 63u, nb = min(64u - b0, p + L - q);
+        const unsigned long long bits = (nb >= 64u ? ~0ull : ((1ull << nb) - 1ull)) << b0;
+        atomicAnd(&S.u.d.mask[w], ~bits);
+        q += nb;
+      }
     }
     __syncthreads();
   } else {
@@ -1503,7 +1565,7 @@ __global__ __launch_bounds__(PARSE_THREADS) void k_lz_parse(const uint8_t* __res
   // of xmap finished at the barrier above phase D1 only for the walk; D1 itself does not read xmap.
 
   PSTAMP(4);
-  }  // (!havemask)
+  }  // (neither mask nor list: the chain is searched)
   unsigned long long mymask[2] = {0ull, 0ull};  // thread t owns chunks 2t, 2t+1 for the scan
   // ---- D2: token offsets = exclusive scan of the per-chunk counts ----
   uint32_t cnt2[2];
