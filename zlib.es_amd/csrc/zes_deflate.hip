@@ -2359,12 +2359,25 @@ __global__ __launch_bounds__(EMIT_THREADS) void k_emit(uint8_t* __restrict__ d_o
     const uint32_t nwords = (head + tile_bits + 31u) >> 5;
     for (uint32_t i = tid; i < nwords + 1; i += EMIT_THREADS) S.stage[i] = (i == 0) ? S.carry : 0u;
     __syncthreads();
-    // 4. OR the items in
+    // 4. OR the items in.  A thread's items are consecutive in the stream: they are gathered into 64-bit pieces first
+    // (seven 9-bit literals make one), so that the staging window sees two or three LDS atomics per piece instead of
+    // one or two per item — the atomics, with their bank conflicts, are what this step costs.
     rel += head;
+    {
+      uint64_t acc = 0;
+      uint32_t accn = 0, accpos = rel;
 #pragma unroll
-    for (int k = 0; k < EMIT_ITEMS; k++) {
-      if (nb[k]) stage_or(S.stage, rel, val[k], nb[k]);
-      rel += nb[k];
+      for (int k = 0; k < EMIT_ITEMS; k++) {
+        if (accn + nb[k] > 64u) {
+          stage_or(S.stage, accpos, acc, accn);
+          accpos += accn;
+          acc = 0;
+          accn = 0;
+        }
+        acc |= val[k] << accn;  // (an item has at most 48 bits; accn + nb[k] <= 64 here)
+        accn += nb[k];
+      }
+      if (accn) stage_or(S.stage, accpos, acc, accn);
     }
     __syncthreads();
     // 5. flush complete dwords; the trailing partial dword is carried into the next tile
