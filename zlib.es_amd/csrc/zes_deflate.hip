@@ -93,6 +93,8 @@ static_assert((1u << SORT_HASH_BITS) * 2u / 8u <= ZES_BLK, "counter table must f
 static_assert(SORT_OWN * SORT_THREADS == ZES_BLK, "one thread per 128 positions");
 
 __device__ __forceinline__ static uint32_t sort_hash(uint32_t key24) { return (key24 * 0x9E3779B1u) >> (32u - SORT_HASH_BITS); }
+// second, independent hash for the second filter level
+__device__ __forceinline__ static uint32_t sort_hash2(uint32_t key24) { return ((key24 ^ (key24 >> 11)) * 0xC2B2AE35u) >> (32u - SORT_HASH_BITS); }
 
 // 16 bytes at offset `off` of the block (zero past its end); the 16-byte path needs an aligned block
 __device__ __forceinline__ static uint4 sort_ld16(const uint8_t* __restrict__ src, bool aligned, uint32_t off, uint32_t T) {
@@ -183,6 +185,10 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
   }
   __syncthreads();
   const bool dense = (S.nsat & 0xFFFFu) * 4u >= (S.nsat >> 16) * 3u;
+  // Few kept (incompressible data: a fifth, nearly all of them collisions of the hash, not repeats of a key): a second
+  // filter level over the kept ones with another hash leaves ~2 % of the positions, and the three sorting passes —
+  // two thirds of this kernel on such data — have a twelfth of the elements.
+  const bool two = (S.nsat & 0xFFFFu) * 5u < (S.nsat >> 16) * 2u;
   uint32_t ns = cnt;
   if (!dense) {
   // pass 2: keep the positions whose counter reached two; 128 flags per thread
@@ -204,9 +210,11 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
           bits |= 1u << k;
           // digit histograms of the kept positions (pass 0 sorts by byte 2, pass 2 by byte 0), four
           // copies picked by lane: neighbouring lanes see the same common bytes at the same time
-          atomicAdd(&sub[0][(key >> 16) & 255u], 1u);
-          atomicAdd(&sub[1][(key >> 8) & 255u], 1u);
-          atomicAdd(&sub[2][key & 255u], 1u);
+          if (!two) {
+            atomicAdd(&sub[0][(key >> 16) & 255u], 1u);
+            atomicAdd(&sub[1][(key >> 8) & 255u], 1u);
+            atomicAdd(&sub[2][key & 255u], 1u);
+          }
         }
       }
       const uint32_t v = bits << (16u * (c & 1u));
@@ -215,6 +223,72 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
       f2 |= (c >> 1) == 2u ? v : 0u;
       f3 |= (c >> 1) == 3u ? v : 0u;
       cur = nxt;
+    }
+  }
+  if (two) {  // uniform
+    __syncthreads();  // every thread is done with the first level's counters
+    {
+      uint4* t4 = reinterpret_cast<uint4*>(S.in);
+      for (uint32_t i = tid; i < ZES_BLK / 16; i += SORT_THREADS) t4[i] = make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    // level 2, count: the kept positions only, under the second hash
+    if (p0 < cnt) {
+      uint4 cur = sort_ld16(src, aligned, p0, T);
+#pragma unroll 1
+      for (uint32_t c = 0; c < SORT_OWN / 16; c++) {
+        const uint4 nxt = sort_ld16(src, aligned, p0 + 16u * (c + 1u), T);
+        const uint32_t w[5] = {cur.x, cur.y, cur.z, cur.w, nxt.x};
+        const uint32_t fw = (c >> 1) == 0u ? f0 : (c >> 1) == 1u ? f1 : (c >> 1) == 2u ? f2 : f3;
+        const uint32_t bits = (fw >> (16u * (c & 1u))) & 0xffffu;
+#pragma unroll
+        for (uint32_t k = 0; k < 16; k++) {
+          const uint32_t key = __builtin_amdgcn_alignbyte(w[(k >> 2) + 1], w[k >> 2], k & 3u) & 0xffffffu;
+          const uint32_t h = sort_hash2(key);
+          const uint32_t sh = (h & 15u) * 2u;
+          if ((bits >> k) & 1u) {
+            const uint32_t old = atomicOr(&tbl[h >> 4], 1u << sh);
+            if (((old >> sh) & 3u) == 1u) atomicOr(&tbl[h >> 4], 2u << sh);
+          }
+        }
+        cur = nxt;
+      }
+    }
+    __syncthreads();
+    // level 2, flags: kept by both levels; their digit histograms
+    if (p0 < cnt) {
+      uint32_t g0 = 0, g1 = 0, g2 = 0, g3 = 0;
+      uint4 cur = sort_ld16(src, aligned, p0, T);
+#pragma unroll 1
+      for (uint32_t c = 0; c < SORT_OWN / 16; c++) {
+        const uint4 nxt = sort_ld16(src, aligned, p0 + 16u * (c + 1u), T);
+        const uint32_t w[5] = {cur.x, cur.y, cur.z, cur.w, nxt.x};
+        const uint32_t fw = (c >> 1) == 0u ? f0 : (c >> 1) == 1u ? f1 : (c >> 1) == 2u ? f2 : f3;
+        const uint32_t bits = (fw >> (16u * (c & 1u))) & 0xffffu;
+        uint32_t nb = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 16; k++) {
+          const uint32_t key = __builtin_amdgcn_alignbyte(w[(k >> 2) + 1], w[k >> 2], k & 3u) & 0xffffffu;
+          const uint32_t h = sort_hash2(key);
+          const uint32_t keep = (tbl[h >> 4] >> ((h & 15u) * 2u + 1u)) & 1u;
+          if (keep && ((bits >> k) & 1u)) {
+            nb |= 1u << k;
+            atomicAdd(&sub[0][(key >> 16) & 255u], 1u);
+            atomicAdd(&sub[1][(key >> 8) & 255u], 1u);
+            atomicAdd(&sub[2][key & 255u], 1u);
+          }
+        }
+        const uint32_t v = nb << (16u * (c & 1u));
+        g0 |= (c >> 1) == 0u ? v : 0u;
+        g1 |= (c >> 1) == 1u ? v : 0u;
+        g2 |= (c >> 1) == 2u ? v : 0u;
+        g3 |= (c >> 1) == 3u ? v : 0u;
+        cur = nxt;
+      }
+      f0 = g0;
+      f1 = g1;
+      f2 = g2;
+      f3 = g3;
     }
   }
   SSTAMP(3);
@@ -240,7 +314,17 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
   }
   uint32_t* fbits = reinterpret_cast<uint32_t*>(S.in);         // [4096] flag words
   uint32_t* fpre = reinterpret_cast<uint32_t*>(S.in) + 4096;   // [4096] kept positions before each word
-  {
+  if (two) {  // a few positions per thread: straight from the flag words in registers
+    uint32_t o = woff + incl - mine;
+#pragma unroll
+    for (uint32_t w = 0; w < 4; w++) {
+      uint32_t f = w == 0u ? f0 : w == 1u ? f1 : w == 2u ? f2 : f3;
+      while (f) {
+        B[o++] = p0 + 32u * w + (uint32_t)__builtin_ctz(f);
+        f &= f - 1u;
+      }
+    }
+  } else {
     uint32_t o = woff + incl - mine;
     fbits[4 * tid + 0] = f0;
     fpre[4 * tid + 0] = o;
@@ -260,9 +344,11 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
     (&S.hist[0][0])[tid] = hs[tid] + hs[768 + tid] + hs[1536 + tid] + hs[2304 + tid];
   }
   __syncthreads();
-  for (uint32_t p = tid; p < cnt; p += SORT_THREADS) {
-    const uint32_t w = fbits[p >> 5];
-    if ((w >> (p & 31u)) & 1u) B[fpre[p >> 5] + (uint32_t)__popc(w & ((1u << (p & 31u)) - 1u))] = p;
+  if (!two) {
+    for (uint32_t p = tid; p < cnt; p += SORT_THREADS) {
+      const uint32_t w = fbits[p >> 5];
+      if ((w >> (p & 31u)) & 1u) B[fpre[p >> 5] + (uint32_t)__popc(w & ((1u << (p & 31u)) - 1u))] = p;
+    }
   }
   }  // !dense
   __syncthreads();  // flag words (or, dense, the counter table) read before the block is staged over them
