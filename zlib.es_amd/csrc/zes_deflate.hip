@@ -1790,12 +1790,17 @@ __device__ static inline uint32_t upper_bound_u32(const uint32_t* a, uint32_t n,
 }
 
 // Code lengths of alphabet hist[0..nsym) limited to L, into lens[0..nsym).  All threads call it.
+// A level of the package-merge is one round trip: every thread looks up the slots of its items of the level (a leaf
+// and a package, two of each for alphabets of more than 256 used symbols) side by side — leaf i goes behind the packages lighter than it, package j behind the leaves not heavier
+// (leaves precede packages on ties: src/huffman.ts:79-99) — by fixed-length binary searches whose loads overlap;
+// a package's weight is read as the sum of its two items of the level before, so there is no separate pass (and
+// barrier) that builds the packages.
 __device__ static void pm_lengths(HuffSmem& S, const uint32_t* hist, uint32_t nsym, uint32_t L, uint8_t* lens) {
-  const uint32_t tid = threadIdx.x;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
   __syncthreads();
   // rank sort of the used symbols by (count, symbol)  — src/huffman.ts:67,79-85,95-99
   uint32_t n = 0;
-  for (uint32_t j = 0; j < nsym; j++) n += (hist[j] != 0);
+  for (uint32_t s0 = 0; s0 < nsym; s0 += HUFF_THREADS) n += (uint32_t)__syncthreads_count(s0 + tid < nsym && hist[s0 + tid] != 0u);
   for (uint32_t s = tid; s < nsym; s += HUFF_THREADS) {
     lens[s] = 0;
     const uint32_t c = hist[s];
@@ -1824,36 +1829,70 @@ __device__ static void pm_lengths(HuffSmem& S, const uint32_t* hist, uint32_t ns
   uint32_t len_prev = n & ~1u;
   uint32_t sel = 0;
   __syncthreads();
+  static_assert(PM_MAXN <= 2 * HUFF_THREADS && PM_MAXN < 512, "two items of either kind per thread, nine search steps");
+  const uint32_t st0 = 1u << (31u - (uint32_t)__builtin_clz(n));  // first search step: the largest power of two <= n (>= np)
+  const bool wide = n > HUFF_THREADS;                             // (uniform) a second leaf / package per thread
   for (uint32_t k = 1; k < L; k++) {
-    const uint32_t np = len_prev >> 1;
-    const uint32_t* wp = S.w[sel];
+    const uint32_t np = len_prev >> 1;  // packages of this level: pairs of the level before (src/huffman.ts:87-94); 1 <= np < n
+    const uint2* wp2 = reinterpret_cast<const uint2*>(S.w[sel]);
     uint32_t* wc = S.w[sel ^ 1];
-    for (uint32_t j = tid; j < np; j += HUFF_THREADS) S.pk[j] = wp[2 * j] + wp[2 * j + 1];  // src/huffman.ts:87-94
-    __syncthreads();
-    for (uint32_t i = tid; i < n; i += HUFF_THREADS) {  // leaves precede packages on ties
-      const uint32_t pos = i + lower_bound_u32(S.pk, np, S.lw[i]);
-      wc[pos] = S.lw[i];
-      S.leafpos[k][i] = (uint16_t)pos;
+    // thread t: leaves t and t + 256, packages t and t + 256 (fixed roles: no selects inside the search)
+    const uint32_t i0 = min(tid, n - 1u), i1 = min(tid + HUFF_THREADS, n - 1u);
+    const uint32_t j0 = min(tid, np - 1u), j1 = min(tid + HUFF_THREADS, np - 1u);
+    const uint32_t lv0 = S.lw[i0], lv1 = S.lw[i1];
+    const uint2 pa = wp2[j0], pb = wp2[j1];
+    const uint32_t pv0 = pa.x + pa.y, pv1 = pb.x + pb.y;
+    uint32_t ll0 = 0, ll1 = 0, pl0 = 0, pl1 = 0;  // leaf: #{packages < lv}; package: #{leaves <= pv}
+    if (!wide) {
+#pragma unroll 1
+      for (uint32_t st = st0; st; st >>= 1) {
+        const uint32_t ml = ll0 + st, mp = pl0 + st;
+        const uint2 x = wp2[min(ml, np) - 1u];
+        const uint32_t y = S.lw[min(mp, n) - 1u];
+        ll0 = (ml <= np && x.x + x.y < lv0) ? ml : ll0;
+        pl0 = (mp <= n && y <= pv0) ? mp : pl0;
+      }
+    } else {
+#pragma unroll 1
+      for (uint32_t st = st0; st; st >>= 1) {
+        const uint32_t ml0 = ll0 + st, ml1 = ll1 + st, mp0 = pl0 + st, mp1 = pl1 + st;
+        const uint2 x0 = wp2[min(ml0, np) - 1u], x1 = wp2[min(ml1, np) - 1u];
+        const uint32_t y0 = S.lw[min(mp0, n) - 1u], y1 = S.lw[min(mp1, n) - 1u];
+        ll0 = (ml0 <= np && x0.x + x0.y < lv0) ? ml0 : ll0;
+        ll1 = (ml1 <= np && x1.x + x1.y < lv1) ? ml1 : ll1;
+        pl0 = (mp0 <= n && y0 <= pv0) ? mp0 : pl0;
+        pl1 = (mp1 <= n && y1 <= pv1) ? mp1 : pl1;
+      }
     }
-    for (uint32_t j = tid; j < np; j += HUFF_THREADS) {
-      const uint32_t pos = j + upper_bound_u32(S.lw, n, S.pk[j]);
-      wc[pos] = S.pk[j];
+    if (tid < n) {
+      wc[tid + ll0] = lv0;
+      S.leafpos[k][tid] = (uint16_t)(tid + ll0);
+    }
+    if (tid < np) wc[tid + pl0] = pv0;
+    if (wide) {
+      if (tid + HUFF_THREADS < n) {
+        wc[tid + HUFF_THREADS + ll1] = lv1;
+        S.leafpos[k][tid + HUFF_THREADS] = (uint16_t)(tid + HUFF_THREADS + ll1);
+      }
+      if (tid + HUFF_THREADS < np) wc[tid + HUFF_THREADS + pl1] = pv1;
     }
     len_prev = (n + np) & ~1u;
     sel ^= 1;
     __syncthreads();
   }
-  // selected prefix per level, from the last level down (src/huffman.ts:106-115)
-  if (tid == 0) {
+  // selected prefix per level, from the last level down (src/huffman.ts:106-115): a = #{i : leafpos[k][i] < m}, counted
+  // by the first wavefront (leaf positions ascend with i, so the leaves below m are a prefix)
+  if (tid < 64u) {
     uint32_t m = len_prev;
     for (int k = (int)L - 1; k >= 0; k--) {
-      uint32_t lo = 0, hi = n;  // a = #{i : leafpos[k][i] < m}
-      while (lo < hi) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (S.leafpos[k][mid] < m) lo = mid + 1; else hi = mid;
+      uint32_t a = 0;
+#pragma unroll
+      for (uint32_t c = 0; c < (PM_MAXN + 63) / 64; c++) {
+        const uint32_t i = c * 64u + lane;
+        a += (uint32_t)__popcll(__ballot(i < n && S.leafpos[k][min(i, n - 1u)] < m));
       }
-      S.a_k[k] = lo;
-      m = 2u * (m - lo);
+      if (lane == 0) S.a_k[k] = a;
+      m = 2u * (m - a);
     }
   }
   __syncthreads();
