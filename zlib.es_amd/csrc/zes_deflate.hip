@@ -2357,7 +2357,7 @@ __global__ __launch_bounds__(256) void k_layout(uint8_t* __restrict__ d_out, con
 // whole dwords.  Only the first and last dword of a block (shared with its neighbours) use
 // global atomics.
 // ------------------------------------------------------------------------------------------
-#define EMIT_ITEMS 8  // tokens per thread per tile (a multiple of 4: 16-byte loads)
+#define EMIT_ITEMS 4  // tokens per thread per tile (a multiple of 4: 16-byte loads)
 #define EMIT_TILE (EMIT_THREADS * EMIT_ITEMS)
 #define EMIT_STAGE_WORDS (EMIT_TILE * 48 / 32 + 8)
 struct EmitSmem {
@@ -2375,7 +2375,11 @@ __device__ static inline void stage_or(uint32_t* stage, uint32_t rel_bit, uint64
   if (sh + nbits > 64u) atomicOr(&stage[w + 2], (uint32_t)(v >> (64u - sh)));
 }
 
-__global__ __launch_bounds__(EMIT_THREADS) void k_emit(uint8_t* __restrict__ d_out, const ZesBuf* __restrict__ bufs,
+// Workgroup barrier for LDS traffic only: __syncthreads() also waits for every global load and store of the thread
+// (vmcnt(0)), which here would hold each tile until its flush stores and the next tile's token loads have landed.
+__device__ __forceinline__ static void emit_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__global__ __launch_bounds__(EMIT_THREADS, 8) void k_emit(uint8_t* __restrict__ d_out, const ZesBuf* __restrict__ bufs,
                                                        const ZesBlk* __restrict__ blks, const uint32_t* __restrict__ tok_in,
                                                        const uint32_t* __restrict__ codes_in, const uint32_t* __restrict__ hdr_in) {
   __shared__ EmitSmem S;
@@ -2398,23 +2402,28 @@ __global__ __launch_bounds__(EMIT_THREADS) void k_emit(uint8_t* __restrict__ d_o
   uint64_t cur_bit = bk.bit_off;                               // uniform
   __syncthreads();
 
+  // tokens of the tile in hand (the first tile holds header items only; tile 1 starts at token 0)
+  uint4 pre[EMIT_ITEMS / 4];
+#pragma unroll
+  for (int k4 = 0; k4 < EMIT_ITEMS / 4; k4++) pre[k4] = make_uint4(0, 0, 0, 0);
   for (uint32_t t0 = 0; t0 < nitems; t0 += EMIT_TILE) {
     // 1. each thread builds its (value, nbits) items
     uint64_t val[EMIT_ITEMS];
     uint32_t nb[EMIT_ITEMS];
     uint32_t mysum = 0;
     uint32_t tv4[EMIT_ITEMS];
-    {
-      const uint32_t ti0 = (t0 >= EMIT_TILE ? t0 - EMIT_TILE : 0u) + tid * EMIT_ITEMS;  // first token of this thread
+#pragma unroll
+    for (int k4 = 0; k4 < EMIT_ITEMS / 4; k4++) {
+      tv4[4 * k4 + 0] = pre[k4].x;
+      tv4[4 * k4 + 1] = pre[k4].y;
+      tv4[4 * k4 + 2] = pre[k4].z;
+      tv4[4 * k4 + 3] = pre[k4].w;
+    }
+    {  // the next tile's tokens: on their way while this tile is worked on (the barriers below do not wait for them)
+      const uint32_t ti0 = t0 + tid * EMIT_ITEMS;  // first token of this thread in tile t0 + EMIT_TILE
       const uint4* qp = reinterpret_cast<const uint4*>(tk + min(ti0, ZES_BLK - EMIT_ITEMS));
 #pragma unroll
-      for (int k4 = 0; k4 < EMIT_ITEMS / 4; k4++) {
-        const uint4 q = qp[k4];
-        tv4[4 * k4 + 0] = q.x;
-        tv4[4 * k4 + 1] = q.y;
-        tv4[4 * k4 + 2] = q.z;
-        tv4[4 * k4 + 3] = q.w;
-      }
+      for (int k4 = 0; k4 < EMIT_ITEMS / 4; k4++) pre[k4] = qp[k4];
     }
 #pragma unroll
     for (int k = 0; k < EMIT_ITEMS; k++) {
@@ -2470,7 +2479,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void k_emit(uint8_t* __restrict__ d_o
       if ((int)lane >= d) incl += t;
     }
     if (lane == 63) S.wsum[wave] = incl;
-    __syncthreads();  // also: previous tile's flush finished reading stage/carry
+    emit_lds_barrier();  // also: previous tile's flush finished reading stage/carry
     uint32_t wbase = 0, tile_bits = 0;
 #pragma unroll
     for (uint32_t w = 0; w < EMIT_THREADS / 64; w++) {
@@ -2483,7 +2492,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void k_emit(uint8_t* __restrict__ d_o
     const uint32_t head = (uint32_t)(cur_bit & 31u);
     const uint32_t nwords = (head + tile_bits + 31u) >> 5;
     for (uint32_t i = tid; i < nwords + 1; i += EMIT_THREADS) S.stage[i] = (i == 0) ? S.carry : 0u;
-    __syncthreads();
+    emit_lds_barrier();
     // 4. OR the items in.  A thread's items are consecutive in the stream: they are gathered into 64-bit pieces first
     // (seven 9-bit literals make one), so that the staging window sees two or three LDS atomics per piece instead of
     // one or two per item — the atomics, with their bank conflicts, are what this step costs.
@@ -2504,7 +2513,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void k_emit(uint8_t* __restrict__ d_o
       }
       if (accn) stage_or(S.stage, accpos, acc, accn);
     }
-    __syncthreads();
+    emit_lds_barrier();
     // 5. flush complete dwords; the trailing partial dword is carried into the next tile
     const uint64_t first_dw = cur_bit >> 5;
     const uint32_t end_bits = head + tile_bits;
@@ -2517,7 +2526,7 @@ __global__ __launch_bounds__(EMIT_THREADS) void k_emit(uint8_t* __restrict__ d_o
       else out32[gw] = w;
     }
     const uint32_t carry_next = (!last_tile && (end_bits & 31u)) ? S.stage[end_bits >> 5] : 0u;
-    __syncthreads();
+    emit_lds_barrier();
     if (tid == 0) S.carry = carry_next;
     cur_bit += tile_bits;
   }
