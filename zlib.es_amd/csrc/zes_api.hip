@@ -557,7 +557,7 @@ int deflate_batch_core(const uint8_t* d_in, const uint64_t* in_off, const uint64
   {
     Timed t("k_lz_match_lazy");  // the blocks k_lz_sort flagged (most positions kept); the others return at once
     hipLaunchKernelGGL(k_lz_match_lazy, dim3(nblk), dim3(MATCH_THREADS), 0, g.stream, d_in, dbufs, dblks, idx_a,
-                       (const uint32_t*)g.inv.p, (const uint16_t*)g.sdelta.p, idx_b, (uint32_t*)g.tmask.p);
+                       (const uint32_t*)g.inv.p, (const uint16_t*)g.sdelta.p, idx_b, (uint32_t*)g.tmask.p, (uint32_t*)g.mlist.p);
   }
   if (sort_dbg) {  // average shader-clock cycles per phase of k_lz_match_lazy
     HIPCHK(hipStreamSynchronize(g.stream));
@@ -583,7 +583,14 @@ int deflate_batch_core(const uint8_t* d_in, const uint64_t* in_off, const uint64
     zes_parse_set_dbg((unsigned long long*)g.dbg.p);
   }
   {
-    Timed t("k_lz_parse");  // tokens go to idx_a (free after the match pass)
+    Timed t("k_lz_parse_small");  // tokens go to idx_a (free after the match pass)
+    // two launches over all blocks: the blocks with a chain mask or a short match list run two to a compute unit
+    // (k_lz_parse_small), the others need the exit maps' 128 KiB; each kernel leaves the other's blocks at once
+    hipLaunchKernelGGL(k_lz_parse_small, dim3(nblk), dim3(PARSE_THREADS), 0, g.stream, d_in, dbufs, dblks, idx_b, idx_a, (uint32_t*)g.hists.p,
+                       (const uint32_t*)g.tmask.p, (const uint32_t*)g.mlist.p);
+  }
+  {
+    Timed t("k_lz_parse");
     hipLaunchKernelGGL(k_lz_parse, dim3(nblk), dim3(PARSE_THREADS), 0, g.stream, d_in, dbufs, dblks, idx_b, idx_a, (uint32_t*)g.hists.p,
                        (const uint32_t*)g.tmask.p, (const uint32_t*)g.mlist.p);
   }
@@ -2444,7 +2451,9 @@ int zes_stage_lz77_dev(const uint8_t* d_in, uint64_t n, uint64_t start, uint32_t
                      (const ZesBlk*)g.blks.p, (const uint32_t*)g.idx_a.p, (uint32_t*)g.idx_b.p, (uint32_t*)g.mlist.p);
   hipLaunchKernelGGL(k_lz_match_lazy, dim3(1), dim3(MATCH_THREADS), 0, g.stream, d_in, (const ZesBuf*)g.bufs.p,
                      (const ZesBlk*)g.blks.p, (const uint32_t*)g.idx_a.p, (const uint32_t*)g.inv.p, (const uint16_t*)g.sdelta.p, (uint32_t*)g.idx_b.p,
-                     (uint32_t*)g.tmask.p);
+                     (uint32_t*)g.tmask.p, (uint32_t*)g.mlist.p);
+  hipLaunchKernelGGL(k_lz_parse_small, dim3(1), dim3(PARSE_THREADS), 0, g.stream, d_in, (const ZesBuf*)g.bufs.p, (ZesBlk*)g.blks.p,
+                     (const uint32_t*)g.idx_b.p, (uint32_t*)g.idx_a.p, (uint32_t*)g.hists.p, (const uint32_t*)g.tmask.p, (const uint32_t*)g.mlist.p);
   hipLaunchKernelGGL(k_lz_parse, dim3(1), dim3(PARSE_THREADS), 0, g.stream, d_in, (const ZesBuf*)g.bufs.p, (ZesBlk*)g.blks.p,
                      (const uint32_t*)g.idx_b.p, (uint32_t*)g.idx_a.p, (uint32_t*)g.hists.p, (const uint32_t*)g.tmask.p, (const uint32_t*)g.mlist.p);
   HIPCHK(hipGetLastError());

@@ -1190,10 +1190,12 @@ __device__ __forceinline__ static uint32_t lazy_chains(LazySmem& S, const uint32
 __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match_lazy(const uint8_t* __restrict__ d_in, const ZesBuf* __restrict__ bufs,
                                                                  const ZesBlk* __restrict__ blks, const uint32_t* __restrict__ idx_a,
                                                                  const uint32_t* __restrict__ inv_all, const uint16_t* __restrict__ sd_all,
-                                                                 uint32_t* __restrict__ match_out, uint32_t* __restrict__ tmask_all) {
+                                                                 uint32_t* __restrict__ match_out, uint32_t* __restrict__ tmask_all,
+                                                                 uint32_t* __restrict__ mlist_all) {
   __shared__ __align__(16) LazySmem S;
   const uint32_t g = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   if (!(idx_a[(uint64_t)g * ZES_BLK + ZES_BLK - 1] & ZES_SORT_LAZY)) return;  // this block belongs to k_lz_match
+  if (threadIdx.x == 0) mlist_all[(uint64_t)g * ZES_MLIST_WORDS] = 0xFFFFFFFFu;  // "no list: a block of this kernel" (k_lz_parse)
   const uint32_t* inv = inv_all + (uint64_t)g * ZES_BLK;
   const uint16_t* sd = sd_all + (uint64_t)g * ZES_BLK;
   const ZesBlk bk = blks[g];
@@ -1414,7 +1416,10 @@ void zes_parse_set_dbg(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMB
 #define PARSE_REGION 128                    // chunks per wave
 #define PARSE_NOENTRY 0xFFu
 #define PARSE_BATCH 8u                      // chunks whose global loads are issued together
-struct ParseSmem {
+template <bool SMALL>
+struct ParseSmemT;
+template <>
+struct ParseSmemT<false> {
   union {
     uint8_t xmap[PARSE_CHUNKS][64];         // phase A-C
     struct {
@@ -1426,6 +1431,22 @@ struct ParseSmem {
   uint8_t centry[PARSE_CHUNKS];
   uint8_t cplain[PARSE_CHUNKS];              // 1: the chunk holds no match word at all (every hop is +1)
   uint32_t rentry[PARSE_THREADS / 64 + 1];
+  uint32_t wsum[PARSE_THREADS / 64];
+  uint32_t lh[288];
+  uint32_t dh[32];
+};
+// Blocks whose chain arrives as a bit mask or is built from the match list need none of the exit maps: 31 KiB
+// instead of 143, and with 64 registers two workgroups share a compute unit (k_lz_parse_small).
+template <>
+struct ParseSmemT<true> {
+  struct {
+    struct {
+      unsigned long long mask[PARSE_CHUNKS];
+      uint32_t cpre[PARSE_CHUNKS];
+    } d;
+  } u;
+  uint32_t list[2 * ZES_MLIST_WORDS + ZES_MLIST_WORDS / 4];  // the match list as it came, sorted, "taken" flags
+  uint8_t cplain[PARSE_CHUNKS];
   uint32_t wsum[PARSE_THREADS / 64];
   uint32_t lh[288];
   uint32_t dh[32];
@@ -1448,11 +1469,12 @@ __device__ static uint32_t parse_follow(const uint32_t* mi, uint32_t T, uint32_t
   return cur - 64u;
 }
 
-__global__ __launch_bounds__(PARSE_THREADS) void k_lz_parse(const uint8_t* __restrict__ d_in, const ZesBuf* __restrict__ bufs,
-                                                            ZesBlk* __restrict__ blks, const uint32_t* __restrict__ match_in,
-                                                            uint32_t* __restrict__ tok_out, uint32_t* __restrict__ hists,
-                                                            const uint32_t* __restrict__ tmask_all, const uint32_t* __restrict__ mlist_all) {
-  __shared__ __align__(16) ParseSmem S;
+#define PARSE_ARRIVE4(a) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]))
+template <bool SMALL>
+__device__ __forceinline__ static void parse_body(ParseSmemT<SMALL>& S, const uint8_t* __restrict__ d_in, const ZesBuf* __restrict__ bufs,
+                                                  ZesBlk* __restrict__ blks, const uint32_t* __restrict__ match_in,
+                                                  uint32_t* __restrict__ tok_out, uint32_t* __restrict__ hists,
+                                                  const uint32_t* __restrict__ tmask_all, const uint32_t* __restrict__ mlist_all) {
   const uint32_t g = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const ZesBlk bk = blks[g];
   const ZesBuf bf = bufs[bk.buf];
@@ -1462,25 +1484,26 @@ __global__ __launch_bounds__(PARSE_THREADS) void k_lz_parse(const uint8_t* __res
   uint32_t* to = tok_out + (uint64_t)g * ZES_BLK;
   const uint32_t nchunks = (T + 63u) >> 6;
   const uint32_t nregions = (nchunks + PARSE_REGION - 1) / PARSE_REGION;
+  // k_lz_match_lazy's blocks come with the positions of the chain as a bit mask (unless its chains did not merge):
+  // phases A to D1, which find those positions, are skipped.  Which kernel a block belonged to stands in the head
+  // word of its match list (a count from k_lz_match, all ones from k_lz_match_lazy).
+  const uint32_t* tmk = tmask_all + (uint64_t)g * ZES_TMASK_WORDS;
+  const uint32_t* ml = mlist_all + (uint64_t)g * ZES_MLIST_WORDS;
+  const uint32_t nml = ml[0];
+  const bool lazyblk = nml == 0xFFFFFFFFu;
+  const bool havemask = lazyblk && tmk[0] == 1u;              // (uniform)
+  const bool fewmatches = !lazyblk && nml <= ZES_MLIST_CAP;  // (uniform)
+  if (SMALL != (havemask || fewmatches)) return;              // the other kernel's block
   for (uint32_t i = tid; i < 288; i += PARSE_THREADS) S.lh[i] = 0;
   if (tid < 32) S.dh[tid] = 0;
-  for (uint32_t i = tid; i < PARSE_CHUNKS; i += PARSE_THREADS) S.centry[i] = PARSE_NOENTRY;
-
-  // k_lz_match_lazy's blocks come with the positions of the chain as a bit mask (unless its chains did not merge):
-  // phases A to D1, which find those positions, are skipped.  (The sort's flag word sits where the last token would
-  // go: read before anything is written there.)
-  const uint32_t* tmk = tmask_all + (uint64_t)g * ZES_TMASK_WORDS;
-  const bool havemask = (to[ZES_BLK - 1] & ZES_SORT_LAZY) != 0u && tmk[0] == 1u;  // (uniform)
+  if constexpr (!SMALL)
+    for (uint32_t i = tid; i < PARSE_CHUNKS; i += PARSE_THREADS) S.centry[i] = PARSE_NOENTRY;
   PSTAMP(0);
   // ---- A: exit map of every chunk ----
   const uint32_t c_lo = wave * PARSE_REGION, c_hi = min(nchunks, c_lo + PARSE_REGION);
   // k_lz_match's blocks with few matches (incompressible data: ~260): the chain is every position except the insides
   // of the matches the greedy parse takes — a listed match is taken iff it starts at or behind the end of the last
   // one taken (src/lz77.ts:39-47,95): sorted, then one pass in order.  (Phases A to D1 cost 213k cycles a block there.)
-  const uint32_t* ml = mlist_all + (uint64_t)g * ZES_MLIST_WORDS;
-  const bool lazyblk = (to[ZES_BLK - 1] & ZES_SORT_LAZY) != 0u;
-  const uint32_t nml = lazyblk ? 0xFFFFFFFFu : ml[0];
-  const bool fewmatches = !lazyblk && nml <= ZES_MLIST_CAP;  // (uniform)
   if (havemask) {
     const unsigned long long* t64 = reinterpret_cast<const unsigned long long*>(tmk + 4);
     for (uint32_t c = tid; c < PARSE_CHUNKS; c += PARSE_THREADS) {
@@ -1489,8 +1512,10 @@ __global__ __launch_bounds__(PARSE_THREADS) void k_lz_parse(const uint8_t* __res
     }
     __syncthreads();
   } else if (fewmatches) {
-    // scratch behind the masks and prefixes (the exit maps' area is free): the list as it came, sorted, "taken" flags
-    uint32_t* raw = reinterpret_cast<uint32_t*>(&S.u.xmap[512][0]);     // byte offset 32 KiB
+    // the list as it came, sorted, "taken" flags (in the big kernel: behind the masks and prefixes, in the exit maps' area)
+    uint32_t* raw;
+    if constexpr (SMALL) raw = S.list;
+    else raw = reinterpret_cast<uint32_t*>(&S.u.xmap[512][0]);  // byte offset 32 KiB
     uint32_t* srt = raw + ZES_MLIST_WORDS;
     uint8_t* acc = reinterpret_cast<uint8_t*>(srt + ZES_MLIST_WORDS);
     if (tid < nml) raw[tid] = ml[1u + tid];
@@ -1528,7 +1553,7 @@ __global__ __launch_bounds__(PARSE_THREADS) void k_lz_parse(const uint8_t* __res
       }
     }
     __syncthreads();
-  } else {
+  } else if constexpr (!SMALL) {
   // Batches of PARSE_BATCH chunks: all their match words are requested before the first is used (one
   // memory latency per batch instead of per chunk).  A chunk without any match (nearly all of them on
   // incompressible input) needs no pointer doubling: every lane leaves at offset 0.
@@ -1684,11 +1709,12 @@ __global__ __launch_bounds__(PARSE_THREADS) void k_lz_parse(const uint8_t* __res
 
   PSTAMP(5);
   // ---- D3: tokens + histograms ----
-  for (uint32_t cb = c_lo; cb < c_hi; cb += PARSE_BATCH) {
-    uint32_t mw[PARSE_BATCH], by[PARSE_BATCH];
-    unsigned long long mks[PARSE_BATCH];
+  constexpr uint32_t DB = SMALL ? 4u : PARSE_BATCH;  // chunks per batch of loads
+  for (uint32_t cb = c_lo; cb < c_hi; cb += DB) {
+    uint32_t mw[DB], by[DB];
+    unsigned long long mks[DB];
 #pragma unroll
-    for (uint32_t k = 0; k < PARSE_BATCH; k++) {  // input bytes of visited positions; match words where the chunk has any
+    for (uint32_t k = 0; k < DB; k++) {  // input bytes of visited positions; match words where the chunk has any
       const uint32_t c = cb + k;
       mks[k] = c < c_hi ? S.u.d.mask[c] : 0ull;
       const bool vis = (mks[k] >> lane) & 1ull;  // implies p < T
@@ -1696,10 +1722,15 @@ __global__ __launch_bounds__(PARSE_THREADS) void k_lz_parse(const uint8_t* __res
       by[k] = src[vis ? p : min(lane, T - 1u)];  // unconditional loads (see phase A)
       mw[k] = mi[(vis && !S.cplain[min(c, PARSE_CHUNKS - 1u)]) ? p : lane];
     }
-    PARSE_ARRIVE8(by);
-    PARSE_ARRIVE8(mw);
+    if constexpr (SMALL) {
+      PARSE_ARRIVE4(by);
+      PARSE_ARRIVE4(mw);
+    } else {
+      PARSE_ARRIVE8(by);
+      PARSE_ARRIVE8(mw);
+    }
 #pragma unroll
-    for (uint32_t k = 0; k < PARSE_BATCH; k++) {
+    for (uint32_t k = 0; k < DB; k++) {
       const uint32_t c = cb + k;
       const unsigned long long mk = mks[k];
       if ((mk >> lane) & 1ull) {
@@ -1729,6 +1760,23 @@ __global__ __launch_bounds__(PARSE_THREADS) void k_lz_parse(const uint8_t* __res
   for (uint32_t i = tid; i < 288; i += PARSE_THREADS) hg[i] = S.lh[i];
   if (tid < 32) hg[288 + tid] = S.dh[tid];
   PSTAMP(7);
+}
+
+__global__ __launch_bounds__(PARSE_THREADS) void k_lz_parse(const uint8_t* __restrict__ d_in, const ZesBuf* __restrict__ bufs,
+                                                            ZesBlk* __restrict__ blks, const uint32_t* __restrict__ match_in,
+                                                            uint32_t* __restrict__ tok_out, uint32_t* __restrict__ hists,
+                                                            const uint32_t* __restrict__ tmask_all, const uint32_t* __restrict__ mlist_all) {
+  __shared__ __align__(16) ParseSmemT<false> S;
+  parse_body<false>(S, d_in, bufs, blks, match_in, tok_out, hists, tmask_all, mlist_all);
+}
+// the blocks with a chain mask or a short match list: two workgroups per compute unit
+__global__ __launch_bounds__(PARSE_THREADS, 8) void k_lz_parse_small(const uint8_t* __restrict__ d_in, const ZesBuf* __restrict__ bufs,
+                                                                     ZesBlk* __restrict__ blks, const uint32_t* __restrict__ match_in,
+                                                                     uint32_t* __restrict__ tok_out, uint32_t* __restrict__ hists,
+                                                                     const uint32_t* __restrict__ tmask_all,
+                                                                     const uint32_t* __restrict__ mlist_all) {
+  __shared__ __align__(16) ParseSmemT<true> S;
+  parse_body<true>(S, d_in, bufs, blks, match_in, tok_out, hists, tmask_all, mlist_all);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -13,7 +13,7 @@
 #define ZES_PAR_DBG_ROW 32  // u64 slots per work item of k_inf_block_par's ZES_DEBUG_PHASES stamps
 // k_lz_match_lazy -> k_lz_parse, per block: [0] = 1 when the mask is there, [4..] a bit per position of the greedy chain
 #define ZES_TMASK_WORDS (131072 / 32 + 4)
-// k_lz_match -> k_lz_parse, per block: [0] = matches found, [1..] the first ZES_MLIST_CAP of them as position | (length - 3) << 17
+// k_lz_match -> k_lz_parse, per block: [0] = matches found (all ones: a block of k_lz_match_lazy), [1..] the first ZES_MLIST_CAP of them as position | (length - 3) << 17
 #define ZES_MLIST_CAP 511u
 #define ZES_MLIST_WORDS 512u
 #define PAR_THREADS 1024
@@ -122,9 +122,10 @@ void zes_lazy_set_dbg(unsigned long long*);
 void zes_huff_set_dbg(unsigned long long*);
 __global__ void k_make_blks(ZesBuf, uint32_t, ZesBuf*, ZesBlk*, uint32_t, unsigned long long*);
 __global__ void k_lz_sort(const uint8_t*, const ZesBuf*, const ZesBlk*, uint32_t*, uint32_t*, uint32_t*, uint16_t*);
-__global__ void k_lz_match_lazy(const uint8_t*, const ZesBuf*, const ZesBlk*, const uint32_t*, const uint32_t*, const uint16_t*, uint32_t*, uint32_t*);
+__global__ void k_lz_match_lazy(const uint8_t*, const ZesBuf*, const ZesBlk*, const uint32_t*, const uint32_t*, const uint16_t*, uint32_t*, uint32_t*, uint32_t*);
 __global__ void k_lz_match(const uint8_t*, const ZesBuf*, const ZesBlk*, const uint32_t*, uint32_t*, uint32_t*);
 __global__ void k_lz_parse(const uint8_t*, const ZesBuf*, ZesBlk*, const uint32_t*, uint32_t*, uint32_t*, const uint32_t*, const uint32_t*);
+__global__ void k_lz_parse_small(const uint8_t*, const ZesBuf*, ZesBlk*, const uint32_t*, uint32_t*, uint32_t*, const uint32_t*, const uint32_t*);
 __global__ void k_huff(ZesBlk*, const uint32_t*, uint32_t*, uint32_t*);
 __global__ void k_huff_lengths_only(const uint32_t*, uint32_t, uint32_t, uint8_t*);
 __global__ void k_adler(const uint8_t*, uint64_t, uint64_t, unsigned long long*);
