@@ -50,7 +50,7 @@ __device__ static inline uint64_t g_load64_le(const uint8_t* p, uint64_t byte, u
 #define SCAN_BYTES INF_SCAN_BYTES  // bytes of the stream per workgroup
 #define RANK_LDS 8192u  // candidates k_inf_ranksort keeps in LDS
 #define VERIFY_STEPS 32u  // code-length symbols a lane of k_inf_verify decodes before it hands its survivor to a whole wave
-#define SCAN_LIST 4096u             // survivors a workgroup can stage (expected: ~0.2 % of 65536 positions)
+#define SCAN_LIST 1024u             // survivors a workgroup can stage (expected: ~0.2 % of 65536 positions = 130; 16 KiB of LDS in all, so eight workgroups share a compute unit)
 // Copies whole 128 KiB slots: item i moves slot src_slot[i] of src to slot dst_slot[i] of dst (32 workgroups
 // per item, 16 bytes per lane and step).  Used to close the gaps false candidates leave in the output.
 __global__ __launch_bounds__(256) void k_inf_move_slots(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src,

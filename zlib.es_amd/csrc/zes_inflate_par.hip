@@ -411,17 +411,6 @@ struct F8List {
   // thirty-two u16 positions relative to the segment base, four per word, 0xFFFF = empty (named fields: see SegTab)
   uint64_t q0, q1, q2, q3, q4, q5, q6, q7;
 };
-// store a group of four positions as word k of the list
-__device__ __forceinline__ static void f8_flush(F8List& l, uint32_t k, uint64_t grp) {
-  l.q0 = (k == 0u) ? grp : l.q0;
-  l.q1 = (k == 1u) ? grp : l.q1;
-  l.q2 = (k == 2u) ? grp : l.q2;
-  l.q3 = (k == 3u) ? grp : l.q3;
-  l.q4 = (k == 4u) ? grp : l.q4;
-  l.q5 = (k == 5u) ? grp : l.q5;
-  l.q6 = (k == 6u) ? grp : l.q6;
-  l.q7 = (k == 7u) ? grp : l.q7;
-}
 // smallest listed position q >= x on x's bit phase (0xFFFF if none)
 __device__ __forceinline__ static uint32_t f8_next(const F8List& l, uint64_t tail, uint32_t x) {
   uint32_t nx = 0xFFFFu;
@@ -496,11 +485,19 @@ __device__ __forceinline__ static bool seg_table_f8(ParSmem& S, const BitSrc& sr
       const bool take = hv && rel < sl + 48u;
       grp = take ? ((grp << 16) | rel) : grp;
       nl += take ? 1u : 0u;
+      // a complete group of four goes to the list: the words move up by one (f8_next does not care about their order;
+      // past 32 positions the oldest drop out, and the lane falls back anyway).  No branch and no indexed word: both
+      // cost this loop two dozen register copies per turn.
       const bool full = take && (nl & 3u) == 0u;
-      if (__ballot(full)) {
-        if (full && nl <= F8_LIST) f8_flush(li, (nl >> 2) - 1u, grp);
-        grp = full ? ~0ull : grp;
-      }
+      li.q7 = full ? li.q6 : li.q7;
+      li.q6 = full ? li.q5 : li.q6;
+      li.q5 = full ? li.q4 : li.q5;
+      li.q4 = full ? li.q3 : li.q4;
+      li.q3 = full ? li.q2 : li.q3;
+      li.q2 = full ? li.q1 : li.q2;
+      li.q1 = full ? li.q0 : li.q1;
+      li.q0 = full ? grp : li.q0;
+      grp = full ? ~0ull : grp;
     }
   }
   ok = ok && nl <= F8_LIST;
