@@ -523,6 +523,33 @@ def test_inflate_false_positive_block_headers_are_survivable(z, oracle, gpu):
     assert back.numel() == len(a) and (back.cpu().numpy() == a).all()
 
 
+def test_inflate_periodic_stream_with_more_scan_survivors_than_the_list_holds(z, oracle, gpu):
+    """The compressed form of periodic data is periodic itself: the bits of one repeated match pass the block-start
+    scan at every repetition, thousands of times in an 8 KiB chunk (found by tools/gpu_fuzz.py, seed 77: the scan used
+    to give such a chunk up with its reserved survivor slots unwritten, and the header test then read through stale
+    entries: a GPU memory fault).  tools/gpu_scan_overflow_probe.py lists the inputs: zlib -6 of a 259-byte period has
+    1549 survivors in 2099 bytes (n = 400000) and 11626 in 13435 (n = 3000000)."""
+    import zlib as pz
+
+    for n in (400000, 3000000):
+        a = np.resize(z.gen("xorshift", 266, n)[:259], n).copy()
+        fz = np.frombuffer(pz.compress(a.tobytes(), 6), dtype=np.uint8)
+        assert z.inflate(fz).tobytes() == a.tobytes()
+        own = z.deflate(a)
+        assert z.inflate(own).tobytes() == a.tobytes()
+        for src in (fz, own):  # cut short: the same answer as the oracle, whichever tier ends up with it
+            cut = src[: len(src) * 2 // 3]
+            try:
+                exp = ("out", oracle.inflate(cut).tobytes())
+            except oracle.OracleError as ex:
+                exp = ("err", ex.code)
+            try:
+                got = ("out", z.inflate(cut).tobytes())
+            except z.ZlibEsError as ex:
+                got = ("err", ex.code)
+            assert got == exp
+
+
 @pytest.mark.parametrize("kind,seed", [("itext", 1093), ("xorshift", 1025)])
 def test_inflate_false_candidate_inside_a_block_stays_block_parallel(z, oracle, gpu, kind, seed):
     """These two 1 MiB inputs compress to streams whose *bits* contain a spurious, fully valid dynamic

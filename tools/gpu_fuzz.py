@@ -35,6 +35,8 @@ while time.time() < t_end:
         n += 1
     a = z.gen(kind, int(rng.integers(1 << 30)), n)
     shape = int(rng.integers(6))
+    if os.environ.get("FUZZ_CASES"):  # name every case on stderr (beside ZES_TRACE_KERNELS: which call a GPU fault belongs to)
+        print("case", n_cases, kind, n, "shape", shape, file=sys.stderr, flush=True)
     if shape == 0:  # runs and short periods: maximal matches at tiny distances, chunked code-length runs
         per = int(rng.choice([1, 2, 3, 5, 27, 257, 258, 259, 4097]))
         a = np.resize(a[:per], n).copy()

@@ -405,6 +405,14 @@ struct Timed {
       (void)hipEventRecord(b, g.stream);
       g.pending.push_back({name, {a, b}});
     }
+    // ZES_TRACE_KERNELS: wait for the launch and name it on stderr (the kernel after the last name printed is the one
+    // a GPU fault belongs to)
+    static const bool trace = getenv("ZES_TRACE_KERNELS") != nullptr;
+    if (trace) {
+      const hipError_t e = hipStreamSynchronize(g.stream);
+      fprintf(stderr, "zes kernel done: %s (%s)\n", name, hipGetErrorName(e));
+      fflush(stderr);
+    }
   }
 };
 

@@ -2260,7 +2260,35 @@ __device__ __forceinline__ static void adler_chunk(const uint8_t* __restrict__ p
   // B = sum over j of (clen - j) * b[j]  (j = offset inside the chunk)
   uint64_t A = 0, B = 0;
   const bool aligned = (((uintptr_t)p) & 15u) == 0;
-  for (uint64_t o = (uint64_t)tid * 16; o < clen; o += (uint64_t)ADLER_THREADS * 16) {
+  uint64_t o_first = (uint64_t)tid * 16;
+  // Whole aligned rounds first, four 16-byte loads in flight per thread and the byte sums by dot-product instructions
+  // (the one-load-at-a-time loop below ran at 1.6 TB/s: a workgroup per 64 KiB leaves four waves on a SIMD, each
+  // waiting for its single load).
+  if (aligned) {
+    constexpr uint64_t ROUND = (uint64_t)ADLER_THREADS * 16 * 4;
+    const uint64_t nround = clen / ROUND;
+    for (uint64_t r = 0; r < nround; r++) {
+      uint4 v[4];
+#pragma unroll
+      for (uint32_t q = 0; q < 4; q++) v[q] = *reinterpret_cast<const uint4*>(p + r * ROUND + (uint64_t)q * ADLER_THREADS * 16 + (uint64_t)tid * 16);
+#pragma unroll
+      for (uint32_t q = 0; q < 4; q++) {
+        const uint64_t o = r * ROUND + (uint64_t)q * ADLER_THREADS * 16 + (uint64_t)tid * 16;
+        uint32_t a = __builtin_amdgcn_udot4(v[q].x, 0x01010101u, 0u, false);
+        a = __builtin_amdgcn_udot4(v[q].y, 0x01010101u, a, false);
+        a = __builtin_amdgcn_udot4(v[q].z, 0x01010101u, a, false);
+        a = __builtin_amdgcn_udot4(v[q].w, 0x01010101u, a, false);
+        uint32_t w = __builtin_amdgcn_udot4(v[q].x, 0x0D0E0F10u, 0u, false);  // byte k of the 16 weighs 16 - k
+        w = __builtin_amdgcn_udot4(v[q].y, 0x090A0B0Cu, w, false);
+        w = __builtin_amdgcn_udot4(v[q].z, 0x05060708u, w, false);
+        w = __builtin_amdgcn_udot4(v[q].w, 0x01020304u, w, false);
+        A += a;
+        B += (uint64_t)w + (uint64_t)a * (clen - o - 16);
+      }
+    }
+    o_first += nround * ROUND;
+  }
+  for (uint64_t o = o_first; o < clen; o += (uint64_t)ADLER_THREADS * 16) {
     uint8_t b[16];
     if (aligned && o + 16 <= clen) {
       *reinterpret_cast<uint4*>(b) = *reinterpret_cast<const uint4*>(p + o);

@@ -139,54 +139,66 @@ __global__ __launch_bounds__(INF_SCAN_THREADS) void k_inf_scan(const uint8_t* __
   // the buffer's first byte rides back with the counters (CM nibble check on the host, src/zlib.ts:13)
   if (tid == 0 && b0 == 0) first_bytes[bi] = (uint8_t)(s[0] & 0xffu);
   const uint64_t end_bits = c * 8;
+  // Two passes at most.  The first stages the survivors in LDS; a chunk with more of them than the list holds (a
+  // periodic stream: the bit pattern of one repeated match passes the test at every repetition) is walked again and
+  // writes them straight to their reserved slots — every reserved slot below surv_cap gets written, whatever the data.
+  uint32_t gb = 0;
+  for (uint32_t pass = 0; pass < 2u; pass++) {
 #pragma unroll 1
-  for (uint32_t k = 0; k < SCAN_BYTES / 4 / INF_SCAN_THREADS; k++) {
-    const uint32_t grp = k * INF_SCAN_THREADS + tid;  // dword of positions inside the chunk
-    const uint64_t w0 = (uint64_t)s[grp] | ((uint64_t)s[grp + 1] << 32);
-    const uint64_t w1 = (uint64_t)s[grp + 2] | ((uint64_t)s[grp + 3] << 32);
-    // bit i of m: position i has bit1 = 0, bit2 = 1 (BTYPE 2), not all of bits 4..7 (HLIT <= 29),
-    // not all of bits 9..12 (HDIST <= 29)
-    uint32_t m = (uint32_t)(~(w0 >> 1) & (w0 >> 2) & ~((w0 >> 4) & (w0 >> 5) & (w0 >> 6) & (w0 >> 7)) &
-                            ~((w0 >> 9) & (w0 >> 10) & (w0 >> 11) & (w0 >> 12)));
-    const uint64_t abs_base = b0 * 8 + (uint64_t)grp * 32;
-    // Only the last block of a stream has BFINAL set, and a block this tier decodes has at most 144 KiB of
-    // compressed data: further from the end than that, a position with bit0 = 1 is not a block start (half of
-    // all positions, so half of the survivors the verify kernel would have to decode).
-    if (!loose && abs_base + 32 + SCAN_FINAL_ZONE_BITS <= end_bits) m &= (uint32_t)~w0;
-    while (m) {
-      const uint32_t i = (uint32_t)__builtin_ctz(m);
-      m &= m - 1u;
-      const uint64_t abs_bit = abs_base + i;
-      if (abs_bit < 16ull + bufs[bi].start_rel || abs_bit + 17 + 12 > end_bits) continue;  // (start_rel: 0 unless the buffer is a piece of a longer stream)
-      const uint64_t lo = i ? ((w0 >> i) | (w1 << (64u - i))) : w0;
-      const uint64_t hi = w1 >> i;
-      const uint32_t ncl = (uint32_t)((lo >> 13) & 15u) + 4u;
-      const uint64_t clb = ((lo >> 17) | (hi << 47)) & ((1ull << (3u * ncl)) - 1ull);  // ncl x 3 bits, up to 57
-      // The reference sends exactly as many code-length-code lengths as reach its last used symbol
-      // (src/deflate.ts:143-148), so the last one is never zero.  T1 only has to find reference-made
-      // blocks: a stream from an encoder that pads this list is still decoded, by T2.
-      if (((clb >> (3u * ncl - 3u)) & 7ull) == 0ull) continue;
-      const uint32_t c_lo = (uint32_t)clb, c_hi = (uint32_t)(clb >> 32);
-      const uint32_t kraft = (uint32_t)s_kraft[c_lo & 4095u] + s_kraft[(c_lo >> 12) & 4095u] +
-                             s_kraft[((c_lo >> 24) | (c_hi << 8)) & 4095u] + s_kraft[(c_hi >> 4) & 4095u] +
-                             s_kraft[(c_hi >> 16) & 4095u];
-      if (kraft != 128u) continue;
-      const uint32_t slot = atomicAdd(&s_cnt, 1u);  // LDS: one global atomic per workgroup below
-      if (slot < SCAN_LIST) s_list[slot] = (uint32_t)(abs_bit - 16);  // relative to bit 16 (fits u32 for c < 512 MiB)
+    for (uint32_t k = 0; k < SCAN_BYTES / 4 / INF_SCAN_THREADS; k++) {
+      const uint32_t grp = k * INF_SCAN_THREADS + tid;  // dword of positions inside the chunk
+      const uint64_t w0 = (uint64_t)s[grp] | ((uint64_t)s[grp + 1] << 32);
+      const uint64_t w1 = (uint64_t)s[grp + 2] | ((uint64_t)s[grp + 3] << 32);
+      // bit i of m: position i has bit1 = 0, bit2 = 1 (BTYPE 2), not all of bits 4..7 (HLIT <= 29),
+      // not all of bits 9..12 (HDIST <= 29)
+      uint32_t m = (uint32_t)(~(w0 >> 1) & (w0 >> 2) & ~((w0 >> 4) & (w0 >> 5) & (w0 >> 6) & (w0 >> 7)) &
+                              ~((w0 >> 9) & (w0 >> 10) & (w0 >> 11) & (w0 >> 12)));
+      const uint64_t abs_base = b0 * 8 + (uint64_t)grp * 32;
+      // Only the last block of a stream has BFINAL set, and a block this tier decodes has at most 144 KiB of
+      // compressed data: further from the end than that, a position with bit0 = 1 is not a block start (half of
+      // all positions, so half of the survivors the verify kernel would have to decode).
+      if (!loose && abs_base + 32 + SCAN_FINAL_ZONE_BITS <= end_bits) m &= (uint32_t)~w0;
+      while (m) {
+        const uint32_t i = (uint32_t)__builtin_ctz(m);
+        m &= m - 1u;
+        const uint64_t abs_bit = abs_base + i;
+        if (abs_bit < 16ull + bufs[bi].start_rel || abs_bit + 17 + 12 > end_bits) continue;  // (start_rel: 0 unless the buffer is a piece of a longer stream)
+        const uint64_t lo = i ? ((w0 >> i) | (w1 << (64u - i))) : w0;
+        const uint64_t hi = w1 >> i;
+        const uint32_t ncl = (uint32_t)((lo >> 13) & 15u) + 4u;
+        const uint64_t clb = ((lo >> 17) | (hi << 47)) & ((1ull << (3u * ncl)) - 1ull);  // ncl x 3 bits, up to 57
+        // The reference sends exactly as many code-length-code lengths as reach its last used symbol
+        // (src/deflate.ts:143-148), so the last one is never zero.  T1 only has to find reference-made
+        // blocks: a stream from an encoder that pads this list is still decoded, by T2.
+        if (((clb >> (3u * ncl - 3u)) & 7ull) == 0ull) continue;
+        const uint32_t c_lo = (uint32_t)clb, c_hi = (uint32_t)(clb >> 32);
+        const uint32_t kraft = (uint32_t)s_kraft[c_lo & 4095u] + s_kraft[(c_lo >> 12) & 4095u] +
+                               s_kraft[((c_lo >> 24) | (c_hi << 8)) & 4095u] + s_kraft[(c_hi >> 4) & 4095u] +
+                               s_kraft[(c_hi >> 16) & 4095u];
+        if (kraft != 128u) continue;
+        const uint32_t slot = atomicAdd(&s_cnt, 1u);  // LDS: one global atomic per workgroup below
+        const uint32_t rel16 = (uint32_t)(abs_bit - 16);  // relative to bit 16 (fits u32 for c < 512 MiB)
+        if (pass == 0u) {
+          if (slot < SCAN_LIST) s_list[slot] = rel16;
+        } else if (gb + slot < surv_cap) {
+          surv[gb + slot] = ((unsigned long long)bi << 32) | rel16;
+        }
+      }
     }
+    __syncthreads();
+    const uint32_t n = s_cnt;
+    if (n == 0 || pass == 1u) return;  // (uniform)
+    if (tid == 0) s_base = atomicAdd(&counters[0], n);
+    __syncthreads();
+    gb = s_base;
+    if (n <= SCAN_LIST) {
+      for (uint32_t i = tid; i < n; i += INF_SCAN_THREADS)
+        if (gb + i < surv_cap) surv[gb + i] = ((unsigned long long)bi << 32) | s_list[i];
+      return;
+    }
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
   }
-  __syncthreads();
-  const uint32_t n = s_cnt;
-  if (n == 0) return;
-  if (tid == 0) s_base = atomicAdd(&counters[0], n);
-  __syncthreads();
-  const uint32_t gb = s_base;
-  if (n > SCAN_LIST) {  // cannot happen for sane data (a chunk has 65536 positions); poison the count
-    if (tid == 0) atomicAdd(&counters[0], 0x40000000u);
-    return;
-  }
-  for (uint32_t i = tid; i < n; i += INF_SCAN_THREADS)
-    if (gb + i < surv_cap) surv[gb + i] = ((unsigned long long)bi << 32) | s_list[i];
 }
 
 // ------------------------------------------------------------------------------------------
