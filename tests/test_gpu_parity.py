@@ -523,6 +523,24 @@ def test_inflate_false_positive_block_headers_are_survivable(z, oracle, gpu):
     assert back.numel() == len(a) and (back.cpu().numpy() == a).all()
 
 
+@pytest.mark.parametrize("repeats,length", [(40, 3), (300, 4), (700, 3), (1500, 5), (6000, 3), (3000, 40)])
+def test_deflate_match_poor_blocks_with_listed_matches(z, oracle, gpu, repeats, length):
+    """Incompressible data with a number of short repeats copied in: blocks whose matches k_lz_match only lists
+    (no more sorted slots than the list holds: the result words are not cleared), blocks with a full list over
+    cleared words, and blocks whose list overflows (the parse searches the result words) — bit-exact either way."""
+    n = 3 * 131072 + 777
+    a = z.gen("xorshift", 4000 + repeats, n).copy()
+    rng = np.random.default_rng(repeats * 7 + length)
+    for _ in range(repeats):
+        src = int(rng.integers(0, n - 2 * length - 40000))
+        dst = src + length + int(rng.integers(0, 30000))
+        a[dst:dst + length] = a[src:src + length]
+    exp = oracle.deflate(a)
+    got = z.deflate(a)
+    assert got.tobytes() == exp.tobytes()
+    assert z.inflate(got).tobytes() == a.tobytes()
+
+
 def test_inflate_periodic_stream_with_more_scan_survivors_than_the_list_holds(z, oracle, gpu):
     """The compressed form of periodic data is periodic itself: the bits of one repeated match pass the block-start
     scan at every repetition, thousands of times in an 8 KiB chunk (found by tools/gpu_fuzz.py, seed 77: the scan used

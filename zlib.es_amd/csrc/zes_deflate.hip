@@ -574,7 +574,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
 struct MatchSmem {
   uint32_t in[(MATCH_IN_DWORDS + 31) / 32 * 32];  // whole 32-dword rows: the swizzle permutes inside a row
   uint32_t ring[MATCH_WAVES][MATCH_RING];         // position | same-key-as-previous-slot flag (bit 31)
-  uint32_t ml[ZES_MLIST_WORDS];                   // the block's matches as a list (count first), for k_lz_parse
+  uint32_t nml;                                   // matches found so far (they are listed in global memory, for k_lz_parse)
 };
 
 __device__ __forceinline__ static uint32_t mswz(uint32_t i) { return i ^ ((i >> 5) & 31u) ^ ((i >> 10) & 31u); }
@@ -636,16 +636,20 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match(const uint8_t* __res
   // no match, so the block's result words are zero-filled with coalesced 16-byte stores first
   // and only real matches are scattered.  This also covers the last two positions, which are
   // always literals (src/lz77.ts:116-117).
-  {
+  // The matches are also listed (up to ZES_MLIST_CAP; incompressible data has ~60 a block): k_lz_parse builds the greedy
+  // chain of such a block from the list instead of searching all 131072 result words for it, and reads a result word
+  // only where a listed match is taken.  A block with no more sorted slots than the list holds cannot overflow it — every
+  // match belongs to a slot — so its 512 KiB of result words are not cleared at all (half of this kernel's time on
+  // incompressible data, 256 MiB of stores per 64 MiB of input).
+  const bool sparse = cnt <= ZES_MLIST_CAP;  // (uniform)
+  if (!sparse) {
     uint4* mo4 = reinterpret_cast<uint4*>(mo);
     const uint32_t n4 = (T + 3u) >> 2;
     for (uint32_t i = tid; i < n4; i += MATCH_THREADS) mo4[i] = make_uint4(0, 0, 0, 0);
   }
-  // the matches are also listed (the first few hundred: incompressible data has ~260 a block): k_lz_parse builds the
-  // greedy chain of such a block from the list instead of searching all 131072 result words for it
-  uint32_t* ml = S.ml;  // (collected in LDS: a global atomic per match cost 0.02 ms on random64)
-  if (tid == 0) ml[0] = 0;
-  __syncthreads();  // from here on every wave works alone, up to the flush of the list at the very end
+  uint32_t* gl = mlist_all + (uint64_t)g * ZES_MLIST_WORDS;
+  if (tid == 0) S.nml = 0;  // (the count in LDS: a global atomic per match cost 0.02 ms on random64; the entries go straight out)
+  __syncthreads();  // from here on every wave works alone, up to the count's way out at the very end
 
   const uint32_t R = ((cnt + MATCH_WAVES * 64u - 1) / (MATCH_WAVES * 64u)) * 64u;
   const uint32_t r0 = min(cnt, wave * R), r1 = min(cnt, r0 + R);
@@ -772,19 +776,15 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match(const uint8_t* __res
     if (mode == 3u) {
       if (best >= 3u && p + best + 3u <= T) {  // nowIndex + len <= endIndex = start + T - 3 (src/lz77.ts:95)
         mo[p] = ZES_TOK_MATCH | ((best - 3u) << 16) | (p - bestq - 1u);
-        const uint32_t slot = atomicAdd(&ml[0], 1u);
-        if (slot < ZES_MLIST_CAP) ml[1u + slot] = p | ((best - 3u) << 17);
+        const uint32_t slot = atomicAdd(&S.nml, 1u);
+        if (slot < ZES_MLIST_CAP) gl[1u + slot] = p | ((best - 3u) << 17);
       }
       mode = 0u;
     }
   }
   }
   __syncthreads();
-  {
-    uint32_t* gl = mlist_all + (uint64_t)g * ZES_MLIST_WORDS;
-    const uint32_t n = min(S.ml[0], ZES_MLIST_CAP) + 1u;
-    for (uint32_t i = tid; i < n; i += MATCH_THREADS) gl[i] = S.ml[i];
-  }
+  if (tid == 0) gl[0] = S.nml;  // (more than ZES_MLIST_CAP: the list is cut short, and k_lz_parse searches the cleared result words)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1445,7 +1445,9 @@ struct ParseSmemT<true> {
       uint32_t cpre[PARSE_CHUNKS];
     } d;
   } u;
-  uint32_t list[2 * ZES_MLIST_WORDS + ZES_MLIST_WORDS / 4];  // the match list as it came, sorted, "taken" flags
+  uint32_t srt[ZES_MLIST_WORDS];     // the match list sorted by position
+  uint8_t acc[ZES_MLIST_WORDS];      // "taken by the greedy parse"
+  uint32_t mstart[ZES_BLK / 32];     // a bit per position: a listed match starts here; in the end: a taken one
   uint8_t cplain[PARSE_CHUNKS];
   uint32_t wsum[PARSE_THREADS / 64];
   uint32_t lh[288];
@@ -1512,47 +1514,79 @@ __device__ __forceinline__ static void parse_body(ParseSmemT<SMALL>& S, const ui
     }
     __syncthreads();
   } else if (fewmatches) {
-    // the list as it came, sorted, "taken" flags (in the big kernel: behind the masks and prefixes, in the exit maps' area)
-    uint32_t* raw;
-    if constexpr (SMALL) raw = S.list;
-    else raw = reinterpret_cast<uint32_t*>(&S.u.xmap[512][0]);  // byte offset 32 KiB
-    uint32_t* srt = raw + ZES_MLIST_WORDS;
-    uint8_t* acc = reinterpret_cast<uint8_t*>(srt + ZES_MLIST_WORDS);
-    if (tid < nml) raw[tid] = ml[1u + tid];
+    if constexpr (SMALL) {
+    // Sorted by position without comparing anything: the listed positions are distinct, so a bit per position and a
+    // running count per 32-bit word of that bitmap give every entry its rank (any list length up to ZES_MLIST_CAP).
+    uint16_t* wpre = reinterpret_cast<uint16_t*>(S.u.d.cpre);  // [ZES_BLK / 32] listed positions in front of each word (cpre is written in D2)
     for (uint32_t c = tid; c < PARSE_CHUNKS; c += PARSE_THREADS) {
       const uint32_t lo = c * 64u;
       S.u.d.mask[c] = lo + 64u <= T ? ~0ull : (lo < T ? ((1ull << (T - lo)) - 1ull) : 0ull);  // every position, so far
       S.cplain[c] = 1;
     }
+    for (uint32_t i = tid; i < ZES_BLK / 32; i += PARSE_THREADS) S.mstart[i] = 0;
     __syncthreads();
-    if (tid < nml) {  // rank sort by position (positions are distinct)
-      const uint32_t e = raw[tid], pe = e & 0x1FFFFu;
-      uint32_t r = 0;
-      for (uint32_t j = 0; j < nml; j++) r += (raw[j] & 0x1FFFFu) < pe ? 1u : 0u;
-      srt[r] = e;
+    for (uint32_t i = tid; i < nml; i += PARSE_THREADS) {
+      const uint32_t pe = ml[1u + i] & 0x1FFFFu;
+      atomicOr(&S.mstart[pe >> 5], 1u << (pe & 31u));
+    }
+    __syncthreads();
+    {
+      static_assert(ZES_BLK / 32 == 4 * PARSE_THREADS, "four bitmap words per thread");
+      uint32_t c4[4], sum = 0;
+#pragma unroll
+      for (uint32_t k = 0; k < 4; k++) {
+        c4[k] = (uint32_t)__popc(S.mstart[4u * tid + k]);
+        sum += c4[k];
+      }
+      uint32_t incl = sum;
+#pragma unroll
+      for (int dlt = 1; dlt < 64; dlt <<= 1) {
+        const uint32_t t = __shfl_up(incl, dlt);
+        if ((int)lane >= dlt) incl += t;
+      }
+      if (lane == 63) S.wsum[wave] = incl;
+      __syncthreads();
+      uint32_t run = incl - sum;
+      for (uint32_t w = 0; w < wave; w++) run += S.wsum[w];
+#pragma unroll
+      for (uint32_t k = 0; k < 4; k++) {
+        wpre[4u * tid + k] = (uint16_t)run;
+        run += c4[k];
+      }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < nml; i += PARSE_THREADS) {
+      const uint32_t e = ml[1u + i], pe = e & 0x1FFFFu;
+      const uint32_t r = (uint32_t)wpre[pe >> 5] + (uint32_t)__popc(S.mstart[pe >> 5] & ((1u << (pe & 31u)) - 1u));
+      S.srt[r] = e;
     }
     __syncthreads();
     if (tid == 0) {
       uint32_t cur = 0;
       for (uint32_t i = 0; i < nml; i++) {
-        const uint32_t e = srt[i], p = e & 0x1FFFFu, L = (e >> 17) + 3u;
+        const uint32_t e = S.srt[i], p = e & 0x1FFFFu, L = (e >> 17) + 3u;
         const bool take = p >= cur;
-        acc[i] = take ? 1 : 0;
+        S.acc[i] = take ? 1 : 0;
         cur = take ? p + L : cur;
       }
     }
     __syncthreads();
-    if (tid < nml && acc[tid]) {  // the positions inside a taken match are not on the chain
-      const uint32_t e = srt[tid], p = e & 0x1FFFFu, L = (e >> 17) + 3u;
-      S.cplain[p >> 6] = 0;
-      for (uint32_t q = p + 1u; q < p + L;) {
-        const uint32_t w = q >> 6, b0 = q & 63u, nb = min(64u - b0, p + L - q);
-        const unsigned long long bits = (nb >= 64u ? ~0ull : ((1ull << nb) - 1ull)) << b0;
-        atomicAnd(&S.u.d.mask[w], ~bits);
-        q += nb;
+    for (uint32_t i = tid; i < nml; i += PARSE_THREADS) {
+      const uint32_t e = S.srt[i], p = e & 0x1FFFFu, L = (e >> 17) + 3u;
+      if (S.acc[i]) {  // the positions inside a taken match are not on the chain
+        S.cplain[p >> 6] = 0;
+        for (uint32_t q = p + 1u; q < p + L;) {
+          const uint32_t w = q >> 6, b0 = q & 63u, nb = min(64u - b0, p + L - q);
+          const unsigned long long bits = (nb >= 64u ? ~0ull : ((1ull << nb) - 1ull)) << b0;
+          atomicAnd(&S.u.d.mask[w], ~bits);
+          q += nb;
+        }
+      } else {
+        atomicAnd(&S.mstart[p >> 5], ~(1u << (p & 31u)));  // what is left in the bitmap: the starts of the taken matches
       }
     }
     __syncthreads();
+    }  // (the big kernel never gets such a block)
   } else if constexpr (!SMALL) {
   // Batches of PARSE_BATCH chunks: all their match words are requested before the first is used (one
   // memory latency per batch instead of per chunk).  A chunk without any match (nearly all of them on
@@ -1713,6 +1747,7 @@ __device__ __forceinline__ static void parse_body(ParseSmemT<SMALL>& S, const ui
   for (uint32_t cb = c_lo; cb < c_hi; cb += DB) {
     uint32_t mw[DB], by[DB];
     unsigned long long mks[DB];
+    bool ism[DB];
 #pragma unroll
     for (uint32_t k = 0; k < DB; k++) {  // input bytes of visited positions; match words where the chunk has any
       const uint32_t c = cb + k;
@@ -1720,7 +1755,15 @@ __device__ __forceinline__ static void parse_body(ParseSmemT<SMALL>& S, const ui
       const bool vis = (mks[k] >> lane) & 1ull;  // implies p < T
       const uint32_t p = c * 64u + lane;
       by[k] = src[vis ? p : min(lane, T - 1u)];  // unconditional loads (see phase A)
-      mw[k] = mi[(vis && !S.cplain[min(c, PARSE_CHUNKS - 1u)]) ? p : lane];
+      // a block parsed from its match list has result words only where a match was found (k_lz_match did not clear the
+      // others): a word is read where a taken match starts, nowhere else
+      bool want = vis && !S.cplain[min(c, PARSE_CHUNKS - 1u)];
+      if constexpr (SMALL) {
+        const uint32_t pw = min(p, ZES_BLK - 1u);
+        if (fewmatches) want = want && ((S.mstart[pw >> 5] >> (pw & 31u)) & 1u);
+      }
+      ism[k] = want;
+      mw[k] = mi[want ? p : lane];
     }
     if constexpr (SMALL) {
       PARSE_ARRIVE4(by);
@@ -1734,7 +1777,7 @@ __device__ __forceinline__ static void parse_body(ParseSmemT<SMALL>& S, const ui
       const uint32_t c = cb + k;
       const unsigned long long mk = mks[k];
       if ((mk >> lane) & 1ull) {
-        const uint32_t m = S.cplain[c] ? 0u : mw[k];
+        const uint32_t m = ism[k] ? mw[k] : 0u;
         const uint32_t rank = (uint32_t)__popcll(mk & zes_lanemask_lt());
         uint32_t tv;
         if (m & ZES_TOK_MATCH) {

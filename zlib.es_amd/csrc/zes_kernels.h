@@ -14,8 +14,8 @@
 // k_lz_match_lazy -> k_lz_parse, per block: [0] = 1 when the mask is there, [4..] a bit per position of the greedy chain
 #define ZES_TMASK_WORDS (131072 / 32 + 4)
 // k_lz_match -> k_lz_parse, per block: [0] = matches found (all ones: a block of k_lz_match_lazy), [1..] the first ZES_MLIST_CAP of them as position | (length - 3) << 17
-#define ZES_MLIST_CAP 511u
-#define ZES_MLIST_WORDS 512u
+#define ZES_MLIST_CAP 4095u
+#define ZES_MLIST_WORDS 4096u
 #define PAR_THREADS 1024
 #define PAR_WAVES (PAR_THREADS / 64)
 #define INF_SCAN_THREADS 256
