@@ -541,6 +541,23 @@ def test_deflate_match_poor_blocks_with_listed_matches(z, oracle, gpu, repeats, 
     assert z.inflate(got).tobytes() == a.tobytes()
 
 
+def test_inflate_damaged_block_that_runs_past_both_end_estimates(z, oracle, gpu):
+    """tools/gpu_fuzz.py seed 910, case 1709: another encoder's stream with one bit flipped inside a block.  The block
+    misses its end-of-block code and decodes on through the next blocks' bits to a BTYPE 3 header: the reference throws
+    'Not supported BTYPE'.  The block decoder's segments (64 bits at least) reached beyond the bytes staged for the
+    two end estimates, its chain walked stale bytes of the staging area, and the serial tail behind the last segment met
+    a real block end: 134226 bytes of garbage accepted.  Now a chain that leaves the staged bytes fails."""
+    data = np.fromfile(os.path.join(GOLDEN, "fuzz", "damaged_zlib_stream_seed910_case1709.bin"), dtype=np.uint8)
+    with pytest.raises(oracle.OracleError) as ex:
+        oracle.inflate(data)
+    with pytest.raises(z.ZlibEsError) as got:
+        z.inflate(data)
+    assert got.value.code == ex.value.code
+    with pytest.raises(z.ZlibEsError) as got:
+        z.inflate(data, z.ZES_F_NO_FASTPATH)
+    assert got.value.code == ex.value.code
+
+
 def test_inflate_periodic_stream_with_more_scan_survivors_than_the_list_holds(z, oracle, gpu):
     """The compressed form of periodic data is periodic itself: the bits of one repeated match pass the block-start
     scan at every repetition, thousands of times in an 8 KiB chunk (found by tools/gpu_fuzz.py, seed 77: the scan used

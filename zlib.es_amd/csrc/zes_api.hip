@@ -1190,6 +1190,21 @@ int inflate_segments_run(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, cons
                        (uint32_t*)g.maps.p, (uint32_t*)g.sym16.p, ratio, fail_list, (unsigned long long*)((uint64_t*)g.symoff.p + work),
                        (uint64_t)((share_syms / 2 + 3) & ~3ull), bump_syms, (uint64_t*)g.symoff.p);
   }
+  auto dump_items = [&](const char* tag) {  // ZES_T2_DBG: what every work item has come to so far
+    if (!getenv("ZES_T2_DBG")) return;
+    (void)hipStreamSynchronize(g.stream);
+    std::vector<ZesSegRes> sr(work);
+    std::vector<uint32_t> fl(work + 1, 0);
+    (void)hipMemcpy(sr.data(), g.sres.p, sr.size() * sizeof(ZesSegRes), hipMemcpyDeviceToHost);
+    if (fail_list) (void)hipMemcpy(fl.data(), fail_list, fl.size() * 4, hipMemcpyDeviceToHost);
+    fprintf(stderr, "zes T2 items %s (fail list: %u:", tag, fl[0]);
+    for (uint32_t i = 0; i < fl[0] && i < 16; i++) fprintf(stderr, " %u", fl[1 + i]);
+    fprintf(stderr, ")\n");
+    for (size_t w = 0; w < sr.size(); w++)
+      fprintf(stderr, "   item %zu: end_bit %llu out_len %llu flags %u next %u\n", w, (unsigned long long)sr[w].end_bit,
+              (unsigned long long)sr[w].out_len, sr[w].flags, sr[w].next);
+  };
+  dump_items("after the block decoder");
   {
     Timed t("k_inf_seg_scan");
     hipLaunchKernelGGL(k_inf_seg_scan_short, dim3(work), dim3(64), 0, g.stream, d_in, (const ZesSegJob*)g.segjobs.p, nb, cs, (ZesSegRes*)g.sres.p,
@@ -1230,6 +1245,13 @@ int inflate_segments_run(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, cons
     if (getenv("ZES_DEBUG"))
       fprintf(stderr, "zes T2: c=%llu candidates=%u chain status=%d segments=%u (%u decoded twice) out_len=%llu\n", (unsigned long long)j.c,
               ncand[k], hr[k].status, hr[k].aux, novf[k], (unsigned long long)hr[k].out_len);
+    if (getenv("ZES_T2_DBG")) {  // what every work item came to
+      std::vector<ZesSegRes> sr(ncand[k] + 1);
+      HIPCHK(hipMemcpy(sr.data(), (const ZesSegRes*)g.sres.p + hj[k].work_first, sr.size() * sizeof(ZesSegRes), hipMemcpyDeviceToHost));
+      for (size_t w = 0; w < sr.size(); w++)
+        fprintf(stderr, "   item %zu: end_bit %llu out_len %llu flags %u next %u\n", w, (unsigned long long)sr[w].end_bit,
+                (unsigned long long)sr[w].out_len, sr[w].flags, sr[w].next);
+    }
     if (hr[k].status != 0 || hr[k].aux == 0) continue;
     if (hr[k].out_len > j.cap) {  // the caller learns the size without the output passes
       j.tier = 2;

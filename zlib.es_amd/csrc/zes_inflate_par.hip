@@ -1190,15 +1190,24 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
   src.s32 = reinterpret_cast<const uint32_t*>(S.out);
   src.s_first = start >> 5;
   uint32_t ds = 0, seglen = 0, base = 0, stop = 0, ecode = 0, tail_code = 0;
+  uint32_t plimit = limit;  // end of what the phases that read the staged copy may look at: the data's end, or the staged copy's
   Lit8 f8 = {0, 0, 0};
   STAMP(0);
   // P0 + P1 for one estimate of the block's end.  Returns 0 = go on, 1 = not decodable here.
   auto stage_and_tables = [&](const uint32_t de_est) __attribute__((always_inline)) -> uint32_t {
     // ---- P0: stage the block's compressed bytes in LDS (swizzled), header + tables by wave 0 ----
     {
-      const uint64_t end_bit = min((uint64_t)limit, (uint64_t)de_est + 1280u);  // segment rounding + one token + slack
+      // segment rounding + one token + slack behind the estimate; the longest header (17 + 57 + 320 x 14 bits) in any case
+      const uint64_t end_bit = min((uint64_t)limit, max((uint64_t)de_est, (uint64_t)start + 4800u) + 1280u);
       const uint32_t end_dw = min(lastdw, (uint32_t)((end_bit + 63u) >> 5));
       src.s_count = end_dw - src.s_first + 1u;
+      // Segments are at least 64 bits long, so for a short estimate (a block of less than 8 KiB, or a false candidate
+      // right behind the block's start) the 1024 segments — and even the header — reach beyond the staged bytes.  A
+      // chain that gets there must not go on through whatever the staging area holds: behind `plimit` every position
+      // fails, the item is declined, and the wave decoder (T2) or the chain check (T1) has it.  (tools/gpu_fuzz.py seed
+      // 910: a damaged block ran past both estimates, walked stale bytes of the area to the last lane, and the serial
+      // tail from there met a real block end — garbage accepted where the reference throws.)
+      plimit = (uint32_t)min((uint64_t)limit, ((uint64_t)end_dw + 1u) * 32u);
     }
     // a block whose compressed bytes do not fit the staging area (> 144 KiB for <= 128 KiB of output)
     // is not reference-made: leave it to T2
@@ -1210,7 +1219,7 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
     }
     __syncthreads();
     if (wave == 0 && use_lds) {
-      const bool ok = par_header<true>(S, src, limit, start, dbg ? dbg + (size_t)blockIdx.x * ZES_PAR_DBG_ROW : nullptr);
+      const bool ok = par_header<true>(S, src, plimit, start, dbg ? dbg + (size_t)blockIdx.x * ZES_PAR_DBG_ROW : nullptr);
       if (!ok && lane == 0) S.status = 1;
     }
     __syncthreads();
@@ -1228,7 +1237,7 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
     base = (uint32_t)(b_me64 < 0xFFFFFF00ull ? b_me64 : 0xFFFFFF00ull);
     stop = (uint32_t)((b_me64 + seglen) < 0xFFFFFF00ull ? (b_me64 + seglen) : 0xFFFFFF00ull);
     SegTab tab = {0, 0, 0, 0, 0, 0, 0, 0};
-    seg_table<true, TWO>(S, src, limit, base, stop, f8, tab, dbg ? dbg + (size_t)blockIdx.x * ZES_PAR_DBG_ROW : nullptr);
+    seg_table<true, TWO>(S, src, plimit, base, stop, f8, tab, dbg ? dbg + (size_t)blockIdx.x * ZES_PAR_DBG_ROW : nullptr);
     STAMP(2);
     // Composition.  With room behind the staged block (compressible data: the block's bytes fill a third of the
     // staging area) every lane parks its table in LDS, 52 bytes apart, and a step of the walks below is one byte
@@ -1317,7 +1326,7 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
 
   // ---- P2: count pass from the true entries, totals, end bit, output offsets ----
   uint32_t entry = base + ecode, exit_pos = 0, outbytes = 0, flags = 0;
-  seg_run<false, true, FOREIGN>(S, src, limit, entry, stop, ecode < 48u, f8, 0, exit_pos, outbytes, flags);
+  seg_run<false, true, FOREIGN>(S, src, plimit, entry, stop, ecode < 48u, f8, 0, exit_pos, outbytes, flags);
   if (ecode >= 48u) flags = F_VOID;
   if (tid == 0) {
     S.tail_bytes = 0;
