@@ -1,5 +1,6 @@
 """Randomised differential run (not a pytest; run on the GPU box): deflate vs the oracle, inflate of own / foreign /
-damaged streams vs the oracle, single and batch entry points.  usage: gpu_fuzz.py [seconds] [seed]"""
+damaged streams vs the oracle, single and batch entry points.  usage: gpu_fuzz.py [seconds] [seed]
+(FUZZ_DAMAGE=2: several bit flips and overwritten spans per damaged copy)"""
 import os, sys, time, zlib as pz
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -77,6 +78,20 @@ while time.time() < t_end:
         bad = src.copy()
         pos = int(rng.integers(2, len(bad)))
         bad[pos] ^= np.uint8(1 << int(rng.integers(8)))
+        if os.environ.get("FUZZ_DAMAGE") == "2":  # heavier damage (another sequence of cases per seed than the default)
+            for _ in range(int(rng.integers(0, 4))):
+                bad[int(rng.integers(2, len(bad)))] ^= np.uint8(1 << int(rng.integers(8)))
+            if rng.integers(5) == 0:  # a span overwritten: zeros, ones or a copy from elsewhere in the stream
+                ln = int(rng.integers(1, min(300, len(bad) - 2)))
+                at = int(rng.integers(2, len(bad) - ln))
+                kind2 = int(rng.integers(3))
+                if kind2 == 0:
+                    bad[at:at + ln] = 0
+                elif kind2 == 1:
+                    bad[at:at + ln] = 255
+                else:
+                    frm = int(rng.integers(0, len(bad) - ln))
+                    bad[at:at + ln] = src[frm:frm + ln]
         if rng.integers(3) == 0:
             bad = bad[:int(rng.integers(2, len(bad)))]
         if os.environ.get("FUZZ_TRACE"):
