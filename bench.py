@@ -128,22 +128,36 @@ class Leg:
         self.c = self.csize(comp)
         ok = bool(back.numel() == self.n and bool((back == self.d_in).all()))
         golden = False
-        if self.env["rank"] == 0 and not self.foreign:
-            try:
-                if self.nbuf == 1:
-                    man = json.load(open(os.path.join(ROOT, "tests", "golden", "manifest.json")))
-                    e = [x for x in man["big"] if x["kind"] == self.kind and x["seed"] == self.seed and x["n"] == self.n][0]
-                    digest = hashlib.sha256(comp.cpu().numpy().tobytes()).hexdigest()
-                    ok = ok and self.c == e["deflate_len"] and digest == e["deflate_sha256"]
-                else:  # rank 0's share of configs[3]: every buffer against the reference's own output
-                    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "batch1m.json")))[: self.nbuf]
+        rank = self.env["rank"]
+        gdir = os.path.join(ROOT, "tests", "golden")
+        try:
+            if self.foreign:  # the reference's own inflate of this very stream (foreign_big.json, make_zlibtext64.py)
+                e = [x for x in json.load(open(os.path.join(gdir, "foreign_big.json")))
+                     if x["kind"] == self.kind and x["seed"] == self.seed + rank and x["n"] == self.n][0]
+                if hashlib.sha256(self.foreign_bytes).hexdigest() == e["stream_sha256"]:  # same zlib build, same stream
+                    digest = hashlib.sha256(back.cpu().numpy().tobytes()).hexdigest()
+                    ok = ok and back.numel() == e["output_len"] and digest == e["output_sha256"]
+                    golden = True
+            elif self.nbuf == 1:  # every rank against the reference's output for ITS seed (rank 0: manifest.big)
+                man = json.load(open(os.path.join(gdir, "manifest.json")))["big"]
+                rk = os.path.join(gdir, "ranks_%s.json" % self.kind)
+                if os.path.exists(rk):
+                    man = man + json.load(open(rk))
+                e = [x for x in man if x["kind"] == self.kind and x["seed"] == self.seed + rank and x["n"] == self.n][0]
+                digest = hashlib.sha256(comp.cpu().numpy().tobytes()).hexdigest()
+                ok = ok and self.c == e["deflate_len"] and digest == e["deflate_sha256"]
+                golden = True
+            else:  # this rank's share of configs[3]: every buffer against the reference's own output
+                gold = json.load(open(os.path.join(gdir, "batch1m.json")))[rank * self.nbuf: (rank + 1) * self.nbuf]
+                if len(gold) == self.nbuf:
                     hostc = self.d_comp[0].cpu().numpy()
                     for k, e in enumerate(gold):
+                        assert e["i"] == rank * self.nbuf + k and e["seed"] == self.seed + e["i"]
                         digest = hashlib.sha256(hostc[self.c_off[k]: self.c_off[k] + comp[k]].tobytes()).hexdigest()
                         ok = ok and comp[k] == e["deflate_len"] and digest == e["deflate_sha256"]
-                golden = True
-            except (OSError, IndexError, KeyError):
-                pass
+                    golden = True
+        except (OSError, IndexError, KeyError):
+            pass
         self.verified, self.golden_checked = ok, golden
         return ok
 
@@ -194,6 +208,55 @@ class Leg:
                 "deflate_gibs": round(ns / (t2 - t1) / GIB, 5), "inflate_gibs": round(ns / (t3 - t2) / GIB, 5)}
 
 
+def _free_port():
+    import socket
+
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
+
+
+def launch_command(ngpus, argv, port):
+    """What `python bench.py --gpus N` (N > 1, not yet under a launcher) runs as its child: the driver's own form."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def launch_ranks(args, argv, run=None):
+    """Parent side of `--gpus N` without a launcher.  No GPU call is made in this process (no torch.cuda, no zes_init:
+    a process that has initialised the GPU must not start the ranks by exec, and need not start them at all).
+    The child's stdout is relayed; if the ranks fail with the gather on, they are started once more with
+    --no-gather so that a transport problem costs the gather's measurement, not the scaling point."""
+    import subprocess
+
+    run = run or subprocess.run
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    tries = [list(argv)] + ([] if args.no_gather else [list(argv) + ["--no-gather"]])
+    rc = 1
+    for k, av in enumerate(tries):
+        cmd = launch_command(args.gpus, av, _free_port())
+        print("bench.py: starting %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+        res = run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+        rc = res.returncode
+        lines = [ln for ln in (res.stdout or "").splitlines() if ln.startswith("{") and '"metric"' in ln]
+        if lines:
+            line = lines[-1]
+            if k > 0:  # say so in the line itself
+                rec = json.loads(line)
+                rec["config"]["gather"] = "FAILED with the gather on (rc %d of the first launch); measured again with --no-gather" % first_rc
+                line = json.dumps(rec)
+            print(line, flush=True)
+            return rc
+        first_rc = rc
+        print("bench.py: the ranks ended with rc %d and no result line%s" % (rc, "; once more without the gather" if k + 1 < len(tries) else ""),
+              file=sys.stderr, flush=True)
+    return rc or 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -204,6 +267,11 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="N > 1: leave the compressed shards where they are")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process never touches the GPU — it starts the N ranks as a CHILD
+        # (torch.distributed.run, one process per GPU) and relays rank 0's JSON line and the exit code.
+        sys.exit(launch_ranks(args, sys.argv[1:]))
+
     import torch
     import torch.distributed as dist
 
@@ -212,9 +280,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and world == 1:
-        print("bench.py: --gpus %d needs torch.distributed.run (one process per GPU)" % args.gpus, file=sys.stderr)
-        sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -249,21 +314,31 @@ def main():
             ok = bool(okt.item())
         return elapsed, ok
 
+    def reduce_flag(flag):
+        """True only if true on every rank (e.g. "this rank's output matched the reference's for its own seed")."""
+        if world > 1:
+            t = torch.tensor([1 if flag else 0], dtype=torch.int64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            flag = bool(t.item())
+        return bool(flag)
+
     # ------------------------------------------------------------------ main leg
     leg = Leg(main_name, env)
     verified = leg.verify()
+    leg.golden_checked = reduce_flag(leg.golden_checked)
     owned = [[r * leg.nbuf + i for i in range(leg.nbuf)] for r in range(world)]
     gathered_bytes = [0]
+
+    hint = [None]  # the step before's lengths: the next gather posts its transfers from them without waiting for the sizes
 
     def finish(pending):
         if pending is None:
             return
-        got, works = pending
-        for w in works:
-            w.wait()
+        got = pending.finish()
+        hint[0] = pending.lengths
         torch.cuda.current_stream(dev).synchronize()  # the library runs on its own stream: the host must know the transfer is over
         if got is not None:
-            gathered_bytes[0] += int(got.arena.numel())
+            gathered_bytes[0] += int(sum(got.length))
 
     def step(k, pending, timed):
         slot = k & 1 if world > 1 else 0
@@ -280,7 +355,7 @@ def main():
             # the gather of the step before has had this step's kernels to hide behind; its arena is free again
             finish(pending)
             local, lens = leg.local_result(comp, slot)
-            pending = shard.gather_results(local, owned[rank], lens, [0] * leg.nbuf, owned, world * leg.nbuf, dst=0, async_op=True)
+            pending = shard.gather_results(local, owned[rank], lens, [0] * leg.nbuf, owned, world * leg.nbuf, dst=0, async_op=True, hint=hint[0])
         return pending, tb - ta, tc - tb
 
     pending = None
@@ -309,6 +384,7 @@ def main():
     if second_name:
         tl = Leg(second_name, env)
         tok = tl.verify()
+        tl.golden_checked = reduce_flag(tl.golden_checked)
         comp = tl.run_deflate()
         for _ in range(args.warmup):
             tl.run_deflate()
@@ -394,8 +470,9 @@ def main():
                        "buffers_per_step": world * leg.nbuf, "bytes_per_buffer": leg.n1,
                        "compressed_bytes": c, "parallelism": "independent buffers, one per GPU",
                        "gather": (None if shard is None else
-                                  "every step's compressed shards gathered into rank 0's HBM over RCCL/xGMI (sizes all_reduce + one exact-length "
-                                  "send per rank), overlapped with the next step, completed inside the timed region: %d bytes received per step"
+                                  "every step's compressed shards gathered into rank 0's HBM over RCCL/xGMI (one message per rank posted from the step "
+                                  "before's lengths, sizes all_reduce read behind it), overlapped with the next step, completed inside the timed "
+                                  "region: %d result bytes on rank 0 per step"
                                   % (gathered_bytes[0] // max(args.steps, 1)))},
             "deflate_gibs_per_gpu": None if foreign else round(n * args.steps / t_def / GIB, 4),
             "inflate_gibs_per_gpu": round(n * args.steps / t_inf / GIB, 4),

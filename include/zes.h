@@ -80,8 +80,10 @@ int zes_deflate_bound(uint64_t n, uint64_t* cap);
 /* zlib-wrapped compress: out = 78 9C | raw deflate | Adler-32 BE.  Bit-exact with
  * replaces: `export function deflate(input)` src/zlib.ts:25-49 (→ src/deflate.ts:14-39, src/lz77.ts, src/huffman.ts:55-153, src/adler32.ts).
  * n == 0, n == 1 and n % 131072 == 1 return ZES_E_CORRUPT exactly as the reference throws.
- * Device forms (here and below): d_in / d_out, and in the batch forms every in_off / out_off, must be 16-byte
- * aligned — the kernels read and write whole 16-byte groups — else ZES_E_ARG.  The host forms take any alignment. */
+ * Device forms (here and below): d_out, and in the batch forms every out_off, must be 16-byte aligned — results are
+ * written as whole 16-byte groups — else ZES_E_ARG; the inflate device forms ask the same of d_in / in_off.  The
+ * deflate device forms read an input at any alignment (the kernels fall back to narrower loads for an unaligned
+ * block).  The host forms take any alignment. */
 int zes_deflate(const uint8_t* in, uint64_t n, uint8_t* out, uint64_t cap, uint64_t* out_len);
 int zes_deflate_dev(const uint8_t* d_in, uint64_t n, uint8_t* d_out, uint64_t cap, uint64_t* out_len);
 
@@ -151,7 +153,9 @@ int zes_inflate_batch_alloc(const uint8_t* const* in, const uint64_t* in_len, ze
  *   ((*out_bits + 7) / 8 bytes, zero padded; cap >= zes_deflate_bound(n)); *adler = Adler-32 of the range's bytes.
  * zes_deflate_join_dev: 78 9C | the pieces, bit-concatenated | zero pad | Adler-32 of the whole (combined from the
  *   pieces' values and lengths: src/adler32.ts:1-10 is associative in that sense), into d_out.  The pieces are device
- *   pointers on this GPU (4-byte aligned), in order.
+ *   pointers on this GPU (4-byte aligned), in order; they are read, and d_out is written, in whole dwords: piece i
+ *   must be readable up to the dword that holds its last bit (zes_deflate_range_dev's own output is), and
+ *   cap >= the result's length rounded up to 4 — otherwise ZES_E_NOSPACE with *out_len = the result's length.
  * replaces: the block loop of src/deflate.ts:20-34 and the wrapper of src/zlib.ts:25-49, split at block boundaries. */
 int zes_deflate_range_dev(const uint8_t* d_in, uint64_t n, uint64_t n_readable, int final_range, uint8_t* d_out, uint64_t cap,
                           uint64_t* out_bits, uint32_t* adler);

@@ -103,6 +103,41 @@ function tryCall(f) {
   try { return {ok: f()}; } catch (e) { return {err: e.message}; }
 }
 
+/* ---- 0. GOLDEN_RANKS=kind[,kind…]: the 64 MiB (xorshift, itext) / 256 MiB (lowent4k) buffers of ranks 1..7 of a
+ * multi-GPU bench run (seed 12345 + rank; rank 0 is in manifest.big).  About a minute of the reference per
+ * xorshift buffer: runs alone, writes ranks_<kind>.json and leaves every other fixture untouched.
+ * GOLDEN_FOREIGN=<file>: the reference's inflate of a stream another encoder made (bench.py's zlibtext64 leg:
+ * CPython zlib level 6 of itext 64 MiB, written by tests/golden/make_zlibtext64.py) -> foreign_big.json ---- */
+if (process.env.GOLDEN_RANKS) {
+  for (const kn of process.env.GOLDEN_RANKS.split(',')) {
+    const n = (kn === 'lowent4k' ? 256 : 64) * 1048576;
+    const entries = [];
+    for (let seed = 12346; seed <= 12352; seed++) {
+      const input = GEN[KIND[kn]](n, seed);
+      const o = Z.deflate(input);
+      const e = {kind: kn, seed: seed, n: n, input_sha256: sha(input), deflate_len: o.length, deflate_sha256: sha(o)};
+      if (sha(Z.inflate(o)) !== e.input_sha256) throw new Error('reference roundtrip failed');
+      entries.push(e);
+      console.log('ranks', kn, seed);
+    }
+    fs.writeFileSync(path.join(OUT, 'ranks_' + kn + '.json'), JSON.stringify(entries, null, 1));
+  }
+  process.exit(0);
+}
+if (process.env.GOLDEN_FOREIGN) {
+  const spec = JSON.parse(fs.readFileSync(process.env.GOLDEN_FOREIGN + '.json', 'utf8'));
+  const comp = new Uint8Array(fs.readFileSync(process.env.GOLDEN_FOREIGN));
+  const back = Z.inflate(comp);
+  const e = Object.assign({}, spec, {stream_len: comp.length, stream_sha256: sha(comp), output_len: back.length, output_sha256: sha(back)});
+  let all = [];
+  try { all = JSON.parse(fs.readFileSync(path.join(OUT, 'foreign_big.json'), 'utf8')); } catch (err) { /* first */ }
+  all = all.filter((x) => x.name !== e.name);
+  all.push(e);
+  fs.writeFileSync(path.join(OUT, 'foreign_big.json'), JSON.stringify(all, null, 1));
+  console.log('foreign', e.name, e.output_len);
+  process.exit(0);
+}
+
 /* ---- 1. reference test-suite vectors (test/index.js:7-10) + small deflate KATs ---- */
 const RAW = new Uint8Array([84, 104, 105, 115, 32, 105, 115, 32, 122, 108, 105, 98, 46, 101, 115]);
 const KAT = {

@@ -55,14 +55,28 @@ def _worker(rank, world, port, q):
     mine = owned[rank]
     outs = [engine(bufs[i]) for i in mine]
     local = torch.cat([torch.from_numpy(d) for _, d in outs]) if outs else torch.empty(0, dtype=torch.uint8)
-    got, works = shard.gather_results(local, mine, [len(d) for _, d in outs], [st for st, _ in outs], owned, len(bufs), async_op=True)
-    for w in works:
-        w.wait()
-    if rank == 0:
-        for i, (st, data) in enumerate(res):
-            assert got.status[i] == st and got.result(i).numpy().tobytes() == data.tobytes()
-    else:
-        assert got is None
+    lens, stats = [len(d) for _, d in outs], [st for st, _ in outs]
+    pend = shard.gather_results(local, mine, lens, stats, owned, len(bufs), async_op=True)
+    got = pend.finish()
+
+    def same(g):
+        if rank == 0:
+            for i, (st, data) in enumerate(res):
+                assert g.status[i] == st and g.result(i).numpy().tobytes() == data.tobytes()
+        else:
+            assert g is None
+
+    same(got)
+    # the hinted form (no wait for the size exchange before the transfers are posted): the step before as the hint,
+    # then hints that are too long (padded message), a little too short (second round) and far too short (the arena
+    # segment overflows: every rank repeats the gather with exact lengths)
+    true_len = pend.lengths
+    assert true_len == [len(d) for _, d in res] if rank == 0 else True
+    for hint in (true_len, [x + 777 for x in true_len], [max(x - 100, 0) for x in true_len], [x // 3 for x in true_len],
+                 [0] * len(true_len)):
+        ph = shard.gather_results(local, mine, lens, stats, owned, len(bufs), async_op=True, hint=hint)
+        same(ph.finish())
+        assert ph.lengths == true_len
     if rank == 0:
         ok = True
         for b, (st, data) in zip(bufs, res):

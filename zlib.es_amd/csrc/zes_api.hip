@@ -149,7 +149,7 @@ struct CopyPool {
   size_t n = 0, part = 0;
   uint32_t gen = 0, parts = 0;
   std::atomic<uint32_t> next{0};
-  uint32_t done = 0;
+  uint32_t done = 0, active = 0;
   bool stop = false;
 
   void worker() {
@@ -159,11 +159,13 @@ struct CopyPool {
       cv_work.wait(lk, [&] { return stop || gen != seen; });
       if (stop) return;
       seen = gen;
-      lk.unlock();
-      const uint32_t did = run_parts();
+      active++;  // checked in under the lock: copy() does not return (and the next job is not written) before every
+      lk.unlock();  // worker that picked this generation up has checked out again — no claim of an old job can
+      const uint32_t did = run_parts();  // meet the fields of a new one
       lk.lock();
       done += did;
-      if (done == parts) cv_done.notify_all();
+      active--;
+      if (done >= parts && active == 0) cv_done.notify_all();
     }
   }
   uint32_t run_parts() {
@@ -203,7 +205,7 @@ struct CopyPool {
     const uint32_t did = run_parts();
     std::unique_lock<std::mutex> lk(mu);
     done += did;
-    cv_done.wait(lk, [&] { return done == parts; });
+    cv_done.wait(lk, [&] { return done >= parts && active == 0; });
   }
   void shutdown() {
     {
@@ -306,11 +308,18 @@ bool is_pinned(const void* p) {
 // it page-locks the range for the copy itself), where the staging ring below costs a memcpy of every byte (~1 ms per
 // 32 MiB with seven helper threads).  The copy is complete when upload()/download() return; in the pipelined calls
 // they run on the side threads.  (Page-locking the caller's buffer in place with hipHostRegister for the whole call
-// was tried: as fast, but a GPU memory fault on a host address turned up in a long fuzz run; the runtime's path it is.)
+// was as fast — 0.25 ms per 64 MiB to register — and was taken out when a GPU memory fault turned up in a long fuzz
+// run with it.  That fault was traced later (ZES_TRACE_KERNELS tail of tools/gpu_fuzz.py seed 77) to k_inf_verify
+// reading stale surv[] entries the scan had reserved but not written — fixed in the scan, DESIGN §6 — so registration
+// was not its cause.  It stays off because it buys nothing over the runtime's path on this host and would pin a
+// caller's pages for the length of the call.)
 // The ring remains for buffers of 256 KiB to 4 MiB: the per-call cost of the runtime's path shows there.
 constexpr uint64_t RUNTIME_COPY_MIN = 4ull << 20;
 
-// host -> device on `stream` (the library's stream by default); returns once the caller's memory has been read
+// host -> device on `stream` (the library's stream by default).  A pageable source has been read when this returns;
+// a PINNED source (or one of <= STAGE_DIRECT_MAX bytes, which the runtime stages itself) is only enqueued: the DMA
+// reads it asynchronously, and every caller synchronises `stream` before it returns to its own caller (they all do:
+// each entry point ends with the read-back of its result on g.stream, the pipelined ones join their side threads).
 int upload(uint8_t* d_dst, const uint8_t* src, uint64_t n, hipStream_t stream = nullptr) {
   if (!stream) stream = g.stream;
   if (!n) return ZES_OK;
@@ -1784,10 +1793,10 @@ int zes_host_alloc(uint64_t n, void** p) {
 
 int zes_host_free(void* p) {
   if (!p) return ZES_OK;
+  // page-locked memory belongs to the process, not to a stream: it can be given back after zes_shutdown too (a JS
+  // finalizer may run that late), and hipHostFree waits by itself for device work that still uses the block
   std::lock_guard<std::mutex> lk(g_mu);
-  if (!g.ready) return ZES_E_ARG;
-  (void)hipSetDevice(g.device);
-  HIPCHK(hipStreamSynchronize(g.stream));
+  if (g.ready) (void)hipSetDevice(g.device);
   HIPCHK(hipHostFree(p));
   return ZES_OK;
 }
@@ -2290,11 +2299,13 @@ int zes_deflate_join_dev(const uint8_t* const* d_piece, const uint64_t* piece_bi
   }
   const uint64_t raw_end = 2 + (bits + 7) / 8, total = raw_end + 4;
   *out_len = total;
-  if (total > cap) return ZES_E_NOSPACE;
+  // the pieces are placed dword by dword: the kernel writes (and the memset clears) up to the dword that holds the
+  // result's last byte, so the buffer must reach that far (include/zes.h says so; zes_deflate_bound always does)
+  if (((total + 3) & ~3ull) > cap) return ZES_E_NOSPACE;
   std::lock_guard<std::mutex> lk(g_mu);
   int rc = init_locked(-1);
   if (rc) return rc;
-  HIPCHK(hipMemsetAsync(d_out, 0, (total + 3) & ~3ull, g.stream));  // (cap of a deflate result always has the slack: zes_deflate_bound)
+  HIPCHK(hipMemsetAsync(d_out, 0, (total + 3) & ~3ull, g.stream));
   uint64_t pos = 16;  // behind 78 9C
   for (uint32_t i = 0; i < count; i++) {
     if (!piece_bits[i]) continue;

@@ -477,7 +477,9 @@ napi_value DeflateBatchAsync(napi_env env, napi_callback_info info) { return sta
 napi_value InflateBatchAsync(napi_env env, napi_callback_info info) { return start_batch(env, info, true, true); }
 
 // allocPinned(n): a Uint8Array in page-locked memory (zes_host_alloc) — buffers from here cross PCIe without the
-// library's staging copy; released when the array is collected
+// library's staging copy; released when the array is collected.  The finalizer runs on the JS thread and takes
+// the library's lock for a moment (no stream is waited for: hipHostFree itself waits for work that uses the block), so
+// it can stall behind a call that is holding the lock; zes_host_free also works after zes_shutdown.
 void free_pinned(napi_env, void* data, void*) { zes_host_free(data); }
 napi_value AllocPinned(napi_env env, napi_callback_info info) {
   size_t argc = 1;
@@ -492,11 +494,12 @@ napi_value AllocPinned(napi_env env, napi_callback_info info) {
   const int rc = zes_host_alloc((uint64_t)d, &p);
   if (rc) return throw_status(env, rc);
   napi_value ab, ta;
-  if (napi_create_external_arraybuffer(env, p, (size_t)d, free_pinned, nullptr, &ab) != napi_ok ||
-      napi_create_typedarray(env, napi_uint8_array, (size_t)d, ab, 0, &ta) != napi_ok) {
-    zes_host_free(p);
+  if (napi_create_external_arraybuffer(env, p, (size_t)d, free_pinned, nullptr, &ab) != napi_ok) {
+    zes_host_free(p);  // no ArrayBuffer took the block over
     return nullptr;
   }
+  // from here on the ArrayBuffer's finalizer (free_pinned) owns the block, whatever happens to the view
+  if (napi_create_typedarray(env, napi_uint8_array, (size_t)d, ab, 0, &ta) != napi_ok) return nullptr;
   return ta;
 }
 

@@ -56,14 +56,42 @@ class Gathered:
         return self.arena[self.offset[i]: self.offset[i] + self.length[i]]
 
 
-def gather_results(local, my_ids: Sequence[int], my_len: Sequence[int], my_status: Sequence[int], owned: List[List[int]],
-                   count: int, group=None, dst: int = 0, async_op: bool = False):
-    """The exchange step.  `local` = this rank's results back to back, in the order of `my_ids` (a uint8
-    tensor on this rank's device; for "nccl" a CUDA tensor, and it never leaves the device).
+class PendingGather:
+    """A gather whose transfers are in flight.  `finish()` completes it: returns the Gathered on `dst`, None
+    elsewhere.  Nothing in `gather_begin` waits for the device or for a peer — the host learns the sizes here."""
 
-    Returns a Gathered on `dst`, None elsewhere.  With async_op=True returns (gathered_or_None, works): the
-    transfers are in flight until every work in `works` has been waited for (bench.py overlaps them with the
-    next step's kernels).
+    def __init__(self, fin):
+        self._fin, self._out, self._done = fin, None, False
+
+    def finish(self):
+        if not self._done:
+            self._out, self._done, self._fin = self._fin(), True, None
+        return self._out
+
+    wait = finish
+
+
+def _slack(nbytes: int) -> int:
+    """Room kept behind a rank's hinted total in the destination's arena: results may grow by this much against
+    the hint before the slow path (a second, exact-length gather) is taken."""
+    return max(nbytes >> 6, 4096)
+
+
+def gather_begin(local, my_ids: Sequence[int], my_len: Sequence[int], my_status: Sequence[int], owned: List[List[int]],
+                 count: int, group=None, dst: int = 0, hint: Optional[Sequence[int]] = None) -> PendingGather:
+    """Starts the exchange step and returns at once.  `local` = this rank's results back to back, in the order of
+    `my_ids` (a uint8 tensor on this rank's device; for "nccl" a CUDA tensor, and it never leaves the device).
+
+    Without `hint` the receiver has to learn the lengths before it can post exact-length receives: the
+    (length, status) all_reduce is read on the host first (one wait for that small collective).
+
+    With `hint` — the per-buffer lengths every rank expects, e.g. `Gathered.length` / `PendingGather.lengths` of
+    the step before — nothing waits: the all_reduce is started, and a first round of messages is posted from the
+    hint alone, rank r -> dst exactly H[r] = sum of its hinted lengths (a sender whose results came out shorter
+    pads the message, one whose results came out longer sends the rest in a second round).  `finish()` reads the
+    all_reduce — by then behind the transfers — and posts that second round where needed: both sides decide from
+    the same table, so sends and receives always pair up with equal sizes.  A rank whose results outgrew its
+    arena segment (hint + slack) makes every rank repeat the gather the exact-length way.
     """
     import torch
     import torch.distributed as dist
@@ -76,38 +104,117 @@ def gather_results(local, my_ids: Sequence[int], my_len: Sequence[int], my_statu
         ids = torch.as_tensor(list(my_ids), dtype=torch.int64, device=dev)
         meta[ids] = torch.as_tensor(list(my_len), dtype=torch.int64, device=dev)
         meta[ids + count] = torch.as_tensor(list(my_status), dtype=torch.int64, device=dev)
-    dist.all_reduce(meta, op=dist.ReduceOp.SUM, group=group)
-    meta_h = meta.cpu().numpy()
-    length = [int(x) for x in meta_h[:count]]
-    status = [int(x) for x in meta_h[count:]]
-    totals = [sum(length[i] for i in owned[r]) for r in range(world)]
-    assert totals[rank] == local.numel(), (totals[rank], local.numel())
-    ops, out = [], None
+    my_total = int(sum(int(x) for x in my_len))
+    assert my_total == local.numel(), (my_total, local.numel())
+
+    def read_meta(work):
+        work.wait()
+        meta_h = meta.cpu().numpy()
+        return [int(x) for x in meta_h[:count]], [int(x) for x in meta_h[count:]]
+
+    def exact(length, status):
+        """The exact-length round: every rank's whole result in one message."""
+        totals = [sum(length[i] for i in owned[r]) for r in range(world)]
+        ops, out = [], None
+        if rank == dst:
+            base, pos = [0] * world, 0
+            for r in range(world):
+                base[r] = pos
+                pos += totals[r]
+            arena = torch.empty(max(pos, 1), dtype=torch.uint8, device=dev)
+            offset = [0] * count
+            for r in range(world):
+                p = base[r]
+                for i in owned[r]:
+                    offset[i] = p
+                    p += length[i]
+                if r == rank:
+                    arena[base[r]: base[r] + totals[r]].copy_(local)
+                elif totals[r]:
+                    ops.append(dist.P2POp(dist.irecv, arena[base[r]: base[r] + totals[r]], r, group=group))
+            out = Gathered(arena, offset, length, status)
+        elif totals[rank]:
+            ops.append(dist.P2POp(dist.isend, local, dst, group=group))
+        return out, (dist.batch_isend_irecv(ops) if ops else [])
+
+    work_meta = dist.all_reduce(meta, op=dist.ReduceOp.SUM, group=group, async_op=True)
+    if hint is None:
+        length, status = read_meta(work_meta)
+        out, works = exact(length, status)
+
+        def fin_plain():
+            for w in works:
+                w.wait()
+            return out
+
+        pg = PendingGather(fin_plain)
+        pg.lengths = length
+        return pg
+
+    hint = [int(x) for x in hint]
+    assert len(hint) == count
+    H = [sum(hint[i] for i in owned[r]) for r in range(world)]
+    cap = [H[r] + _slack(H[r]) for r in range(world)]
+    base, pos = [0] * world, 0
+    for r in range(world):
+        base[r] = pos
+        pos += (cap[r] + 15) // 16 * 16
+    ops, arena, keep = [], None, None
     if rank == dst:
-        base, pos = [0] * world, 0
-        for r in range(world):
-            base[r] = pos
-            pos += totals[r]
         arena = torch.empty(max(pos, 1), dtype=torch.uint8, device=dev)
-        offset = [0] * count
         for r in range(world):
-            p = base[r]
-            for i in owned[r]:
-                offset[i] = p
-                p += length[i]
-            if r == rank:
-                arena[base[r]: base[r] + totals[r]].copy_(local)
-            elif totals[r]:
-                ops.append(dist.P2POp(dist.irecv, arena[base[r]: base[r] + totals[r]], r, group=group))
-        out = Gathered(arena, offset, length, status)
-    elif totals[rank]:
-        ops.append(dist.P2POp(dist.isend, local, dst, group=group))
+            if r != rank and H[r]:
+                ops.append(dist.P2POp(dist.irecv, arena[base[r]: base[r] + H[r]], r, group=group))
+    elif H[rank]:
+        src = local
+        if local.numel() < H[rank]:  # shorter than expected: the message keeps its hinted size, the tail is padding
+            src = torch.zeros(H[rank], dtype=torch.uint8, device=dev)
+            src[: local.numel()].copy_(local)
+            keep = src
+        ops.append(dist.P2POp(dist.isend, src[: H[rank]], dst, group=group))
     works = dist.batch_isend_irecv(ops) if ops else []
-    if async_op:
-        return out, works
-    for w in works:
-        w.wait()
-    return out
+
+    def fin_hinted():
+        length, status = read_meta(work_meta)
+        pg.lengths = length
+        totals = [sum(length[i] for i in owned[r]) for r in range(world)]
+        for w in works:
+            w.wait()
+        if any(totals[r] > cap[r] for r in range(world)):  # somebody outgrew the arena: once more, exact lengths
+            out, w2 = exact(length, status)
+            for w in w2:
+                w.wait()
+            return out
+        ops2 = []
+        if rank == dst:
+            offset = [0] * count
+            for r in range(world):
+                p = base[r]
+                for i in owned[r]:
+                    offset[i] = p
+                    p += length[i]
+                if r == rank:
+                    arena[base[r]: base[r] + totals[r]].copy_(local)
+                elif totals[r] > H[r]:
+                    ops2.append(dist.P2POp(dist.irecv, arena[base[r] + H[r]: base[r] + totals[r]], r, group=group))
+        elif totals[rank] > H[rank]:
+            ops2.append(dist.P2POp(dist.isend, local[H[rank]:], dst, group=group))
+        for w in (dist.batch_isend_irecv(ops2) if ops2 else []):
+            w.wait()
+        return (Gathered(arena, offset, length, status), keep)[0] if rank == dst else None  # (`keep`: the padded message lives until here)
+
+    pg = PendingGather(fin_hinted)
+    pg.lengths = None
+    return pg
+
+
+def gather_results(local, my_ids: Sequence[int], my_len: Sequence[int], my_status: Sequence[int], owned: List[List[int]],
+                   count: int, group=None, dst: int = 0, async_op: bool = False, hint: Optional[Sequence[int]] = None):
+    """The exchange step (see gather_begin).  Returns a Gathered on `dst`, None elsewhere; with async_op=True the
+    PendingGather whose `finish()` returns that (bench.py overlaps the transfers with the next step's kernels and
+    passes the step's lengths as the next step's `hint`, so no step waits for the size exchange)."""
+    pg = gather_begin(local, my_ids, my_len, my_status, owned, count, group=group, dst=dst, hint=hint)
+    return pg if async_op else pg.finish()
 
 
 def run_sharded(buffers: Sequence[np.ndarray], engine: Callable[[np.ndarray], Tuple[int, object]], group=None,
