@@ -542,9 +542,22 @@ int deflate_batch_core(const uint8_t* d_in, const uint64_t* in_off, const uint64
     HIPCHK(hipStreamSynchronize(g.stream));
     zes_sort_set_dbg((unsigned long long*)g.dbg.p);
   }
+  // dense blocks (text, periodic data) get their index from k_lz_index (LDS-resident class sorts); a block it cannot take
+  // goes back to k_lz_sort in a second launch that every other block leaves at once
+  static const bool use_index = getenv("ZES_NO_INDEX") == nullptr;
   {
     Timed t("k_lz_sort");
-    hipLaunchKernelGGL(k_lz_sort, dim3(nblk), dim3(SORT_THREADS), 0, g.stream, d_in, dbufs, dblks, idx_a, idx_b, (uint32_t*)g.inv.p, (uint16_t*)g.sdelta.p);
+    hipLaunchKernelGGL(k_lz_sort, dim3(nblk), dim3(SORT_THREADS), 0, g.stream, d_in, dbufs, dblks, idx_a, idx_b, (uint32_t*)g.inv.p, (uint16_t*)g.sdelta.p,
+                       ZES_SORT_MODE_FIRST | (use_index ? ZES_SORT_USE_INDEX : 0u));
+  }
+  if (use_index) {
+    {
+      Timed t("k_lz_index");
+      hipLaunchKernelGGL(k_lz_index, dim3(nblk), dim3(IDX_THREADS), 0, g.stream, d_in, dbufs, dblks, idx_a, idx_b, (uint32_t*)g.inv.p, (uint16_t*)g.sdelta.p);
+    }
+    Timed t("k_lz_sort_redo");
+    hipLaunchKernelGGL(k_lz_sort, dim3(nblk), dim3(SORT_THREADS), 0, g.stream, d_in, dbufs, dblks, idx_a, idx_b, (uint32_t*)g.inv.p, (uint16_t*)g.sdelta.p,
+                       ZES_SORT_MODE_REDO);
   }
   if (sort_dbg) {  // average shader-clock cycles per step of k_lz_sort
     HIPCHK(hipStreamSynchronize(g.stream));
@@ -2486,8 +2499,30 @@ int zes_stage_lz77_dev(const uint8_t* d_in, uint64_t n, uint64_t start, uint32_t
   if ((rc = ensure(g.mlist, ZES_MLIST_WORDS * 4))) return rc;
   HIPCHK(hipMemcpyAsync(g.bufs.p, &b, sizeof b, hipMemcpyHostToDevice, g.stream));
   HIPCHK(hipMemcpyAsync(g.blks.p, &z, sizeof z, hipMemcpyHostToDevice, g.stream));
+  const bool use_index = getenv("ZES_NO_INDEX") == nullptr;  // the same three launches as the whole pipeline
   hipLaunchKernelGGL(k_lz_sort, dim3(1), dim3(SORT_THREADS), 0, g.stream, d_in, (const ZesBuf*)g.bufs.p, (const ZesBlk*)g.blks.p,
-                     (uint32_t*)g.idx_a.p, (uint32_t*)g.idx_b.p, (uint32_t*)g.inv.p, (uint16_t*)g.sdelta.p);
+                     (uint32_t*)g.idx_a.p, (uint32_t*)g.idx_b.p, (uint32_t*)g.inv.p, (uint16_t*)g.sdelta.p,
+                     ZES_SORT_MODE_FIRST | (use_index ? ZES_SORT_USE_INDEX : 0u));
+  if (use_index) {
+    hipLaunchKernelGGL(k_lz_index, dim3(1), dim3(IDX_THREADS), 0, g.stream, d_in, (const ZesBuf*)g.bufs.p, (const ZesBlk*)g.blks.p,
+                       (uint32_t*)g.idx_a.p, (uint32_t*)g.idx_b.p, (uint32_t*)g.inv.p, (uint16_t*)g.sdelta.p);
+    hipLaunchKernelGGL(k_lz_sort, dim3(1), dim3(SORT_THREADS), 0, g.stream, d_in, (const ZesBuf*)g.bufs.p, (const ZesBlk*)g.blks.p,
+                       (uint32_t*)g.idx_a.p, (uint32_t*)g.idx_b.p, (uint32_t*)g.inv.p, (uint16_t*)g.sdelta.p, ZES_SORT_MODE_REDO);
+  }
+  if (const char* dump = getenv("ZES_DUMP_INDEX")) {  // development: the block's index as the match finders will see it
+    HIPCHK(hipStreamSynchronize(g.stream));
+    std::vector<uint32_t> hinv(ZES_BLK), hflag(1);
+    std::vector<uint16_t> hsd(ZES_BLK);
+    HIPCHK(hipMemcpy(hinv.data(), g.inv.p, ZES_BLK * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hsd.data(), g.sdelta.p, ZES_BLK * 2, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hflag.data(), (uint32_t*)g.idx_a.p + ZES_BLK - 1, 4, hipMemcpyDeviceToHost));
+    if (FILE* f = fopen(dump, "wb")) {
+      fwrite(hflag.data(), 4, 1, f);
+      fwrite(hinv.data(), 4, ZES_BLK, f);
+      fwrite(hsd.data(), 2, ZES_BLK, f);
+      fclose(f);
+    }
+  }
   hipLaunchKernelGGL(k_lz_match, dim3(1), dim3(MATCH_THREADS), 0, g.stream, d_in, (const ZesBuf*)g.bufs.p,
                      (const ZesBlk*)g.blks.p, (const uint32_t*)g.idx_a.p, (uint32_t*)g.idx_b.p, (uint32_t*)g.mlist.p);
   hipLaunchKernelGGL(k_lz_match_lazy, dim3(1), dim3(MATCH_THREADS), 0, g.stream, d_in, (const ZesBuf*)g.bufs.p,

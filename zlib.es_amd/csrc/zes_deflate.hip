@@ -72,8 +72,6 @@ void zes_sort_set_dbg(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBO
     if (g_sort_dbg && threadIdx.x == 0) g_sort_dbg[(size_t)blockIdx.x * 8 + (i)] = (unsigned long long)clock64(); \
   } while (0)
 
-#define ZES_SORT_LAZY 0x80000000u  // flag beside ns in idx_a[g][ZES_BLK-1]
-#define ZES_INV_NONE 0xFFFFFFFFu   // inv entry of a position without a candidate
 #define SORT_HASH_BITS 19u
 #define SORT_OWN 128u  // consecutive positions owned by one thread in the filter phase
 #ifndef SORT_ROUNDS
@@ -107,7 +105,8 @@ __device__ __forceinline__ static uint4 sort_ld16(const uint8_t* __restrict__ sr
 
 __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restrict__ d_in, const ZesBuf* __restrict__ bufs,
                                                           const ZesBlk* __restrict__ blks, uint32_t* __restrict__ idx_a,
-                                                          uint32_t* __restrict__ idx_b, uint32_t* __restrict__ inv_all, uint16_t* __restrict__ sd_all) {
+                                                          uint32_t* __restrict__ idx_b, uint32_t* __restrict__ inv_all, uint16_t* __restrict__ sd_all,
+                                                          uint32_t mode) {
   __shared__ __align__(16) SortSmem S;
   const uint32_t g = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const ZesBlk bk = blks[g];
@@ -117,6 +116,9 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
   uint32_t* A = idx_a + (uint64_t)g * ZES_BLK;
   uint32_t* B = idx_b + (uint64_t)g * ZES_BLK;
   const uint32_t cnt = T >= 3 ? T - 2 : 0;
+  // second launch: only the blocks k_lz_index handed back (they are dense: all positions are sorted)
+  const bool redo = (mode & 0xffu) == ZES_SORT_MODE_REDO;
+  if (redo && !(A[ZES_BLK - 1] & ZES_SORT_REDO)) return;
   if (cnt == 0) {
     if (tid == 0) A[ZES_BLK - 1] = 0;
     return;
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
   uint32_t samp[SORT_OWN / 16];  // hash of the first key of each 16-position chunk: the survivor rate is sampled on these
 #pragma unroll
   for (uint32_t c = 0; c < SORT_OWN / 16; c++) samp[c] = ~0u;
-  if (p0 < cnt) {
+  if (p0 < cnt && !redo) {
     uint4 cur = sort_ld16(src, aligned, p0, T);
 #pragma unroll 1
     for (uint32_t c = 0; c < SORT_OWN / 16; c++) {
@@ -184,11 +186,17 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
     atomicAdd(&S.nsat, kept | (tried << 16));
   }
   __syncthreads();
-  const bool dense = (S.nsat & 0xFFFFu) * 4u >= (S.nsat >> 16) * 3u;
+  const bool dense = redo || (S.nsat & 0xFFFFu) * 4u >= (S.nsat >> 16) * 3u;
+#ifndef NO_LAZY
+  if (dense && !redo && (mode & ZES_SORT_USE_INDEX) && inv_all != nullptr) {  // (uniform) k_lz_index builds this block's index inside LDS
+    if (tid == 0) A[ZES_BLK - 1] = cnt | ZES_SORT_LAZY | ZES_SORT_INDEX;
+    return;
+  }
+#endif
   // Few kept (incompressible data: a fifth, nearly all of them collisions of the hash, not repeats of a key): a second
   // filter level over the kept ones with another hash leaves ~2 % of the positions, and the three sorting passes —
   // two thirds of this kernel on such data — have a twelfth of the elements.
-  const bool two = (S.nsat & 0xFFFFu) * 5u < (S.nsat >> 16) * 2u;
+  const bool two = !redo && (S.nsat & 0xFFFFu) * 5u < (S.nsat >> 16) * 2u;
   uint32_t ns = cnt;
   if (!dense) {
   // pass 2: keep the positions whose counter reached two; 128 flags per thread
@@ -846,8 +854,8 @@ __device__ static uint32_t lazy_wave_eval(const LazySmem& S, uint32_t iv, const 
   uint32_t best = 0, bestq = 0, check = 0, q = p;
   if (iv == ZES_INV_NONE) return LAZY_EVAL_LIT;
   uint32_t s = iv & 0x1FFFFu;  // slot whose sd entry leads from the current candidate to the next
-  uint32_t dq = (iv >> 17) + 1u, dqv = 0;
-  bool pending = false;  // dqv (requested while the candidate before was compared) still has to be read
+  uint32_t dq = 0, dqv = sd[s];  // (the entry of p's own slot: the distance to its nearest candidate)
+  bool pending = true;  // dqv (requested while the candidate before was compared) still has to be read
   const uint32_t pd = m_ld32u(S.in, p + 4u * lane), pt = m_ld32u(S.in, p + 256u);
   for (;;) {
     if (check >= 128u || (best >= 8u && check >= 16u) || best >= maxl) break;  // :66-69, :89-91 (before the wait: a full match needs no further distance)
@@ -914,6 +922,11 @@ __device__ __forceinline__ static uint32_t lazy_chains(LazySmem& S, const uint32
   bool fw = false;                                           // wpend holds this row's next window
   uint32_t sdp = 0, sdp_r = 0;                               // first sixteen distances requested ahead for slot sdp_r
   bool sdp_ok = false;
+  // Requests made for a LATER turn stay in registers of their own (spend: the first sixteen distances of the chain's
+  // next position; dpend: the next round's sixteen) and are folded into sdp / dnext where that turn first needs them:
+  // a select on the loaded value right behind the load makes the wave wait for memory in the turn that asked.
+  uint32_t spend = 0, dpend = 0;
+  bool sfresh = false, dfresh = false;
   // the position a row is on (rounds of sixteen candidates; a row whose position needs another round does not hold up
   // the other three: every turn of the loop is one round for each row that has one to do)
   uint32_t r = 0, maxl = 0, best = 0, bestq = 0, base = 0, lastq = 0, dnext = 0, litrun = 1;
@@ -1046,6 +1059,8 @@ __device__ __forceinline__ static uint32_t lazy_chains(LazySmem& S, const uint32
       // the distances of a round are requested one round ahead (round 0: at the end of the turn before, when the chain's
       // next position was known — sdp/sdp_r say for which slot)
       {
+        sdp = sfresh ? spend : sdp;  // what the turn before asked for
+        sfresh = false;
         const bool hit = has && sdp_ok && sdp_r == r;
         if (__ballot(has && !hit)) {
           const uint32_t t = sd[(has && sub <= r) ? r - sub : 0u];
@@ -1059,11 +1074,11 @@ __device__ __forceinline__ static uint32_t lazy_chains(LazySmem& S, const uint32
       const bool was = more;
       const uint32_t k = base + sub;
       const bool inl = more && k <= r;  // (slot 0 has nobody in front of it: sd[0] is 0)
+      dnext = dfresh ? dpend : dnext;  // (a row that has just started a position took its sixteen from sdp: dfresh is off)
       uint32_t d = inl ? dnext : 0u;
       {
         const uint32_t k2 = k + LAZY_G;
-        const uint32_t t = sd[(more && k2 <= r) ? r - k2 : 0u];  // next round's sixteen, in flight while this round is worked on
-        dnext = more ? t : dnext;
+        dpend = sd[(more && k2 <= r) ? r - k2 : 0u];  // next round's sixteen, in flight until the next turn's round
       }
       LLAP(2);
       // candidate positions: prefix sum of the distances over the row
@@ -1137,6 +1152,7 @@ __device__ __forceinline__ static uint32_t lazy_chains(LazySmem& S, const uint32
       lastq = more ? lq : lastq;
       base += more ? LAZY_G : 0u;
       more = more && nx == LAZY_G && base < 128u && best < 8u && best < maxl;
+      dfresh = more;
       fin = fin || (was && !more);
 #ifdef LAZY_PROF
       nrnd++;
@@ -1168,10 +1184,14 @@ __device__ __forceinline__ static uint32_t lazy_chains(LazySmem& S, const uint32
         const uint32_t ivn = off < LAZY_G ? e0 : e1;
         const bool want = in2 && ivn != ZES_INV_NONE && !(fw && off >= LAZY_G);  // (a window still on its way: not this time)
         const uint32_t rn = ivn & 0x1FFFFu;
+        // (a row in the middle of its rounds keeps what it has — it is not the one asking; a row whose request of the
+        // turn before was never folded in has moved on without evaluating: that request is dead)
         if (__ballot(want)) {
-          const uint32_t t = sd[(want && sub <= rn) ? rn - sub : 0u];
-          sdp = fin ? t : sdp;  // (a row in the middle of its rounds keeps what it has: it is not the one asking)
+          sdp = sfresh ? spend : sdp;  // (the new request overwrites spend in every lane: another row's pending one is folded in first)
+          sfresh = false;
+          spend = sd[(want && sub <= rn) ? rn - sub : 0u];
         }
+        sfresh = fin ? true : sfresh;
         sdp_ok = fin ? want : sdp_ok;
         sdp_r = fin ? rn : sdp_r;
       }
@@ -1364,7 +1384,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match_lazy(const uint8_t* 
             const bool inr = pj < tbase && pj + ZES_MAXMATCH + 3u <= T && pj + ZES_MAXMATCH <= avail;
             const uint32_t ivj = inv[inr ? pj : 0u];
             const bool has = inr && ivj != ZES_INV_NONE;
-            const uint32_t dj = (ivj >> 17) + 1u;
+            const uint32_t dj = sd[has ? (ivj & 0x1FFFFu) : 0u];  // distance to the nearest candidate
             const uint32_t qj = has ? pj - dj : 0u, pp = has ? pj : 0u;
             bool full = has;
             for (uint32_t wv = 0; wv < 64u && __ballot(full); wv++)  // bytes 0..255, four at a time

@@ -1,0 +1,478 @@
+// zes_index.hip — k_lz_index: the LZ77 index of a *dense* block (text, periodic data: nearly every position shares
+// its 3-byte key with another one) built inside LDS.  Replaces, for those blocks, the three global scatter passes of
+// k_lz_sort and its four re-reads of the sorted list (src/lz77.ts:11-22: generateLZ77IndexMap).
+//
+// What the lazy match finder needs from the index (k_lz_match_lazy):
+//   sd[r]   u16 per slot: distance from the position in slot r to the one in slot r-1 when both hold the same key and
+//           lie within 32768 of each other, else 0 — the candidates of a position, most recent first (src/lz77.ts:65),
+//           are consecutive entries;
+//   inv[p]  u32 per position: the slot of p, or ZES_INV_NONE when p has no candidate.
+// Nothing asks for the slots to be ordered BY key: positions of one key must be neighbours, in ascending order.  So:
+//
+//   1  every position's key is hashed by a bijection of the 24-bit key space, H = key * odd mod 2^24; the top 11 bits
+//      are its *class* (2048 classes, ~64 positions each), the other 13 bits travel with the position in one word
+//      (H13 << 17 | position): equal words' upper parts <=> equal keys inside a class;
+//   2  two sweeps over the block (read straight from memory, 16 bytes per lane): class sizes by LDS atomics, a scan,
+//      then every word goes to its class's run of a global array E — in whatever order the atomics hand out;
+//   3  each class is sorted by ONE wavefront, by the whole word (key part, then position): <= 64 words in registers
+//      (bitonic network on DPP row operations), more in LDS (radix passes of 6 bits over the digits that differ at
+//      all, ping-pong in the wave's own scratch); the few classes above 1024 words (a heavy key: " th") wait for a
+//      second round in which four wavefronts have a quarter of the LDS each;
+//   4  a sorted class gives its sd[] entries (coalesced 2-byte stores) and, per position, the word
+//      position-in-slice | slot | has-a-candidate, appended to the bucket of the position's 16384-byte slice (8 LDS
+//      cursors, the buckets in global memory);
+//   5  slice by slice the buckets are read back, scattered into an LDS image of the slice and written out as inv[]
+//      with coalesced 16-byte stores.
+//
+// Global traffic per position: 1 (input) + 8 (E) + 8 (buckets) + 2 (sd) + 4 (inv) = 23 bytes, all of it in whole
+// lines (k_lz_sort: 51).  A block with a class above IDX_BIGCAP words (all zeros; a period of a few bytes) is handed
+// back to k_lz_sort (ZES_SORT_REDO).
+#include "zes_common.h"
+#include "zes_kernels.h"
+
+#define IDX_WAVES (IDX_THREADS / 64)
+#define IDX_CB 11u
+#define IDX_NCLASS (1u << IDX_CB)
+#define IDX_RSHIFT (24u - IDX_CB)
+#define IDX_MUL 0x9E3779u  // odd: key -> key * IDX_MUL mod 2^24 is a bijection
+#define IDX_WCAP 1024u     // words a wavefront sorts in its own scratch (two halves of this size)
+#define IDX_BIGCAP 4096u   // ... in the second round, four wavefronts
+#define IDX_NBIGW 4u
+#define IDX_SLICE 16384u
+#define IDX_NSLICE (ZES_BLK / IDX_SLICE)
+#define IDX_MAXBIG 128u  // classes above IDX_WCAP words: at most 131070 / 1025
+
+struct IndexSmem {
+  uint32_t scr[IDX_WAVES * 2 * IDX_WCAP];  // sweeps: class counters / cursors in [0, 2048 + 64); sorting: scratch; last: a slice of inv
+  uint32_t cnt[IDX_WAVES][5 * 64];         // digit counters of the radix passes, per wavefront
+  uint32_t base[IDX_NCLASS + 1];           // first slot of each class
+  uint32_t big[IDX_MAXBIG];
+  uint32_t wsum[IDX_WAVES];
+  uint32_t pcur[IDX_NSLICE];
+  uint32_t next, nbig, nextbig, maxc;
+#ifdef IDX_CHECK
+  uint32_t done[IDX_NCLASS / 32];
+  uint32_t emitted, nsum;
+  uint32_t wemit[IDX_WAVES];
+#endif
+};
+static_assert(sizeof(IndexSmem) <= 160 * 1024, "LDS");
+
+__device__ __forceinline__ static uint32_t idx_ld_sc1(const uint32_t* p) {  // past this CU's L1: written by another wave of this workgroup
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// 20 bytes at offset `off` of the block (zero past its end)
+__device__ __forceinline__ static void idx_ld20(const uint8_t* __restrict__ src, bool aligned, uint32_t off, uint32_t T, uint32_t w[5]) {
+  if (aligned && off + 20u <= T) {
+    const uint4 v = *reinterpret_cast<const uint4*>(src + off);
+    w[0] = v.x;
+    w[1] = v.y;
+    w[2] = v.z;
+    w[3] = v.w;
+    w[4] = *reinterpret_cast<const uint32_t*>(src + off + 16u);
+    return;
+  }
+#pragma unroll
+  for (uint32_t k = 0; k < 5; k++) w[k] = 0;
+  for (uint32_t k = 0; k < 20u; k++)
+    if (off + k < T) w[k >> 2] |= (uint32_t)src[off + k] << (8u * (k & 3u));
+}
+
+template <int CTRL, int BANK>
+__device__ __forceinline__ static uint32_t idx_dpp(uint32_t old, uint32_t x) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)x, CTRL, 0xf, BANK, false);
+}
+// value of lane (lane ^ D)
+template <int D>
+__device__ __forceinline__ static uint32_t idx_xor_lane(uint32_t x) {
+  if (D == 1) return idx_dpp<0xB1, 0xf>(x, x);  // quad_perm [1,0,3,2]
+  if (D == 2) return idx_dpp<0x4E, 0xf>(x, x);  // quad_perm [2,3,0,1]
+  if (D == 4) {                                  // row_ror:4 for lanes 4-7, 12-15; row_ror:12 for lanes 0-3, 8-11
+    const uint32_t t = idx_dpp<0x124, 0xA>(x, x);
+    return idx_dpp<0x12C, 0x5>(t, x);
+  }
+  if (D == 8) return idx_dpp<0x128, 0xf>(x, x);                        // row_ror:8
+  if (D == 16) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)x, 0x401F);  // bit mode: xor 0x10
+  return (uint32_t)__builtin_amdgcn_ds_bpermute((int)((zes_lane() ^ 32u) << 2), (int)x);
+}
+template <int K, int D>
+__device__ __forceinline__ static uint32_t idx_cmpx(uint32_t x, uint32_t lane) {
+  const uint32_t y = idx_xor_lane<D>(x);
+  // the lower lane of a pair keeps the smaller word where the run of K lanes is sorted upwards (K = 64: all of them)
+  const bool keep_min = ((lane & (uint32_t)D) == 0u) == ((lane & (uint32_t)K) == 0u);
+  return keep_min ? min(x, y) : max(x, y);
+}
+// ascending over the 64 lanes
+__device__ __forceinline__ static uint32_t idx_bitonic64(uint32_t x) {
+  const uint32_t lane = zes_lane();
+  x = idx_cmpx<2, 1>(x, lane);
+  x = idx_cmpx<4, 2>(x, lane);
+  x = idx_cmpx<4, 1>(x, lane);
+  x = idx_cmpx<8, 4>(x, lane);
+  x = idx_cmpx<8, 2>(x, lane);
+  x = idx_cmpx<8, 1>(x, lane);
+  x = idx_cmpx<16, 8>(x, lane);
+  x = idx_cmpx<16, 4>(x, lane);
+  x = idx_cmpx<16, 2>(x, lane);
+  x = idx_cmpx<16, 1>(x, lane);
+  x = idx_cmpx<32, 16>(x, lane);
+  x = idx_cmpx<32, 8>(x, lane);
+  x = idx_cmpx<32, 4>(x, lane);
+  x = idx_cmpx<32, 2>(x, lane);
+  x = idx_cmpx<32, 1>(x, lane);
+  x = idx_cmpx<64, 32>(x, lane);
+  x = idx_cmpx<64, 16>(x, lane);
+  x = idx_cmpx<64, 8>(x, lane);
+  x = idx_cmpx<64, 4>(x, lane);
+  x = idx_cmpx<64, 2>(x, lane);
+  x = idx_cmpx<64, 1>(x, lane);
+  return x;
+}
+
+// what a sorted class leaves behind, for word x in slot `slot` whose predecessor in the class is `prev` (any word with
+// another key part for the first one)
+__device__ __forceinline__ static void idx_emit(IndexSmem& S, bool valid, uint32_t x, uint32_t prev, uint32_t slot, uint16_t* __restrict__ sd,
+                                                uint32_t* __restrict__ P) {
+  const uint32_t pos = x & 0x1FFFFu;
+  const uint32_t delta = pos - (prev & 0x1FFFFu);  // > 0: positions ascend inside a key
+  const bool has = ((x ^ prev) >> 17) == 0u && delta <= ZES_WINDOW;  // src/lz77.ts:49
+#ifdef IDX_CHECK
+  if (valid && (slot >= ZES_BLK || pos >= ZES_BLK - 2u)) printf("idx: emit slot %u pos %u x %#x\n", slot, pos, x);
+#endif
+  if (valid) {
+#ifdef IDX_CHECK
+    atomicAdd(&S.emitted, 1u);
+    atomicAdd(&S.wemit[threadIdx.x >> 6], 1u);
+#endif
+    sd[slot] = (uint16_t)(has ? delta : 0u);
+    const uint32_t sl = pos / IDX_SLICE;
+    const uint32_t k = atomicAdd(&S.pcur[sl], 1u);
+    P[sl * IDX_SLICE + k] = (pos & (IDX_SLICE - 1u)) | (slot << 14) | (has ? 0x80000000u : 0u);
+  }
+}
+
+// one class, by one wavefront.  scratch: 2 * cap words of LDS; cntw: 5 * 64 counters
+__device__ static void idx_class_(IndexSmem& S, uint32_t b0, uint32_t n, uint32_t* scratch, uint32_t cap, uint32_t* cntw,
+                                 const uint32_t* __restrict__ E, uint16_t* __restrict__ sd, uint32_t* __restrict__ P) {
+  const uint32_t lane = zes_lane();
+#ifndef IDX_NO_BITONIC
+  if (n <= 64u) {
+    uint32_t x = lane < n ? idx_ld_sc1(E + b0 + lane) : 0xFFFFFFFFu;
+    x = idx_bitonic64(x);
+    const uint32_t prev = idx_dpp<0x138, 0xf>(~x, x);  // wave_shr:1 (lane 0 keeps ~x: another key part)
+    idx_emit(S, lane < n, x, prev, b0 + lane, sd, P);
+    return;
+  }
+#endif
+  uint32_t* src = scratch;
+  uint32_t* dst = scratch + cap;
+#pragma unroll
+  for (uint32_t d = 0; d < 5; d++) cntw[d * 64u + lane] = 0;
+  // load, digit histograms (the multiset of a digit's values does not change from pass to pass), which bits differ at all
+  uint32_t diff = 0;
+  const uint32_t x0 = idx_ld_sc1(E + b0);
+  for (uint32_t i = lane; i < n; i += 64u) {
+    const uint32_t x = idx_ld_sc1(E + b0 + i);
+    src[i] = x;
+    diff |= x ^ x0;
+#pragma unroll
+    for (uint32_t d = 0; d < 5; d++) atomicAdd(&cntw[d * 64u + ((x >> (6u * d)) & 63u)], 1u);
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) diff |= (uint32_t)__shfl_xor((int)diff, o);
+  diff = (uint32_t)__builtin_amdgcn_readfirstlane((int)diff);
+  for (uint32_t d = 0; d < 5; d++) {
+    if (((diff >> (6u * d)) & 63u) == 0u) continue;  // every word has the same digit here
+    uint32_t* cw = cntw + d * 64u;
+    {  // exclusive scan of the digit counts
+      const uint32_t c = cw[lane];
+      uint32_t in = c;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)in, o);
+        if ((int)lane >= o) in += t;
+      }
+      cw[lane] = in - c;
+    }
+    for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
+      const uint32_t i = i0 + lane;
+      const bool valid = i < n;
+      const uint32_t x = src[valid ? i : 0u];
+      const uint32_t dg = (x >> (6u * d)) & 63u;
+      // lanes holding the same digit (stable rank = lower lanes first)
+      uint64_t m = __ballot(valid);
+#pragma unroll
+      for (int b = 0; b < 6; b++) {
+        const bool bit = (dg >> b) & 1u;
+        const uint64_t bal = __ballot(bit);
+        m &= bit ? bal : ~bal;
+      }
+      const uint32_t rank = (uint32_t)__popcll(m & zes_lanemask_lt());
+      uint32_t old = 0;
+      if (valid && rank == 0u) old = atomicAdd(&cw[dg], (uint32_t)__popcll(m));
+      const uint32_t first = valid ? (uint32_t)__builtin_ctzll(m) : 0u;
+      const uint32_t at = (uint32_t)__shfl((int)old, (int)first) + rank;
+      if (valid) dst[at] = x;
+    }
+    uint32_t* t = src;
+    src = dst;
+    dst = t;
+  }
+#ifdef IDX_CHECK
+  {
+    unsigned long long s1 = 0, s2 = 0;
+    for (uint32_t i = lane; i < n; i += 64u) {
+      s1 += idx_ld_sc1(E + b0 + i);
+      s2 += src[i];
+    }
+    for (int o = 32; o >= 1; o >>= 1) {
+      s1 += __shfl_xor(s1, o);
+      s2 += __shfl_xor(s2, o);
+    }
+    if (lane == 0 && s1 != s2) printf("idx: class at %u n %u cap %u wave %u diff %#x: sum in %llu out %llu\n", b0, n, cap, threadIdx.x >> 6, diff, s1, s2);
+  }
+  for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
+    const uint32_t i = i0 + lane;
+    const bool bad = i < n && i && src[i - 1u] >= src[i];
+    if (bad) printf("idx: class at %u n %u cap %u wave %u diff %#x: [%u] %#x >= [%u] %#x\n", b0, n, cap, threadIdx.x >> 6, diff, i - 1u, src[i - 1u], i, src[i]);
+  }
+#endif
+  for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
+    const uint32_t i = i0 + lane;
+    const bool valid = i < n;
+    const uint32_t x = src[valid ? i : 0u];
+    const uint32_t prev = (valid && i) ? src[i - 1u] : ~x;
+    idx_emit(S, valid, x, prev, b0 + i, sd, P);
+  }
+}
+
+__device__ static void idx_class(IndexSmem& S, uint32_t b0, uint32_t n, uint32_t* scratch, uint32_t cap, uint32_t* cntw,
+                                 const uint32_t* __restrict__ E, uint16_t* __restrict__ sd, uint32_t* __restrict__ P) {
+#ifdef IDX_CHECK
+  {
+    const uint64_t ex = __ballot(true);
+    if (ex != ~0ull && zes_lane() == (uint32_t)__builtin_ctzll(ex)) printf("idx: call b0 %u n %u wave %u with exec %#llx\n", b0, n, threadIdx.x >> 6, (unsigned long long)ex);
+  }
+  const uint32_t e0 = S.emitted;
+  if (zes_lane() == 0) S.wemit[threadIdx.x >> 6] = 0;
+  if (zes_lane() == 0) atomicAdd(&S.nsum, n);
+  {
+    const uint32_t nn = (uint32_t)__builtin_amdgcn_readfirstlane((int)n), bb = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);
+    if (nn != n || bb != b0) printf("idx: lane %u of wave %u has n %u b0 %u, lane 0 has %u %u\n", zes_lane(), threadIdx.x >> 6, n, b0, nn, bb);
+  }
+#endif
+  idx_class_(S, b0, n, scratch, cap, cntw, E, sd, P);
+#ifdef IDX_CHECK
+  (void)e0;
+  {
+    const uint32_t got = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.wemit[threadIdx.x >> 6]);
+    if (zes_lane() == 0 && got != n) printf("idx: call b0 %u n %u cap %u wave %u emitted %u\n", b0, n, cap, threadIdx.x >> 6, got);
+  }
+#endif
+}
+
+__global__ __launch_bounds__(IDX_THREADS) void k_lz_index(const uint8_t* __restrict__ d_in, const ZesBuf* __restrict__ bufs,
+                                                          const ZesBlk* __restrict__ blks, uint32_t* __restrict__ idx_a,
+                                                          uint32_t* __restrict__ idx_b, uint32_t* __restrict__ inv_all, uint16_t* __restrict__ sd_all) {
+  __shared__ __align__(16) IndexSmem S;
+  const uint32_t g = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+#ifdef IDX_PROF
+  unsigned long long tp[8];
+  int np = 0;
+#define ISTAMP() tp[np++] = clock64()
+#else
+#define ISTAMP()
+#endif
+  uint32_t* A = idx_a + (uint64_t)g * ZES_BLK;  // [ZES_BLK-1]: the flag word; the rest: the slice buckets
+  if (!(A[ZES_BLK - 1] & ZES_SORT_INDEX)) return;  // not a block k_lz_sort left to this kernel
+  uint32_t* E = idx_b + (uint64_t)g * ZES_BLK;
+  uint32_t* inv = inv_all + (uint64_t)g * ZES_BLK;
+  uint16_t* sd = sd_all + (uint64_t)g * ZES_BLK;
+  const ZesBlk bk = blks[g];
+  const ZesBuf bf = bufs[bk.buf];
+  const uint32_t T = bk.len;
+  const uint8_t* src = d_in + bf.in_off + (uint64_t)bk.blk * ZES_BLK;
+  const uint32_t cnt = T - 2u;  // (a block of this kernel has positions: k_lz_sort saw them)
+  const bool aligned = (((uintptr_t)src) & 15u) == 0;
+  uint32_t* cur = S.scr;  // [IDX_NCLASS] + 64 words that take the atomics of lanes without a position
+
+  for (uint32_t i = tid; i < IDX_NCLASS + 64u; i += IDX_THREADS) cur[i] = 0;
+  if (tid < IDX_NSLICE) S.pcur[tid] = 0;
+#ifdef IDX_CHECK
+  if (tid < IDX_NCLASS / 32) S.done[tid] = 0;
+  if (tid == 0) S.emitted = S.nsum = 0;
+#endif
+  if (tid == 0) {
+    S.next = 0;
+    S.nbig = 0;
+    S.nextbig = 0;
+    S.maxc = 0;
+  }
+  __syncthreads();
+  ISTAMP();
+  // ---- sweep 1: class sizes ----
+#pragma unroll 1
+  for (uint32_t ch = 0; ch < ZES_BLK / (16u * IDX_THREADS); ch++) {
+    const uint32_t o = (ch * IDX_THREADS + tid) * 16u;
+    if (o >= cnt) continue;
+    uint32_t w[5];
+    idx_ld20(src, aligned, o, T, w);
+#pragma unroll
+    for (uint32_t k = 0; k < 16; k++) {
+      const uint32_t raw = __builtin_amdgcn_alignbyte(w[(k >> 2) + 1], w[k >> 2], k & 3u);
+      const uint32_t h = __umul24(raw, IDX_MUL);
+      const uint32_t c = (h >> IDX_RSHIFT) & (IDX_NCLASS - 1u);
+      atomicAdd(&cur[o + k < cnt ? c : IDX_NCLASS + lane], 1u);
+    }
+  }
+  __syncthreads();
+  ISTAMP();
+  // ---- first slot of every class ----
+  {
+    const uint32_t a = cur[2u * tid], b = cur[2u * tid + 1u];
+    uint32_t incl = a + b;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = (uint32_t)__shfl_up((int)incl, o);
+      if ((int)lane >= o) incl += t;
+    }
+    if (lane == 63) S.wsum[wave] = incl;
+    atomicMax(&S.maxc, max(a, b));
+    __syncthreads();
+    uint32_t woff = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < IDX_WAVES; w++) woff += w < wave ? S.wsum[w] : 0u;
+    const uint32_t ex = woff + incl - (a + b);
+    S.base[2u * tid] = ex;
+    S.base[2u * tid + 1u] = ex + a;
+    if (tid == IDX_THREADS - 1u) S.base[IDX_NCLASS] = ex + a + b;
+    cur[2u * tid] = ex;  // the cursors of sweep 2
+    cur[2u * tid + 1u] = ex + a;
+  }
+  __syncthreads();
+  if (S.maxc > IDX_BIGCAP) {  // (uniform) a class no wavefront can hold: the block goes back to k_lz_sort
+    if (tid == 0) A[ZES_BLK - 1] = cnt | ZES_SORT_REDO;
+    return;
+  }
+  ISTAMP();
+  // ---- sweep 2: every word to its class's run of E ----
+#pragma unroll 1
+  for (uint32_t ch = 0; ch < ZES_BLK / (16u * IDX_THREADS); ch++) {
+    const uint32_t o = (ch * IDX_THREADS + tid) * 16u;
+    if (o >= cnt) continue;
+    uint32_t w[5];
+    idx_ld20(src, aligned, o, T, w);
+    uint32_t at[16], el[16];
+#pragma unroll
+    for (uint32_t k = 0; k < 16; k++) {
+      const uint32_t raw = __builtin_amdgcn_alignbyte(w[(k >> 2) + 1], w[k >> 2], k & 3u);
+      const uint32_t h = __umul24(raw, IDX_MUL);
+      const uint32_t c = (h >> IDX_RSHIFT) & (IDX_NCLASS - 1u);
+      el[k] = (h << 17) | (o + k);  // bits 17-29: the rest of H; 30, 31: the class's low bits (the same in the whole class)
+      at[k] = atomicAdd(&cur[o + k < cnt ? c : IDX_NCLASS + lane], 1u);
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < 16; k++) E[o + k < cnt ? at[k] : ZES_BLK - 2u] = el[k];  // (slot ZES_BLK-2 is never a class's: cnt <= ZES_BLK-2)
+  }
+  // the words are in memory (L2) before anybody sorts them: every storing wave waits for its own stores — a
+  // workgroup-scope fence does not (it compiles to lgkmcnt only) — and the readers load past the L1
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef IDX_FENCE
+  __threadfence();
+#endif
+  __syncthreads();
+#ifdef IDX_CHECK
+  for (uint32_t c = tid; c < IDX_NCLASS; c += IDX_THREADS)
+    if (cur[c] != S.base[c + 1u]) printf("idx: class %u base %u next %u cursor ended at %u\n", c, S.base[c], S.base[c + 1u], cur[c]);
+  if (tid == 0) printf("idx: total %u cnt %u\n", S.base[IDX_NCLASS], cnt);
+  __syncthreads();
+#endif
+  ISTAMP();
+  // ---- classes, one wavefront each ----
+  // (Every lane takes part in the atomic that hands out the next class, 63 of them adding nothing.  "Lane 0 asks,
+  // readfirstlane tells the others" does not survive the compiler here: it threads the loop's exit test into lane 0's
+  // branch, lane 0 leaves alone, and the other lanes run another turn on their own zero-initialised copy — class 0
+  // indexed a second time by most of a wavefront.)
+  for (;;) {
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)atomicAdd(&S.next, lane == 0 ? 1u : 0u));
+    if (c >= IDX_NCLASS) break;
+    const uint32_t b0 = S.base[c], n = S.base[c + 1u] - b0;
+    if (n == 0u) continue;
+    if (n > IDX_WCAP) {
+      if (lane == 0) S.big[atomicAdd(&S.nbig, 1u)] = c;
+      continue;
+    }
+#ifdef IDX_CHECK
+    if (lane == 0) {
+      const uint32_t was = atomicOr(&S.done[c >> 5], 1u << (c & 31u));
+      if (was & (1u << (c & 31u))) printf("idx: class %u twice (phase A)\n", c);
+    }
+#endif
+    idx_class(S, b0, n, S.scr + wave * (2u * IDX_WCAP), IDX_WCAP, S.cnt[wave], E, sd, A);
+  }
+  __syncthreads();
+#ifdef IDX_CHECK
+  if (tid == 0) printf("idx: after phase A emitted %u, big classes %u\n", S.emitted, S.nbig);
+#endif
+  ISTAMP();
+  if (wave < IDX_NBIGW) {  // the heavy classes: four wavefronts, a quarter of the scratch each
+    const uint32_t nbig = S.nbig;
+    for (;;) {
+      const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)atomicAdd(&S.nextbig, lane == 0 ? 1u : 0u));
+      if (k >= nbig) break;
+      const uint32_t c = S.big[k];
+      const uint32_t b0 = S.base[c], n = S.base[c + 1u] - b0;
+#ifdef IDX_CHECK
+      if (lane == 0) {
+        const uint32_t was = atomicOr(&S.done[c >> 5], 1u << (c & 31u));
+        printf("idx: phase B wave %u takes list entry %u class %u n %u%s\n", wave, k, c, n, (was & (1u << (c & 31u))) ? " TWICE" : "");
+      }
+#endif
+      idx_class(S, b0, n, S.scr + wave * (2u * IDX_BIGCAP), IDX_BIGCAP, S.cnt[wave], E, sd, A);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the bucket words, as above)
+#ifdef IDX_FENCE
+  __threadfence();
+#endif
+  __syncthreads();
+  ISTAMP();
+  // ---- inv[], a slice of 16384 positions at a time: the bucket's words scattered into an LDS image of the slice ----
+  uint32_t* stage = S.scr;
+  for (uint32_t s = 0; s < IDX_NSLICE; s++) {
+    const uint32_t lo = s * IDX_SLICE;
+    if (lo >= T) break;  // uniform
+    const uint32_t have = min(cnt, lo + IDX_SLICE) > lo ? min(cnt, lo + IDX_SLICE) - lo : 0u;  // positions of the slice that have a key
+    for (uint32_t i = tid; i < IDX_SLICE; i += IDX_THREADS)
+      if (i >= have) stage[i] = ZES_INV_NONE;
+#ifdef IDX_CHECK
+    for (uint32_t i = tid; i < have; i += IDX_THREADS) stage[i] = 0xDEADBEEFu;
+    if (tid == 0) printf("idx: slice %u have %u cursor %u\n", s, have, S.pcur[s]);
+    __syncthreads();
+#endif
+    for (uint32_t i = tid; i < have; i += IDX_THREADS) {
+      const uint32_t e = idx_ld_sc1(A + lo + i);
+      stage[e & (IDX_SLICE - 1u)] = (e >> 31) ? ((e >> 14) & 0x1FFFFu) : ZES_INV_NONE;
+    }
+    __syncthreads();
+#ifdef IDX_CHECK
+    for (uint32_t i = tid; i < have; i += IDX_THREADS)
+      if (stage[i] == 0xDEADBEEFu) printf("idx: slice %u position %u has no entry\n", s, i);
+#endif
+    const uint4* st4 = reinterpret_cast<const uint4*>(stage);
+    uint4* o4 = reinterpret_cast<uint4*>(inv + lo);
+    for (uint32_t i = tid; i < IDX_SLICE / 4u; i += IDX_THREADS) o4[i] = st4[i];
+    __syncthreads();
+  }
+#ifdef IDX_CHECK
+  if (tid == 0) printf("idx: emitted in all %u, sum of n over the calls %u\n", S.emitted, S.nsum);
+#endif
+  ISTAMP();
+#ifdef IDX_PROF
+  if (tid == 0 && (g == 7 || g == 300))
+    printf("idx prof block %u: count %llu scan %llu scatter %llu classes %llu heavy %llu inv %llu | heavy classes %u\n", g, tp[1] - tp[0], tp[2] - tp[1],
+           tp[3] - tp[2], tp[4] - tp[3], tp[5] - tp[4], tp[6] - tp[5], S.nbig);
+#endif
+  if (tid == 0) A[ZES_BLK - 1] = cnt | ZES_SORT_LAZY;
+}

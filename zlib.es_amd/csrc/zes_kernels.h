@@ -5,6 +5,12 @@
 #define SORT_THREADS 1024
 #define SORT_WAVES (SORT_THREADS / 64)
 #define MATCH_THREADS 1024
+#define IDX_THREADS 1024
+// k_lz_sort / k_lz_index -> the match finders, per block in idx_a[g][ZES_BLK-1]: kept positions | flags
+#define ZES_SORT_LAZY 0x80000000u   // the block's index is sd[] / inv[]: it belongs to k_lz_match_lazy
+#define ZES_SORT_INDEX 0x40000000u  // a dense block k_lz_sort left to k_lz_index
+#define ZES_SORT_REDO 0x20000000u   // k_lz_index handed the block back (a class too large for its LDS): k_lz_sort, second launch
+#define ZES_INV_NONE 0xFFFFFFFFu    // inv entry of a position without a candidate
 #define PARSE_THREADS 1024
 #define EMIT_THREADS 1024
 #define HUFF_THREADS_HOST 256
@@ -121,7 +127,11 @@ void zes_parse_set_dbg(unsigned long long*);
 void zes_lazy_set_dbg(unsigned long long*);
 void zes_huff_set_dbg(unsigned long long*);
 __global__ void k_make_blks(ZesBuf, uint32_t, ZesBuf*, ZesBlk*, uint32_t, unsigned long long*);
-__global__ void k_lz_sort(const uint8_t*, const ZesBuf*, const ZesBlk*, uint32_t*, uint32_t*, uint32_t*, uint16_t*);
+__global__ void k_lz_sort(const uint8_t*, const ZesBuf*, const ZesBlk*, uint32_t*, uint32_t*, uint32_t*, uint16_t*, uint32_t);
+__global__ void k_lz_index(const uint8_t*, const ZesBuf*, const ZesBlk*, uint32_t*, uint32_t*, uint32_t*, uint16_t*);
+#define ZES_SORT_MODE_FIRST 0u   // k_lz_sort: every block; dense ones are left to k_lz_index when bit 8 is set
+#define ZES_SORT_MODE_REDO 1u    // k_lz_sort: only the blocks k_lz_index handed back
+#define ZES_SORT_USE_INDEX 256u
 __global__ void k_lz_match_lazy(const uint8_t*, const ZesBuf*, const ZesBlk*, const uint32_t*, const uint32_t*, const uint16_t*, uint32_t*, uint32_t*, uint32_t*);
 __global__ void k_lz_match(const uint8_t*, const ZesBuf*, const ZesBlk*, const uint32_t*, uint32_t*, uint32_t*);
 __global__ void k_lz_parse(const uint8_t*, const ZesBuf*, ZesBlk*, const uint32_t*, uint32_t*, uint32_t*, const uint32_t*, const uint32_t*);
