@@ -57,11 +57,26 @@ const char* zes_strerror(int status);
 
 /* Library/device lifecycle.  zes_init(device) binds the process to one HIP device (one process per GPU;
  * bench.py passes LOCAL_RANK).  Idempotent; a second call with another device returns ZES_E_ARG.  Every entry
- * point may be called from any thread: calls are serialised by one lock and each makes the bound device current
- * on its calling thread for the duration of the call (HIP's current device is per thread).
+ * point may be called from any thread: calls on one device are serialised by that device's lock and each makes the device
+ * current on its calling thread for the duration of the call (HIP's current device is per thread).
  * replaces: nothing (the reference has no state); required because device scratch is pooled across calls. */
 int zes_init(int device);
 int zes_shutdown(void);
+/* Several GPUs from ONE process (what a Node host is: SURVEY §8b `zes_init(int ngpus)`, "the batch API is where
+ * multi-GPU concurrency lives").  zes_init_devices(n) gives the library n contexts, context i on device i (n <= 0: every
+ * visible device) — its own stream, scratch pools, staging and lock each.  From then on the host-pointer entry points use
+ * all of them: zes_deflate_batch / zes_inflate_batch_alloc partition their buffers by size (zes_partition) and run
+ * every share on its own host thread against its own device, results straight into the caller's memory (the allocator
+ * callback may then be called from several threads at once, always for distinct buffers); single host calls take the
+ * devices in turn, so concurrent deflateAsync() calls land on different GPUs; device-pointer entry points run on the
+ * device that holds their memory.  Results are identical to the one-device ones, buffer for buffer.  zes_init(device)
+ * keeps meaning "this process drives that one device" (one process per GPU under torch.distributed).
+ * zes_partition: owner[i] in [0, parts) for buffer i — longest first onto the lightest part so far, ties to the lower
+ * index (the rule of zlib.es_amd/shard.py's partition()); no GPU involved.  zes_device_count: contexts in use.
+ * replaces: the caller's own loop over buffers, README.md:28-42 (the reference is single-threaded). */
+int zes_init_devices(int n);
+int zes_device_count(void);
+int zes_partition(const uint64_t* sizes, uint32_t count, uint32_t parts, uint32_t* owner);
 /* Fills name (<= cap bytes) with the device's gcnArchName, *cus with its CU count. */
 int zes_device_info(char* name, int cap, int* cus, uint64_t* hbm_bytes);
 

@@ -74,3 +74,29 @@ def test_generators_are_deterministic(z):
     assert t == z.gen("itext", 7, 200).tobytes() and b" " in t
     lo = z.gen("lowent4k", 3, 9000)
     assert (lo[:4096] == lo[4096:8192]).all()
+
+
+def test_partition_of_a_host_batch_is_the_rule_of_shard_partition(z):
+    """zes_partition (what zes_deflate_batch / zes_inflate_batch_alloc cut a batch with when the library drives several
+    GPUs from one process) against zlib.es_amd/shard.py's partition(): the same owners, so that a Node batch and a
+    torch.distributed job split the same work the same way.  Pure host code: no GPU needed."""
+    import importlib.util
+    import random
+
+    spec = importlib.util.spec_from_file_location("shard_mod", os.path.join(ROOT, "zlib.es_amd", "shard.py"))
+    shard = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(shard)
+    rnd = random.Random(7)
+    cases = [[], [5], [1 << 20] * 1024, [3, 3, 3, 3, 3], [10, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1],
+             [rnd.randrange(0, 1 << 22) for _ in range(300)], [rnd.choice((0, 1, 2, 131072, 131073, 1 << 20)) for _ in range(77)]]
+    for sizes in cases:
+        for parts in (1, 2, 3, 8, 16):
+            own = z.partition(sizes, parts)
+            want = [None] * len(sizes)
+            for r, ids in enumerate(shard.partition(sizes, parts)):
+                for i in ids:
+                    want[i] = r
+            assert own == want, (sizes[:8], parts)
+            load = [sum(s for s, o in zip(sizes, own) if o == r) for r in range(parts)]
+            if sizes:
+                assert max(load) - min(load) <= max(sizes)  # greedy longest-first: no part is ahead by more than one buffer

@@ -79,6 +79,8 @@ def lib():
         L.zes_strerror.restype = C.c_char_p
         L.zes_strerror.argtypes = [C.c_int]
         L.zes_init.argtypes = [C.c_int]
+        L.zes_init_devices.argtypes = [C.c_int]
+        L.zes_partition.argtypes = [C.POINTER(C.c_uint64), C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
         L.zes_device_info.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int), u64p]
         L.zes_deflate_bound.argtypes = [C.c_uint64, u64p]
         for name in ("zes_deflate", "zes_deflate_dev"):
@@ -125,6 +127,26 @@ def init(device=0):
     rc = lib().zes_init(int(device))
     if rc:
         _raise(rc)
+
+
+def init_devices(n=0):
+    """One process, n GPUs (n <= 0: every visible one): the host batch forms then spread over all of them
+    (zes_init_devices).  Returns the number of devices in use."""
+    rc = lib().zes_init_devices(int(n))
+    if rc:
+        _raise(rc)
+    return int(lib().zes_device_count())
+
+
+def partition(sizes, parts):
+    """owner[i] of buffer i among `parts` devices: the library's rule for host batches (zes_partition; no GPU needed)."""
+    n = len(sizes)
+    arr = (C.c_uint64 * max(n, 1))(*[int(x) for x in sizes])
+    own = (C.c_uint32 * max(n, 1))()
+    rc = lib().zes_partition(arr, n, int(parts), own)
+    if rc:
+        _raise(rc)
+    return [int(own[i]) for i in range(n)]
 
 
 def device_info():

@@ -38,6 +38,7 @@ struct KTime {
 struct Ctx {
   bool ready = false;
   int device = -1;
+  int want = -1;  // zes_init_devices: the device this context binds to at its first use
   hipStream_t stream = nullptr;
   hipStream_t cs_in = nullptr, cs_out = nullptr;  // copy streams of the pipelined host calls (H2D / D2H beside the kernels)
   hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_k = nullptr;
@@ -62,8 +63,34 @@ struct Ctx {
   uint64_t hbm = 0;
 };
 
-Ctx g;
-std::mutex g_mu;
+// One context per device the library drives (zes_init(ngpus); "the batch API is where multi-GPU
+// concurrency lives").  zes_init(device) binds context 0 — one process per GPU, what bench.py's ranks do;
+// zes_init_devices(n) binds contexts 0 .. n-1 to devices 0 .. n-1, and the host-pointer entry points spread their
+// work over them: a batch is partitioned by size (zes_partition, the rule of shard.partition) and every share runs
+// on its own host thread against its own context — stream, scratch pools, staging ring, lock — while single calls
+// go round robin.  Results of the host forms land in the caller's memory, so no device-to-device gather is needed
+// here; HBM-resident results are gathered by shard.py over RCCL.  Which context a thread works on is thread-local.
+constexpr int ZES_MAX_DEV = 16;
+Ctx g_ctx[ZES_MAX_DEV];
+std::mutex g_mus[ZES_MAX_DEV];
+int g_nctx = 1;                  // contexts in use
+std::mutex g_cfg_mu;             // guards g_nctx and the context -> device binding
+thread_local int t_dev = 0;      // the context of the call this thread is inside
+thread_local bool t_routed = false;
+#define g (g_ctx[t_dev])
+#define g_mu (g_mus[t_dev])
+struct UseDev {                  // a call's context for its duration (nested entry points keep the outer one's)
+  int prev;
+  bool prev_routed;
+  explicit UseDev(int d) : prev(t_dev), prev_routed(t_routed) {
+    if (!t_routed) t_dev = d;
+    t_routed = true;
+  }
+  ~UseDev() {
+    t_dev = prev;
+    t_routed = prev_routed;
+  }
+};
 
 #define HIPCHK(x)                                                                              \
   do {                                                                                         \
@@ -98,7 +125,7 @@ int init_locked(int device) {
   }
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return ZES_E_DEVICE;
-  if (device < 0) device = 0;
+  if (device < 0) device = g.want >= 0 ? g.want : 0;
   if (device >= n) return ZES_E_DEVICE;
   HIPCHK(hipSetDevice(device));
   hipDeviceProp_t prop;
@@ -128,6 +155,27 @@ int init_locked(int device) {
   g.device = device;
   g.ready = true;
   return ZES_OK;
+}
+
+// ---- which context serves a call ----
+int route_host() {  // host-pointer work: the contexts in turn
+  if (t_routed) return t_dev;
+  const int n = g_nctx;
+  if (n <= 1) return 0;
+  static std::atomic<uint32_t> rr{0};
+  return (int)(rr.fetch_add(1) % (uint32_t)n);
+}
+int route_dev(const void* p) {  // device-pointer work: the context of the device that holds the memory
+  if (t_routed) return t_dev;
+  if (g_nctx <= 1 || !p) return 0;
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  for (int i = 0; i < g_nctx; i++)
+    if ((g_ctx[i].ready ? g_ctx[i].device : g_ctx[i].want) == a.device) return i;
+  return 0;
 }
 
 // ---- host <-> device staging of the host-pointer entry points ----
@@ -247,7 +295,9 @@ struct Stager {
     }
   }
 };
-Stager g_up, g_down;
+Stager g_ups[ZES_MAX_DEV], g_downs[ZES_MAX_DEV];
+#define g_up (g_ups[t_dev])
+#define g_down (g_downs[t_dev])
 
 // A thread that runs the side legs of a pipelined host call (one for uploads, one for downloads): submit() hands it
 // a task, the returned future gives the task's status.
@@ -257,7 +307,9 @@ struct SideThread {
   std::condition_variable cv;
   std::vector<std::packaged_task<int()>> q;
   bool stop = false;
+  int owner = 0;
   void loop() {
+    t_dev = owner;                                     // the context this thread serves
     if (g.device >= 0) (void)hipSetDevice(g.device);  // HIP's current device is per thread
     std::unique_lock<std::mutex> lk(mu);
     for (;;) {
@@ -275,7 +327,10 @@ struct SideThread {
     std::future<int> f = t.get_future();
     {
       std::lock_guard<std::mutex> lk(mu);
-      if (!th.joinable()) th = std::thread([this] { loop(); });
+      if (!th.joinable()) {
+        owner = t_dev;
+        th = std::thread([this] { loop(); });
+      }
       q.push_back(std::move(t));
     }
     cv.notify_one();
@@ -292,7 +347,9 @@ struct SideThread {
   }
   ~SideThread() { shutdown(); }
 };
-SideThread g_side_up, g_side_down;
+SideThread g_side_ups[ZES_MAX_DEV], g_side_downs[ZES_MAX_DEV];
+#define g_side_up (g_side_ups[t_dev])
+#define g_side_down (g_side_downs[t_dev])
 
 bool is_pinned(const void* p) {
   hipPointerAttribute_t a;
@@ -544,7 +601,7 @@ int deflate_batch_core(const uint8_t* d_in, const uint64_t* in_off, const uint64
   }
   // dense blocks (text, periodic data) get their index from k_lz_index (LDS-resident class sorts); a block it cannot take
   // goes back to k_lz_sort in a second launch that every other block leaves at once
-  static const bool use_index = getenv("ZES_NO_INDEX") == nullptr;
+  static const bool use_index = getenv("ZES_INDEX") != nullptr;  // (development: slower than k_lz_sort on text as it stands)
   {
     Timed t("k_lz_sort");
     hipLaunchKernelGGL(k_lz_sort, dim3(nblk), dim3(SORT_THREADS), 0, g.stream, d_in, dbufs, dblks, idx_a, idx_b, (uint32_t*)g.inv.p, (uint16_t*)g.sdelta.p,
@@ -1759,11 +1816,51 @@ const char* zes_strerror(int status) {
 }
 
 int zes_init(int device) {
+  UseDev ud(0);
   std::lock_guard<std::mutex> lk(g_mu);
   return init_locked(device);
 }
 
+int zes_init_devices(int n) {
+  int have = 0;
+  if (hipGetDeviceCount(&have) != hipSuccess || have <= 0) return ZES_E_DEVICE;
+  // ZES_OVERSUBSCRIBE: more contexts than devices, context i on device i % devices (exercises the multi-device paths on a one-GPU box)
+  const bool over = getenv("ZES_OVERSUBSCRIBE") != nullptr;
+  if (n <= 0) n = have;
+  if (n > ZES_MAX_DEV || (n > have && !over)) return ZES_E_ARG;
+  std::lock_guard<std::mutex> cfg(g_cfg_mu);
+  for (int i = 0; i < n; i++) {
+    std::lock_guard<std::mutex> lk(g_mus[i]);
+    const int dev = i % have;
+    if (g_ctx[i].ready ? g_ctx[i].device != dev : (g_ctx[i].want >= 0 && g_ctx[i].want != dev)) return ZES_E_ARG;  // bound elsewhere already
+    g_ctx[i].want = dev;
+  }
+  if (n > g_nctx) g_nctx = n;
+  for (int i = 0; i < n; i++) {  // bring every context up now: a first batch should not pay for it
+    UseDev ud(i);
+    std::lock_guard<std::mutex> lk(g_mu);
+    const int rc = init_locked(-1);
+    if (rc) return rc;
+  }
+  return ZES_OK;
+}
+
+static int shutdown_one(void);
 int zes_shutdown(void) {
+  std::lock_guard<std::mutex> cfg(g_cfg_mu);
+  int rc = ZES_OK;
+  for (int i = 0; i < ZES_MAX_DEV; i++) {
+    t_dev = i;  // (not a routed call: every context in turn)
+    const int r = shutdown_one();
+    if (r && !rc) rc = r;
+    g_ctx[i].want = -1;
+  }
+  t_dev = 0;
+  g_nctx = 1;
+  return rc;
+}
+
+static int shutdown_one(void) {
   std::lock_guard<std::mutex> lk(g_mu);
   if (!g.ready) return ZES_OK;
   (void)hipSetDevice(g.device);
@@ -1795,6 +1892,7 @@ int zes_shutdown(void) {
 }
 
 int zes_host_alloc(uint64_t n, void** p) {
+  UseDev ud(route_host());
   if (!p) return ZES_E_ARG;
   *p = nullptr;
   std::lock_guard<std::mutex> lk(g_mu);
@@ -1832,6 +1930,7 @@ int zes_deflate_bound(uint64_t n, uint64_t* cap) {
 
 int zes_deflate_batch_dev(const uint8_t* d_in, const uint64_t* in_off, const uint64_t* in_len, uint8_t* d_out,
                           const uint64_t* out_off, const uint64_t* out_cap, uint64_t* out_len, int32_t* status, uint32_t count) {
+  UseDev ud(route_dev(d_in));
   if (!in_off || !in_len || !out_off || !out_cap || !out_len || !status) return ZES_E_ARG;
   std::lock_guard<std::mutex> lk(g_mu);
   int rc = init_locked(-1);
@@ -1840,6 +1939,7 @@ int zes_deflate_batch_dev(const uint8_t* d_in, const uint64_t* in_off, const uin
 }
 
 int zes_deflate_dev(const uint8_t* d_in, uint64_t n, uint8_t* d_out, uint64_t cap, uint64_t* out_len) {
+  UseDev ud(route_dev(d_in));
   if (!out_len) return ZES_E_ARG;
   uint64_t zero = 0;
   int32_t st = 0;
@@ -1964,6 +2064,7 @@ static int deflate_host_pipelined(const uint8_t* in, uint64_t n, uint8_t* out, u
 }
 
 int zes_deflate(const uint8_t* in, uint64_t n, uint8_t* out, uint64_t cap, uint64_t* out_len) {
+  UseDev ud(route_host());
   if (!out_len || (!in && n) || !out) return ZES_E_ARG;
   *out_len = 0;
   if (deflate_throws(n)) return ZES_E_CORRUPT;
@@ -1988,6 +2089,7 @@ int zes_deflate(const uint8_t* in, uint64_t n, uint8_t* out, uint64_t cap, uint6
 }
 
 int zes_inflate_dev(const uint8_t* d_in, uint64_t c, uint8_t* d_out, uint64_t cap, uint64_t* out_len, uint32_t flags) {
+  UseDev ud(route_dev(d_in));
   if (!out_len) return ZES_E_ARG;
   if ((((uintptr_t)d_in) & 15u) || (((uintptr_t)d_out) & 15u)) return ZES_E_ARG;
   std::lock_guard<std::mutex> lk(g_mu);
@@ -1999,6 +2101,7 @@ int zes_inflate_dev(const uint8_t* d_in, uint64_t c, uint8_t* d_out, uint64_t ca
 int zes_inflate_batch_dev(const uint8_t* d_in, const uint64_t* in_off, const uint64_t* in_len, uint8_t* d_out,
                           const uint64_t* out_off, const uint64_t* out_cap, uint64_t* out_len, int32_t* status, uint32_t count,
                           uint32_t flags) {
+  UseDev ud(route_dev(d_in));
   if (!in_off || !in_len || !out_off || !out_cap || !out_len || !status) return ZES_E_ARG;
   if ((((uintptr_t)d_in) & 15u) || (((uintptr_t)d_out) & 15u)) return ZES_E_ARG;
   std::lock_guard<std::mutex> lk(g_mu);
@@ -2146,20 +2249,22 @@ static int inflate_host(const uint8_t* in, uint64_t c, uint8_t* out, uint64_t ca
 }
 
 int zes_inflate(const uint8_t* in, uint64_t c, uint8_t* out, uint64_t cap, uint64_t* out_len, uint32_t flags) {
+  UseDev ud(route_host());
   return inflate_host(in, c, out, cap, out_len, flags, false, nullptr, nullptr);
 }
 int zes_inflate_size(const uint8_t* in, uint64_t c, uint64_t* n, uint32_t flags) {
+  UseDev ud(route_host());
   return inflate_host(in, c, nullptr, 0, n, flags, true, nullptr, nullptr);
 }
 int zes_inflate_alloc(const uint8_t* in, uint64_t c, zes_alloc_fn alloc, void* user, uint64_t* out_len, uint32_t flags) {
+  UseDev ud(route_host());
   if (!alloc) return ZES_E_ARG;
   return inflate_host(in, c, nullptr, 0, out_len, flags, false, alloc, user);
 }
 
 // ---- batch over host pointers: one arena up, the device batch, results down ----
-int zes_deflate_batch(const uint8_t* const* in, const uint64_t* in_len, uint8_t* const* out, const uint64_t* out_cap,
-                      uint64_t* out_len, int32_t* status, uint32_t count) {
-  if (!in || !in_len || !out || !out_cap || !out_len || !status) return ZES_E_ARG;
+static int deflate_batch_one(const uint8_t* const* in, const uint64_t* in_len, uint8_t* const* out, const uint64_t* out_cap,
+                             uint64_t* out_len, int32_t* status, uint32_t count) {
   std::lock_guard<std::mutex> lk(g_mu);
   int rc = init_locked(-1);
   if (rc) return rc;
@@ -2191,9 +2296,8 @@ int zes_deflate_batch(const uint8_t* const* in, const uint64_t* in_len, uint8_t*
   return ZES_OK;
 }
 
-int zes_inflate_batch_alloc(const uint8_t* const* in, const uint64_t* in_len, zes_alloc_fn alloc, void* user, uint64_t* out_len,
-                            int32_t* status, uint32_t count, uint32_t flags) {
-  if (!in || !in_len || !alloc || !out_len || !status) return ZES_E_ARG;
+static int inflate_batch_alloc_one(const uint8_t* const* in, const uint64_t* in_len, zes_alloc_fn alloc, void* user, uint64_t* out_len,
+                                   int32_t* status, uint32_t count, uint32_t flags) {
   std::lock_guard<std::mutex> lk(g_mu);
   int rc = init_locked(-1);
   if (rc) return rc;
@@ -2252,6 +2356,125 @@ int zes_inflate_batch_alloc(const uint8_t* const* in, const uint64_t* in_len, ze
   return ZES_OK;
 }
 
+// ---- a host batch over every device the library drives ----
+// Size-balanced owner lists: the longest buffers first, each onto the lightest part so far (ties: the lower index) —
+// the rule of shard.partition, so that a Node batch and a torch.distributed job cut the same work the same way.
+int zes_partition(const uint64_t* sizes, uint32_t count, uint32_t parts, uint32_t* owner) {
+  if ((!sizes || !owner) && count) return ZES_E_ARG;
+  if (parts == 0) return ZES_E_ARG;
+  std::vector<uint32_t> order(count);
+  for (uint32_t i = 0; i < count; i++) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return sizes[a] > sizes[b]; });
+  std::vector<uint64_t> load(parts, 0);
+  for (uint32_t i : order) {
+    uint32_t best = 0;
+    for (uint32_t r = 1; r < parts; r++)
+      if (load[r] < load[best]) best = r;
+    owner[i] = best;
+    load[best] += sizes[i];
+  }
+  return ZES_OK;
+}
+
+int zes_device_count(void) {
+  std::lock_guard<std::mutex> lk(g_cfg_mu);
+  return g_nctx;
+}
+
+}  // extern "C"
+// runs fn(ids) for every non-empty share, each on its own thread bound to its context; the first non-zero return wins
+template <class F>
+static int over_devices(const uint64_t* sizes, uint32_t count, F fn) {
+  const int n = g_nctx;
+  std::vector<uint32_t> owner(count);
+  int rc = zes_partition(sizes, count, (uint32_t)n, owner.data());
+  if (rc) return rc;
+  std::vector<std::vector<uint32_t>> ids((size_t)n);
+  for (uint32_t i = 0; i < count; i++) ids[owner[i]].push_back(i);
+  std::vector<int> rcs((size_t)n, ZES_OK);
+  std::vector<std::thread> th;
+  for (int d = 1; d < n; d++)
+    if (!ids[(size_t)d].empty()) th.emplace_back([&, d] {
+      UseDev ud(d);
+      rcs[(size_t)d] = fn(ids[(size_t)d]);
+    });
+  if (!ids[0].empty()) {
+    UseDev ud(0);
+    rcs[0] = fn(ids[0]);
+  }
+  for (auto& t : th) t.join();
+  for (int r : rcs)
+    if (r) return r;
+  return ZES_OK;
+}
+extern "C" {
+
+int zes_deflate_batch(const uint8_t* const* in, const uint64_t* in_len, uint8_t* const* out, const uint64_t* out_cap,
+                      uint64_t* out_len, int32_t* status, uint32_t count) {
+  if (!in || !in_len || !out || !out_cap || !out_len || !status) return ZES_E_ARG;
+  if (g_nctx <= 1 || count <= 1 || t_routed) {
+    UseDev ud(route_host());
+    return deflate_batch_one(in, in_len, out, out_cap, out_len, status, count);
+  }
+  return over_devices(in_len, count, [&](const std::vector<uint32_t>& ids) {
+    const uint32_t m = (uint32_t)ids.size();
+    std::vector<const uint8_t*> sin(m);
+    std::vector<uint8_t*> sout(m);
+    std::vector<uint64_t> slen(m), scap(m), sol(m);
+    std::vector<int32_t> sst(m);
+    for (uint32_t k = 0; k < m; k++) {
+      sin[k] = in[ids[k]];
+      slen[k] = in_len[ids[k]];
+      sout[k] = out[ids[k]];
+      scap[k] = out_cap[ids[k]];
+    }
+    const int rc = deflate_batch_one(sin.data(), slen.data(), sout.data(), scap.data(), sol.data(), sst.data(), m);
+    if (rc) return rc;
+    for (uint32_t k = 0; k < m; k++) {
+      out_len[ids[k]] = sol[k];
+      status[ids[k]] = sst[k];
+    }
+    return (int)ZES_OK;
+  });
+}
+
+struct SubAlloc {  // a share's buffer k is the caller's buffer ids[k]
+  zes_alloc_fn fn;
+  void* user;
+  const uint32_t* ids;
+};
+static uint8_t* sub_alloc(void* u, uint32_t k, uint64_t n) {
+  const SubAlloc* a = static_cast<const SubAlloc*>(u);
+  return a->fn(a->user, a->ids[k], n);
+}
+
+int zes_inflate_batch_alloc(const uint8_t* const* in, const uint64_t* in_len, zes_alloc_fn alloc, void* user, uint64_t* out_len,
+                            int32_t* status, uint32_t count, uint32_t flags) {
+  if (!in || !in_len || !alloc || !out_len || !status) return ZES_E_ARG;
+  if (g_nctx <= 1 || count <= 1 || t_routed) {
+    UseDev ud(route_host());
+    return inflate_batch_alloc_one(in, in_len, alloc, user, out_len, status, count, flags);
+  }
+  return over_devices(in_len, count, [&](const std::vector<uint32_t>& ids) {
+    const uint32_t m = (uint32_t)ids.size();
+    std::vector<const uint8_t*> sin(m);
+    std::vector<uint64_t> slen(m), sol(m);
+    std::vector<int32_t> sst(m);
+    for (uint32_t k = 0; k < m; k++) {
+      sin[k] = in[ids[k]];
+      slen[k] = in_len[ids[k]];
+    }
+    SubAlloc sa{alloc, user, ids.data()};
+    const int rc = inflate_batch_alloc_one(sin.data(), slen.data(), sub_alloc, &sa, sol.data(), sst.data(), m, flags);
+    if (rc) return rc;
+    for (uint32_t k = 0; k < m; k++) {
+      out_len[ids[k]] = sol[k];
+      status[ids[k]] = sst[k];
+    }
+    return (int)ZES_OK;
+  });
+}
+
 static int adler32_locked(const uint8_t* d_in, uint64_t n, uint32_t* adler_out) {
   int rc;
   if ((rc = ensure(g.adler, 16))) return rc;
@@ -2275,6 +2498,7 @@ static int adler32_locked(const uint8_t* d_in, uint64_t n, uint32_t* adler_out) 
 // ---- one buffer over several GPUs: block ranges and their join ----
 int zes_deflate_range_dev(const uint8_t* d_in, uint64_t n, uint64_t n_readable, int final_range, uint8_t* d_out, uint64_t cap,
                           uint64_t* out_bits, uint32_t* adler) {
+  UseDev ud(route_dev(d_in));
   if (!out_bits || !d_in || !d_out || n == 0 || n_readable < n) return ZES_E_ARG;
   if (!final_range && (n % ZES_BLK)) return ZES_E_ARG;  // only the input's last range may end inside a block
   if ((n % ZES_BLK) == 1) return ZES_E_CORRUPT;         // the reference throws on a 1-byte last block
@@ -2298,6 +2522,7 @@ int zes_deflate_range_dev(const uint8_t* d_in, uint64_t n, uint64_t n_readable, 
 
 int zes_deflate_join_dev(const uint8_t* const* d_piece, const uint64_t* piece_bits, const uint32_t* piece_adler, const uint64_t* piece_len,
                          uint32_t count, uint8_t* d_out, uint64_t cap, uint64_t* out_len) {
+  UseDev ud(route_dev(d_out));
   if (!d_piece || !piece_bits || !piece_adler || !piece_len || !d_out || !out_len || count == 0) return ZES_E_ARG;
   if (((uintptr_t)d_out) & 15u) return ZES_E_ARG;
   uint64_t bits = 0;
@@ -2343,6 +2568,7 @@ int zes_deflate_join_dev(const uint8_t* const* d_piece, const uint64_t* piece_bi
 
 int zes_inflate_range_dev(const uint8_t* d_in, uint64_t c, uint64_t lo_bit, uint64_t own_bit, int exact_start, uint8_t* d_out, uint64_t cap,
                           uint64_t* out_len, uint64_t* first_bit, uint64_t* end_bit, uint32_t* nblocks, int* final_block) {
+  UseDev ud(route_dev(d_in));
   if (!d_in || !out_len || !first_bit || !end_bit || !nblocks || !final_block || lo_bit < 16 || own_bit <= lo_bit) return ZES_E_ARG;
   if ((((uintptr_t)d_in) & 15u) || (((uintptr_t)d_out) & 15u) || c >= (1ull << 29)) return ZES_E_ARG;
   std::lock_guard<std::mutex> lk(g_mu);
@@ -2361,6 +2587,7 @@ int zes_inflate_range_dev(const uint8_t* d_in, uint64_t c, uint64_t lo_bit, uint
 }
 
 int zes_adler32_dev(const uint8_t* d_in, uint64_t n, uint32_t* adler_out) {
+  UseDev ud(route_dev(d_in));
   if (!adler_out) return ZES_E_ARG;
   std::lock_guard<std::mutex> lk(g_mu);
   int rc = init_locked(-1);
@@ -2379,6 +2606,7 @@ static int inflate_raw_staged(uint64_t n, uint8_t* d_out, uint64_t cap, uint64_t
 
 int zes_inflate_raw_dev(const uint8_t* d_in, uint64_t c, uint64_t offset, uint8_t* d_out, uint64_t cap, uint64_t* out_len,
                         uint32_t flags) {
+  UseDev ud(route_dev(d_in));
   if (!out_len || (!d_in && c)) return ZES_E_ARG;
   if ((((uintptr_t)d_out) & 15u)) return ZES_E_ARG;
   std::lock_guard<std::mutex> lk(g_mu);
@@ -2391,6 +2619,7 @@ int zes_inflate_raw_dev(const uint8_t* d_in, uint64_t c, uint64_t offset, uint8_
 }
 
 int zes_inflate_raw(const uint8_t* in, uint64_t c, uint64_t offset, uint8_t* out, uint64_t cap, uint64_t* out_len, uint32_t flags) {
+  UseDev ud(route_host());
   if (!out_len || (!in && c)) return ZES_E_ARG;
   *out_len = 0;
   std::lock_guard<std::mutex> lk(g_mu);
@@ -2431,6 +2660,7 @@ static int deflate_raw_common(const uint8_t* d_in, uint64_t n, uint64_t* raw_len
 }
 
 int zes_deflate_raw_dev(const uint8_t* d_in, uint64_t n, uint8_t* d_out, uint64_t cap, uint64_t* out_len) {
+  UseDev ud(route_dev(d_in));
   if (!out_len || !d_out) return ZES_E_ARG;
   *out_len = 0;
   if (deflate_throws(n)) return ZES_E_CORRUPT;
@@ -2447,6 +2677,7 @@ int zes_deflate_raw_dev(const uint8_t* d_in, uint64_t n, uint8_t* d_out, uint64_
 }
 
 int zes_deflate_raw(const uint8_t* in, uint64_t n, uint8_t* out, uint64_t cap, uint64_t* out_len) {
+  UseDev ud(route_host());
   if (!out_len || (!in && n) || !out) return ZES_E_ARG;
   *out_len = 0;
   if (deflate_throws(n)) return ZES_E_CORRUPT;
@@ -2463,6 +2694,7 @@ int zes_deflate_raw(const uint8_t* in, uint64_t n, uint8_t* out, uint64_t cap, u
 }
 
 int zes_adler32(const uint8_t* in, uint64_t n, uint32_t* adler_out) {
+  UseDev ud(route_host());
   if (!adler_out || (!in && n)) return ZES_E_ARG;
   std::lock_guard<std::mutex> lk(g_mu);  // staging and kernel under one lock: nobody else's call can replace st_in in between
   int rc = init_locked(-1);
@@ -2473,6 +2705,7 @@ int zes_adler32(const uint8_t* in, uint64_t n, uint32_t* adler_out) {
 }
 
 int zes_stage_lz77_dev(const uint8_t* d_in, uint64_t n, uint64_t start, uint32_t len, uint32_t* h_tokens, uint32_t* ntokens) {
+  UseDev ud(route_dev(d_in));
   if (!h_tokens || !ntokens || len < 2 || len > ZES_BLK || start + len > n || (start % ZES_BLK)) return ZES_E_ARG;
   std::lock_guard<std::mutex> lk(g_mu);
   int rc = init_locked(-1);
@@ -2499,7 +2732,7 @@ int zes_stage_lz77_dev(const uint8_t* d_in, uint64_t n, uint64_t start, uint32_t
   if ((rc = ensure(g.mlist, ZES_MLIST_WORDS * 4))) return rc;
   HIPCHK(hipMemcpyAsync(g.bufs.p, &b, sizeof b, hipMemcpyHostToDevice, g.stream));
   HIPCHK(hipMemcpyAsync(g.blks.p, &z, sizeof z, hipMemcpyHostToDevice, g.stream));
-  const bool use_index = getenv("ZES_NO_INDEX") == nullptr;  // the same three launches as the whole pipeline
+  const bool use_index = getenv("ZES_INDEX") != nullptr;  // the same three launches as the whole pipeline
   hipLaunchKernelGGL(k_lz_sort, dim3(1), dim3(SORT_THREADS), 0, g.stream, d_in, (const ZesBuf*)g.bufs.p, (const ZesBlk*)g.blks.p,
                      (uint32_t*)g.idx_a.p, (uint32_t*)g.idx_b.p, (uint32_t*)g.inv.p, (uint16_t*)g.sdelta.p,
                      ZES_SORT_MODE_FIRST | (use_index ? ZES_SORT_USE_INDEX : 0u));

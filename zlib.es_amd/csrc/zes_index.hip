@@ -130,6 +130,48 @@ __device__ __forceinline__ static uint32_t idx_bitonic64(uint32_t x) {
   return x;
 }
 
+__device__ __forceinline__ static uint32_t idx_xor_lane_d(uint32_t x, int d) {  // (d is a constant wherever this is called: unrolled loops)
+  switch (d) {
+    case 1: return idx_xor_lane<1>(x);
+    case 2: return idx_xor_lane<2>(x);
+    case 4: return idx_xor_lane<4>(x);
+    case 8: return idx_xor_lane<8>(x);
+    case 16: return idx_xor_lane<16>(x);
+    default: return idx_xor_lane<32>(x);
+  }
+}
+// 64 * M words, word e = j * 64 + lane in register j of its lane: ascending in e.  Steps over a distance of 64 or more
+// are compare-exchanges between two registers of a lane; the others trade with another lane of the same register.
+template <int M>
+__device__ __forceinline__ static void idx_bitonic(uint32_t (&x)[M]) {
+  const uint32_t lane = zes_lane();
+#pragma unroll
+  for (int k = 2; k <= 64 * M; k <<= 1) {
+#pragma unroll
+    for (int d = k >> 1; d >= 1; d >>= 1) {
+      if (d >= 64) {
+        const int dj = d >> 6;
+#pragma unroll
+        for (int j = 0; j < M; j++) {
+          if (j & dj) continue;
+          const bool asc = (j & (k >> 6)) == 0;  // (k = 64 M: every run goes upwards)
+          const uint32_t lo = min(x[j], x[j | dj]), hi = max(x[j], x[j | dj]);
+          x[j] = asc ? lo : hi;
+          x[j | dj] = asc ? hi : lo;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < M; j++) {
+          const uint32_t y = idx_xor_lane_d(x[j], d);
+          const bool asc = k < 64 ? ((lane & (uint32_t)k) == 0u) : ((j & (k >> 6)) == 0);
+          const bool keep_min = ((lane & (uint32_t)d) == 0u) == asc;
+          x[j] = keep_min ? min(x[j], y) : max(x[j], y);
+        }
+      }
+    }
+  }
+}
+
 // what a sorted class leaves behind, for word x in slot `slot` whose predecessor in the class is `prev` (any word with
 // another key part for the first one)
 __device__ __forceinline__ static void idx_emit(IndexSmem& S, bool valid, uint32_t x, uint32_t prev, uint32_t slot, uint16_t* __restrict__ sd,
@@ -152,16 +194,43 @@ __device__ __forceinline__ static void idx_emit(IndexSmem& S, bool valid, uint32
   }
 }
 
+// a class of at most 64 * M words, sorted in registers
+template <int M>
+__device__ __forceinline__ static void idx_class_regs(IndexSmem& S, uint32_t b0, uint32_t n, const uint32_t* __restrict__ E, uint16_t* __restrict__ sd,
+                                                      uint32_t* __restrict__ P) {
+  const uint32_t lane = zes_lane();
+  uint32_t x[M];
+#pragma unroll
+  for (int j = 0; j < M; j++) x[j] = (uint32_t)j * 64u + lane < n ? idx_ld_sc1(E + b0 + (uint32_t)j * 64u + lane) : 0xFFFFFFFFu;
+  idx_bitonic<M>(x);
+#pragma unroll
+  for (int j = 0; j < M; j++) {
+    // the word in front: the lane below, lane 0 from the last lane of the register before (the class's first word: another key part)
+    const uint32_t carry = j ? (uint32_t)__builtin_amdgcn_readlane((int)x[j ? j - 1 : 0], 63) : ~x[0];
+    const uint32_t prev = idx_dpp<0x138, 0xf>(carry, x[j]);  // wave_shr:1
+    idx_emit(S, (uint32_t)j * 64u + lane < n, x[j], prev, b0 + (uint32_t)j * 64u + lane, sd, P);
+  }
+}
+
 // one class, by one wavefront.  scratch: 2 * cap words of LDS; cntw: 5 * 64 counters
 __device__ static void idx_class_(IndexSmem& S, uint32_t b0, uint32_t n, uint32_t* scratch, uint32_t cap, uint32_t* cntw,
                                  const uint32_t* __restrict__ E, uint16_t* __restrict__ sd, uint32_t* __restrict__ P) {
   const uint32_t lane = zes_lane();
 #ifndef IDX_NO_BITONIC
   if (n <= 64u) {
-    uint32_t x = lane < n ? idx_ld_sc1(E + b0 + lane) : 0xFFFFFFFFu;
-    x = idx_bitonic64(x);
-    const uint32_t prev = idx_dpp<0x138, 0xf>(~x, x);  // wave_shr:1 (lane 0 keeps ~x: another key part)
-    idx_emit(S, lane < n, x, prev, b0 + lane, sd, P);
+    idx_class_regs<1>(S, b0, n, E, sd, P);
+    return;
+  }
+  if (n <= 128u) {
+    idx_class_regs<2>(S, b0, n, E, sd, P);
+    return;
+  }
+  if (n <= 256u) {
+    idx_class_regs<4>(S, b0, n, E, sd, P);
+    return;
+  }
+  if (n <= 512u) {
+    idx_class_regs<8>(S, b0, n, E, sd, P);
     return;
   }
 #endif
@@ -390,13 +459,11 @@ __global__ __launch_bounds__(IDX_THREADS) void k_lz_index(const uint8_t* __restr
 #endif
   ISTAMP();
   // ---- classes, one wavefront each ----
-  // (Every lane takes part in the atomic that hands out the next class, 63 of them adding nothing.  "Lane 0 asks,
-  // readfirstlane tells the others" does not survive the compiler here: it threads the loop's exit test into lane 0's
-  // branch, lane 0 leaves alone, and the other lanes run another turn on their own zero-initialised copy — class 0
-  // indexed a second time by most of a wavefront.)
-  for (;;) {
-    const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)atomicAdd(&S.next, lane == 0 ? 1u : 0u));
-    if (c >= IDX_NCLASS) break;
+  // classes dealt to the wavefronts in turn: the hash spreads the keys, and the heavy classes wait for the second round.
+  // (A dispenser — "lane 0 takes the next class from an LDS counter, readfirstlane tells the others" — does not survive
+  // the compiler in this loop: it threads the loop's exit test into lane 0's branch, lane 0 leaves alone, and the other
+  // lanes run another turn on their own zero-initialised copy: class 0 indexed a second time by most of a wavefront.)
+  for (uint32_t c = wave; c < IDX_NCLASS; c += IDX_WAVES) {
     const uint32_t b0 = S.base[c], n = S.base[c + 1u] - b0;
     if (n == 0u) continue;
     if (n > IDX_WCAP) {

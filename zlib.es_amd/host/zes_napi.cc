@@ -206,6 +206,21 @@ napi_value Init(napi_env env, napi_callback_info info) {
   return v;
 }
 
+// initDevices(n): one process, n GPUs (n omitted or <= 0: every visible one) — the batch calls then partition their
+// buffers over all of them, single calls take them in turn (zes_init_devices).  Returns the number of devices in use.
+napi_value InitDevices(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr);
+  int32_t n = 0;
+  if (argc >= 1) napi_get_value_int32(env, argv[0], &n);
+  const int rc = zes_init_devices(n);
+  if (rc) return throw_status(env, rc);
+  napi_value v;
+  napi_create_int32(env, zes_device_count(), &v);
+  return v;
+}
+
 // ---- Promise-returning forms: the blocking C-ABI call runs on a libuv worker thread ----
 struct AsyncJob {
   napi_async_work work = nullptr;
@@ -518,6 +533,7 @@ napi_value ModuleInit(napi_env env, napi_value exports) {
       {"allocPinned", nullptr, AllocPinned, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"adler32", nullptr, Adler32, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"init", nullptr, Init, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"initDevices", nullptr, InitDevices, nullptr, nullptr, nullptr, napi_default, nullptr},
   };
   napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props);
   return exports;

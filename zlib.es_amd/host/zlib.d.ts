@@ -1,4 +1,4 @@
-/** Same declarations as the reference's dist/tsc/zlib.d.ts:4-5, plus the raw, Promise and batch forms and three extras. */
+/** Same declarations as the reference's dist/tsc/zlib.d.ts:4-5, plus the raw, Promise and batch forms and four extras. */
 export declare function inflate(input: Uint8Array): Uint8Array;
 export declare function deflate(input: Uint8Array): Uint8Array;
 export declare function deflateRaw(input: Uint8Array): Uint8Array;
@@ -13,3 +13,4 @@ export declare function inflateBatchAsync(inputs: Uint8Array[]): Promise<BatchRe
 export declare function allocPinned(n: number): Uint8Array;
 export declare function adler32(input: Uint8Array): number;
 export declare function init(device: number): void;
+export declare function initDevices(n?: number): number;

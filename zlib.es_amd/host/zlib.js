@@ -88,6 +88,16 @@ function init(device) {
   addon.init(device);
 }
 
+/**
+ * Extra: drive `n` GPUs from this one process (n omitted or <= 0: every visible one; returns the number in use).  After
+ * this the batch forms partition their buffers over all of them by size — a caller's loop over deflate()/inflate()
+ * (reference README.md:28-42) spread over the node — and single calls (deflateAsync from several promises at once) take
+ * the GPUs in turn.  Results are the same bytes, buffer for buffer.
+ */
+function initDevices(n) {
+  return addon.initDevices(n);
+}
+
 exports.inflate = inflate;
 exports.deflate = deflate;
 exports.deflateRaw = deflateRaw;
@@ -101,3 +111,4 @@ exports.inflateBatchAsync = inflateBatchAsync;
 exports.allocPinned = allocPinned;
 exports.adler32 = adler32;
 exports.init = init;
+exports.initDevices = initDevices;

@@ -15,3 +15,4 @@ export const inflateBatchAsync = z.inflateBatchAsync;
 export const allocPinned = z.allocPinned;
 export const adler32 = z.adler32;
 export const init = z.init;
+export const initDevices = z.initDevices;

@@ -86,3 +86,13 @@ export function adler32(input: Uint8Array): number {
 export function init(device: number): void {
   addon.init(device);
 }
+
+/**
+ * Extra: drive `n` GPUs from this one process (n omitted or <= 0: every visible one; returns the number in use).  After
+ * this the batch forms partition their buffers over all of them by size — a caller's loop over deflate()/inflate()
+ * (reference README.md:28-42) spread over the node — and single calls (deflateAsync from several promises at once) take
+ * the GPUs in turn.  Results are the same bytes, buffer for buffer.
+ */
+export function initDevices(n: number = 0): number {
+  return addon.initDevices(n);
+}
