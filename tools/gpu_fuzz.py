@@ -1,6 +1,7 @@
-"""Randomised differential run (not a pytest; run on the GPU box): deflate vs the oracle, inflate of own / foreign /
-damaged streams vs the oracle, single and batch entry points.  usage: gpu_fuzz.py [seconds] [seed]
-(FUZZ_DAMAGE=2: several bit flips and overwritten spans per damaged copy)"""
+"""Randomised differential run on the GPU box: deflate vs the oracle, inflate of own / foreign / damaged streams vs the
+oracle, single and batch entry points.  usage: gpu_fuzz.py [seconds] [seed]
+(FUZZ_DAMAGE=2: several bit flips and overwritten spans per damaged copy; FUZZ_MAX_CASES=n: stop after n cases — the
+fixed-seed slice tests/test_gpu_fuzz.py runs in the suite)"""
 import os, sys, time, zlib as pz
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -14,6 +15,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 kinds = ("itext", "lowent4k", "xorshift")
 t_end = time.time() + budget
 n_cases = n_batch = 0
+max_cases = int(os.environ.get("FUZZ_MAX_CASES", "0"))
 
 def ref_inflate(comp):
     try:
@@ -27,7 +29,7 @@ def gpu_inflate(comp, flags=0):
     except z.ZlibEsError as ex:
         return ("err", ex.code)
 
-while time.time() < t_end:
+while time.time() < t_end and (not max_cases or n_cases < max_cases):
     kind = kinds[int(rng.integers(3))]
     n = int(rng.choice([2, 3, 100, 4097, 65536, 131071, 131072, 131074, 262144 + 5, 400000, 1 << 20, 3000000, int(rng.integers(2, 2500000))]))
     if n % 131072 in (0, 1) and n < 3:
