@@ -601,7 +601,7 @@ int deflate_batch_core(const uint8_t* d_in, const uint64_t* in_off, const uint64
   }
   // dense blocks (text, periodic data) get their index from k_lz_index (LDS-resident class sorts); a block it cannot take
   // goes back to k_lz_sort in a second launch that every other block leaves at once
-  static const bool use_index = getenv("ZES_INDEX") != nullptr;  // (development: slower than k_lz_sort on text as it stands)
+  static const bool use_index = getenv("ZES_NO_INDEX") == nullptr;
   {
     Timed t("k_lz_sort");
     hipLaunchKernelGGL(k_lz_sort, dim3(nblk), dim3(SORT_THREADS), 0, g.stream, d_in, dbufs, dblks, idx_a, idx_b, (uint32_t*)g.inv.p, (uint16_t*)g.sdelta.p,
@@ -2732,7 +2732,7 @@ int zes_stage_lz77_dev(const uint8_t* d_in, uint64_t n, uint64_t start, uint32_t
   if ((rc = ensure(g.mlist, ZES_MLIST_WORDS * 4))) return rc;
   HIPCHK(hipMemcpyAsync(g.bufs.p, &b, sizeof b, hipMemcpyHostToDevice, g.stream));
   HIPCHK(hipMemcpyAsync(g.blks.p, &z, sizeof z, hipMemcpyHostToDevice, g.stream));
-  const bool use_index = getenv("ZES_INDEX") != nullptr;  // the same three launches as the whole pipeline
+  const bool use_index = getenv("ZES_NO_INDEX") == nullptr;  // the same three launches as the whole pipeline
   hipLaunchKernelGGL(k_lz_sort, dim3(1), dim3(SORT_THREADS), 0, g.stream, d_in, (const ZesBuf*)g.bufs.p, (const ZesBlk*)g.blks.p,
                      (uint32_t*)g.idx_a.p, (uint32_t*)g.idx_b.p, (uint32_t*)g.inv.p, (uint16_t*)g.sdelta.p,
                      ZES_SORT_MODE_FIRST | (use_index ? ZES_SORT_USE_INDEX : 0u));

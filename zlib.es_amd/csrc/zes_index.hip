@@ -40,16 +40,30 @@
 #define IDX_NBIGW 4u
 #define IDX_SLICE 16384u
 #define IDX_NSLICE (ZES_BLK / IDX_SLICE)
-#define IDX_MAXBIG 128u  // classes above IDX_WCAP words: at most 131070 / 1025
+#define IDX_MAXBIG 256u  // classes above IDX_REGCAP words: at most 131070 / 513
+#define IDX_REGCAP 512u  // words a wavefront sorts in registers
+#define IDX_NGROUP 16u   // groups of classes: the top four bits of H
+#define IDX_GCLASS (IDX_NCLASS / IDX_NGROUP)
+#define IDX_GCAP 16384u  // words of a group the LDS holds
+#define IDX_TILE 16384u  // positions per tile of sweep 2 (16 per thread)
+#define IDX_SUB 4096u    // sub-tile: the low 12 bits of a position travel in the word
+#define IDX_NRUN (ZES_BLK / IDX_SUB)
 
 struct IndexSmem {
   uint32_t scr[IDX_WAVES * 2 * IDX_WCAP];  // sweeps: class counters / cursors in [0, 2048 + 64); sorting: scratch; last: a slice of inv
-  uint32_t cnt[IDX_WAVES][5 * 64];         // digit counters of the radix passes, per wavefront
+  uint32_t cnt[IDX_NBIGW][5 * 64];         // digit counters of the radix passes (heavy classes), per wavefront
   uint32_t base[IDX_NCLASS + 1];           // first slot of each class
   uint32_t big[IDX_MAXBIG];
+  uint32_t runs[IDX_NGROUP][IDX_NRUN + 1];  // group g's words of sub-tile r start runs[g][r] words into the group's part of E
+  uint32_t gto[IDX_NGROUP + 1];             // sweep 2, per tile: where group g's words start in the tile buffer
+  uint32_t bcnt[IDX_NGROUP * 4], bpos[IDX_NGROUP * 4];
+  uint32_t gfill[IDX_NGROUP];
+  uint32_t ccur[IDX_GCLASS];                // group stage: cursors of the group's classes
+  uint32_t catcnt[5], catpos[5];
+  uint8_t order[IDX_GCLASS];
   uint32_t wsum[IDX_WAVES];
   uint32_t pcur[IDX_NSLICE];
-  uint32_t next, nbig, nextbig, maxc;
+  uint32_t next, nbig, nextbig, maxc, nheavy;
 #ifdef IDX_CHECK
   uint32_t done[IDX_NCLASS / 32];
   uint32_t emitted, nsum;
@@ -196,12 +210,12 @@ __device__ __forceinline__ static void idx_emit(IndexSmem& S, bool valid, uint32
 
 // a class of at most 64 * M words, sorted in registers
 template <int M>
-__device__ __forceinline__ static void idx_class_regs(IndexSmem& S, uint32_t b0, uint32_t n, const uint32_t* __restrict__ E, uint16_t* __restrict__ sd,
+__device__ __forceinline__ static void idx_class_regs(IndexSmem& S, uint32_t b0, uint32_t n, const uint32_t* E /* LDS: the class's words */, uint16_t* __restrict__ sd,
                                                       uint32_t* __restrict__ P) {
   const uint32_t lane = zes_lane();
   uint32_t x[M];
 #pragma unroll
-  for (int j = 0; j < M; j++) x[j] = (uint32_t)j * 64u + lane < n ? idx_ld_sc1(E + b0 + (uint32_t)j * 64u + lane) : 0xFFFFFFFFu;
+  for (int j = 0; j < M; j++) x[j] = (uint32_t)j * 64u + lane < n ? E[(uint32_t)j * 64u + lane] : 0xFFFFFFFFu;
   idx_bitonic<M>(x);
 #pragma unroll
   for (int j = 0; j < M; j++) {
@@ -216,24 +230,6 @@ __device__ __forceinline__ static void idx_class_regs(IndexSmem& S, uint32_t b0,
 __device__ static void idx_class_(IndexSmem& S, uint32_t b0, uint32_t n, uint32_t* scratch, uint32_t cap, uint32_t* cntw,
                                  const uint32_t* __restrict__ E, uint16_t* __restrict__ sd, uint32_t* __restrict__ P) {
   const uint32_t lane = zes_lane();
-#ifndef IDX_NO_BITONIC
-  if (n <= 64u) {
-    idx_class_regs<1>(S, b0, n, E, sd, P);
-    return;
-  }
-  if (n <= 128u) {
-    idx_class_regs<2>(S, b0, n, E, sd, P);
-    return;
-  }
-  if (n <= 256u) {
-    idx_class_regs<4>(S, b0, n, E, sd, P);
-    return;
-  }
-  if (n <= 512u) {
-    idx_class_regs<8>(S, b0, n, E, sd, P);
-    return;
-  }
-#endif
   uint32_t* src = scratch;
   uint32_t* dst = scratch + cap;
 #pragma unroll
@@ -347,7 +343,7 @@ __global__ __launch_bounds__(IDX_THREADS) void k_lz_index(const uint8_t* __restr
   __shared__ __align__(16) IndexSmem S;
   const uint32_t g = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 #ifdef IDX_PROF
-  unsigned long long tp[8];
+  unsigned long long tp[8], tpart = 0, tsort = 0, twait = 0;
   int np = 0;
 #define ISTAMP() tp[np++] = clock64()
 #else
@@ -368,6 +364,7 @@ __global__ __launch_bounds__(IDX_THREADS) void k_lz_index(const uint8_t* __restr
 
   for (uint32_t i = tid; i < IDX_NCLASS + 64u; i += IDX_THREADS) cur[i] = 0;
   if (tid < IDX_NSLICE) S.pcur[tid] = 0;
+  if (tid < 5u) S.catcnt[tid] = S.catpos[tid] = 0;
 #ifdef IDX_CHECK
   if (tid < IDX_NCLASS / 32) S.done[tid] = 0;
   if (tid == 0) S.emitted = S.nsum = 0;
@@ -377,6 +374,7 @@ __global__ __launch_bounds__(IDX_THREADS) void k_lz_index(const uint8_t* __restr
     S.nbig = 0;
     S.nextbig = 0;
     S.maxc = 0;
+    S.nheavy = 0;
   }
   __syncthreads();
   ISTAMP();
@@ -408,6 +406,7 @@ __global__ __launch_bounds__(IDX_THREADS) void k_lz_index(const uint8_t* __restr
     }
     if (lane == 63) S.wsum[wave] = incl;
     atomicMax(&S.maxc, max(a, b));
+    if (a > IDX_REGCAP || b > IDX_REGCAP) atomicAdd(&S.nheavy, (a > IDX_REGCAP ? a : 0u) + (b > IDX_REGCAP ? b : 0u));
     __syncthreads();
     uint32_t woff = 0;
 #pragma unroll
@@ -420,82 +419,195 @@ __global__ __launch_bounds__(IDX_THREADS) void k_lz_index(const uint8_t* __restr
     cur[2u * tid + 1u] = ex + a;
   }
   __syncthreads();
-  if (S.maxc > IDX_BIGCAP) {  // (uniform) a class no wavefront can hold: the block goes back to k_lz_sort
-    if (tid == 0) A[ZES_BLK - 1] = cnt | ZES_SORT_REDO;
-    return;
+  {
+    uint32_t gmax = 0;  // the largest group (uniform after the loop)
+#pragma unroll
+    for (uint32_t q = 0; q < IDX_NGROUP; q++) gmax = max(gmax, S.base[(q + 1u) * IDX_GCLASS] - S.base[q * IDX_GCLASS]);
+    // (uniform) a class or a group the LDS cannot hold — or a block with much of its weight in a few heavy keys (text: " th",
+    // "he " ... a fifth of the positions sit in classes that need the radix passes, and k_lz_sort is the faster one there):
+    // the block goes back to k_lz_sort
+    if (S.maxc > IDX_BIGCAP || gmax > IDX_GCAP || S.nheavy * 16u > cnt) {
+      if (tid == 0) A[ZES_BLK - 1] = cnt | ZES_SORT_REDO;
+      return;
+    }
   }
+  __syncthreads();  // (cur[] — the tile buffer from here on — has been read by everybody)
+  if (tid < IDX_NGROUP * 4u) S.bcnt[tid] = 0;
+  if (tid < IDX_NGROUP) S.gfill[tid] = 0;
+  for (uint32_t i = tid; i < IDX_NGROUP * (IDX_NRUN + 1u); i += IDX_THREADS) (&S.runs[0][0])[i] = 0;
+  __syncthreads();
   ISTAMP();
-  // ---- sweep 2: every word to its class's run of E ----
+  // ---- sweep 2: tile by tile, every position's word (class-in-group 7 | rest of H 13 | low 12 bits of the position) goes
+  // to the tile buffer, binned by group and sub-tile, and each group's bin leaves for the group's part of E as one run ----
+  uint32_t* tbuf = S.scr;
+  const uint32_t st = tid >> 8;  // a thread's 16 positions lie in one sub-tile of 4096: the tile's sub-tile (tid * 16) >> 12
 #pragma unroll 1
-  for (uint32_t ch = 0; ch < ZES_BLK / (16u * IDX_THREADS); ch++) {
+  for (uint32_t ch = 0; ch < ZES_BLK / IDX_TILE; ch++) {
     const uint32_t o = (ch * IDX_THREADS + tid) * 16u;
-    if (o >= cnt) continue;
+    if (ch * IDX_TILE >= cnt) break;  // uniform
     uint32_t w[5];
-    idx_ld20(src, aligned, o, T, w);
-    uint32_t at[16], el[16];
+    if (o < cnt) {
+      idx_ld20(src, aligned, o, T, w);
+    } else {
+#pragma unroll
+      for (uint32_t k = 0; k < 5; k++) w[k] = 0;
+    }
+    uint32_t el[16], bn[16];
 #pragma unroll
     for (uint32_t k = 0; k < 16; k++) {
       const uint32_t raw = __builtin_amdgcn_alignbyte(w[(k >> 2) + 1], w[k >> 2], k & 3u);
       const uint32_t h = __umul24(raw, IDX_MUL);
-      const uint32_t c = (h >> IDX_RSHIFT) & (IDX_NCLASS - 1u);
-      el[k] = (h << 17) | (o + k);  // bits 17-29: the rest of H; 30, 31: the class's low bits (the same in the whole class)
-      at[k] = atomicAdd(&cur[o + k < cnt ? c : IDX_NCLASS + lane], 1u);
+      el[k] = (h << 12) | ((o + k) & (IDX_SUB - 1u));  // (the group's four bits fall off the top)
+      bn[k] = o + k < cnt ? ((h >> 20) & (IDX_NGROUP - 1u)) * 4u + st : 0xFFFFFFFFu;
+      if (bn[k] != 0xFFFFFFFFu) atomicAdd(&S.bcnt[bn[k]], 1u);
     }
+    __syncthreads();
+    if (wave == 0) {  // bins in order (group, sub-tile): offsets in the tile buffer; the groups' runs in E grow by what the tile brings
+      const uint32_t c = S.bcnt[lane];
+      uint32_t incl = c;
 #pragma unroll
-    for (uint32_t k = 0; k < 16; k++) E[o + k < cnt ? at[k] : ZES_BLK - 2u] = el[k];  // (slot ZES_BLK-2 is never a class's: cnt <= ZES_BLK-2)
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)incl, d);
+        if ((int)lane >= d) incl += t;
+      }
+      const uint32_t ex = incl - c;
+      S.bpos[lane] = ex;
+      S.bcnt[lane] = 0;  // for the next tile
+      const uint32_t q = lane >> 2;
+      const uint32_t gstart = (uint32_t)__shfl((int)ex, (int)(lane & ~3u));  // where the group's four bins start in the tile buffer
+      if ((lane & 3u) == 0u) S.gto[q] = ex;
+      if (lane == 63) S.gto[IDX_NGROUP] = incl;
+      // run (ch * 4 + sub-tile) of group q starts at gfill[q] + (ex - gstart) words into the group's part of E
+      const uint32_t fill = S.gfill[q];
+      S.runs[q][ch * 4u + (lane & 3u)] = fill + (ex - gstart);
+      const uint32_t gtot = (uint32_t)__shfl((int)incl, (int)(lane | 3u)) - gstart;
+      if ((lane & 3u) == 3u) {
+        S.gfill[q] = fill + gtot;
+        S.runs[q][ch * 4u + 4u] = fill + gtot;  // (the end of the tile's last run; the next tile's first overwrites it with the same value)
+      }
+    }
+    __syncthreads();
+    {
+      uint32_t at[16];
+#pragma unroll
+      for (uint32_t k = 0; k < 16; k++) at[k] = bn[k] != 0xFFFFFFFFu ? atomicAdd(&S.bpos[bn[k]], 1u) : 0u;
+#pragma unroll
+      for (uint32_t k = 0; k < 16; k++)
+        if (bn[k] != 0xFFFFFFFFu) tbuf[at[k]] = el[k];
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (uint32_t q = 0; q < IDX_NGROUP; q++) {  // the group's run of this tile: contiguous in the buffer and in E
+      const uint32_t a0 = S.gto[q], a1 = S.gto[q + 1u];
+      uint32_t* dst = E + S.base[q * IDX_GCLASS] + S.runs[q][ch * 4u];
+      for (uint32_t i = a0 + tid; i < a1; i += IDX_THREADS) dst[i - a0] = tbuf[i];
+    }
+    __syncthreads();
   }
-  // the words are in memory (L2) before anybody sorts them: every storing wave waits for its own stores — a
+  // tiles the block does not reach: their runs are empty
+  {
+    const uint32_t ntile = (cnt + IDX_TILE - 1u) / IDX_TILE;
+    for (uint32_t i = tid; i < IDX_NGROUP * (IDX_NRUN + 1u); i += IDX_THREADS) {
+      const uint32_t q = i / (IDX_NRUN + 1u), r = i % (IDX_NRUN + 1u);
+      if (r > ntile * 4u) S.runs[q][r] = S.gfill[q];
+    }
+  }
+  // the words are in memory (L2) before anybody reads them back: every storing wave waits for its own stores — a
   // workgroup-scope fence does not (it compiles to lgkmcnt only) — and the readers load past the L1
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifdef IDX_FENCE
-  __threadfence();
-#endif
   __syncthreads();
-#ifdef IDX_CHECK
-  for (uint32_t c = tid; c < IDX_NCLASS; c += IDX_THREADS)
-    if (cur[c] != S.base[c + 1u]) printf("idx: class %u base %u next %u cursor ended at %u\n", c, S.base[c], S.base[c + 1u], cur[c]);
-  if (tid == 0) printf("idx: total %u cnt %u\n", S.base[IDX_NCLASS], cnt);
-  __syncthreads();
-#endif
   ISTAMP();
-  // ---- classes, one wavefront each ----
-  // classes dealt to the wavefronts in turn: the hash spreads the keys, and the heavy classes wait for the second round.
-  // (A dispenser — "lane 0 takes the next class from an LDS counter, readfirstlane tells the others" — does not survive
-  // the compiler in this loop: it threads the loop's exit test into lane 0's branch, lane 0 leaves alone, and the other
-  // lanes run another turn on their own zero-initialised copy: class 0 indexed a second time by most of a wavefront.)
-  for (uint32_t c = wave; c < IDX_NCLASS; c += IDX_WAVES) {
-    const uint32_t b0 = S.base[c], n = S.base[c + 1u] - b0;
-    if (n == 0u) continue;
-    if (n > IDX_WCAP) {
-      if (lane == 0) S.big[atomicAdd(&S.nbig, 1u)] = c;
-      continue;
+  // ---- group by group: the group's words come back into LDS, each to its class's run (cursors from the class sizes of
+  // sweep 1), and every class is sorted by one wavefront, in registers ----
+  uint32_t* gbuf = S.scr + IDX_GCAP;
+#pragma unroll 1
+  for (uint32_t q = 0; q < IDX_NGROUP; q++) {
+    const uint32_t gb = S.base[q * IDX_GCLASS], gn = S.base[(q + 1u) * IDX_GCLASS] - gb;
+    if (gn == 0u) continue;  // uniform
+    // The group's classes in the order the wavefronts take them, largest first: a class costs by the register form that
+    // sorts it (64, 128, 256 or 512 words: a factor of ten), so the classes are dealt by size category — every wavefront
+    // gets its share of each — instead of by number.  (Handing them out one at a time by an LDS counter was tried: the
+    // 64-lane atomic that keeps the loop's exit test uniform cost more than the imbalance.)
+    uint32_t mycat = 5u;
+    if (tid < IDX_GCLASS) {
+      const uint32_t b0 = S.base[q * IDX_GCLASS + tid], n = S.base[q * IDX_GCLASS + tid + 1u] - b0;
+      S.ccur[tid] = b0 - gb;
+      mycat = n == 0u ? 4u : (n > 256u ? 0u : (n > 128u ? 1u : (n > 64u ? 2u : 3u)));
+      atomicAdd(&S.catcnt[mycat], 1u);
     }
-#ifdef IDX_CHECK
-    if (lane == 0) {
-      const uint32_t was = atomicOr(&S.done[c >> 5], 1u << (c & 31u));
-      if (was & (1u << (c & 31u))) printf("idx: class %u twice (phase A)\n", c);
+    __syncthreads();
+    if (tid < IDX_GCLASS && mycat < 4u) {
+      uint32_t at = atomicAdd(&S.catpos[mycat], 1u);
+      for (uint32_t k = 0; k < mycat; k++) at += S.catcnt[k];
+      S.order[at] = (uint8_t)tid;
     }
+#ifdef IDX_PROF
+    const unsigned long long tg0 = clock64();
 #endif
-    idx_class(S, b0, n, S.scr + wave * (2u * IDX_WCAP), IDX_WCAP, S.cnt[wave], E, sd, A);
+    for (uint32_t i0 = 0; i0 < gn; i0 += 8u * IDX_THREADS) {  // eight words per thread in flight
+      uint32_t e[8];
+#pragma unroll
+      for (uint32_t k = 0; k < 8; k++) {
+        const uint32_t i = i0 + k * IDX_THREADS + tid;
+        e[k] = idx_ld_sc1(E + gb + min(i, gn - 1u));
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < 8; k++) {
+        const uint32_t i = i0 + k * IDX_THREADS + tid;
+        if (i < gn) {
+          // which sub-tile's run holds word i: the largest r with runs[q][r] <= i (binary search over the 33 bounds)
+          uint32_t r = 0;
+#pragma unroll
+          for (uint32_t sh = IDX_NRUN / 2u; sh >= 1u; sh >>= 1) r += S.runs[q][r + sh] <= i ? sh : 0u;
+          const uint32_t pos = r * IDX_SUB + (e[k] & (IDX_SUB - 1u));
+          const uint32_t at = atomicAdd(&S.ccur[e[k] >> 25], 1u);
+          gbuf[at] = ((e[k] >> 12) << 17) | pos;  // bits 17-29: the rest of H; 30, 31: the class's low bits (the same in the whole class)
+        }
+      }
+    }
+    __syncthreads();
+#ifdef IDX_PROF
+    const unsigned long long tg1 = clock64();
+    tpart += tg1 - tg0;
+#endif
+    const uint32_t nact = IDX_GCLASS - S.catcnt[4];
+    for (uint32_t k = wave; k < nact; k += IDX_WAVES) {
+      const uint32_t j = S.order[k];
+      const uint32_t c = q * IDX_GCLASS + j;
+      const uint32_t b0 = S.base[c], n = S.base[c + 1u] - b0;
+      if (n == 0u) continue;
+      const uint32_t* cw = gbuf + (b0 - gb);
+      if (n <= 64u) {
+        idx_class_regs<1>(S, b0, n, cw, sd, A);
+      } else if (n <= 128u) {
+        idx_class_regs<2>(S, b0, n, cw, sd, A);
+      } else if (n <= 256u) {
+        idx_class_regs<4>(S, b0, n, cw, sd, A);
+      } else if (n <= IDX_REGCAP) {
+        idx_class_regs<8>(S, b0, n, cw, sd, A);
+      } else {  // a heavy class: its words go back to E, where the class's run is (the group's words have all been read), for the last round
+        for (uint32_t i = lane; i < n; i += 64u) E[b0 + i] = cw[i];
+        if (lane == 0) S.big[atomicAdd(&S.nbig, 1u)] = c;
+      }
+    }
+#ifdef IDX_PROF
+    const unsigned long long tg2 = clock64();
+    tsort += tg2 - tg1;
+#endif
+    __syncthreads();
+#ifdef IDX_PROF
+    twait += clock64() - tg2;
+#endif
+    if (tid < 5u) S.catcnt[tid] = S.catpos[tid] = 0;  // (read again only behind the next group's first barrier)
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the heavy classes' words)
   __syncthreads();
-#ifdef IDX_CHECK
-  if (tid == 0) printf("idx: after phase A emitted %u, big classes %u\n", S.emitted, S.nbig);
-#endif
   ISTAMP();
-  if (wave < IDX_NBIGW) {  // the heavy classes: four wavefronts, a quarter of the scratch each
+  if (wave < IDX_NBIGW) {  // the heavy classes: four wavefronts, a quarter of the LDS each, radix passes
     const uint32_t nbig = S.nbig;
-    for (;;) {
-      const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)atomicAdd(&S.nextbig, lane == 0 ? 1u : 0u));
-      if (k >= nbig) break;
+    for (uint32_t k = wave; k < nbig; k += IDX_NBIGW) {
       const uint32_t c = S.big[k];
       const uint32_t b0 = S.base[c], n = S.base[c + 1u] - b0;
-#ifdef IDX_CHECK
-      if (lane == 0) {
-        const uint32_t was = atomicOr(&S.done[c >> 5], 1u << (c & 31u));
-        printf("idx: phase B wave %u takes list entry %u class %u n %u%s\n", wave, k, c, n, (was & (1u << (c & 31u))) ? " TWICE" : "");
-      }
-#endif
       idx_class(S, b0, n, S.scr + wave * (2u * IDX_BIGCAP), IDX_BIGCAP, S.cnt[wave], E, sd, A);
     }
   }
@@ -518,9 +630,13 @@ __global__ __launch_bounds__(IDX_THREADS) void k_lz_index(const uint8_t* __restr
     if (tid == 0) printf("idx: slice %u have %u cursor %u\n", s, have, S.pcur[s]);
     __syncthreads();
 #endif
-    for (uint32_t i = tid; i < have; i += IDX_THREADS) {
-      const uint32_t e = idx_ld_sc1(A + lo + i);
-      stage[e & (IDX_SLICE - 1u)] = (e >> 31) ? ((e >> 14) & 0x1FFFFu) : ZES_INV_NONE;
+    {
+      uint32_t e[IDX_SLICE / IDX_THREADS];  // the slice's bucket: all loads in flight at once
+#pragma unroll
+      for (uint32_t k = 0; k < IDX_SLICE / IDX_THREADS; k++) e[k] = idx_ld_sc1(A + lo + min(k * IDX_THREADS + tid, have ? have - 1u : 0u));
+#pragma unroll
+      for (uint32_t k = 0; k < IDX_SLICE / IDX_THREADS; k++)
+        if (k * IDX_THREADS + tid < have) stage[e[k] & (IDX_SLICE - 1u)] = (e[k] >> 31) ? ((e[k] >> 14) & 0x1FFFFu) : ZES_INV_NONE;
     }
     __syncthreads();
 #ifdef IDX_CHECK
@@ -540,6 +656,7 @@ __global__ __launch_bounds__(IDX_THREADS) void k_lz_index(const uint8_t* __restr
   if (tid == 0 && (g == 7 || g == 300))
     printf("idx prof block %u: count %llu scan %llu scatter %llu classes %llu heavy %llu inv %llu | heavy classes %u\n", g, tp[1] - tp[0], tp[2] - tp[1],
            tp[3] - tp[2], tp[4] - tp[3], tp[5] - tp[4], tp[6] - tp[5], S.nbig);
+  if (tid == 0 && g == 7) printf("idx prof: groups: partition %llu sorts (wave 0) %llu wait at the barrier %llu\n", tpart, tsort, twait);
 #endif
   if (tid == 0) A[ZES_BLK - 1] = cnt | ZES_SORT_LAZY;
 }
