@@ -1102,7 +1102,7 @@ __device__ __forceinline__ static uint32_t lazy_chains(LazySmem& S, const uint32
         const uint32_t qs = qo & 3u, ps2 = po & 3u;
         uint32_t qlo = S.in[mswz(qi)], plo = S.in[mswz(pi)];
         bool run = v;
-        while (__ballot(run && L < maxl)) {  // 8 bytes per step
+        auto step = [&]() {  // 8 bytes
           const uint32_t qm = S.in[mswz(qi + 1)], pm = S.in[mswz(pi + 1)];
           const uint32_t qhi = S.in[mswz(qi + 2)], phi = S.in[mswz(pi + 2)];
           const uint32_t x1 = __builtin_amdgcn_alignbyte(qm, qlo, qs) ^ __builtin_amdgcn_alignbyte(pm, plo, ps2);
@@ -1119,6 +1119,28 @@ __device__ __forceinline__ static uint32_t lazy_chains(LazySmem& S, const uint32
 #ifdef LAZY_PROF
           nlcp++;
 #endif
+        };
+        if (__ballot(run && L < maxl)) step();
+        if (__ballot(run && L < maxl)) {
+          step();
+          // (text hardly ever gets here: two steps settle nearly all of its compares)
+          // The nearest candidate of a position's first round still going after sixteen bytes, with the full compare length ahead
+          // of it (periodic data: every candidate matches to the end, 32 steps of 8 bytes for sixteen of them): it is tested
+          // WHOLE by the row, sixteen bytes a lane.  If it matches at full length the reference takes it and stops looking
+          // (src/lz77.ts:86-91: the first candidate examined, and no longer one exists) — whatever the others are.
+          const bool wide = ((uint32_t)(__ballot(run && L < maxl && sub == 0u && base == 0u && maxl == ZES_MAXMATCH) >> g0) & 1u) != 0u;  // (the same in a row's lanes)
+          if (__ballot(wide)) {
+            const uint32_t q0 = (uint32_t)__shfl((int)qk, (int)g0);
+            const uint32_t qa = (wide ? q0 : 0u) + 16u * sub, pa = (wide ? p : 0u) + 16u * sub;
+            uint32_t x = 0;
+#pragma unroll
+            for (uint32_t t = 0; t < 4; t++) x |= m_ld32u(S.in, qa + 4u * t) ^ m_ld32u(S.in, pa + 4u * t);
+            if (sub == 0u) x |= (m_ld32u(S.in, qa + 256u) ^ m_ld32u(S.in, pa + 256u)) & 0xffffu;  // bytes 256, 257
+            const bool full = wide && ((uint32_t)(__ballot(wide && x != 0u) >> g0) & 0xffffu) == 0u;
+            L = (full && sub == 0u) ? ZES_MAXMATCH : L;
+            run = run && !full;
+          }
+          while (__ballot(run && L < maxl)) step();
         }
       }
       LLAP(4);
