@@ -42,6 +42,8 @@ struct Ctx {
   hipStream_t stream = nullptr;
   hipStream_t cs_in = nullptr, cs_out = nullptr;  // copy streams of the pipelined host calls (H2D / D2H beside the kernels)
   hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_k = nullptr;
+  hipStream_t s_adler = nullptr;                     // the Adler-32 pass of a deflate call runs beside the LZ77 kernels
+  hipEvent_t ev_a0 = nullptr, ev_a1 = nullptr;
   // deflate scratch
   DevBuf bufs, blks, idx_a, idx_b, inv, sdelta, tmask, mlist, hists, codes, hdrs, adler, res;
   // inflate scratch
@@ -138,6 +140,9 @@ int init_locked(int device) {
   HIPCHK(hipStreamCreateWithFlags(&g.cs_out, hipStreamNonBlocking));
   for (int k = 0; k < 2; k++) HIPCHK(hipEventCreateWithFlags(&g.ev_up[k], hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&g.ev_k, hipEventDisableTiming));
+  HIPCHK(hipStreamCreateWithFlags(&g.s_adler, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&g.ev_a0, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&g.ev_a1, hipEventDisableTiming));
   g.pinned_cap = 1 << 20;
   HIPCHK(hipHostMalloc(&g.pinned, g.pinned_cap, hipHostMallocDefault));
   {
@@ -459,16 +464,17 @@ hipEvent_t take_event() {
 struct Timed {
   hipEvent_t a = nullptr, b = nullptr;
   const char* name;
-  explicit Timed(const char* n) : name(n) {
+  hipStream_t st;
+  explicit Timed(const char* n, hipStream_t stream = nullptr) : name(n), st(stream ? stream : g.stream) {
     if (g.profiling) {
       a = take_event();
       b = take_event();
-      (void)hipEventRecord(a, g.stream);
+      (void)hipEventRecord(a, st);
     }
   }
   ~Timed() {
     if (g.profiling) {
-      (void)hipEventRecord(b, g.stream);
+      (void)hipEventRecord(b, st);
       g.pending.push_back({name, {a, b}});
     }
     // ZES_TRACE_KERNELS: wait for the launch and name it on stderr (the kernel after the last name printed is the one
@@ -582,15 +588,21 @@ int deflate_batch_core(const uint8_t* d_in, const uint64_t* in_off, const uint64
     const uint32_t nthr = std::max(nblk, 2u * nbuf);
     hipLaunchKernelGGL(k_make_blks, dim3((nthr + 255) / 256), dim3(256), 0, g.stream, hb[0], nbuf, dbufs, dblks, nblk, adler);
   }
+  // Adler-32 (src/adler32.ts:1-10) needs the input and the cleared accumulators, and nobody but k_layout needs its
+  // result: it runs on a stream of its own beside the LZ77 kernels — an HBM-bound pass of 64-byte-LDS workgroups next to
+  // kernels that hold a block in LDS and wait on it (0.04 ms per 64 MiB off the critical path).
   {
-    Timed t("k_adler");
+    HIPCHK(hipEventRecord(g.ev_a0, g.stream));
+    HIPCHK(hipStreamWaitEvent(g.s_adler, g.ev_a0, 0));
+    Timed t("k_adler", g.s_adler);
     if (nbuf == 1) {  // one buffer: 64 KiB chunks, twice the workgroups
       const uint32_t nch = (uint32_t)((hb[0].n + ADLER_CHUNK - 1) / ADLER_CHUNK);
-      hipLaunchKernelGGL(k_adler, dim3(nch), dim3(ADLER_THREADS), 0, g.stream, d_in, hb[0].in_off, hb[0].n, adler);
+      hipLaunchKernelGGL(k_adler, dim3(nch), dim3(ADLER_THREADS), 0, g.s_adler, d_in, hb[0].in_off, hb[0].n, adler);
     } else {
-      hipLaunchKernelGGL(k_adler_blocks, dim3(nblk), dim3(ADLER_THREADS), 0, g.stream, d_in, dbufs, dblks, adler);
+      hipLaunchKernelGGL(k_adler_blocks, dim3(nblk), dim3(ADLER_THREADS), 0, g.s_adler, d_in, dbufs, dblks, adler);
     }
   }
+  HIPCHK(hipEventRecord(g.ev_a1, g.s_adler));
   const bool sort_dbg = getenv("ZES_DEBUG_PHASES") != nullptr;
   if (sort_dbg) {
     int rc2 = ensure(g.dbg, (size_t)nblk * 64);
@@ -724,6 +736,7 @@ int deflate_batch_core(const uint8_t* d_in, const uint64_t* in_off, const uint64
               acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[5] / n, acc[6] / n, acc[7] / n);
   }
   {
+    HIPCHK(hipStreamWaitEvent(g.stream, g.ev_a1, 0));  // the checksums
     Timed t("k_layout");
     hipLaunchKernelGGL(k_layout, dim3(nbuf), dim3(256), 0, g.stream, d_out, dbufs, dblks, adler, (ZesRes*)g.res.p);
   }
@@ -1886,6 +1899,10 @@ static int shutdown_one(void) {
   (void)hipStreamDestroy(g.cs_out);
   for (int k = 0; k < 2; k++) (void)hipEventDestroy(g.ev_up[k]);
   (void)hipEventDestroy(g.ev_k);
+  (void)hipStreamDestroy(g.s_adler);
+  (void)hipEventDestroy(g.ev_a0);
+  (void)hipEventDestroy(g.ev_a1);
+  g.s_adler = nullptr;
   g.stream = g.cs_in = g.cs_out = nullptr;
   g.ready = false;
   return ZES_OK;
