@@ -45,7 +45,7 @@ struct Ctx {
   hipStream_t s_adler = nullptr;                     // the Adler-32 pass of a deflate call runs beside the LZ77 kernels
   hipEvent_t ev_a0 = nullptr, ev_a1 = nullptr;
   // deflate scratch
-  DevBuf bufs, blks, idx_a, idx_b, inv, sdelta, tmask, mlist, hists, codes, hdrs, adler, res;
+  DevBuf bufs, blks, idx_a, idx_b, inv, sdelta, tmask, mlist, hists, codes, hdrs, adler, res, order;
   // inflate scratch
   DevBuf surv, vlong, segfail, symoff, cand, cand_sorted, counters, cres, map, resume, dbg, ibufs, ibufs2, mvlist, scratch, sres, maps, seglist, segprefix, wins, sym16, segorder, segjobs, pw16, gwins;
   // staging for the host-pointer API
@@ -654,9 +654,17 @@ int deflate_batch_core(const uint8_t* d_in, const uint64_t* in_off, const uint64
     zes_lazy_set_dbg((unsigned long long*)g.dbg.p);
   }
   {
+    // a batch of unlike buffers: the blocks heaviest first (k_lz_order), so that the launch does not end on a tail of text blocks
+    const uint32_t* order = nullptr;
+    if (nbuf > 1 && nblk > 256) {
+      if ((rc = ensure(g.order, (size_t)nblk * 4))) return rc;
+      Timed t("k_lz_order");
+      hipLaunchKernelGGL(k_lz_order, dim3(1), dim3(1024), 0, g.stream, (const uint32_t*)idx_a, nblk, (uint32_t*)g.order.p);
+      order = (const uint32_t*)g.order.p;
+    }
     Timed t("k_lz_match_lazy");  // the blocks k_lz_sort flagged (most positions kept); the others return at once
     hipLaunchKernelGGL(k_lz_match_lazy, dim3(nblk), dim3(MATCH_THREADS), 0, g.stream, d_in, dbufs, dblks, idx_a,
-                       (const uint32_t*)g.inv.p, (const uint16_t*)g.sdelta.p, idx_b, (uint32_t*)g.tmask.p, (uint32_t*)g.mlist.p);
+                       (const uint32_t*)g.inv.p, (const uint16_t*)g.sdelta.p, idx_b, (uint32_t*)g.tmask.p, (uint32_t*)g.mlist.p, order);
   }
   if (sort_dbg) {  // average shader-clock cycles per phase of k_lz_match_lazy
     HIPCHK(hipStreamSynchronize(g.stream));
@@ -1878,7 +1886,7 @@ static int shutdown_one(void) {
   if (!g.ready) return ZES_OK;
   (void)hipSetDevice(g.device);
   (void)hipStreamSynchronize(g.stream);
-  DevBuf* all[] = {&g.bufs, &g.blks, &g.idx_a, &g.idx_b, &g.inv, &g.sdelta, &g.tmask, &g.mlist, &g.hists, &g.codes, &g.hdrs, &g.adler, &g.res, &g.surv, &g.vlong, &g.segfail, &g.symoff, &g.cand,
+  DevBuf* all[] = {&g.bufs, &g.blks, &g.idx_a, &g.idx_b, &g.inv, &g.sdelta, &g.tmask, &g.mlist, &g.hists, &g.codes, &g.hdrs, &g.adler, &g.res, &g.order, &g.surv, &g.vlong, &g.segfail, &g.symoff, &g.cand,
                    &g.cand_sorted, &g.counters, &g.cres, &g.map, &g.resume, &g.dbg, &g.ibufs, &g.ibufs2, &g.mvlist, &g.scratch, &g.st_in, &g.st_out,
                    &g.sres, &g.maps, &g.seglist, &g.segprefix, &g.wins, &g.sym16, &g.segorder, &g.segjobs, &g.kraft, &g.pw16, &g.gwins};
   for (DevBuf* b : all) {
@@ -2777,7 +2785,7 @@ int zes_stage_lz77_dev(const uint8_t* d_in, uint64_t n, uint64_t start, uint32_t
                      (const ZesBlk*)g.blks.p, (const uint32_t*)g.idx_a.p, (uint32_t*)g.idx_b.p, (uint32_t*)g.mlist.p);
   hipLaunchKernelGGL(k_lz_match_lazy, dim3(1), dim3(MATCH_THREADS), 0, g.stream, d_in, (const ZesBuf*)g.bufs.p,
                      (const ZesBlk*)g.blks.p, (const uint32_t*)g.idx_a.p, (const uint32_t*)g.inv.p, (const uint16_t*)g.sdelta.p, (uint32_t*)g.idx_b.p,
-                     (uint32_t*)g.tmask.p, (uint32_t*)g.mlist.p);
+                     (uint32_t*)g.tmask.p, (uint32_t*)g.mlist.p, (const uint32_t*)nullptr);
   hipLaunchKernelGGL(k_lz_parse_small, dim3(1), dim3(PARSE_THREADS), 0, g.stream, d_in, (const ZesBuf*)g.bufs.p, (ZesBlk*)g.blks.p,
                      (const uint32_t*)g.idx_b.p, (uint32_t*)g.idx_a.p, (uint32_t*)g.hists.p, (const uint32_t*)g.tmask.p, (const uint32_t*)g.mlist.p);
   hipLaunchKernelGGL(k_lz_parse, dim3(1), dim3(PARSE_THREADS), 0, g.stream, d_in, (const ZesBuf*)g.bufs.p, (ZesBlk*)g.blks.p,

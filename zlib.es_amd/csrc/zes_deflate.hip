@@ -1233,9 +1233,10 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match_lazy(const uint8_t* 
                                                                  const ZesBlk* __restrict__ blks, const uint32_t* __restrict__ idx_a,
                                                                  const uint32_t* __restrict__ inv_all, const uint16_t* __restrict__ sd_all,
                                                                  uint32_t* __restrict__ match_out, uint32_t* __restrict__ tmask_all,
-                                                                 uint32_t* __restrict__ mlist_all) {
+                                                                 uint32_t* __restrict__ mlist_all, const uint32_t* __restrict__ order) {
   __shared__ __align__(16) LazySmem S;
-  const uint32_t g = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  // (a batch of unlike buffers: the blocks in the order k_lz_order dealt them, heaviest first)
+  const uint32_t g = order ? order[blockIdx.x] : blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   if (!(idx_a[(uint64_t)g * ZES_BLK + ZES_BLK - 1] & ZES_SORT_LAZY)) return;  // this block belongs to k_lz_match
   if (threadIdx.x == 0) mlist_all[(uint64_t)g * ZES_MLIST_WORDS] = 0xFFFFFFFFu;  // "no list: a block of this kernel" (k_lz_parse)
   const uint32_t* inv = inv_all + (uint64_t)g * ZES_BLK;

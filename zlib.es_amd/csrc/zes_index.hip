@@ -658,5 +658,30 @@ __global__ __launch_bounds__(IDX_THREADS) void k_lz_index(const uint8_t* __restr
            tp[3] - tp[2], tp[4] - tp[3], tp[5] - tp[4], tp[6] - tp[5], S.nbig);
   if (tid == 0 && g == 7) printf("idx prof: groups: partition %llu sorts (wave 0) %llu wait at the barrier %llu\n", tpart, tsort, twait);
 #endif
-  if (tid == 0) A[ZES_BLK - 1] = cnt | ZES_SORT_LAZY;
+  if (tid == 0) A[ZES_BLK - 1] = cnt | ZES_SORT_LAZY | ZES_SORT_INDEX;  // (INDEX stays: "structured data, no heavy keys" — k_lz_order deals such blocks last)
+}
+
+// ------------------------------------------------------------------------------------------
+// k_lz_order: the order in which k_lz_match_lazy's workgroups take the blocks of a batch of unlike buffers.  A text
+// block keeps a compute unit four times as long as a periodic one, and workgroups start in index order: with the
+// buffers' own order a batch ends on a tail of text blocks (BASELINE configs[3]: 3.06 ms where the work is 2.1 ms).
+// Heaviest first: the blocks k_lz_sort indexed itself (heavy keys: text), then the ones k_lz_index took, then the
+// blocks the kernel leaves at once.  One workgroup; the order inside a category does not matter.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_lz_order(const uint32_t* __restrict__ idx_a, uint32_t nblk, uint32_t* __restrict__ order) {
+  __shared__ uint32_t cnt[3], pos[3];
+  const uint32_t tid = threadIdx.x;
+  if (tid < 3) cnt[tid] = pos[tid] = 0;
+  __syncthreads();
+  auto cat = [&](uint32_t b) {
+    const uint32_t f = idx_a[(uint64_t)b * ZES_BLK + ZES_BLK - 1];
+    return !(f & ZES_SORT_LAZY) ? 2u : ((f & ZES_SORT_INDEX) ? 1u : 0u);
+  };
+  for (uint32_t b = tid; b < nblk; b += 1024u) atomicAdd(&cnt[cat(b)], 1u);
+  __syncthreads();
+  const uint32_t base1 = cnt[0], base2 = cnt[0] + cnt[1];
+  for (uint32_t b = tid; b < nblk; b += 1024u) {
+    const uint32_t c = cat(b);
+    order[(c == 0u ? 0u : (c == 1u ? base1 : base2)) + atomicAdd(&pos[c], 1u)] = b;
+  }
 }

@@ -4,7 +4,9 @@
 
 #define SORT_THREADS 1024
 #define SORT_WAVES (SORT_THREADS / 64)
+#ifndef MATCH_THREADS
 #define MATCH_THREADS 1024
+#endif
 #define IDX_THREADS 1024
 // k_lz_sort / k_lz_index -> the match finders, per block in idx_a[g][ZES_BLK-1]: kept positions | flags
 #define ZES_SORT_LAZY 0x80000000u   // the block's index is sd[] / inv[]: it belongs to k_lz_match_lazy
@@ -132,7 +134,9 @@ __global__ void k_lz_index(const uint8_t*, const ZesBuf*, const ZesBlk*, uint32_
 #define ZES_SORT_MODE_FIRST 0u   // k_lz_sort: every block; dense ones are left to k_lz_index when bit 8 is set
 #define ZES_SORT_MODE_REDO 1u    // k_lz_sort: only the blocks k_lz_index handed back
 #define ZES_SORT_USE_INDEX 256u
-__global__ void k_lz_match_lazy(const uint8_t*, const ZesBuf*, const ZesBlk*, const uint32_t*, const uint32_t*, const uint16_t*, uint32_t*, uint32_t*, uint32_t*);
+__global__ void k_lz_match_lazy(const uint8_t*, const ZesBuf*, const ZesBlk*, const uint32_t*, const uint32_t*, const uint16_t*, uint32_t*, uint32_t*, uint32_t*,
+                                const uint32_t*);
+__global__ void k_lz_order(const uint32_t*, uint32_t, uint32_t*);
 __global__ void k_lz_match(const uint8_t*, const ZesBuf*, const ZesBlk*, const uint32_t*, uint32_t*, uint32_t*);
 __global__ void k_lz_parse(const uint8_t*, const ZesBuf*, ZesBlk*, const uint32_t*, uint32_t*, uint32_t*, const uint32_t*, const uint32_t*);
 __global__ void k_lz_parse_small(const uint8_t*, const ZesBuf*, ZesBlk*, const uint32_t*, uint32_t*, uint32_t*, const uint32_t*, const uint32_t*);
