@@ -75,7 +75,7 @@ struct Ctx {
 constexpr int ZES_MAX_DEV = 16;
 Ctx g_ctx[ZES_MAX_DEV];
 std::mutex g_mus[ZES_MAX_DEV];
-int g_nctx = 1;                  // contexts in use
+std::atomic<int> g_nctx{1};     // contexts in use (written under g_cfg_mu; read by every routed call)
 std::mutex g_cfg_mu;             // guards g_nctx and the context -> device binding
 thread_local int t_dev = 0;      // the context of the call this thread is inside
 thread_local bool t_routed = false;
@@ -165,20 +165,20 @@ int init_locked(int device) {
 // ---- which context serves a call ----
 int route_host() {  // host-pointer work: the contexts in turn
   if (t_routed) return t_dev;
-  const int n = g_nctx;
+  const int n = g_nctx.load();
   if (n <= 1) return 0;
   static std::atomic<uint32_t> rr{0};
   return (int)(rr.fetch_add(1) % (uint32_t)n);
 }
 int route_dev(const void* p) {  // device-pointer work: the context of the device that holds the memory
   if (t_routed) return t_dev;
-  if (g_nctx <= 1 || !p) return 0;
+  if (g_nctx.load() <= 1 || !p) return 0;
   hipPointerAttribute_t a;
   if (hipPointerGetAttributes(&a, p) != hipSuccess) {
     (void)hipGetLastError();
     return 0;
   }
-  for (int i = 0; i < g_nctx; i++)
+  for (int i = 0, n = g_nctx.load(); i < n; i++)
     if ((g_ctx[i].ready ? g_ctx[i].device : g_ctx[i].want) == a.device) return i;
   return 0;
 }
@@ -1856,7 +1856,7 @@ int zes_init_devices(int n) {
     if (g_ctx[i].ready ? g_ctx[i].device != dev : (g_ctx[i].want >= 0 && g_ctx[i].want != dev)) return ZES_E_ARG;  // bound elsewhere already
     g_ctx[i].want = dev;
   }
-  if (n > g_nctx) g_nctx = n;
+  if (n > g_nctx.load()) g_nctx.store(n);
   for (int i = 0; i < n; i++) {  // bring every context up now: a first batch should not pay for it
     UseDev ud(i);
     std::lock_guard<std::mutex> lk(g_mu);
@@ -1877,7 +1877,7 @@ int zes_shutdown(void) {
     g_ctx[i].want = -1;
   }
   t_dev = 0;
-  g_nctx = 1;
+  g_nctx.store(1);
   return rc;
 }
 
@@ -1917,13 +1917,13 @@ static int shutdown_one(void) {
 }
 
 int zes_host_alloc(uint64_t n, void** p) {
-  UseDev ud(route_host());
+  UseDev ud(0);  // (page-locked memory belongs to the process: always through context 0)
   if (!p) return ZES_E_ARG;
   *p = nullptr;
   std::lock_guard<std::mutex> lk(g_mu);
   int rc = init_locked(-1);
   if (rc) return rc;
-  HIPCHK(hipHostMalloc(p, n ? n : 1, hipHostMallocDefault));
+  HIPCHK(hipHostMalloc(p, n ? n : 1, hipHostMallocPortable));  // (page-locked for every device the library drives)
   return ZES_OK;
 }
 
@@ -2402,15 +2402,14 @@ int zes_partition(const uint64_t* sizes, uint32_t count, uint32_t parts, uint32_
 }
 
 int zes_device_count(void) {
-  std::lock_guard<std::mutex> lk(g_cfg_mu);
-  return g_nctx;
+  return g_nctx.load();
 }
 
 }  // extern "C"
 // runs fn(ids) for every non-empty share, each on its own thread bound to its context; the first non-zero return wins
 template <class F>
 static int over_devices(const uint64_t* sizes, uint32_t count, F fn) {
-  const int n = g_nctx;
+  const int n = g_nctx.load();
   std::vector<uint32_t> owner(count);
   int rc = zes_partition(sizes, count, (uint32_t)n, owner.data());
   if (rc) return rc;
@@ -2437,7 +2436,7 @@ extern "C" {
 int zes_deflate_batch(const uint8_t* const* in, const uint64_t* in_len, uint8_t* const* out, const uint64_t* out_cap,
                       uint64_t* out_len, int32_t* status, uint32_t count) {
   if (!in || !in_len || !out || !out_cap || !out_len || !status) return ZES_E_ARG;
-  if (g_nctx <= 1 || count <= 1 || t_routed) {
+  if (g_nctx.load() <= 1 || count <= 1 || t_routed) {
     UseDev ud(route_host());
     return deflate_batch_one(in, in_len, out, out_cap, out_len, status, count);
   }
@@ -2476,7 +2475,7 @@ static uint8_t* sub_alloc(void* u, uint32_t k, uint64_t n) {
 int zes_inflate_batch_alloc(const uint8_t* const* in, const uint64_t* in_len, zes_alloc_fn alloc, void* user, uint64_t* out_len,
                             int32_t* status, uint32_t count, uint32_t flags) {
   if (!in || !in_len || !alloc || !out_len || !status) return ZES_E_ARG;
-  if (g_nctx <= 1 || count <= 1 || t_routed) {
+  if (g_nctx.load() <= 1 || count <= 1 || t_routed) {
     UseDev ud(route_host());
     return inflate_batch_alloc_one(in, in_len, alloc, user, out_len, status, count, flags);
   }
