@@ -280,17 +280,25 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # ZES_BENCH_BACKEND=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (the ranks share the devices,
+    # the gather's messages go through host memory) — every line of the rank logic but RCCL itself; never a measurement
+    backend = os.environ.get("ZES_BENCH_BACKEND", "nccl")
+    local_dev = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
+    cdev = dev if backend == "nccl" else torch.device("cpu")  # where the small reduction tensors live
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import datetime
 
         # (a collective that hangs ends the run after three minutes instead of the default ten)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=180))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=180))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
 
     z = ge.load()
-    z.init(local_rank)
+    z.init(local_dev)
     env = {"z": z, "dev": dev, "rank": rank, "world": world}
     main_name = args.workload or "random64"
     second_name = None if args.workload else "text64"
@@ -309,10 +317,10 @@ def main():
 
     def reduce_time(elapsed, ok):
         if world > 1:
-            tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
-            okt = torch.tensor([1 if ok else 0], dtype=torch.int64, device=dev)
+            okt = torch.tensor([1 if ok else 0], dtype=torch.int64, device=cdev)
             dist.all_reduce(okt, op=dist.ReduceOp.MIN)
             ok = bool(okt.item())
         return elapsed, ok
@@ -320,7 +328,7 @@ def main():
     def reduce_flag(flag):
         """True only if true on every rank (e.g. "this rank's output matched the reference's for its own seed")."""
         if world > 1:
-            t = torch.tensor([1 if flag else 0], dtype=torch.int64, device=dev)
+            t = torch.tensor([1 if flag else 0], dtype=torch.int64, device=cdev)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             flag = bool(t.item())
         return bool(flag)
@@ -358,6 +366,8 @@ def main():
             # the gather of the step before has had this step's kernels to hide behind; its arena is free again
             finish(pending)
             local, lens = leg.local_result(comp, slot)
+            if backend != "nccl":
+                local = local.cpu()
             pending = shard.gather_results(local, owned[rank], lens, [0] * leg.nbuf, owned, world * leg.nbuf, dst=0, async_op=True, hint=hint[0])
         return pending, tb - ta, tc - tb
 
@@ -472,6 +482,7 @@ def main():
                                       "compressed by CPython zlib level 6, inflate only" if foreign else "deflate then inflate"),
                        "buffers_per_step": world * leg.nbuf, "bytes_per_buffer": leg.n1,
                        "compressed_bytes": c, "parallelism": "independent buffers, one per GPU",
+                       **({} if backend == "nccl" else {"rehearsal": "ranks over %s, sharing the visible GPUs: not a measurement" % backend}),
                        "gather": (None if shard is None else
                                   "every step's compressed shards gathered into rank 0's HBM over RCCL/xGMI (one message per rank posted from the step "
                                   "before's lengths, sizes all_reduce read behind it), overlapped with the next step, completed inside the timed "
