@@ -45,13 +45,18 @@ bool get_bytes(napi_env env, napi_value v, const uint8_t** data, size_t* len) {
   return false;
 }
 
-// fresh exact-size Uint8Array (byteOffset 0, backing length == length), like src/zlib.ts:42
-napi_value make_u8(napi_env env, const uint8_t* src, size_t n) {
-  void* dst = nullptr;
+void free_external(napi_env, void* data, void*);
+// the library's output buffer becomes the result's ArrayBuffer (shrunk to the exact length: `buffer.byteLength === length`
+// like src/zlib.ts:42): no second copy of the result on the JS thread.  Takes the buffer over (frees it on failure).
+napi_value take_u8(napi_env env, uint8_t* buf, size_t n) {
+  void* shrunk = realloc(buf, n ? n : 1);
+  if (shrunk) buf = static_cast<uint8_t*>(shrunk);
   napi_value ab, ta;
-  if (napi_create_arraybuffer(env, n, &dst, &ab) != napi_ok) return nullptr;
-  if (n) memcpy(dst, src, n);
-  if (napi_create_typedarray(env, napi_uint8_array, n, ab, 0, &ta) != napi_ok) return nullptr;
+  if (napi_create_external_arraybuffer(env, buf, n, free_external, nullptr, &ab) != napi_ok) {
+    free(buf);
+    return nullptr;
+  }
+  if (napi_create_typedarray(env, napi_uint8_array, n, ab, 0, &ta) != napi_ok) return nullptr;  // (the ArrayBuffer's finalizer owns buf)
   return ta;
 }
 
@@ -87,9 +92,11 @@ napi_value Deflate(napi_env env, napi_callback_info info) {
   uint8_t* tmp = static_cast<uint8_t*>(malloc(cap));
   if (!tmp) return throw_status(env, ZES_E_ARG);
   const int rc = zes_deflate(in, n, tmp, cap, &out_len);
-  napi_value res = rc ? throw_status(env, rc) : make_u8(env, tmp, out_len);
-  free(tmp);
-  return res;
+  if (rc) {
+    free(tmp);
+    return throw_status(env, rc);
+  }
+  return take_u8(env, tmp, out_len);
 }
 
 napi_value Inflate(napi_env env, napi_callback_info info) {
@@ -130,9 +137,11 @@ napi_value DeflateRaw(napi_env env, napi_callback_info info) {
   uint8_t* tmp = static_cast<uint8_t*>(malloc(cap));
   if (!tmp) return throw_status(env, ZES_E_ARG);
   const int rc = zes_deflate_raw(in, n, tmp, cap, &out_len);
-  napi_value res = rc ? throw_status(env, rc) : make_u8(env, tmp, out_len);
-  free(tmp);
-  return res;
+  if (rc) {
+    free(tmp);
+    return throw_status(env, rc);
+  }
+  return take_u8(env, tmp, out_len);
 }
 
 // inflateRaw(input, offset = 0): the reference's src/inflate.ts:16 (what src/zlib.ts:21 calls with offset 2)
@@ -168,9 +177,11 @@ napi_value InflateRaw(napi_env env, napi_callback_info info) {
       cap = out_len;
       continue;
     }
-    napi_value res = rc ? throw_status(env, rc) : make_u8(env, tmp, out_len);
-    free(tmp);
-    return res;
+    if (rc) {
+      free(tmp);
+      return throw_status(env, rc);
+    }
+    return take_u8(env, tmp, out_len);
   }
   return throw_status(env, ZES_E_DEVICE);
 }
