@@ -9,24 +9,31 @@
 //   inv[p]  u32 per position: the slot of p, or ZES_INV_NONE when p has no candidate.
 // Nothing asks for the slots to be ordered BY key: positions of one key must be neighbours, in ascending order.  So:
 //
-//   1  every position's key is hashed by a bijection of the 24-bit key space, H = key * odd mod 2^24; the top 11 bits
-//      are its *class* (2048 classes, ~64 positions each), the other 13 bits travel with the position in one word
-//      (H13 << 17 | position): equal words' upper parts <=> equal keys inside a class;
-//   2  two sweeps over the block (read straight from memory, 16 bytes per lane): class sizes by LDS atomics, a scan,
-//      then every word goes to its class's run of a global array E — in whatever order the atomics hand out;
-//   3  each class is sorted by ONE wavefront, by the whole word (key part, then position): <= 64 words in registers
-//      (bitonic network on DPP row operations), more in LDS (radix passes of 6 bits over the digits that differ at
-//      all, ping-pong in the wave's own scratch); the few classes above 1024 words (a heavy key: " th") wait for a
-//      second round in which four wavefronts have a quarter of the LDS each;
-//   4  a sorted class gives its sd[] entries (coalesced 2-byte stores) and, per position, the word
+//   1  every position's key is hashed by a bijection of the 24-bit key space, H = key * odd mod 2^24; the top 4 bits
+//      are its *group* (16), the top 11 its *class* (2048 classes, ~64 positions each), the other 13 bits travel with
+//      the position in one word: equal upper parts <=> equal keys inside a class;
+//   2  sweep 1 over the block (read straight from memory, 16 bytes per lane): class sizes by LDS atomics; a scan gives
+//      every class its run of slots.  A block with a class above IDX_BIGCAP words, a group above IDX_GCAP, or a
+//      sixteenth of its positions in classes above IDX_REGCAP words (heavy keys: text) goes back to k_lz_sort here
+//      (ZES_SORT_REDO: k_lz_sort is the faster one on such data);
+//   3  sweep 2, tile by tile (16384 positions): each position's word (class-in-group 7 | rest of H 13 | low 12 bits of the
+//      position) is binned in an LDS tile buffer by (group, 4096-byte sub-tile), and every group's bin leaves for the
+//      group's part of a global array E as ONE contiguous run; a table of run starts per (group, sub-tile) gives the
+//      upper five bits of the positions back;
+//   4  group by group: the group's words come back in bulk, each goes to its class's run of a second LDS buffer
+//      (cursors from the class sizes), and every class is sorted by ONE wavefront in registers, by the whole word (key
+//      part, then position): a bitonic network over 64 M words (M = 1, 2, 4, 8; DPP quad_perm / row_ror, ds_swizzle,
+//      ds_bpermute, and register against register above 64), the classes dealt by size category;
+//   5  a sorted class gives its sd[] entries (coalesced 2-byte stores) and, per position, the word
 //      position-in-slice | slot | has-a-candidate, appended to the bucket of the position's 16384-byte slice (8 LDS
 //      cursors, the buckets in global memory);
-//   5  slice by slice the buckets are read back, scattered into an LDS image of the slice and written out as inv[]
-//      with coalesced 16-byte stores.
+//   6  classes above IDX_REGCAP words (few, when the block was kept) go back to E and are sorted at the end by radix
+//      passes of 6 bits in LDS, four wavefronts with a quarter of the LDS each;
+//   7  slice by slice the buckets are read back (all loads of a slice in flight), scattered into an LDS image of the
+//      slice and written out as inv[] with coalesced 16-byte stores.
 //
 // Global traffic per position: 1 (input) + 8 (E) + 8 (buckets) + 2 (sd) + 4 (inv) = 23 bytes, all of it in whole
-// lines (k_lz_sort: 51).  A block with a class above IDX_BIGCAP words (all zeros; a period of a few bytes) is handed
-// back to k_lz_sort (ZES_SORT_REDO).
+// lines (k_lz_sort: 51).
 #include "zes_common.h"
 #include "zes_kernels.h"
 
@@ -35,8 +42,7 @@
 #define IDX_NCLASS (1u << IDX_CB)
 #define IDX_RSHIFT (24u - IDX_CB)
 #define IDX_MUL 0x9E3779u  // odd: key -> key * IDX_MUL mod 2^24 is a bijection
-#define IDX_WCAP 1024u     // words a wavefront sorts in its own scratch (two halves of this size)
-#define IDX_BIGCAP 4096u   // ... in the second round, four wavefronts
+#define IDX_BIGCAP 4096u   // words of the largest class taken (the heavy classes' round: four wavefronts, two buffers of this size each)
 #define IDX_NBIGW 4u
 #define IDX_SLICE 16384u
 #define IDX_NSLICE (ZES_BLK / IDX_SLICE)
@@ -50,7 +56,7 @@
 #define IDX_NRUN (ZES_BLK / IDX_SUB)
 
 struct IndexSmem {
-  uint32_t scr[IDX_WAVES * 2 * IDX_WCAP];  // sweeps: class counters / cursors in [0, 2048 + 64); sorting: scratch; last: a slice of inv
+  uint32_t scr[2 * IDX_GCAP];  // sweep 1: class counters in [0, 2048 + 64); sweep 2: the tile buffer; groups: [IDX_GCAP, ...) the group's words; heavy classes: scratch; last: a slice of inv
   uint32_t cnt[IDX_NBIGW][5 * 64];         // digit counters of the radix passes (heavy classes), per wavefront
   uint32_t base[IDX_NCLASS + 1];           // first slot of each class
   uint32_t big[IDX_MAXBIG];
@@ -63,12 +69,7 @@ struct IndexSmem {
   uint8_t order[IDX_GCLASS];
   uint32_t wsum[IDX_WAVES];
   uint32_t pcur[IDX_NSLICE];
-  uint32_t next, nbig, nextbig, maxc, nheavy;
-#ifdef IDX_CHECK
-  uint32_t done[IDX_NCLASS / 32];
-  uint32_t emitted, nsum;
-  uint32_t wemit[IDX_WAVES];
-#endif
+  uint32_t nbig, maxc, nheavy;
 };
 static_assert(sizeof(IndexSmem) <= 160 * 1024, "LDS");
 
@@ -193,14 +194,7 @@ __device__ __forceinline__ static void idx_emit(IndexSmem& S, bool valid, uint32
   const uint32_t pos = x & 0x1FFFFu;
   const uint32_t delta = pos - (prev & 0x1FFFFu);  // > 0: positions ascend inside a key
   const bool has = ((x ^ prev) >> 17) == 0u && delta <= ZES_WINDOW;  // src/lz77.ts:49
-#ifdef IDX_CHECK
-  if (valid && (slot >= ZES_BLK || pos >= ZES_BLK - 2u)) printf("idx: emit slot %u pos %u x %#x\n", slot, pos, x);
-#endif
   if (valid) {
-#ifdef IDX_CHECK
-    atomicAdd(&S.emitted, 1u);
-    atomicAdd(&S.wemit[threadIdx.x >> 6], 1u);
-#endif
     sd[slot] = (uint16_t)(has ? delta : 0u);
     const uint32_t sl = pos / IDX_SLICE;
     const uint32_t k = atomicAdd(&S.pcur[sl], 1u);
@@ -226,8 +220,8 @@ __device__ __forceinline__ static void idx_class_regs(IndexSmem& S, uint32_t b0,
   }
 }
 
-// one class, by one wavefront.  scratch: 2 * cap words of LDS; cntw: 5 * 64 counters
-__device__ static void idx_class_(IndexSmem& S, uint32_t b0, uint32_t n, uint32_t* scratch, uint32_t cap, uint32_t* cntw,
+// a heavy class (above IDX_REGCAP words), by one wavefront: radix passes of 6 bits in LDS.  scratch: 2 * cap words; cntw: 5 * 64 counters
+__device__ static void idx_class_heavy(IndexSmem& S, uint32_t b0, uint32_t n, uint32_t* scratch, uint32_t cap, uint32_t* cntw,
                                  const uint32_t* __restrict__ E, uint16_t* __restrict__ sd, uint32_t* __restrict__ P) {
   const uint32_t lane = zes_lane();
   uint32_t* src = scratch;
@@ -284,25 +278,6 @@ __device__ static void idx_class_(IndexSmem& S, uint32_t b0, uint32_t n, uint32_
     src = dst;
     dst = t;
   }
-#ifdef IDX_CHECK
-  {
-    unsigned long long s1 = 0, s2 = 0;
-    for (uint32_t i = lane; i < n; i += 64u) {
-      s1 += idx_ld_sc1(E + b0 + i);
-      s2 += src[i];
-    }
-    for (int o = 32; o >= 1; o >>= 1) {
-      s1 += __shfl_xor(s1, o);
-      s2 += __shfl_xor(s2, o);
-    }
-    if (lane == 0 && s1 != s2) printf("idx: class at %u n %u cap %u wave %u diff %#x: sum in %llu out %llu\n", b0, n, cap, threadIdx.x >> 6, diff, s1, s2);
-  }
-  for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
-    const uint32_t i = i0 + lane;
-    const bool bad = i < n && i && src[i - 1u] >= src[i];
-    if (bad) printf("idx: class at %u n %u cap %u wave %u diff %#x: [%u] %#x >= [%u] %#x\n", b0, n, cap, threadIdx.x >> 6, diff, i - 1u, src[i - 1u], i, src[i]);
-  }
-#endif
   for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
     const uint32_t i = i0 + lane;
     const bool valid = i < n;
@@ -310,31 +285,6 @@ __device__ static void idx_class_(IndexSmem& S, uint32_t b0, uint32_t n, uint32_
     const uint32_t prev = (valid && i) ? src[i - 1u] : ~x;
     idx_emit(S, valid, x, prev, b0 + i, sd, P);
   }
-}
-
-__device__ static void idx_class(IndexSmem& S, uint32_t b0, uint32_t n, uint32_t* scratch, uint32_t cap, uint32_t* cntw,
-                                 const uint32_t* __restrict__ E, uint16_t* __restrict__ sd, uint32_t* __restrict__ P) {
-#ifdef IDX_CHECK
-  {
-    const uint64_t ex = __ballot(true);
-    if (ex != ~0ull && zes_lane() == (uint32_t)__builtin_ctzll(ex)) printf("idx: call b0 %u n %u wave %u with exec %#llx\n", b0, n, threadIdx.x >> 6, (unsigned long long)ex);
-  }
-  const uint32_t e0 = S.emitted;
-  if (zes_lane() == 0) S.wemit[threadIdx.x >> 6] = 0;
-  if (zes_lane() == 0) atomicAdd(&S.nsum, n);
-  {
-    const uint32_t nn = (uint32_t)__builtin_amdgcn_readfirstlane((int)n), bb = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);
-    if (nn != n || bb != b0) printf("idx: lane %u of wave %u has n %u b0 %u, lane 0 has %u %u\n", zes_lane(), threadIdx.x >> 6, n, b0, nn, bb);
-  }
-#endif
-  idx_class_(S, b0, n, scratch, cap, cntw, E, sd, P);
-#ifdef IDX_CHECK
-  (void)e0;
-  {
-    const uint32_t got = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.wemit[threadIdx.x >> 6]);
-    if (zes_lane() == 0 && got != n) printf("idx: call b0 %u n %u cap %u wave %u emitted %u\n", b0, n, cap, threadIdx.x >> 6, got);
-  }
-#endif
 }
 
 __global__ __launch_bounds__(IDX_THREADS) void k_lz_index(const uint8_t* __restrict__ d_in, const ZesBuf* __restrict__ bufs,
@@ -365,14 +315,8 @@ __global__ __launch_bounds__(IDX_THREADS) void k_lz_index(const uint8_t* __restr
   for (uint32_t i = tid; i < IDX_NCLASS + 64u; i += IDX_THREADS) cur[i] = 0;
   if (tid < IDX_NSLICE) S.pcur[tid] = 0;
   if (tid < 5u) S.catcnt[tid] = S.catpos[tid] = 0;
-#ifdef IDX_CHECK
-  if (tid < IDX_NCLASS / 32) S.done[tid] = 0;
-  if (tid == 0) S.emitted = S.nsum = 0;
-#endif
   if (tid == 0) {
-    S.next = 0;
     S.nbig = 0;
-    S.nextbig = 0;
     S.maxc = 0;
     S.nheavy = 0;
   }
@@ -608,13 +552,10 @@ __global__ __launch_bounds__(IDX_THREADS) void k_lz_index(const uint8_t* __restr
     for (uint32_t k = wave; k < nbig; k += IDX_NBIGW) {
       const uint32_t c = S.big[k];
       const uint32_t b0 = S.base[c], n = S.base[c + 1u] - b0;
-      idx_class(S, b0, n, S.scr + wave * (2u * IDX_BIGCAP), IDX_BIGCAP, S.cnt[wave], E, sd, A);
+      idx_class_heavy(S, b0, n, S.scr + wave * (2u * IDX_BIGCAP), IDX_BIGCAP, S.cnt[wave], E, sd, A);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the bucket words, as above)
-#ifdef IDX_FENCE
-  __threadfence();
-#endif
   __syncthreads();
   ISTAMP();
   // ---- inv[], a slice of 16384 positions at a time: the bucket's words scattered into an LDS image of the slice ----
@@ -625,11 +566,6 @@ __global__ __launch_bounds__(IDX_THREADS) void k_lz_index(const uint8_t* __restr
     const uint32_t have = min(cnt, lo + IDX_SLICE) > lo ? min(cnt, lo + IDX_SLICE) - lo : 0u;  // positions of the slice that have a key
     for (uint32_t i = tid; i < IDX_SLICE; i += IDX_THREADS)
       if (i >= have) stage[i] = ZES_INV_NONE;
-#ifdef IDX_CHECK
-    for (uint32_t i = tid; i < have; i += IDX_THREADS) stage[i] = 0xDEADBEEFu;
-    if (tid == 0) printf("idx: slice %u have %u cursor %u\n", s, have, S.pcur[s]);
-    __syncthreads();
-#endif
     {
       uint32_t e[IDX_SLICE / IDX_THREADS];  // the slice's bucket: all loads in flight at once
 #pragma unroll
@@ -639,18 +575,11 @@ __global__ __launch_bounds__(IDX_THREADS) void k_lz_index(const uint8_t* __restr
         if (k * IDX_THREADS + tid < have) stage[e[k] & (IDX_SLICE - 1u)] = (e[k] >> 31) ? ((e[k] >> 14) & 0x1FFFFu) : ZES_INV_NONE;
     }
     __syncthreads();
-#ifdef IDX_CHECK
-    for (uint32_t i = tid; i < have; i += IDX_THREADS)
-      if (stage[i] == 0xDEADBEEFu) printf("idx: slice %u position %u has no entry\n", s, i);
-#endif
     const uint4* st4 = reinterpret_cast<const uint4*>(stage);
     uint4* o4 = reinterpret_cast<uint4*>(inv + lo);
     for (uint32_t i = tid; i < IDX_SLICE / 4u; i += IDX_THREADS) o4[i] = st4[i];
     __syncthreads();
   }
-#ifdef IDX_CHECK
-  if (tid == 0) printf("idx: emitted in all %u, sum of n over the calls %u\n", S.emitted, S.nsum);
-#endif
   ISTAMP();
 #ifdef IDX_PROF
   if (tid == 0 && (g == 7 || g == 300))
