@@ -516,52 +516,68 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
   // same-key flags are taken) and each slice leaves with coalesced 16-byte stores; the sorted list is re-read per
   // slice (it sits in the L2).
   if (lazy) {
+    // Round 3: one pass over the sorted list instead of five.  Every slot gives its sd[] entry (coalesced) and the word
+    // position-in-slice | slot | has-a-candidate, appended to the bucket of the position's 16384-byte slice (eight LDS
+    // cursors; the buckets live in idx_b, free since the last pass); then the buckets come back slice by slice, are
+    // scattered into an LDS image of the slice and leave as inv[] with 16-byte stores — the transposition k_lz_index
+    // uses.  (Before: the same-key flags in one pass, then four passes over the whole list, one per 32768-position slice
+    // of inv[]: 300k of the kernel's 1.2M cycles on text, and 32 of its 51 bytes of traffic per position.)
+    // inv[p] holds the slot alone; the match finder takes a position's first distance from sd[] like the others.
     uint32_t* inv = inv_all + (uint64_t)g * ZES_BLK;
     uint16_t* sd = sd_all + (uint64_t)g * ZES_BLK;
-    uint32_t* same = reinterpret_cast<uint32_t*>(&S.whist[0][0][0]);  // [4096] bit r: slot r holds the key of slot r-1
-    for (uint32_t wd = tid; wd < ZES_BLK / 32; wd += SORT_THREADS) same[wd] = 0;
+    uint32_t* P = B;  // [8][16384]
+    uint32_t* pcur = S.wsum;
+    static_assert(SORT_WAVES >= 8, "eight bucket cursors live in wsum[]");
+    if (tid < 8u) pcur[tid] = 0;
     __syncthreads();
-    for (uint32_t r0 = wave * 64u; r0 < ns; r0 += SORT_THREADS) {
-      const uint32_t r = r0 + lane;
-      bool sm = false;
-      if (r < ns && r != 0u) sm = ((lds_ld32u(S.in, A[r - 1u]) ^ lds_ld32u(S.in, A[r])) & 0xffffffu) == 0u;
-      const uint64_t m = __ballot(sm);
-      if (lane == 0) {
-        same[r0 >> 5] = (uint32_t)m;
-        same[(r0 >> 5) + 1u] = (uint32_t)(m >> 32);
+    for (uint32_t rb = tid; rb < ns; rb += 8u * SORT_THREADS) {  // eight slots per thread and step: one memory latency for all
+      uint32_t pos[8], prv[8];
+#pragma unroll
+      for (uint32_t k = 0; k < 8; k++) {
+        const uint32_t r = min(rb + k * SORT_THREADS, ns - 1u);
+        pos[k] = A[r];
+        prv[k] = A[r ? r - 1u : 0u];
+      }
+      asm volatile("" : "+v"(pos[0]), "+v"(pos[1]), "+v"(pos[2]), "+v"(pos[3]), "+v"(pos[4]), "+v"(pos[5]), "+v"(pos[6]), "+v"(pos[7]));
+      asm volatile("" : "+v"(prv[0]), "+v"(prv[1]), "+v"(prv[2]), "+v"(prv[3]), "+v"(prv[4]), "+v"(prv[5]), "+v"(prv[6]), "+v"(prv[7]));
+#pragma unroll
+      for (uint32_t k = 0; k < 8; k++) {
+        const uint32_t r = rb + k * SORT_THREADS;
+        if (r < ns) {
+          const bool sm = r != 0u && ((lds_ld32u(S.in, prv[k]) ^ lds_ld32u(S.in, pos[k])) & 0xffffffu) == 0u;  // slot r holds the key of slot r-1
+          const uint32_t delta = pos[k] - prv[k];  // > 0: equal keys are in ascending position order
+          const bool has = sm && delta <= ZES_WINDOW;
+          sd[r] = (uint16_t)(has ? delta : 0u);  // (lanes of a wave write 64 consecutive entries)
+          const uint32_t sl = pos[k] >> 14;
+          const uint32_t at = atomicAdd(&pcur[sl], 1u);
+          P[sl * 16384u + at] = (pos[k] & 16383u) | (r << 14) | (has ? 0x80000000u : 0u);
+        }
       }
     }
-    __syncthreads();  // the block in S.in is dead from here on
-    uint32_t* stage = reinterpret_cast<uint32_t*>(S.in);  // [32768]
-    for (uint32_t b = 0; b < ZES_BLK / 32768u; b++) {
-      if (b * 32768u >= T) break;  // uniform
+    // the bucket words are in memory before anybody reads them back (a workgroup-scope fence does not wait for stores);
+    // the block in S.in is dead from here on
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    uint32_t* stage = reinterpret_cast<uint32_t*>(S.in);  // [16384]
+    for (uint32_t sl = 0; sl < ZES_BLK / 16384u; sl++) {
+      const uint32_t lo = sl * 16384u;
+      if (lo >= T) break;  // uniform
+      const uint32_t have = pcur[sl];  // (positions the filter dropped have no word: their entries stay "none")
       uint4* st4 = reinterpret_cast<uint4*>(S.in);
-      for (uint32_t i = tid; i < 8192u; i += SORT_THREADS) st4[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+      for (uint32_t i = tid; i < 4096u; i += SORT_THREADS) st4[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
       __syncthreads();
-      for (uint32_t rb = tid; rb < ns; rb += 8u * SORT_THREADS) {  // eight slots per thread and step: one memory latency for all
-        uint32_t pos[8], prv[8];
+      {
+        uint32_t e[16];  // the slice's bucket: all loads in flight at once
 #pragma unroll
-        for (uint32_t k = 0; k < 8; k++) {
-          const uint32_t r = min(rb + k * SORT_THREADS, ns - 1u);
-          pos[k] = A[r];
-          prv[k] = A[r ? r - 1u : 0u];
-        }
-        asm volatile("" : "+v"(pos[0]), "+v"(pos[1]), "+v"(pos[2]), "+v"(pos[3]), "+v"(pos[4]), "+v"(pos[5]), "+v"(pos[6]), "+v"(pos[7]));
-        asm volatile("" : "+v"(prv[0]), "+v"(prv[1]), "+v"(prv[2]), "+v"(prv[3]), "+v"(prv[4]), "+v"(prv[5]), "+v"(prv[6]), "+v"(prv[7]));
+        for (uint32_t k = 0; k < 16; k++)
+          e[k] = __hip_atomic_load(P + lo + min(k * SORT_THREADS + tid, have ? have - 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-        for (uint32_t k = 0; k < 8; k++) {
-          const uint32_t r = rb + k * SORT_THREADS;
-          if (r < ns) {
-            const uint32_t delta = pos[k] - prv[k];  // > 0: equal keys are in ascending position order
-            const bool has = ((same[r >> 5] >> (r & 31u)) & 1u) && delta <= ZES_WINDOW;
-            if (b == 0u) sd[r] = (uint16_t)(has ? delta : 0u);  // (lanes of a wave write 64 consecutive entries)
-            if ((pos[k] >> 15) == b) stage[pos[k] & 32767u] = has ? (r | ((delta - 1u) << 17)) : ZES_INV_NONE;
-          }
-        }
+        for (uint32_t k = 0; k < 16; k++)
+          if (k * SORT_THREADS + tid < have && (e[k] >> 31)) stage[e[k] & 16383u] = (e[k] >> 14) & 0x1FFFFu;
       }
       __syncthreads();
-      uint4* o4 = reinterpret_cast<uint4*>(inv + b * 32768u);
-      for (uint32_t i = tid; i < 8192u; i += SORT_THREADS) o4[i] = st4[i];
+      uint4* o4 = reinterpret_cast<uint4*>(inv + lo);
+      for (uint32_t i = tid; i < 4096u; i += SORT_THREADS) o4[i] = st4[i];
       __syncthreads();
     }
   }
