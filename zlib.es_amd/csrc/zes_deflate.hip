@@ -844,7 +844,9 @@ void zes_lazy_set_dbg(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBO
   do {                                                                                                   \
     if (g_lazy_dbg && threadIdx.x == 0) g_lazy_dbg[(size_t)blockIdx.x * 8 + (i)] = (unsigned long long)clock64(); \
   } while (0)
+#ifndef LAZY_WIN
 #define LAZY_WIN 512u
+#endif
 #define LAZY_NWIN (ZES_BLK / LAZY_WIN)
 #define LAZY_TAIL 512u         // positions at the block end that are evaluated up front, one lane each
 #define LAZY_EVAL_LIT 1u       // match word of an evaluated position that stays a literal (no match bit: k_lz_parse reads a literal)
