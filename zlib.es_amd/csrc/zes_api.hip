@@ -1305,37 +1305,59 @@ int inflate_segments_run(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, cons
               (unsigned long long)sr[w].out_len, sr[w].flags, sr[w].next);
   };
   dump_items("after the block decoder");
-  {
-    Timed t("k_inf_seg_scan");
-    hipLaunchKernelGGL(k_inf_seg_scan_short, dim3(work), dim3(64), 0, g.stream, d_in, (const ZesSegJob*)g.segjobs.p, nb, cs, (ZesSegRes*)g.sres.p,
-                       (uint32_t*)g.maps.p, (uint32_t*)g.sym16.p, ratio, blockpar ? (const uint32_t*)fail_list + 1 : (const uint32_t*)g.segorder.p, far_d,
-                       (const uint32_t*)fail_list, (uint64_t*)g.symoff.p);
-  }
-  {
-    uint32_t* hf = (uint32_t*)g.pinned;
-    HIPCHK(hipMemcpyAsync(hf, far_d, 4, hipMemcpyDeviceToHost, g.stream));
-    if (blockpar) HIPCHK(hipMemcpyAsync(hf + 1, fail_list, 4, hipMemcpyDeviceToHost, g.stream));
-    HIPCHK(hipStreamSynchronize(g.stream));
-    if (blockpar && getenv("ZES_DEBUG")) fprintf(stderr, "zes T2: %u work items, %u left to the wave decoder\n", work, hf[1]);
-    if (hf[0] != 0) {
-      Timed t("k_inf_seg_scan");
-      hipLaunchKernelGGL(k_inf_seg_scan, dim3(work), dim3(64), 0, g.stream, d_in, (const ZesSegJob*)g.segjobs.p, nb, cs, (ZesSegRes*)g.sres.p,
-                         (uint32_t*)g.maps.p, (uint32_t*)g.sym16.p, ratio, (const uint32_t*)g.segorder.p, far_d, (const uint32_t*)nullptr,
-                         (uint64_t*)g.symoff.p);
-    }
-  }
-  {
-    Timed t("k_inf_seg_chain");
-    for (uint32_t k = 0; k < nb; k++)
-      hipLaunchKernelGGL(k_inf_seg_chain, dim3(1), dim3(256), 0, g.stream, (const ZesSegRes*)g.sres.p + hj[k].work_first, ncand[k] + 1,
-                         (uint32_t*)g.seglist.p + hj[k].work_first, (uint64_t*)g.segprefix.p + hj[k].work_first, (ZesRes*)g.res.p + k,
-                         novf_d + k);
-  }
-  uint32_t* hs = (uint32_t*)g.pinned;  // [0, nb): not-in-store counts, later failure flags
+  uint32_t* hs = (uint32_t*)g.pinned;  // [0, nb): not-in-store counts, later failure flags; [nb]: declined items
   ZesRes* hres = (ZesRes*)((uint8_t*)g.pinned + 128 * 1024);
-  HIPCHK(hipMemcpyAsync(hs, novf_d, (size_t)nb * 4, hipMemcpyDeviceToHost, g.stream));
-  HIPCHK(hipMemcpyAsync(hres, g.res.p, sizeof(ZesRes) * nb, hipMemcpyDeviceToHost, g.stream));
-  HIPCHK(hipStreamSynchronize(g.stream));  // (the job table upload has completed too: hj may be rewritten)
+  // the chain of every buffer of the group (work item 0 -> the item that starts where it ended -> ... -> the final block)
+  auto run_chains = [&]() -> int {
+    HIPCHK(hipMemsetAsync(novf_d, 0, (size_t)nb * 4, g.stream));
+    {
+      Timed t("k_inf_seg_chain");
+      for (uint32_t k = 0; k < nb; k++)
+        hipLaunchKernelGGL(k_inf_seg_chain, dim3(1), dim3(256), 0, g.stream, (const ZesSegRes*)g.sres.p + hj[k].work_first, ncand[k] + 1,
+                           (uint32_t*)g.seglist.p + hj[k].work_first, (uint64_t*)g.segprefix.p + hj[k].work_first, (ZesRes*)g.res.p + k,
+                           novf_d + k);
+    }
+    HIPCHK(hipMemcpyAsync(hs, novf_d, (size_t)nb * 4, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipMemcpyAsync(hres, g.res.p, sizeof(ZesRes) * nb, hipMemcpyDeviceToHost, g.stream));
+    if (blockpar) HIPCHK(hipMemcpyAsync(hs + nb, fail_list, 4, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));  // (the job table upload has completed too: hj may be rewritten)
+    return ZES_OK;
+  };
+  // Round 3: the chains are tried on what the block decoder left BEFORE the wave decoder gets the declined items.  An
+  // item that starts on a false candidate is declined (its "block" is garbage) and nobody's chain leads to it — but
+  // the lone wave that decodes it on may take milliseconds to find that out (256 x 1 MiB of zlib text: 6.9 of 32 ms).
+  // Only when a chain does run into a declined item (a stored or fixed block, a block behind an unlisted start) do the
+  // declined items go to the wave decoder, and the chains are followed again.
+  bool chained = false;
+  if (blockpar) {
+    if ((rc = run_chains())) return rc;
+    chained = true;
+    const uint32_t ndecl = hs[nb];
+    if (getenv("ZES_DEBUG")) fprintf(stderr, "zes T2: %u work items, %u declined by the block decoder\n", work, ndecl);
+    if (ndecl)
+      for (uint32_t k = 0; k < nb; k++)
+        if (hres[k].status != 0 || hres[k].aux == 0) chained = false;  // a chain ended on an item nobody has decoded
+  }
+  if (!chained) {
+    {
+      Timed t("k_inf_seg_scan");
+      hipLaunchKernelGGL(k_inf_seg_scan_short, dim3(work), dim3(64), 0, g.stream, d_in, (const ZesSegJob*)g.segjobs.p, nb, cs, (ZesSegRes*)g.sres.p,
+                         (uint32_t*)g.maps.p, (uint32_t*)g.sym16.p, ratio, blockpar ? (const uint32_t*)fail_list + 1 : (const uint32_t*)g.segorder.p, far_d,
+                         (const uint32_t*)fail_list, (uint64_t*)g.symoff.p);
+    }
+    {
+      uint32_t* hf = (uint32_t*)g.pinned;
+      HIPCHK(hipMemcpyAsync(hf, far_d, 4, hipMemcpyDeviceToHost, g.stream));
+      HIPCHK(hipStreamSynchronize(g.stream));
+      if (hf[0] != 0) {
+        Timed t("k_inf_seg_scan");
+        hipLaunchKernelGGL(k_inf_seg_scan, dim3(work), dim3(64), 0, g.stream, d_in, (const ZesSegJob*)g.segjobs.p, nb, cs, (ZesSegRes*)g.sres.p,
+                           (uint32_t*)g.maps.p, (uint32_t*)g.sym16.p, ratio, (const uint32_t*)g.segorder.p, far_d, (const uint32_t*)nullptr,
+                           (uint64_t*)g.symoff.p);
+      }
+    }
+    if ((rc = run_chains())) return rc;
+  }
   std::vector<uint32_t> novf(hs, hs + nb);
   std::vector<ZesRes> hr(hres, hres + nb);
   std::vector<char> go(nb, 0);

@@ -1314,7 +1314,11 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
   // serial tail from here can cost ~10 ms); a second false candidate in the same block falls to
   // the serial tail below.  Written as a second straight-line copy, not a loop: a back edge makes
   // the compiler hoist invariants across the whole decoder and spill.
-  if (!bad && tail_code < 48u && it.de_est2) {
+  // (Round 3: also when the chain FAILED on the first estimate.  Since the staged copy's end bounds the phases that
+  // read it, a false candidate a little behind the block's start makes the chain fail at that end rather than run on:
+  // the item used to be declined there — a whole block left to a lone wave of the wave decoder, 7 ms per 100 KiB, e.g.
+  // 8 MiB of zlib text in 8.1 ms instead of 1.3.  A block that is really damaged fails a second time and is declined.)
+  if (!bad && (tail_code < 48u || tail_code == C_FAIL) && it.de_est2) {
     __syncthreads();
     bad = stage_and_tables(it.de_est2);
   }
