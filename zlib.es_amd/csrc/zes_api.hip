@@ -1217,7 +1217,10 @@ int inflate_t1_range(const uint8_t* d_in, uint64_t in_off, uint64_t c, uint64_t 
 // (blocks of every type, 32 KiB history across blocks).  The candidate search runs buffer by buffer; the segment
 // decode — nearly all of the time — and the window pass take all buffers of a group in one launch.  A buffer whose
 // stream is not a clean chain of blocks keeps tier 0: the serial tiers then reproduce the reference's result.
-constexpr uint64_t SEG_MIN_C = 32768;  // shorter streams go straight to the serial wavefront
+#ifndef ZES_SEG_MIN_C
+#define ZES_SEG_MIN_C 4096
+#endif
+constexpr uint64_t SEG_MIN_C = ZES_SEG_MIN_C;  // shorter streams go straight to the serial wavefront (round 3: 32768 -> 4096: 29 KB of zlib stream can be 4 MiB of periodic data — 12.5 ms by the serial wavefront, 2.8 ms here)
 constexpr size_t SERIAL_BATCH_MIN_JOBS = 16;        // this many left-over streams of a call: one serial wavefront each, side by side
 constexpr uint64_t SERIAL_BATCH_MAX_C = 128ull << 10;  // (longer ones go to the segment-parallel tier: its block decoder is ~15 times a lone wave)
 constexpr uint32_t SEG_GROUP_BUFS = 64;      // buffers whose candidates are searched before the first read-back
