@@ -974,7 +974,7 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
   if (dbg) {  // average shader-clock cycles per phase of k_inf_block_par
     std::vector<unsigned long long> h((size_t)work * ZES_PAR_DBG_ROW);
     HIPCHK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
-    double acc[8] = {0}, t0[3] = {0}, t15[3] = {0}, fb_lanes = 0, fb_waves = 0, hs[5] = {0}, p4[5] = {0};
+    double acc[8] = {0}, t0[3] = {0}, t15[3] = {0}, fb_lanes = 0, fb_waves = 0, hs[5] = {0}, p4[5] = {0}, why[3] = {0};
     uint32_t cntd = 0;
     for (uint32_t i = 0; i < work; i++) {
       const unsigned long long* r = &h[(size_t)i * ZES_PAR_DBG_ROW];
@@ -990,6 +990,7 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
       for (int k = 0; k < 5; k++) p4[k] += (double)r[24 + k];
       fb_lanes += (double)r[11];
       fb_waves += (double)r[15];
+      for (int k = 0; k < 3; k++) why[k] += (double)r[29 + k];
     }
     fprintf(stderr, "zes phases (avg cycles over %u blocks): hdr %.0f tables %.0f compose %.0f count %.0f emit %.0f resolve %.0f flush %.0f\n",
             cntd, acc[1] / cntd, acc[2] / cntd, acc[3] / cntd, acc[4] / cntd, acc[5] / cntd, acc[6] / cntd, acc[7] / cntd);
@@ -999,7 +1000,7 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
             hs[0] / cntd, hs[1] / cntd, hs[2] / cntd, hs[3] / cntd, hs[4] / cntd);
     fprintf(stderr, "zes resolve steps (avg cycles): carry+clear %.0f fill %.0f jumping %.0f copy %.0f | %.1f barrier rounds per block\n", p4[0] / cntd,
             p4[1] / cntd, p4[2] / cntd, p4[3] / cntd, p4[4] / cntd);
-    fprintf(stderr, "zes 8-bit table path: %.2f lanes in %.2f waves per block fell back to the generic construction\n", fb_lanes / cntd, fb_waves / cntd);
+    fprintf(stderr, "zes 8-bit table path: %.2f lanes in %.2f waves per block fell back to the generic construction (segment shape or list full %.2f, three positions under one token %.2f, look-back %.2f)\n", fb_lanes / cntd, fb_waves / cntd, why[0] / cntd, why[1] / cntd, why[2] / cntd);
   }
   if (getenv("ZES_DEBUG")) {
     for (uint32_t i = 0, shown_b = 0; i < nbuf && shown_b < 4; i++) {

@@ -389,45 +389,37 @@ __device__ __forceinline__ static uint32_t win_bits(uint32_t a0, uint32_t a1, ui
   return __builtin_amdgcn_alignbit(hi, lo, r & 31u);
 }
 
-// one step of a predicated trajectory: lanes with act decode one token at b.pos (count-free)
-// returns: 0 continue, C_EOB, C_FAIL (as code+1000 so 0 stays "continue")
 // ------------------------------------------------------------------------------------------
 // Transfer table of a segment when nearly every literal has an 8-bit code (incompressible data).
 // There the eight bit phases never merge, and the generic construction below decodes the segment
 // eight times, token by token.  Instead:
 //  (A) one regular pass over the segment's dwords tests every bit position for "an 8-bit literal
 //      code starts here" — four positions of one phase per SWAR range test on the bit-reversed
-//      dword — and keeps the few positions that fail (other code lengths, matches, end of block:
-//      about nine per segment on random data) in a 32-entry list in registers;
-//  (B) a trajectory then runs along its phase straight to the next listed position (or to the
-//      segment end), takes that one token the generic way, and goes on; every entry offset it
-//      passes gets its exit code, so eight trajectories (plus one per listed position inside the
-//      entry zone) settle all 48 entries.
+//      dword.  A token chain on phase f (positions = f mod 8) runs through such positions in steps
+//      of eight; only where the test fails (other code lengths, matches, end of block: about nine
+//      positions per segment on random data, the *listed* positions, kept in a 32-entry list in
+//      registers) it can do anything else;
+//  (B) ONE fold over the listed positions, highest first, each ONE token decode.  E[f] = exit code
+//      of a chain that is on phase f at the fold's position (eight bytes in a register pair; at the
+//      segment's end: the first position of the phase at or behind it).  A token from q to q'
+//      gives q the code q' - end, or end-of-block / fail, or E[q' mod 8] — every listed position
+//      above q is folded into E already — and E[q mod 8] becomes that code.  (Round 2 walked a
+//      trajectory per phase and entry from list search to list search: every listed position
+//      decoded by each chain that meets it, the wave at the pace of its longest chain per
+//      trajectory, 36 list slots compared per search.)
+//      The one thing E cannot tell: listed positions p between q and q' on the phase of q' are
+//      folded in although the token jumps over them (half the listed positions are matches of 20-40
+//      bits: it happens several times per block).  The positions folded last are at hand — the
+//      list is taken four at a time — so they are counted: none -> E; one -> E1, the value E[f]
+//      had before its latest change (that change was p); two -> E2; three, or more positions
+//      under one token than the look-back holds -> the lane gives up and its wave redoes the
+//      generic construction.
+//      The table: entry o = E[o mod 8] as of position o, i.e. word w of the table (entries
+//      8w..8w+7) is E once every listed position >= 8w is folded in.
 // Returns false for a lane that must use the generic construction (list overflow, data end near).
 // ------------------------------------------------------------------------------------------
 #define F8_MAXSEG 1800u  // longest segment (bits) the 11-bit list entries and the scan loop are sized for
 #define F8_LIST 32u
-struct F8List {
-  // thirty-two u16 positions relative to the segment base, four per word, 0xFFFF = empty (named fields: see SegTab)
-  uint64_t q0, q1, q2, q3, q4, q5, q6, q7;
-};
-// smallest listed position q >= x on x's bit phase (0xFFFF if none)
-__device__ __forceinline__ static uint32_t f8_next(const F8List& l, uint64_t tail, uint32_t x) {
-  uint32_t nx = 0xFFFFu;
-#define F8_ONE(q)                                                  \
-  {                                                                \
-    const uint32_t qq = (q);                                       \
-    const bool hit = (((qq - x) & 7u) == 0u) && qq >= x && qq < nx; \
-    nx = hit ? qq : nx;                                            \
-  }
-#define F8_FOUR(r)                                                                                       \
-  F8_ONE((uint32_t)(r) & 0xFFFFu) F8_ONE(((uint32_t)(r)) >> 16) F8_ONE((uint32_t)((r) >> 32) & 0xFFFFu) \
-  F8_ONE((uint32_t)((r) >> 48))
-  F8_FOUR(l.q0) F8_FOUR(l.q1) F8_FOUR(l.q2) F8_FOUR(l.q3) F8_FOUR(l.q4) F8_FOUR(l.q5) F8_FOUR(l.q6) F8_FOUR(l.q7) F8_FOUR(tail)
-#undef F8_FOUR
-#undef F8_ONE
-  return nx;
-}
 
 __device__ __forceinline__ static bool seg_table_f8(ParSmem& S, const BitSrc& src, uint32_t limit, uint32_t base, uint32_t stop,
                                                     const Lit8& f8, SegTab& tab, unsigned long long* dp) {
@@ -438,122 +430,216 @@ __device__ __forceinline__ static bool seg_table_f8(ParSmem& S, const BitSrc& sr
       dp[(threadIdx.x ? 12 : 8) + (i)] = (unsigned long long)clock64();             \
   } while (0)
   const uint32_t sl = stop - base;
-  bool ok = sl >= 64u && sl <= F8_MAXSEG && stop + 128u <= limit;  // every bit the scan looks at is data
+  const uint32_t sl_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)sl);
+  // (every bit the scan looks at is data; the segments of a block have one length)
+  bool ok = sl == sl_u && sl >= 64u && sl <= F8_MAXSEG && stop + 128u <= limit;
+  uint32_t why = ok ? 0u : 1u;  // ZES_DEBUG_PHASES: what made the lane give up
   // ---- (A) positions where no 8-bit literal code starts ----
   // per byte of the bit-reversed dword: t = byte - lo (mod 256); the byte is a literal code iff t < n.
   // With m = 256 - n <= 128: t >= n  <=>  bit7(t) and bit7((t & 0x7f) + m)   (no carries between bytes)
   const uint32_t H = 0x80808080u;
   const uint32_t LO = f8.lo * 0x01010101u, M = (256u - f8.n) * 0x01010101u;
   const uint32_t LOm = LO & ~H, nLO = ~LO;
-  F8List li = {~0ull, ~0ull, ~0ull, ~0ull, ~0ull, ~0ull, ~0ull, ~0ull};
-  uint64_t grp = ~0ull;  // the last up to four positions, newest in the low 16 bits; goes to the list when full
+  // incompressible data proper: the 8-bit codes start at code value 0 and all but a few (< 8) of the 256 byte
+  // patterns are literals: "no literal here" is a run of five one bits and a three-bit comparison — bitwise on the
+  // dword, 32 positions at once (20 operations per dword; the byte-wise range test above: 93)
+  const bool runs = f8.lo == 0u && f8.n >= 248u;  // (uniform; n <= 255: the end-of-block code needs room too)
+  const uint32_t nc0 = (f8.n & 1u) ? 0u : ~0u, nc1 = (f8.n & 2u) ? 0u : ~0u, nc2 = (f8.n & 4u) ? 0u : ~0u;
+  // thirty-two u16 positions relative to the segment base, four per word, 0xFFFF = empty; the newest (highest) four in
+  // grp, newest in its low 16 bits.  Named words and no index on purpose (see SegTab).
+  uint64_t q0 = ~0ull, q1 = ~0ull, q2 = ~0ull, q3 = ~0ull, q4 = ~0ull, q5 = ~0ull, q6 = ~0ull, q7 = ~0ull, grp = ~0ull;
   uint32_t nl = 0;
   const uint32_t d0 = base >> 5, bo = base & 31u;
-  const uint32_t nd = (sl + 48u + 62u) >> 5;  // dwords that cover [base, stop + 48) for any alignment (uniform)
+  const uint32_t nd = (min(sl_u, F8_MAXSEG) + 62u) >> 5;  // dwords that cover [base, stop) for any alignment (uniform)
+  const uint32_t ebit = bo + sl;                           // first bit behind the segment, counted from dword d0
   uint32_t lo = src_ldw<true>(src, d0);
   // four dwords per step: the listing loop below runs as often as the busiest lane has positions to list,
   // so it is entered once per 128 bit positions, not once per 32
 #pragma unroll 1
   for (uint32_t j0 = 0; j0 < nd; j0 += 4u) {
     uint32_t bad[4];
+    if (runs) {  // (uniform)
+#pragma unroll
+      for (uint32_t jj = 0; jj < 4u; jj++) {
+        const uint32_t hi = src_ldw<true>(src, d0 + j0 + jj + 1u);
+        // the bit-reversed byte at p is >= n = 0b11111ccc: stream bits p..p+4 are ones and bits p+5..p+7, read as a
+        // number most significant first, are >= ccc (compared from the last bit up: with the constant's bit set the
+        // stream's bit must be set and the rest hold, with it clear either will do)
+        const uint32_t s1 = __builtin_amdgcn_alignbit(hi, lo, 1), s2 = __builtin_amdgcn_alignbit(hi, lo, 2),
+                       s3 = __builtin_amdgcn_alignbit(hi, lo, 3), s4 = __builtin_amdgcn_alignbit(hi, lo, 4),
+                       s5 = __builtin_amdgcn_alignbit(hi, lo, 5), s6 = __builtin_amdgcn_alignbit(hi, lo, 6),
+                       s7 = __builtin_amdgcn_alignbit(hi, lo, 7);
+        uint32_t ge = s7 | nc0;
+        ge = ((s6 ^ ge) & nc1) | (s6 & ge);
+        ge = ((s5 ^ ge) & nc2) | (s5 & ge);
+        bad[jj] = lo & s1 & s2 & s3 & s4 & ge;
+        lo = hi;
+      }
+    } else {
+#pragma unroll
+      for (uint32_t jj = 0; jj < 4u; jj++) {
+        const uint32_t hi = src_ldw<true>(src, d0 + j0 + jj + 1u);
+        uint32_t bd = 0;  // bit b: no 8-bit literal code starts at bit 32 j + b
+#pragma unroll
+        for (uint32_t phi = 0; phi < 8u; phi++) {
+          const uint32_t x = __brev(__builtin_amdgcn_alignbit(hi, lo, phi));  // top byte = the token at bit 32 j + phi
+          const uint32_t t = ((x | H) - LOm) ^ ((x ^ nLO) & H);
+          const uint32_t inv = t & ((t & ~H) + M) & H;  // bit 31 - 8k: token k of this phase
+          bd |= (__brev(inv) << phi);                    // -> bit phi + 8k
+        }
+        bad[jj] = bd;
+        lo = hi;
+      }
+    }
 #pragma unroll
     for (uint32_t jj = 0; jj < 4u; jj++) {
-      const uint32_t hi = src_ldw<true>(src, d0 + j0 + jj + 1u);
-      uint32_t bd = 0;  // bit b: no 8-bit literal code starts at bit 32 (j0 + jj) + b
-#pragma unroll
-      for (uint32_t phi = 0; phi < 8u; phi++) {
-        const uint32_t x = __brev(__builtin_amdgcn_alignbit(hi, lo, phi));  // top byte = the token at bit 32 j + phi
-        const uint32_t t = ((x | H) - LOm) ^ ((x ^ nLO) & H);
-        const uint32_t inv = t & ((t & ~H) + M) & H;  // bit 31 - 8k: token k of this phase
-        bd |= (__brev(inv) << phi);                    // -> bit phi + 8k
-      }
-      bad[jj] = (j0 + jj < nd) ? bd : 0u;
-      lo = hi;
+      // only positions of the segment: bits [bo, bo + sl) counted from dword d0
+      const uint32_t j = j0 + jj;
+      const int32_t eb = (int32_t)ebit - (int32_t)(32u * j);
+      uint32_t vm = eb >= 32 ? ~0u : eb <= 0 ? 0u : ((1u << (eb & 31)) - 1u);
+      vm &= (j == 0u) ? (~0u << bo) : ~0u;
+      bad[jj] &= vm;
     }
     while (__ballot((bad[0] | bad[1] | bad[2] | bad[3]) != 0u)) {
-      // lowest listed position first (ascending order inside a lane is not needed by f8_next, but cheap to keep)
+      // lowest position first: the list ascends, its newest entry is the highest position
       const uint32_t q = bad[0] ? 0u : bad[1] ? 1u : bad[2] ? 2u : 3u;
       const uint32_t bq = bad[0] ? bad[0] : bad[1] ? bad[1] : bad[2] ? bad[2] : bad[3];
-      const bool hv = bq != 0u;
-      const uint32_t bpos = hv ? (uint32_t)__builtin_ctz(bq) : 0u;
+      const bool take = bq != 0u;
+      const uint32_t bpos = take ? (uint32_t)__builtin_ctz(bq) : 0u;
       const uint32_t cl = bq & (bq - 1u);  // that bit cleared
       bad[0] = (q == 0u) ? cl : bad[0];
-      bad[1] = (q == 1u && hv) ? cl : bad[1];
-      bad[2] = (q == 2u && hv) ? cl : bad[2];
-      bad[3] = (q == 3u && hv) ? cl : bad[3];
-      const uint32_t rel = 32u * (j0 + q) + bpos - bo;  // wraps for positions in front of the segment
-      const bool take = hv && rel < sl + 48u;
+      bad[1] = (q == 1u && take) ? cl : bad[1];
+      bad[2] = (q == 2u && take) ? cl : bad[2];
+      bad[3] = (q == 3u && take) ? cl : bad[3];
+      const uint32_t rel = 32u * (j0 + q) + bpos - bo;
+      // a complete group of four goes to the list when the next position arrives (grp is only empty for an empty list):
+      // the words move up by one; past 32 positions the oldest drop out, and the lane falls back anyway.  No branch and
+      // no indexed word: both cost this loop two dozen register copies per turn.
+      const bool full = take && nl != 0u && (nl & 3u) == 0u;
+      q7 = full ? q6 : q7;
+      q6 = full ? q5 : q6;
+      q5 = full ? q4 : q5;
+      q4 = full ? q3 : q4;
+      q3 = full ? q2 : q3;
+      q2 = full ? q1 : q2;
+      q1 = full ? q0 : q1;
+      q0 = full ? grp : q0;
+      grp = full ? ~0ull : grp;
       grp = take ? ((grp << 16) | rel) : grp;
       nl += take ? 1u : 0u;
-      // a complete group of four goes to the list: the words move up by one (f8_next does not care about their order;
-      // past 32 positions the oldest drop out, and the lane falls back anyway).  No branch and no indexed word: both
-      // cost this loop two dozen register copies per turn.
-      const bool full = take && (nl & 3u) == 0u;
-      li.q7 = full ? li.q6 : li.q7;
-      li.q6 = full ? li.q5 : li.q6;
-      li.q5 = full ? li.q4 : li.q5;
-      li.q4 = full ? li.q3 : li.q4;
-      li.q3 = full ? li.q2 : li.q3;
-      li.q2 = full ? li.q1 : li.q2;
-      li.q1 = full ? li.q0 : li.q1;
-      li.q0 = full ? grp : li.q0;
-      grp = full ? ~0ull : grp;
     }
   }
-  ok = ok && nl <= F8_LIST;
+  ok = ok && nl <= F8_LIST + 4u;
+  why |= nl <= F8_LIST + 4u ? 0u : 2u;
   T8STAMP(0);
-  // ---- (B) trajectories ----
-  SegTab t = {0, 0, 0, 0, 0, 0, 0, 0};
-  uint64_t pend = (1ull << 48) - 1ull;
-  while (__ballot(ok && pend != 0ull)) {
-    const bool run = ok && pend != 0ull;
-    uint32_t x = run ? (uint32_t)__builtin_ctzll(pend) : 0u;
-    uint64_t vis = 0;
-    uint32_t code = C_FAIL;
-    bool act = run;
-    while (__ballot(act)) {
-      const uint32_t nx = f8_next(li, grp, x);
-      if (act && x < 48u) {  // entry offsets this stretch of the trajectory passes: x, x+8, ... up to the listed position
-        const uint32_t top = min(nx + 1u, 48u);
-        vis |= (0x0101010101010101ull << x) & ((1ull << top) - 1ull);
-      }
-      const bool through = act && nx >= sl;  // nothing listed before the segment ends: 8-bit literals all the way
-      if (through) {
-        code = ((sl - x + 7u) & ~7u) - (sl - x);  // first token start at or past the end, minus the end
-        act = false;
-      }
-      if (__ballot(act)) {  // one token the generic way, at the listed position
-        LaneBits b;
-        lb_seek<true>(b, src, base + (act ? nx : 0u));
-        uint32_t adv;
-        bool eob, bad;
-        len_step(S, src, b, act, adv, eob, bad);
-        x = act ? (b.pos - base) + adv : x;  // (len_step leaves b behind a match's length part, adv = the rest)
-        if (act && eob) {
-          code = C_EOB;
-          act = false;
-        }
-        if (act && bad) {
-          code = C_FAIL;
-          act = false;
-        }
-        if (act && x >= sl) {
-          code = x - sl;
-          act = false;
+  // ---- (B) the fold ----
+  uint64_t E = 0;
+#pragma unroll
+  for (uint32_t f = 0; f < 8u; f++) E |= (uint64_t)((f - sl) & 7u) << (8u * f);
+  uint64_t E1 = E, E2 = E;
+  uint64_t T1 = E, T2 = E, T3 = E, T4 = E, T5 = E;  // table words 1..5: E when the fold has passed entry 8w
+  uint64_t cw = grp;  // the four positions in hand
+#pragma unroll 1
+  while (__ballot(cw != ~0ull)) {
+#pragma unroll
+    for (uint32_t sidx = 0; sidx < 4u; sidx++) {
+      const uint32_t q = (uint32_t)(cw >> (16u * sidx)) & 0xFFFFu;
+      const bool act = q != 0xFFFFu;
+      // the token at q: 64 bits from there on, bit lengths from the byte tables (the full tables behind a ballot)
+      const uint32_t ab = base + (act ? q : 0u);
+      const uint32_t di = ab >> 5, sh = ab & 31u;
+      const uint32_t w0 = src_ldw<true>(src, di), w1 = src_ldw<true>(src, di + 1u), w2 = src_ldw<true>(src, di + 2u);
+      const uint32_t b0 = __builtin_amdgcn_alignbit(w1, w0, sh), b1 = __builtin_amdgcn_alignbit(w2, w1, sh);
+      const uint32_t a = S.len_l[b0 & ((1u << PL_ROOT) - 1u)];
+      uint32_t n = a & 63u;
+      bool m = (a & 0x40u) != 0u, eob = false, bd2 = false;
+      const bool sp = (a & 0x80u) != 0u;
+      if (__ballot(act && sp)) {
+        const uint32_t e = lut_l_entry(S, b0);
+        const uint32_t kind = (e >> 8) & 3u;
+        if (sp) {
+          eob = kind == 1u;
+          bd2 = (kind == 3u) || ((e & 15u) == 0u);
+          n = (e & 15u) + ((e >> 4) & 15u);
+          m = kind == 2u;
         }
       }
+      if (__ballot(act && m)) {
+        const uint32_t tb = (uint32_t)(((((uint64_t)b1) << 32) | b0) >> (n & 31u));  // n <= 20
+        const uint32_t dd = S.len_d[tb & ((1u << PD_ROOT) - 1u)];
+        uint32_t n2 = dd & 63u;
+        const bool dsp = (dd & 0x80u) != 0u;
+        if (__ballot(act && m && dsp)) {
+          const uint32_t ed = lut_d_entry(S, tb);
+          if (dsp) {
+            bd2 = bd2 || (m && ((((ed >> 8) & 3u) != 2u) || (ed & 15u) == 0u));
+            n2 = (ed & 15u) + ((ed >> 4) & 15u);
+          }
+        }
+        n += m ? n2 : 0u;
+      }
+      const uint32_t x = q + n;  // where the token ends (1..48 bits on)
+      // listed positions it jumps over on the phase it lands on: x - 8, x - 16, .. above q.  Whether one is listed is
+      // the test of (A) on the 64 bits in hand: the bytes of the window from bit (n mod 8) on are the candidates
+      uint32_t nov = 0;
+      if (__ballot(act && n >= 9u)) {
+        const uint64_t y = ((((uint64_t)b1) << 32) | b0) >> (n & 7u);
+        const uint32_t r0 = __brev((uint32_t)y), r1 = __brev((uint32_t)(y >> 32));  // byte k of the window: top byte k of r0, r1
+        const uint32_t t0 = ((r0 | H) - LOm) ^ ((r0 ^ nLO) & H), t1 = ((r1 | H) - LOm) ^ ((r1 ^ nLO) & H);
+        const uint32_t i0 = t0 & ((t0 & ~H) + M) & H, i1 = t1 & ((t1 & ~H) + M) & H;
+        // candidates: bytes kmin..kmax, kmin = 1 when the window starts at q itself, kmax = n / 8 - 1
+        const uint32_t kmin = (n & 7u) ? 0u : 1u, kmax = (n >> 3) - 1u;  // (n >= 9 here: kmax >= 0; n <= 48: kmax <= 5)
+        const uint64_t im = (((uint64_t)i0) << 32) | i1;                 // byte k flagged at bit 63 - 8k
+        const uint64_t vm = (~0ull >> (8u * kmin)) & (~0ull << (56u - 8u * (kmax & 7u)));
+        nov = (n >= 9u) ? (uint32_t)__popcll(im & vm) : 0u;
+      }
+      const uint32_t fx = (x & 7u) * 8u;
+      uint64_t ev = nov == 0u ? E : E1;
+      ev = nov == 2u ? E2 : ev;
+      uint32_t code = x >= sl ? x - sl : ((uint32_t)(ev >> fx) & 0xffu);
+      code = bd2 ? C_FAIL : code;
+      code = eob ? C_EOB : code;
+      ok = ok && !(act && !eob && !bd2 && x < sl && nov >= 3u);
+      why |= (act && !eob && !bd2 && x < sl && nov >= 3u) ? 4u : 0u;
+      const uint32_t fq = (q & 7u) * 8u;
+      const uint64_t fm = act ? (0xffull << fq) : 0ull;
+      E2 = (E2 & ~fm) | (E1 & fm);
+      E1 = (E1 & ~fm) | (E & fm);
+      E = (E & ~fm) | (((uint64_t)code << fq) & fm);
+      T1 = (act && q >= 8u) ? E : T1;
+      T2 = (act && q >= 16u) ? E : T2;
+      T3 = (act && q >= 24u) ? E : T3;
+      T4 = (act && q >= 32u) ? E : T4;
+      T5 = (act && q >= 40u) ? E : T5;
     }
-    pend &= run ? ~vis : ~0ull;
-    while (__ballot(run && vis != 0ull)) {
-      const bool w = run && vis != 0ull;
-      const uint32_t e = w ? (uint32_t)__builtin_ctzll(vis) : 0u;
-      vis &= vis - 1ull;
-      if (w) tab_set(t, e, code);
+    cw = q0;
+    q0 = q1;
+    q1 = q2;
+    q2 = q3;
+    q3 = q4;
+    q4 = q5;
+    q5 = q6;
+    q6 = q7;
+    q7 = ~0ull;
+  }
+  T8STAMP(1);
+  tab.a = E;
+  tab.b = T1;
+  tab.c = T2;
+  tab.d = T3;
+  tab.e = T4;
+  tab.f = T5;
+  tab.g = 0;
+  tab.h = 0;
+  T8STAMP(2);
+  if (dp) {
+    const uint64_t w1 = __ballot((why & 3u) != 0u), w4 = __ballot((why & 4u) != 0u), w8 = 0;
+    if (zes_lane() == 0) {
+      if (w1) atomicAdd(&dp[29], (unsigned long long)__popcll(w1));
+      if (w4) atomicAdd(&dp[30], (unsigned long long)__popcll(w4));
+      if (w8) atomicAdd(&dp[31], (unsigned long long)__popcll(w8));
     }
   }
-  tab = t;
-  T8STAMP(1);
-  T8STAMP(2);
 #undef T8STAMP
   return ok;
 }
@@ -1112,15 +1198,11 @@ __device__ __forceinline__ static bool par_header(ParSmem& S, const BitSrc& src,
   b.pos = wbase + off;
   HSTAMP(2);
   if (b.pos > limit) return false;
-  if (!par_build(S, 0, 288, PL_ROOT, false, S.lut_l, S.syms_l, S.first_l, S.cnt_l, S.offs_l)) return false;
-  HSTAMP(3);
-  if (!par_build(S, 288, 32, PD_ROOT, true, S.lut_d, S.syms_d, S.first_d, S.cnt_d, S.offs_d)) return false;
-  HSTAMP(4);
   if (lane == 0) {
     S.hdr_end = b.pos;
     S.bfinal = bfinal;
   }
-  return true;
+  return true;  // the tables: par_build, by two waves side by side (the caller)
 }
 
 // What a work item is and where its results go.  T1 (k_inf_block_par): candidate ci of a reference-made stream, output
@@ -1218,11 +1300,22 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
       for (uint32_t k = tid; k < src.s_count; k += PAR_THREADS) st[k ^ ((k >> 5) & 31u)] = src.g32[src.s_first + k];
     }
     __syncthreads();
+    unsigned long long* hdbg = dbg ? dbg + (size_t)blockIdx.x * ZES_PAR_DBG_ROW : nullptr;
     if (wave == 0 && use_lds) {
-      const bool ok = par_header<true>(S, src, plimit, start, dbg ? dbg + (size_t)blockIdx.x * ZES_PAR_DBG_ROW : nullptr);
+      const bool ok = par_header<true>(S, src, plimit, start, hdbg);
       if (!ok && lane == 0) S.status = 1;
     }
     __syncthreads();
+    if (S.status) return 1u;
+    // the two alphabets' tables side by side: lit/len by wave 0, distances by wave 1
+    if (wave == 0) {
+      if (!par_build(S, 0, 288, PL_ROOT, false, S.lut_l, S.syms_l, S.first_l, S.cnt_l, S.offs_l) && lane == 0) atomicOr(&S.status, 1u);
+      HSTAMP(3);
+    } else if (wave == 1) {
+      if (!par_build(S, 288, 32, PD_ROOT, true, S.lut_d, S.syms_d, S.first_d, S.cnt_d, S.offs_d) && lane == 0) atomicOr(&S.status, 1u);
+    }
+    __syncthreads();
+    if (wave == 0) HSTAMP(4);
     if (S.status) return 1u;
     STAMP(1);
     ds = S.hdr_end;
