@@ -644,6 +644,98 @@ __device__ __forceinline__ static bool seg_table_f8(ParSmem& S, const BitSrc& sr
   return ok;
 }
 
+// ------------------------------------------------------------------------------------------
+// Transfer table of a segment of compressible data, when there is room behind the staged block (round 3): the
+// exit code of EVERY bit position, last position first.  code[p] = where the token that starts at p ends, if that is
+// behind the segment (or end-of-block / fail), else code[p + its length] — a position the sweep has been at.  One
+// token-LENGTH decode per position (two byte lookups: 13-bit and 12-bit tables built for this sweep, so that codes
+// longer than the root tables' 10 / 9 bits, which garbage positions hit all the time, stay off the slow path), one
+// byte read and one byte write of the lane's 64-byte ring in LDS; the ring's first 48 bytes are the segment's table
+// when the sweep arrives at position 0.  ~35 instructions per bit position, every lane the same number of steps —
+// the window-and-trajectory construction below decodes fewer positions (~100 + 7 chains x 25 tokens per segment of
+// text) but at the pace of the slowest lane of each step: ~120 instructions per bit position on the text workload.
+// ------------------------------------------------------------------------------------------
+#define DP_ROW 68u          // bytes per lane: 64 ring entries, 17 dwords apart (odd: the lanes' slots fall into different banks)
+#define DP_LROOT 13u
+#define DP_DROOT 12u
+#define DP_BYTES (PAR_THREADS * DP_ROW + (1u << DP_LROOT) + (1u << DP_DROOT))
+
+// the two byte tables (all threads): what len_l / len_d hold, for DP_LROOT / DP_DROOT bits of lookahead
+__device__ __forceinline__ static void dp_build(ParSmem& S, uint8_t* T13, uint8_t* D12) {
+  for (uint32_t i = threadIdx.x; i < (1u << DP_LROOT); i += PAR_THREADS) {
+    uint32_t a = S.len_l[i & ((1u << PL_ROOT) - 1u)];
+    if (a == 0x80u) {
+      const uint32_t e = lut_l_entry(S, i);
+      const uint32_t len = e & 15u, kind = (e >> 8) & 3u, bl = len + ((e >> 4) & 15u);
+      a = (len == 0u || len > DP_LROOT) ? 0x80u : (kind == 0u) ? bl : (kind == 2u) ? (bl | 0x40u) : 0x80u;
+    }
+    T13[i] = (uint8_t)a;
+  }
+  for (uint32_t i = threadIdx.x; i < (1u << DP_DROOT); i += PAR_THREADS) {
+    uint32_t a = S.len_d[i & ((1u << PD_ROOT) - 1u)];
+    if (a == 0x80u) {
+      const uint32_t e = lut_d_entry(S, i);
+      const uint32_t len = e & 15u, kind = (e >> 8) & 3u, bl = len + ((e >> 4) & 15u);
+      a = (len == 0u || len > DP_DROOT || kind != 2u) ? 0x80u : bl;
+    }
+    D12[i] = (uint8_t)a;
+  }
+}
+
+// (segments of the sweep start on dword boundaries and are a multiple of 32 bits long: every lane is at the same bit of
+// its dword and the same ring slot, so positions need no per-lane bookkeeping)
+__device__ __forceinline__ static void seg_table_dp(ParSmem& S, const BitSrc& src, uint32_t limit, uint32_t base, uint32_t seglen,
+                                                    const uint8_t* T13, const uint8_t* D12, uint8_t* row) {
+  const uint32_t d0 = base >> 5;
+  const uint32_t nd = seglen >> 5;
+  const uint32_t room = limit > base ? limit - base : 0u;  // bits of data from base on
+  // (uniform) some lane's segment ends within 64 bits of the data's end, or behind it: tokens are checked against it
+  const bool near = __ballot((uint64_t)base + seglen + 64u > (uint64_t)limit) != 0ull;
+  uint32_t mid = src_ldw<true>(src, d0 + nd), hi = src_ldw<true>(src, d0 + nd + 1u);
+#pragma unroll 1
+  for (uint32_t j = nd; j-- > 0u;) {
+    const uint32_t lo = src_ldw<true>(src, d0 + j);
+#pragma unroll 2
+    for (uint32_t bb = 32u; bb-- > 0u;) {
+      const uint32_t p = 32u * j + bb;
+      const uint32_t w32 = __builtin_amdgcn_alignbit(mid, lo, bb), wh = __builtin_amdgcn_alignbit(hi, mid, bb);
+      const uint32_t a = T13[w32 & ((1u << DP_LROOT) - 1u)];
+      uint32_t n = a & 63u, ovr = 0;
+      bool m = (a & 0x40u) != 0u;
+      const bool sp = (a & 0x80u) != 0u;
+      if (__ballot(sp)) {  // end of block, a code longer than 13 bits, no code
+        const uint32_t e = lut_l_entry(S, w32);
+        const uint32_t kind = (e >> 8) & 3u;
+        if (sp) {
+          ovr = (kind == 1u) ? C_EOB : ((kind == 3u) || ((e & 15u) == 0u)) ? C_FAIL : 0u;
+          n = (e & 15u) + ((e >> 4) & 15u);
+          m = kind == 2u;
+        }
+      }
+      const uint32_t t = (uint32_t)(((((uint64_t)wh) << 32) | w32) >> (n & 31u));  // n <= 20
+      const uint32_t dd = D12[t & ((1u << DP_DROOT) - 1u)];
+      uint32_t n2 = dd & 63u;
+      const bool dsp = m && (dd & 0x80u) != 0u;
+      if (__ballot(dsp)) {
+        const uint32_t ed = lut_d_entry(S, t);
+        if (dsp) {
+          ovr = ((((ed >> 8) & 3u) != 2u) || (ed & 15u) == 0u) ? C_FAIL : ovr;
+          n2 = (ed & 15u) + ((ed >> 4) & 15u);
+        }
+      }
+      n += m ? n2 : 0u;
+      const uint32_t x = p + n;  // 1..48 bits on
+      const uint32_t r = row[x & 63u];
+      uint32_t code = x < seglen ? r : x - seglen;
+      code = ovr ? ovr : code;
+      if (near) code = x > room ? C_FAIL : code;  // the token runs past the data
+      row[p & 63u] = (uint8_t)code;
+    }
+    hi = mid;
+    mid = lo;
+  }
+}
+
 template <bool LDS, bool TWO>
 __device__ __forceinline__ static void seg_table(ParSmem& S, const BitSrc& src, uint32_t limit, uint32_t base, uint32_t stop,
                                                  const Lit8& f8, SegTab& tab, unsigned long long* dp) {
@@ -1271,7 +1363,7 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
   src.lastdw = lastdw;
   src.s32 = reinterpret_cast<const uint32_t*>(S.out);
   src.s_first = start >> 5;
-  uint32_t ds = 0, seglen = 0, base = 0, stop = 0, ecode = 0, tail_code = 0;
+  uint32_t ds = 0, seg0 = 0, seglen = 0, base = 0, stop = 0, ecode = 0, tail_code = 0;  // (seg0: first bit of segment 0)
   uint32_t plimit = limit;  // end of what the phases that read the staged copy may look at: the data's end, or the staged copy's
   Lit8 f8 = {0, 0, 0};
   STAMP(0);
@@ -1322,23 +1414,46 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
     f8.lo = S.f8lo;
     f8.n = S.f8n;
     f8.off = S.f8off;
-    const uint32_t span = de_est > ds ? de_est - ds : 1u;
-    seglen = max(64u, (span + PAR_THREADS - 1) / PAR_THREADS);
+    const uint32_t tab_off = ((src.s_count + 31u) & ~31u) * 4u;  // the swizzle permutes inside rows of 32 dwords
+    {
+      const uint32_t span = de_est > ds ? de_est - ds : 1u;
+      seglen = max(64u, (span + PAR_THREADS - 1) / PAR_THREADS);
+    }
+    // compressible data with room behind the staged block: every bit position's exit code, last first (seg_table_dp);
+    // its segments are whole dwords, so segment 0 starts up to 31 bits in front of the header's end
+    const bool dp = TWO && tab_off + DP_BYTES <= STAGE_DW * 4u && !(f8.n && seglen >= 256u);  // (uniform)
+    seg0 = ds;
+    if (dp) {
+      seg0 = ds & ~31u;
+      const uint32_t span = de_est > seg0 ? de_est - seg0 : 1u;
+      seglen = (max(64u, (span + PAR_THREADS - 1) / PAR_THREADS) + 31u) & ~31u;
+    }
 
     // ---- P1: transfer tables in registers, then composition by lane broadcasts ----
-    const uint64_t b_me64 = (uint64_t)ds + (uint64_t)tid * seglen;
+    const uint64_t b_me64 = (uint64_t)seg0 + (uint64_t)tid * seglen;
     base = (uint32_t)(b_me64 < 0xFFFFFF00ull ? b_me64 : 0xFFFFFF00ull);
     stop = (uint32_t)((b_me64 + seglen) < 0xFFFFFF00ull ? (b_me64 + seglen) : 0xFFFFFF00ull);
     SegTab tab = {0, 0, 0, 0, 0, 0, 0, 0};
-    seg_table<true, TWO>(S, src, plimit, base, stop, f8, tab, dbg ? dbg + (size_t)blockIdx.x * ZES_PAR_DBG_ROW : nullptr);
+    if (dp) {
+      uint8_t* T13 = S.out + tab_off + PAR_THREADS * DP_ROW;
+      uint8_t* D12 = T13 + (1u << DP_LROOT);
+      dp_build(S, T13, D12);
+      __syncthreads();
+      seg_table_dp(S, src, plimit, base, seglen, T13, D12, S.out + tab_off + tid * DP_ROW);
+    } else {
+      seg_table<true, TWO>(S, src, plimit, base, stop, f8, tab, dbg ? dbg + (size_t)blockIdx.x * ZES_PAR_DBG_ROW : nullptr);
+    }
     STAMP(2);
     // Composition.  With room behind the staged block (compressible data: the block's bytes fill a third of the
-    // staging area) every lane parks its table in LDS, 52 bytes apart, and a step of the walks below is one byte
-    // read; otherwise (incompressible data) the tables stay in registers and a step broadcasts a lane's table.
-    const uint32_t tab_off = ((src.s_count + 31u) & ~31u) * 4u;  // the swizzle permutes inside rows of 32 dwords
-    const bool lds_tabs = tab_off + PAR_THREADS * 52u <= STAGE_DW * 4u;  // uniform
-    const uint8_t* tb = S.out + tab_off + wave * 64u * 52u;  // this wave's 64 tables
-    if (lds_tabs) {
+    // staging area) every lane parks its table in LDS, 52 bytes apart (the sweep's tables are there already, 68 apart),
+    // and a step of the walks below is one byte read; otherwise (incompressible data) the tables stay in registers and
+    // a step broadcasts a lane's table.
+    const bool lds_tabs = dp || tab_off + PAR_THREADS * 52u <= STAGE_DW * 4u;  // uniform
+    const uint32_t tstride = dp ? DP_ROW : 52u;
+    const uint8_t* tb = S.out + tab_off + wave * 64u * tstride;  // this wave's 64 tables
+    if (dp) {
+      __syncthreads();
+    } else if (lds_tabs) {
       uint32_t* tw = reinterpret_cast<uint32_t*>(S.out + tab_off) + tid * 13u;
       tw[0] = (uint32_t)tab.a;
       tw[1] = (uint32_t)(tab.a >> 32);
@@ -1359,7 +1474,7 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
       uint32_t cur = lane;
       if (lds_tabs) {
         for (uint32_t sgm = 0; sgm < 64u; sgm++) {
-          const uint32_t v = tb[sgm * 52u + (cur < 48u ? cur : 0u)];
+          const uint32_t v = tb[sgm * tstride + (cur < 48u ? cur : 0u)];
           cur = cur < 48u ? v : cur;  // (end of block / fail stay what they are)
         }
       } else {
@@ -1372,7 +1487,7 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
     }
     __syncthreads();
     if (tid == 0) {
-      uint32_t e = 0;  // segment 0 starts exactly at the header end
+      uint32_t e = ds - seg0;  // the first token starts at the header's end
       for (uint32_t k = 0; k < PAR_WAVES; k++) {
         S.wentry[k] = (uint8_t)e;
         if (e < 48u) e = S.wtab[k][e];
@@ -1386,7 +1501,7 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
     if (lds_tabs) {
       for (uint32_t sgm = 0; sgm < 64u; sgm++) {
         if (lane == sgm) mine = e;
-        if (e < 48u) e = (uint32_t)__builtin_amdgcn_readfirstlane((int)tb[sgm * 52u + e]);
+        if (e < 48u) e = (uint32_t)__builtin_amdgcn_readfirstlane((int)tb[sgm * tstride + e]);
       }
     } else {
       // every lane looks the (uniform) entry up in its own table and the owning lane's answer is broadcast
@@ -1435,7 +1550,7 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
   // candidate sits inside this block) is finished serially by one lane, from global memory
   uint32_t tail_start = 0;
   if (tail_code < 48u) {
-    const uint64_t last_stop = (uint64_t)ds + (uint64_t)PAR_THREADS * seglen;
+    const uint64_t last_stop = (uint64_t)seg0 + (uint64_t)PAR_THREADS * seglen;
     tail_start = (uint32_t)(last_stop + tail_code);
     if (tid == 0) {
       uint32_t ex, ob, fl;
