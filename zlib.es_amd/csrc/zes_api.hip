@@ -933,11 +933,8 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
     HIPCHK(hipMemsetAsync(g.dbg.p, 0, (size_t)work * ZES_PAR_DBG_ROW * 8, g.stream));
     dbg = (unsigned long long*)g.dbg.p;
   }
-  {
-    Timed t("k_inf_ranksort");
-    hipLaunchKernelGGL(k_inf_ranksort, dim3(nbuf), dim3(nbuf == 1 ? 1024 : 256), 0, g.stream, dbufs, (const uint32_t*)cnt, (const uint32_t*)g.cand.p,
-                       (uint32_t*)g.cand_sorted.p, 0xFFFFFFFFu);
-  }
+  // (the candidates are ranked by the block decoder itself: every work item finds its own rank and the two candidates
+  // behind it in the unsorted list, and leaves the sorted list for the chain check)
   {
     // compressible data (the streams are shorter than 0.7 of the room for their outputs): the variant whose transfer
     // tables look at two windows; incompressible data runs ~4 % faster in the smaller kernel
@@ -947,7 +944,8 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
     Timed t(two ? "k_inf_block_par2" : "k_inf_block_par");
     auto kern = two ? k_inf_block_par2 : k_inf_block_par;
     hipLaunchKernelGGL(kern, dim3((uint32_t)work), dim3(PAR_THREADS), 0, g.stream, d_in, d_out, dbufs, nbuf,
-                       (const uint32_t*)cnt, (const uint32_t*)g.cand_sorted.p, (const uint32_t*)nullptr, (ZesCandRes*)g.cres.p, dbg, (const uint32_t*)nullptr);
+                       (const uint32_t*)cnt, (const uint32_t*)g.cand_sorted.p, (const uint32_t*)nullptr, (ZesCandRes*)g.cres.p, dbg, (const uint32_t*)nullptr,
+                       (const uint32_t*)g.cand.p, (uint32_t*)g.cand_sorted.p);
   }
   {
     Timed t("k_inf_chain");
@@ -1082,7 +1080,8 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
         // cnt / candidates / map / results are indexed from this buffer's region: the table's cand_base does that
         hipLaunchKernelGGL(k_inf_block_par, dim3(nre), dim3(PAR_THREADS), 0, g.stream, d_in, d_out, (const ZesInfBuf*)g.ibufs2.p, 1u,
                            (const uint32_t*)cnt + i, (const uint32_t*)g.cand_sorted.p, (const uint32_t*)g.map.p,
-                           (ZesCandRes*)g.cres.p, (unsigned long long*)nullptr, (const uint32_t*)(dl + 3 * (size_t)nmv));
+                           (ZesCandRes*)g.cres.p, (unsigned long long*)nullptr, (const uint32_t*)(dl + 3 * (size_t)nmv), (const uint32_t*)nullptr,
+                           (uint32_t*)nullptr);
       }
       std::vector<ZesCandRes> hcr(nre);
       for (uint32_t q = 0; q < nre; q++)
@@ -1177,13 +1176,10 @@ int inflate_t1_range(const uint8_t* d_in, uint64_t in_off, uint64_t c, uint64_t 
   hb[1].work_first = ncand;
   HIPCHK(hipMemcpyAsync(g.ibufs.p, hb, sizeof(ZesInfBuf) * 2, hipMemcpyHostToDevice, g.stream));
   {
-    Timed t("k_inf_ranksort");
-    hipLaunchKernelGGL(k_inf_ranksort, dim3(1), dim3(1024), 0, g.stream, dbufs, (const uint32_t*)cnt, (const uint32_t*)g.cand.p, (uint32_t*)g.cand_sorted.p, 0xFFFFFFFFu);
-  }
-  {
     Timed t("k_inf_block_par");
     hipLaunchKernelGGL((c * 10 < cap * 7) ? k_inf_block_par2 : k_inf_block_par, dim3(ncand), dim3(PAR_THREADS), 0, g.stream, d_in, d_out, dbufs, 1u, (const uint32_t*)cnt,
-                       (const uint32_t*)g.cand_sorted.p, (const uint32_t*)nullptr, (ZesCandRes*)g.cres.p, (unsigned long long*)nullptr, (const uint32_t*)nullptr);
+                       (const uint32_t*)g.cand_sorted.p, (const uint32_t*)nullptr, (ZesCandRes*)g.cres.p, (unsigned long long*)nullptr, (const uint32_t*)nullptr,
+                       (const uint32_t*)g.cand.p, (uint32_t*)g.cand_sorted.p);
   }
   {
     Timed t("k_inf_chain");

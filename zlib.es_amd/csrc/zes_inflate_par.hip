@@ -2021,7 +2021,8 @@ __device__ __forceinline__ static void block_par_t1(ParSmem& S, const uint8_t* _
                                                     const ZesInfBuf* __restrict__ bufs, uint32_t nbuf, const uint32_t* __restrict__ cnt,
                                                     const uint32_t* __restrict__ cand_all, const uint32_t* __restrict__ map_all,
                                                     ZesCandRes* __restrict__ cres_all, unsigned long long* __restrict__ dbg,
-                                                    const uint32_t* __restrict__ redo) {
+                                                    const uint32_t* __restrict__ redo, const uint32_t* __restrict__ raw_all,
+                                                    uint32_t* __restrict__ sorted_all) {
   // buffer of this work item: the last entry whose first work item is <= blockIdx.x
   uint32_t bi = 0;
   {
@@ -2033,7 +2034,7 @@ __device__ __forceinline__ static void block_par_t1(ParSmem& S, const uint8_t* _
     bi = lo;
   }
   // work item inside the buffer = output slot (a one-buffer launch may name the slots to decode again: redo[])
-  const uint32_t w = redo ? redo[blockIdx.x] : blockIdx.x - bufs[bi].work_first;
+  uint32_t w = redo ? redo[blockIdx.x] : blockIdx.x - bufs[bi].work_first;
   const uint32_t ncand = min(cnt[bi], bufs[bi].cand_cap);
   uint32_t nwork = bufs[bi + 1].work_first - bufs[bi].work_first;
   if (bufs[nbuf].work_first == ZES_WORK_AUTO) {  // one buffer, launched before the host saw the candidate count
@@ -2042,19 +2043,70 @@ __device__ __forceinline__ static void block_par_t1(ParSmem& S, const uint8_t* _
   }
   const uint32_t* cand = cand_all + bufs[bi].cand_base;
   const uint32_t* map = map_all ? map_all + bufs[bi].cand_base : nullptr;
+  // First launch over a group (raw_all): the candidate list is still in the order the verify kernels found it.  Work
+  // item x takes list entry x, ranks it — its rank is its block's number, hence its output slot — and looks up the two
+  // candidates behind it (the end estimates): a pass over a list of a few hundred positions per workgroup instead of a
+  // sorting kernel of one workgroup in front of this one (17 us + a launch boundary per call).  The sorted list, which
+  // the chain check and the repair paths read, is written on the way.
+  uint32_t w_rank = 0, raw_next = 0xFFFFFFFFu, raw_next2 = 0xFFFFFFFFu, raw_min = 0, raw_mine = 0;
+  const bool ranked = raw_all && !map_all && !redo;
+  if (ranked) {
+    const uint32_t* raw = raw_all + bufs[bi].cand_base;
+    const uint32_t x = blockIdx.x - bufs[bi].work_first;
+    if (x >= ncand) return;
+    const uint32_t u = raw[x];
+    if (threadIdx.x == 0) {
+      S.wave_sum[0] = 0;
+      S.wave_sum[1] = 0xFFFFFFFFu;
+      S.wave_sum[2] = 0xFFFFFFFFu;
+      S.wave_sum[3] = 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    uint32_t less = 0, nx = 0xFFFFFFFFu, mn = 0xFFFFFFFFu;
+    for (uint32_t j = threadIdx.x; j < ncand; j += PAR_THREADS) {
+      const uint32_t v = raw[j];
+      less += (v < u || (v == u && j < x)) ? 1u : 0u;
+      nx = (v > u && v < nx) ? v : nx;
+      mn = min(mn, v);
+    }
+    if (less) atomicAdd(&S.wave_sum[0], less);
+    if (nx != 0xFFFFFFFFu) atomicMin(&S.wave_sum[1], nx);
+    atomicMin(&S.wave_sum[3], mn);
+    __syncthreads();
+    raw_next = S.wave_sum[1];
+    uint32_t nx2 = 0xFFFFFFFFu;
+    for (uint32_t j = threadIdx.x; j < ncand; j += PAR_THREADS) {
+      const uint32_t v = raw[j];
+      nx2 = (v > raw_next && v < nx2) ? v : nx2;
+    }
+    if (raw_next != 0xFFFFFFFFu && nx2 != 0xFFFFFFFFu) atomicMin(&S.wave_sum[2], nx2);
+    __syncthreads();
+    w_rank = S.wave_sum[0];
+    raw_next2 = S.wave_sum[2];
+    raw_min = S.wave_sum[3];
+    raw_mine = u;
+    if (threadIdx.x == 0) sorted_all[bufs[bi].cand_base + w_rank] = u;
+    __syncthreads();  // (the words are used again further down)
+  }
   // the first block of a reference-made stream starts at bit 16 and passes the candidate rules: if the sorted
   // list does not begin there, k_inf_chain rejects the buffer whatever is decoded here (another encoder's stream)
-  if (!map_all && !redo && ((cand[0] != bufs[bi].start_rel && !(bufs[bi].range_flags & ZES_START_ANY)) || cnt[bi] > bufs[bi].cand_cap)) return;  // (or more candidates than the output has blocks)
+  if (!map_all && !redo && (((ranked ? raw_min : cand[0]) != bufs[bi].start_rel && !(bufs[bi].range_flags & ZES_START_ANY)) || cnt[bi] > bufs[bi].cand_cap)) return;  // (or more candidates than the output has blocks)
   const uint64_t c = bufs[bi].c;
+  if (ranked) w = w_rank;
   const uint32_t ci = map ? map[w] : w;
   ParItem it;
   it.g32 = reinterpret_cast<const uint32_t*>(d_in + bufs[bi].in_off);
   it.lastdw = (uint32_t)((c - 1) >> 2);
   it.limit = (uint32_t)(c * 8);
-  it.start = cand[ci] + 16u;
+  it.start = (ranked ? raw_mine : cand[ci]) + 16u;
   it.de_est = it.limit;
   it.de_est2 = 0;
-  if (map) {
+  if (ranked) {
+    if (raw_next != 0xFFFFFFFFu) {
+      it.de_est = raw_next + 16u;
+      it.de_est2 = raw_next2 != 0xFFFFFFFFu ? raw_next2 + 16u : it.limit;
+    }
+  } else if (map) {
     if (w + 1 < nwork) it.de_est = cand[map[w + 1]] + 16u;
   } else if (ci + 1u < ncand) {
     it.de_est = cand[ci + 1u] + 16u;
@@ -2083,18 +2135,20 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __
                                                                const ZesInfBuf* __restrict__ bufs, uint32_t nbuf,
                                                                const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ cand_all,
                                                                const uint32_t* __restrict__ map_all, ZesCandRes* __restrict__ cres_all,
-                                                               unsigned long long* __restrict__ dbg, const uint32_t* __restrict__ redo) {
+                                                               unsigned long long* __restrict__ dbg, const uint32_t* __restrict__ redo,
+                                                               const uint32_t* __restrict__ raw_all, uint32_t* __restrict__ sorted_all) {
   __shared__ __align__(16) ParSmem S;
-  block_par_t1<false>(S, d_in, d_out, bufs, nbuf, cnt, cand_all, map_all, cres_all, dbg, redo);
+  block_par_t1<false>(S, d_in, d_out, bufs, nbuf, cnt, cand_all, map_all, cres_all, dbg, redo, raw_all, sorted_all);
 }
 // the same for compressible data (the launch's streams are shorter than 0.7 of their outputs' capacity)
 __global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par2(const uint8_t* __restrict__ d_in, uint8_t* __restrict__ d_out,
                                                                 const ZesInfBuf* __restrict__ bufs, uint32_t nbuf,
                                                                 const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ cand_all,
                                                                 const uint32_t* __restrict__ map_all, ZesCandRes* __restrict__ cres_all,
-                                                                unsigned long long* __restrict__ dbg, const uint32_t* __restrict__ redo) {
+                                                                unsigned long long* __restrict__ dbg, const uint32_t* __restrict__ redo,
+                                                                const uint32_t* __restrict__ raw_all, uint32_t* __restrict__ sorted_all) {
   __shared__ __align__(16) ParSmem S;
-  block_par_t1<true>(S, d_in, d_out, bufs, nbuf, cnt, cand_all, map_all, cres_all, dbg, redo);
+  block_par_t1<true>(S, d_in, d_out, bufs, nbuf, cnt, cand_all, map_all, cres_all, dbg, redo, raw_all, sorted_all);
 }
 
 // T2: one workgroup per block of another encoder's stream (work items as in k_inf_seg_scan: a buffer's item 0 starts at

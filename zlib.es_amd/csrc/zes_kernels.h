@@ -113,9 +113,9 @@ __global__ void k_inf_seg_win_fin(const uint32_t*, const ZesSegJob*, const uint8
 __global__ void k_inf_seg_decode(const uint8_t*, uint64_t, uint64_t, uint8_t*, uint64_t, uint64_t, const uint32_t*, const ZesSegRes*,
                                  const uint32_t*, const uint64_t*, const uint8_t*, uint32_t*, uint32_t);
 __global__ void k_inf_block_par(const uint8_t*, uint8_t*, const ZesInfBuf*, uint32_t, const uint32_t*, const uint32_t*, const uint32_t*,
-                                ZesCandRes*, unsigned long long*, const uint32_t*);
+                                ZesCandRes*, unsigned long long*, const uint32_t*, const uint32_t*, uint32_t*);
 __global__ void k_inf_block_par2(const uint8_t*, uint8_t*, const ZesInfBuf*, uint32_t, const uint32_t*, const uint32_t*, const uint32_t*,
-                                ZesCandRes*, unsigned long long*, const uint32_t*);
+                                ZesCandRes*, unsigned long long*, const uint32_t*, const uint32_t*, uint32_t*);
 __global__ void k_inf_move_slots(uint8_t*, const uint8_t*, const uint32_t*, const uint32_t*, uint32_t);
 __global__ void k_inf_chain(const ZesInfBuf*, const uint32_t*, const uint32_t*, const ZesCandRes*, const uint32_t*, uint32_t*, ZesRes*);
 __global__ void k_inf_chain_range(const ZesInfBuf*, const uint32_t*, const uint32_t*, const ZesCandRes*, ZesRes*);
