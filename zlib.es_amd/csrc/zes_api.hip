@@ -47,7 +47,7 @@ struct Ctx {
   // deflate scratch
   DevBuf bufs, blks, idx_a, idx_b, inv, sdelta, tmask, mlist, hists, codes, hdrs, adler, res, order;
   // inflate scratch
-  DevBuf surv, vlong, segfail, symoff, cand, cand_sorted, counters, cres, map, resume, dbg, ibufs, ibufs2, mvlist, scratch, sres, maps, seglist, segprefix, wins, sym16, segorder, segjobs, pw16, gwins;
+  DevBuf surv, vlong, segfail, symoff, cand, cand_sorted, counters, cres, map, resume, dbg, ibufs, ibufs2, mvlist, scratch, sres, maps, seglist, segprefix, wins, sym16, segorder, segjobs, pw16, gwins, seglive, segouts;
   // staging for the host-pointer API
   DevBuf st_in, st_out;
   DevBuf kraft;  // k_inf_scan's table: Kraft contribution of four 3-bit code-length fields at once
@@ -1266,9 +1266,7 @@ int inflate_segments_run(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, cons
   uint32_t* novf_d = dscratch;
   uint32_t* fail_d = dscratch + nb;
   const uint32_t* cs = (const uint32_t*)g.cand_sorted.p;
-  for (uint32_t k = 0; k < nb; k++)
-    hipLaunchKernelGGL(k_inf_seg_order, dim3(1), dim3(1024), 0, g.stream, cs + cbase[k], ncand[k], jobs[ids[k]].c,
-                       (uint32_t*)g.segorder.p + hj[k].work_first);
+  hipLaunchKernelGGL(k_inf_seg_order, dim3(nb), dim3(1024), 0, g.stream, (const ZesSegJob*)g.segjobs.p, cs, (uint32_t*)g.segorder.p);
   // The decoders run with the short marker ring first (three per CU instead of two); a match that reaches behind the
   // ring takes its symbols from the symbol store, so a segment that has outgrown its share of the store and then meets
   // such a match cannot go on: far_d counts those, and the whole group runs again with the full ring (rare: streams
@@ -1311,11 +1309,9 @@ int inflate_segments_run(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, cons
   auto run_chains = [&]() -> int {
     HIPCHK(hipMemsetAsync(novf_d, 0, (size_t)nb * 4, g.stream));
     {
-      Timed t("k_inf_seg_chain");
-      for (uint32_t k = 0; k < nb; k++)
-        hipLaunchKernelGGL(k_inf_seg_chain, dim3(1), dim3(256), 0, g.stream, (const ZesSegRes*)g.sres.p + hj[k].work_first, ncand[k] + 1,
-                           (uint32_t*)g.seglist.p + hj[k].work_first, (uint64_t*)g.segprefix.p + hj[k].work_first, (ZesRes*)g.res.p + k,
-                           novf_d + k);
+      Timed t("k_inf_seg_chain");  // (one launch: a workgroup per buffer of the group)
+      hipLaunchKernelGGL(k_inf_seg_chain, dim3(nb), dim3(256), 0, g.stream, (const ZesSegJob*)g.segjobs.p, (const ZesSegRes*)g.sres.p,
+                         (uint32_t*)g.seglist.p, (uint64_t*)g.segprefix.p, (ZesRes*)g.res.p, novf_d);
     }
     HIPCHK(hipMemcpyAsync(hs, novf_d, (size_t)nb * 4, hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipMemcpyAsync(hres, g.res.p, sizeof(ZesRes) * nb, hipMemcpyDeviceToHost, g.stream));
@@ -1334,9 +1330,44 @@ int inflate_segments_run(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, cons
     chained = true;
     const uint32_t ndecl = hs[nb];
     if (getenv("ZES_DEBUG")) fprintf(stderr, "zes T2: %u work items, %u declined by the block decoder\n", work, ndecl);
-    if (ndecl)
+    // Chains that stand in front of an undecoded item: exactly those items go to the wave decoder (a zlib stream's
+    // last block is often a fixed one: one small item per stream, where the declined list of 256 streams of 1 MiB also
+    // held ~200 false candidates that cost the lone waves 6.8 ms), and the chains are followed again; a few rounds,
+    // then — streams with many stored or fixed blocks — everything that was declined.
+    std::vector<uint32_t> last_stuck(nb, 0xFFFFFFFFu);
+    for (int round = 0; ndecl && round < 4; round++) {
+      std::vector<uint32_t> items;
+      for (uint32_t k = 0; k < nb; k++) {
+        if (hres[k].status == 0 || hres[k].out_len == 0) continue;
+        const uint32_t w = (uint32_t)(hres[k].out_len - 1);
+        if (w == last_stuck[k]) continue;  // it has been to the wave decoder: the stream is not for this tier
+        last_stuck[k] = w;
+        items.push_back(hj[k].work_first + w);
+      }
+      if (items.empty()) break;
+      if ((rc = ensure(g.seglive, ((size_t)nb + 1) * 4))) return rc;
+      uint32_t* hl = (uint32_t*)((uint8_t*)g.pinned + 768 * 1024);  // (upload area, behind the job table)
+      hl[0] = (uint32_t)items.size();
+      memcpy(hl + 1, items.data(), items.size() * 4);
+      HIPCHK(hipMemcpyAsync(g.seglive.p, hl, (items.size() + 1) * 4, hipMemcpyHostToDevice, g.stream));
+      {
+        Timed t("k_inf_seg_scan");
+        hipLaunchKernelGGL(k_inf_seg_scan_short, dim3((uint32_t)items.size()), dim3(64), 0, g.stream, d_in, (const ZesSegJob*)g.segjobs.p, nb, cs,
+                           (ZesSegRes*)g.sres.p, (uint32_t*)g.maps.p, (uint32_t*)g.sym16.p, ratio, (const uint32_t*)g.seglive.p + 1, far_d,
+                           (const uint32_t*)g.seglive.p, (uint64_t*)g.symoff.p);
+      }
+      uint32_t* hf = (uint32_t*)((uint8_t*)g.pinned + 192 * 1024);
+      HIPCHK(hipMemcpyAsync(hf, far_d, 4, hipMemcpyDeviceToHost, g.stream));
+      if ((rc = run_chains())) return rc;
+      if (hf[0] != 0) {  // a far match behind the short ring: the full-ring pass below decides
+        chained = false;
+        break;
+      }
+    }
+    if (chained && ndecl)
       for (uint32_t k = 0; k < nb; k++)
-        if (hres[k].status != 0 || hres[k].aux == 0) chained = false;  // a chain ended on an item nobody has decoded
+        if (hres[k].status != 0 && hres[k].out_len != 0 && (uint32_t)(hres[k].out_len - 1) != last_stuck[k])
+          chained = false;  // rounds used up with a chain still in front of an undecoded item
   }
   if (!chained) {
     {
@@ -1403,17 +1434,36 @@ int inflate_segments_run(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, cons
     hipLaunchKernelGGL(k_inf_seg_win_fin, dim3(max_nseg, nb), dim3(1024), 0, g.stream, (const uint32_t*)g.pw16.p,
                        (const ZesSegJob*)g.segjobs.p, (const uint8_t*)g.gwins.p, (uint8_t*)g.wins.p);
   }
+  {
+    // symbols -> bytes: one launch over (segments, workgroups per segment, buffers)
+    if ((rc = ensure(g.segouts, sizeof(ZesSegOut) * nb))) return rc;
+    ZesSegOut* ho = (ZesSegOut*)((uint8_t*)g.pinned + 832 * 1024);  // (upload area)
+    uint32_t max_tr = 0, min_tr = 0xFFFFFFFFu;
+    for (uint32_t k = 0; k < nb; k++) {
+      const InfJob& j = jobs[ids[k]];
+      ho[k].out_off = j.out_off;
+      ho[k].cap = j.cap;
+      ho[k].nseg = (go[k] && novf[k] < hr[k].aux) ? hr[k].aux : 0u;
+      ho[k].pad = 0;
+      if (ho[k].nseg) {
+        max_tr = std::max(max_tr, ho[k].nseg);
+        min_tr = std::min(min_tr, ho[k].nseg);
+      }
+    }
+    if (max_tr) {
+      HIPCHK(hipMemcpyAsync(g.segouts.p, ho, sizeof(ZesSegOut) * nb, hipMemcpyHostToDevice, g.stream));
+      Timed t("k_inf_seg_translate");
+      // few long segments: split each over several workgroups (by the buffer with the fewest)
+      const uint32_t ny = std::max(1u, std::min(16u, 2048u / std::max(1u, min_tr * std::min(nb, 8u))));
+      hipLaunchKernelGGL(k_inf_seg_translate, dim3(max_tr, ny, nb), dim3(256), 0, g.stream, d_out, (const ZesSegJob*)g.segjobs.p,
+                         (const ZesSegOut*)g.segouts.p, cs, (const ZesSegRes*)g.sres.p, (const uint32_t*)g.seglist.p,
+                         (const uint64_t*)g.segprefix.p, (const uint8_t*)g.wins.p, (const uint32_t*)g.sym16.p, (const uint64_t*)g.symoff.p, fail_d);
+    }
+  }
   for (uint32_t k = 0; k < nb; k++) {
     if (!go[k]) continue;
     const InfJob& j = jobs[ids[k]];
     const uint32_t nseg = hr[k].aux, wf = hj[k].work_first;
-    if (novf[k] < nseg) {
-      Timed t("k_inf_seg_translate");
-      const uint32_t ny = std::max(1u, std::min(16u, 2048u / nseg));  // few long segments: split each over several workgroups
-      hipLaunchKernelGGL(k_inf_seg_translate, dim3(nseg, ny), dim3(256), 0, g.stream, d_out, j.out_off, j.cap, cs + cbase[k],
-                         (const ZesSegRes*)g.sres.p + wf, (const uint32_t*)g.seglist.p + wf, (const uint64_t*)g.segprefix.p + wf,
-                         (const uint8_t*)g.wins.p + (size_t)wf * ZES_WINDOW, (const uint32_t*)g.sym16.p, (const uint64_t*)g.symoff.p + wf, fail_d + k);
-    }
     if (novf[k] > 0) {
       Timed t("k_inf_seg_decode");
       hipLaunchKernelGGL(k_inf_seg_decode, dim3(nseg), dim3(64), 0, g.stream, d_in, j.in_off, j.c, d_out, j.out_off, j.cap, cs + cbase[k],
@@ -1805,8 +1855,30 @@ int inflate_jobs(const uint8_t* d_in, uint8_t* d_out, std::vector<InfJob>& jobs,
     }
   }
   if (!(flags & ZES_F_NO_FASTPATH)) {
-    for (uint32_t i : todo)
-      if (jobs[i].tier == 0 && jobs[i].status == ZES_OK && jobs[i].c >= STORED_MIN_C && (rc = inflate_stored(d_in, d_out, jobs[i]))) return rc;
+    {
+      // the stored-blocks walk is a launch and a read-back per buffer: with several buffers left, only those whose first
+      // block IS a stored one (BTYPE, bits 1-2 of the byte behind the zlib header; gathered by one launch per group) try it
+      std::vector<uint32_t> st;
+      for (uint32_t i : todo)
+        if (jobs[i].tier == 0 && jobs[i].status == ZES_OK && jobs[i].c >= STORED_MIN_C) st.push_back(i);
+      std::vector<char> want(st.size(), 1);
+      if (st.size() >= 2) {
+        for (size_t g0 = 0; g0 < st.size(); g0 += INF_GROUP) {
+          const uint32_t nb = (uint32_t)std::min<size_t>(INF_GROUP, st.size() - g0);
+          if ((rc = ensure(g.ibufs, (size_t)INF_GROUP * 8 + INF_GROUP))) return rc;
+          uint64_t* ho = (uint64_t*)((uint8_t*)g.pinned + PIN_UP);
+          for (uint32_t k = 0; k < nb; k++) ho[k] = jobs[st[g0 + k]].in_off + 2u;
+          uint8_t* dfirst = (uint8_t*)g.ibufs.p + (size_t)INF_GROUP * 8;
+          HIPCHK(hipMemcpyAsync(g.ibufs.p, ho, (size_t)nb * 8, hipMemcpyHostToDevice, g.stream));
+          hipLaunchKernelGGL(k_inf_first_bytes, dim3((nb + 255) / 256), dim3(256), 0, g.stream, d_in, (const uint64_t*)g.ibufs.p, dfirst, nb);
+          HIPCHK(hipMemcpyAsync(g.pinned, dfirst, nb, hipMemcpyDeviceToHost, g.stream));
+          HIPCHK(hipStreamSynchronize(g.stream));
+          for (uint32_t k = 0; k < nb; k++) want[g0 + k] = ((((const uint8_t*)g.pinned)[k] >> 1) & 3u) == 0u;
+        }
+      }
+      for (size_t q = 0; q < st.size(); q++)
+        if (want[q] && (rc = inflate_stored(d_in, d_out, jobs[st[q]]))) return rc;
+    }
     std::vector<uint32_t> segs;
     for (uint32_t i : todo)
       if (jobs[i].tier == 0 && jobs[i].status == ZES_OK && jobs[i].c >= SEG_MIN_C && jobs[i].c < (1ull << 29)) segs.push_back(i);
@@ -1910,7 +1982,7 @@ static int shutdown_one(void) {
   (void)hipStreamSynchronize(g.stream);
   DevBuf* all[] = {&g.bufs, &g.blks, &g.idx_a, &g.idx_b, &g.inv, &g.sdelta, &g.tmask, &g.mlist, &g.hists, &g.codes, &g.hdrs, &g.adler, &g.res, &g.order, &g.surv, &g.vlong, &g.segfail, &g.symoff, &g.cand,
                    &g.cand_sorted, &g.counters, &g.cres, &g.map, &g.resume, &g.dbg, &g.ibufs, &g.ibufs2, &g.mvlist, &g.scratch, &g.st_in, &g.st_out,
-                   &g.sres, &g.maps, &g.seglist, &g.segprefix, &g.wins, &g.sym16, &g.segorder, &g.segjobs, &g.kraft, &g.pw16, &g.gwins};
+                   &g.sres, &g.maps, &g.seglist, &g.segprefix, &g.wins, &g.sym16, &g.segorder, &g.segjobs, &g.kraft, &g.pw16, &g.gwins, &g.seglive, &g.segouts};
   for (DevBuf* b : all) {
     if (b->p) (void)hipFree(b->p);
     b->p = nullptr;

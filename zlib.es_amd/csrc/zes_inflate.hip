@@ -1621,8 +1621,14 @@ __global__ __launch_bounds__(1024) void k_inf_cand_compact(const uint32_t* __res
 // Launch order of the work items: by compressed span to the next work item, longest first (the span is the only
 // estimate of a segment's decode time there is before decoding it).  Rank sort in LDS; identity for huge lists.
 #define SEGORDER_LDS 12288u
-__global__ __launch_bounds__(1024) void k_inf_seg_order(const uint32_t* __restrict__ cand, uint32_t ncand, uint64_t c,
-                                                        uint32_t* __restrict__ order) {
+__global__ __launch_bounds__(1024) void k_inf_seg_order(const ZesSegJob* __restrict__ jobs, const uint32_t* __restrict__ cand_all,
+                                                        uint32_t* __restrict__ order_all) {
+  // one workgroup per buffer of the group
+  const ZesSegJob jb = jobs[blockIdx.x];
+  const uint32_t* cand = cand_all + jb.cand_base;
+  const uint32_t ncand = jb.ncand;
+  const uint64_t c = jb.c;
+  uint32_t* order = order_all + jb.work_first;
   __shared__ uint32_t s_span[SEGORDER_LDS];
   const uint32_t nwork = ncand + 1, tid = threadIdx.x;
   if (nwork > SEGORDER_LDS) {
@@ -1717,10 +1723,32 @@ __device__ __forceinline__ static void seg_scan_body(SM& S, const uint8_t* __res
     d.sym_ovf = sym_ratio ? 0u : 1u;
   }
   uint16_t* r16 = reinterpret_cast<uint16_t*>(S.ring);
+  // an item the block decoder has decoded up to the end of its block (flags 8: the block behind it is not on the list)
+  // is taken over from there: its symbols are in the store, the ring gets the last R of them
+  const ZesSegRes prev = sres[w];
+  const bool resume = nlive != nullptr && R < RING16 && prev.flags == 8u && d.sym != nullptr && prev.out_len <= d.sym_cap;  // (uniform)
   if (R >= RING16) {
     for (uint32_t i = lane; i < ZES_WINDOW; i += 64) r16[i] = (uint16_t)(256u + i);  // window byte i of the previous segment
-  } else {  // short ring: the last R bytes of that window, output position 0 at ring index 0 (= R)
+  } else if (!resume) {  // short ring: the last R bytes of that window, output position 0 at ring index 0 (= R)
     for (uint32_t i = lane; i < R; i += 64) r16[i] = (uint16_t)(256u + (ZES_WINDOW - R) + i);
+  } else {  // ring index of output position p: p mod R
+    const uint64_t L = prev.out_len;
+    for (uint32_t i = lane; i < R; i += 64) {
+      const int64_t pos = (int64_t)L - (int64_t)R + (int64_t)i;  // the R positions in front of L, oldest first
+      uint32_t v;
+      if (pos < 0) {
+        v = 256u + (uint32_t)((int64_t)ZES_WINDOW + pos);
+      } else {
+        const uint32_t wd = __hip_atomic_load(&d.sym[(uint64_t)pos >> 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v = (pos & 1) ? wd >> 16 : wd & 0xffffu;
+      }
+      r16[(uint32_t)(((uint64_t)(pos + (int64_t)R * 4)) % R)] = (uint16_t)v;  // (pos >= -R)
+    }
+    d.o = L;
+    d.flushed = L & ~1ull;
+    d.unfl = (uint32_t)(L & 1ull);  // symbols are stored in pairs: an odd count's last symbol is flushed again with its successor
+    d.oi = (uint32_t)(L % R);
+    start = prev.end_bit;
   }
   wd_seek(d, start);
   uint32_t bfinal = 0;
@@ -1815,9 +1843,19 @@ __global__ __launch_bounds__(64) void k_inf_seg_scan_short(const uint8_t* __rest
 // One workgroup per stream: the chain of segments from work item 0 to the final block.
 // res->status 0: seg[0..aux) / prefix[] hold the chain, out_len the total; 1: not a clean chain.
 #define SEGCHAIN_LDS 8192u  // (T2 has at most SEG_BUCKETS + 1 work items)
-__global__ __launch_bounds__(256) void k_inf_seg_chain(const ZesSegRes* __restrict__ sres, uint32_t nwork, uint32_t* __restrict__ seg,
-                                                       uint64_t* __restrict__ prefix, ZesRes* __restrict__ res,
-                                                       uint32_t* __restrict__ novf) {
+__global__ __launch_bounds__(256) void k_inf_seg_chain(const ZesSegJob* __restrict__ jobs, const ZesSegRes* __restrict__ sres_all,
+                                                       uint32_t* __restrict__ seg_all, uint64_t* __restrict__ prefix_all,
+                                                       ZesRes* __restrict__ res_all, uint32_t* __restrict__ novf_all) {
+  // one workgroup per buffer of the group.  A chain that arrives at a work item nobody has decoded (declined by the block
+  // decoder: a stored or fixed block, a block behind an unlisted start) reports it: status 1, out_len = item + 1 — the
+  // host sends exactly those items to the wave decoder and follows the chains again (out_len 0: the chain is broken).
+  const ZesSegJob jb = jobs[blockIdx.x];
+  const ZesSegRes* sres = sres_all + jb.work_first;
+  const uint32_t nwork = jb.ncand + 1;
+  uint32_t* seg = seg_all + jb.work_first;
+  uint64_t* prefix = prefix_all + jb.work_first;
+  ZesRes* res = res_all + blockIdx.x;
+  uint32_t* novf = novf_all + blockIdx.x;
   __shared__ uint32_t s_nf[SEGCHAIN_LDS];  // next | flags << 30
   __shared__ unsigned long long s_part[256];
   __shared__ uint32_t s_nseg;
@@ -1837,6 +1875,7 @@ __global__ __launch_bounds__(256) void k_inf_seg_chain(const ZesSegRes* __restri
     for (;;) {
       const uint32_t nf = lds ? s_nf[w] : ((sres[w].next & 0x3FFFFFFFu) | (sres[w].flags << 30));
       if (!(nf >> 30 & 1u) || k >= nwork) {
+        if (k < nwork) res->out_len = (unsigned long long)w + 1ull;  // stuck on an undecoded (or failed) item
         k = 0;
         break;
       }
@@ -1995,11 +2034,23 @@ __global__ __launch_bounds__(1024) void k_inf_seg_win_fin(const uint32_t* __rest
 // Chain segment k from the symbol store: bytes as they are, markers through the window in front of the segment.
 // A marker that points in front of the first byte of the stream (src/inflate.ts:287-290 would read outside the
 // buffer) raises *fail: the serial tiers then reproduce what the reference does.
-__global__ __launch_bounds__(256) void k_inf_seg_translate(uint8_t* __restrict__ d_out, uint64_t out_off, uint64_t cap,
-                                                           const uint32_t* __restrict__ cand, const ZesSegRes* __restrict__ sres,
-                                                           const uint32_t* __restrict__ seg, const uint64_t* __restrict__ prefix,
-                                                           const uint8_t* __restrict__ wins, const uint32_t* __restrict__ sym16_all,
-                                                           const uint64_t* __restrict__ symoff, uint32_t* __restrict__ fail) {
+__global__ __launch_bounds__(256) void k_inf_seg_translate(uint8_t* __restrict__ d_out, const ZesSegJob* __restrict__ jobs,
+                                                           const ZesSegOut* __restrict__ outs, const uint32_t* __restrict__ cand_all,
+                                                           const ZesSegRes* __restrict__ sres_all, const uint32_t* __restrict__ seg_all,
+                                                           const uint64_t* __restrict__ prefix_all, const uint8_t* __restrict__ wins_all,
+                                                           const uint32_t* __restrict__ sym16_all, const uint64_t* __restrict__ symoff_all,
+                                                           uint32_t* __restrict__ fail_all) {
+  // grid: (segments of the longest chain, workgroups sharing a segment, buffers of the group)
+  const ZesSegJob jb = jobs[blockIdx.z];
+  const ZesSegOut ob = outs[blockIdx.z];
+  if (blockIdx.x >= ob.nseg) return;  // (0: this buffer is not translated — not decoded by this tier, or decoded in place)
+  const uint64_t out_off = ob.out_off, cap = ob.cap;
+  const ZesSegRes* sres = sres_all + jb.work_first;
+  const uint32_t* seg = seg_all + jb.work_first;
+  const uint64_t* prefix = prefix_all + jb.work_first;
+  const uint8_t* wins = wins_all + (size_t)jb.work_first * ZES_WINDOW;
+  const uint64_t* symoff = symoff_all + jb.work_first;
+  uint32_t* fail = fail_all + blockIdx.z;
   __shared__ __align__(16) uint8_t W[ZES_WINDOW];
   const uint32_t k = blockIdx.x, tid = threadIdx.x;
   const uint32_t w = seg[k];

@@ -1982,6 +1982,23 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
         }
         if (lo < it.ncand && it.cand[lo] == want) next = lo + 1u;
         if (next == 0u || end_bit >= limit) {
+          // The block is decoded and its symbols are in the store; what is missing is the block behind it (a stored or
+          // fixed one — a zlib stream's short last block — or a start the search missed).  With the symbols in the
+          // item's own share the wave decoder takes the item over from here: flags 8 = "decoded up to end_bit, out_len
+          // symbols stored" (k_inf_seg_scan preloads its ring from the store and appends); a lone wave that decodes this
+          // block again, token by token, needs ~7 ms per 100 KiB of output.
+          if (next == 0u && end_bit < limit && symp == it.sym) {
+            if (tid == 0) {
+              ZesSegRes r;
+              r.end_bit = end_bit;
+              r.out_len = total;
+              r.flags = 8u;
+              r.next = 0;
+              *it.sres = r;
+              it.fail_list[1u + atomicAdd(&it.fail_list[0], 1u)] = it.w;
+            }
+            return;
+          }
           PAR_DECLINE(end_bit, total);
           return;
         }

@@ -82,6 +82,13 @@ struct ZesSegJob {
   uint32_t nseg;       // length of the buffer's chain (0 = not decoded by this tier): k_inf_seg_windows
 };
 
+// where a buffer of a segment-parallel group goes (k_inf_seg_translate)
+struct ZesSegOut {
+  uint64_t out_off, cap;
+  uint32_t nseg;  // segments to translate (0: none)
+  uint32_t pad;
+};
+
 #ifdef __HIPCC__
 // inflate direction (zes_inflate.hip)
 __global__ void k_inf_first_bytes(const uint8_t*, const uint64_t*, uint8_t*, uint32_t);
@@ -96,15 +103,15 @@ __global__ void k_inf_stored_walk(const uint8_t*, uint64_t, uint64_t, uint64_t, 
 __global__ void k_inf_stored_copy(const uint8_t*, uint64_t, uint8_t*, uint64_t, const ZesStoredBlk*);
 __global__ void k_inf_cand_bucket(const uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*);
 __global__ void k_inf_cand_compact(const uint32_t*, uint32_t*, uint32_t*);
-__global__ void k_inf_seg_order(const uint32_t*, uint32_t, uint64_t, uint32_t*);
+__global__ void k_inf_seg_order(const ZesSegJob*, const uint32_t*, uint32_t*);
 __global__ void k_inf_seg_scan(const uint8_t*, const ZesSegJob*, uint32_t, const uint32_t*, ZesSegRes*, uint32_t*, uint32_t*, uint32_t,
                                const uint32_t*, uint32_t*, const uint32_t*, uint64_t*);
 __global__ void k_inf_seg_scan_short(const uint8_t*, const ZesSegJob*, uint32_t, const uint32_t*, ZesSegRes*, uint32_t*, uint32_t*, uint32_t,
                                      const uint32_t*, uint32_t*, const uint32_t*, uint64_t*);
 __global__ void k_inf_seg_block_par(const uint8_t*, const ZesSegJob*, uint32_t, const uint32_t*, ZesSegRes*, uint32_t*, uint32_t*, uint32_t, uint32_t*,
                                     unsigned long long*, uint64_t, uint64_t, uint64_t*);
-__global__ void k_inf_seg_chain(const ZesSegRes*, uint32_t, uint32_t*, uint64_t*, ZesRes*, uint32_t*);
-__global__ void k_inf_seg_translate(uint8_t*, uint64_t, uint64_t, const uint32_t*, const ZesSegRes*, const uint32_t*, const uint64_t*,
+__global__ void k_inf_seg_chain(const ZesSegJob*, const ZesSegRes*, uint32_t*, uint64_t*, ZesRes*, uint32_t*);
+__global__ void k_inf_seg_translate(uint8_t*, const ZesSegJob*, const ZesSegOut*, const uint32_t*, const ZesSegRes*, const uint32_t*, const uint64_t*,
                                     const uint8_t*, const uint32_t*, const uint64_t*, uint32_t*);
 #define SEGWIN_GROUP 32u
 __global__ void k_inf_seg_win_group(const uint32_t*, const uint32_t*, const ZesSegJob*, uint32_t*);
