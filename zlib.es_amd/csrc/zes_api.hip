@@ -2249,15 +2249,32 @@ static int inflate_host_pipelined(const uint8_t* in, uint64_t c, uint8_t* out, u
                                   zes_alloc_fn alloc, void* user, bool* done) {
   *done = false;
   int rc;
-  const uint64_t pb = std::min<uint64_t>(32ull << 20, std::max<uint64_t>(4ull << 20, ((c / 2 + 65535) >> 16) << 16));
-  const uint32_t np = (uint32_t)((c + pb - 1) / pb);
+  // Piece boundaries (multiples of 64 KiB).  A piece's decode is ~0.5 ms whatever its size (seven launches, two
+  // read-backs, one round of the block decoder), so pieces of up to 32 MiB keep pace with their uploads; what cannot
+  // overlap anything is the LAST piece's decode and download: from 48 MiB on the last piece is a small one
+  // (64 MiB: 28 + 28 + 8 instead of 32 + 32).
+  std::vector<uint64_t> B;
+  {
+    const uint64_t pb = std::min<uint64_t>(32ull << 20, std::max<uint64_t>(4ull << 20, ((c / 2 + 65535) >> 16) << 16));
+    uint64_t last = 0;
+    if (c >= (48ull << 20)) last = std::min<uint64_t>(8ull << 20, ((c / 8) >> 16) << 16);
+    const uint64_t rest = c - last;
+    const uint64_t nr = std::max<uint64_t>(1, (rest + pb - 1) / pb);
+    const uint64_t each = (((rest + nr - 1) / nr + 65535) >> 16) << 16;
+    B.push_back(0);
+    for (uint64_t k = 1; k < nr; k++)
+      if (k * each < rest) B.push_back(k * each);
+    if (last && rest > B.back()) B.push_back(rest);
+    B.push_back(c);
+  }
+  const uint32_t np = (uint32_t)B.size() - 1;
   if (np < 2) return ZES_OK;
   const uint64_t dcap = std::max<uint64_t>(alloc ? 0 : cap, std::max<uint64_t>(c * 4, 1 << 20));
   if ((rc = ensure(g.st_in, c + 64))) return rc;
   if ((rc = ensure(g.st_out, dcap + 64))) return rc;
   const uint8_t* d_in = (const uint8_t*)g.st_in.p;
   uint8_t* d_out = (uint8_t*)g.st_out.p;
-  auto cut = [&](uint32_t k) { return k == 0 ? 0ull : k >= np ? c : std::min<uint64_t>(c, (uint64_t)k * pb + T1_PIECE_SLACK); };
+  auto cut = [&](uint32_t k) { return k == 0 ? 0ull : k >= np ? c : std::min<uint64_t>(c, B[k] + T1_PIECE_SLACK); };
   auto up = [&](uint32_t k) -> int {
     int r = upload((uint8_t*)g.st_in.p + cut(k), in + cut(k), cut(k + 1) - cut(k), g.cs_in);
     if (r) return r;
@@ -2279,7 +2296,7 @@ static int inflate_host_pipelined(const uint8_t* in, uint64_t c, uint8_t* out, u
       const uint64_t a = pend_lo, b = pend_hi;
       f_down = g_side_down.submit([=] { return download(out + a, d_out + a, b - a, g.cs_out, false); });
     }
-    const uint64_t lo_bit = k == 0 ? 16 : (uint64_t)k * pb * 8, own_bit = std::min<uint64_t>((uint64_t)(k + 1) * pb, c) * 8;
+    const uint64_t lo_bit = k == 0 ? 16 : B[k] * 8, own_bit = B[k + 1] * 8;
     uint64_t byte0 = (lo_bit >> 3) & ~15ull;
     if (byte0 >= 16) byte0 -= 16;
     const uint64_t pc = std::min<uint64_t>(c - byte0, (own_bit >> 3) - byte0 + T1_PIECE_SLACK);
