@@ -787,6 +787,12 @@ struct InfJob {
   uint64_t out_len;
   int status;  // reference-equivalent status once done
   int tier;    // 0 = not decoded yet
+  // a piece of a longer stream on its way through the segment-parallel tier (inflate_segments_pieces): where work item
+  // 0 starts, how much output exists in front of out_off, "a chain that ends in front of the piece's last, cut block
+  // is fine"; out: the bit behind the last block decoded (relative to in_off), whether it was the stream's final one
+  uint32_t start0 = 16, hist = 0;
+  bool partial = false, final_seen = false;
+  uint64_t end_bit = 0;
 };
 
 bool t1_eligible(const InfJob& j, uint32_t flags) { return !(flags & (ZES_F_NO_FASTPATH | ZES_F_PIECES)) && j.c >= 64 && j.c < (1ull << 29); }
@@ -1220,6 +1226,7 @@ int inflate_t1_range(const uint8_t* d_in, uint64_t in_off, uint64_t c, uint64_t 
 constexpr uint64_t SEG_MIN_C = ZES_SEG_MIN_C;  // shorter streams go straight to the serial wavefront (round 3: 32768 -> 4096: 29 KB of zlib stream can be 4 MiB of periodic data — 12.5 ms by the serial wavefront, 2.8 ms here)
 constexpr size_t SERIAL_BATCH_MIN_JOBS = 16;        // this many left-over streams of a call: one serial wavefront each, side by side
 constexpr uint64_t SERIAL_BATCH_MAX_C = 128ull << 10;  // (longer ones go to the segment-parallel tier: its block decoder is ~15 times a lone wave)
+constexpr uint64_t SEG_PIECES_MIN_C = 48ull << 20;  // streams from this size on go through the tier in pieces of 32 MiB (inflate_segments_pieces)
 constexpr uint32_t SEG_GROUP_BUFS = 64;      // buffers whose candidates are searched before the first read-back
 constexpr uint32_t SEG_GROUP_WORK = 8192;    // work items per segment launch (each owns a 64 KiB map)
 
@@ -1250,6 +1257,8 @@ int inflate_segments_run(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, cons
     hj[k].ncand = ncand[k];
     hj[k].work_first = work;
     hj[k].nseg = 0;
+    hj[k].start0 = j.start0;
+    hj[k].flags = j.partial ? ZES_SEG_PARTIAL : 0u;
     work += ncand[k] + 1;
     sym_base += (j.c + 64) * ratio / 2;
   }
@@ -1260,7 +1269,7 @@ int inflate_segments_run(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, cons
   if ((rc = ensure(g.segprefix, (size_t)work * 8))) return rc;
   if ((rc = ensure(g.segorder, (size_t)work * 4))) return rc;
   if ((rc = ensure(g.symoff, (size_t)work * 8 + 8))) return rc;  // per work item: where its symbols are; behind them: the common area's fill
-  if ((rc = ensure(g.res, sizeof(ZesRes) * nb))) return rc;
+  if ((rc = ensure(g.res, sizeof(ZesRes) * nb * 2))) return rc;  // (second half: where a chain ended, k_inf_seg_chain)
   HIPCHK(hipMemcpyAsync(g.segjobs.p, hj, sizeof(ZesSegJob) * nb, hipMemcpyHostToDevice, g.stream));
   HIPCHK(hipMemsetAsync(dscratch, 0, (size_t)nb * 8 + 4, g.stream));
   uint32_t* novf_d = dscratch;
@@ -1314,7 +1323,7 @@ int inflate_segments_run(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, cons
                          (uint32_t*)g.seglist.p, (uint64_t*)g.segprefix.p, (ZesRes*)g.res.p, novf_d);
     }
     HIPCHK(hipMemcpyAsync(hs, novf_d, (size_t)nb * 4, hipMemcpyDeviceToHost, g.stream));
-    HIPCHK(hipMemcpyAsync(hres, g.res.p, sizeof(ZesRes) * nb, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipMemcpyAsync(hres, g.res.p, sizeof(ZesRes) * nb * 2, hipMemcpyDeviceToHost, g.stream));
     if (blockpar) HIPCHK(hipMemcpyAsync(hs + nb, fail_list, 4, hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));  // (the job table upload has completed too: hj may be rewritten)
     return ZES_OK;
@@ -1335,12 +1344,20 @@ int inflate_segments_run(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, cons
     // held ~200 false candidates that cost the lone waves 6.8 ms), and the chains are followed again; a few rounds,
     // then — streams with many stored or fixed blocks — everything that was declined.
     std::vector<uint32_t> last_stuck(nb, 0xFFFFFFFFu);
+    // the item a buffer's chain stands in front of (status 1: no chain; 3: the chain of a piece, as far as it got)
+    auto stuck_of = [&](uint32_t k) -> uint32_t {
+      if (hres[k].status == 1 && hres[k].out_len != 0) return (uint32_t)(hres[k].out_len - 1);
+      if (hres[k].status == 3 && hres[nb + k].aux != 0) return hres[nb + k].aux - 1u;
+      return 0xFFFFFFFFu;
+    };
     for (int round = 0; ndecl && round < 4; round++) {
       std::vector<uint32_t> items;
       for (uint32_t k = 0; k < nb; k++) {
-        if (hres[k].status == 0 || hres[k].out_len == 0) continue;
-        const uint32_t w = (uint32_t)(hres[k].out_len - 1);
-        if (w == last_stuck[k]) continue;  // it has been to the wave decoder: the stream is not for this tier
+        const uint32_t w = stuck_of(k);
+        if (w == 0xFFFFFFFFu || w == last_stuck[k]) continue;  // (the same item again: it has been to the wave decoder — the stream is not for this tier)
+        // a piece of a longer stream whose chain got through half the piece: what it stands in front of is, as a rule,
+        // the block the piece's end cuts — the next piece starts there
+        if (hres[k].status == 3 && hres[nb + k].out_len >= jobs[ids[k]].c * 4) continue;
         last_stuck[k] = w;
         items.push_back(hj[k].work_first + w);
       }
@@ -1365,9 +1382,15 @@ int inflate_segments_run(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, cons
       }
     }
     if (chained && ndecl)
-      for (uint32_t k = 0; k < nb; k++)
-        if (hres[k].status != 0 && hres[k].out_len != 0 && (uint32_t)(hres[k].out_len - 1) != last_stuck[k])
-          chained = false;  // rounds used up with a chain still in front of an undecoded item
+      for (uint32_t k = 0; k < nb; k++) {
+        const uint32_t w = stuck_of(k);
+        if (w == 0xFFFFFFFFu || w == last_stuck[k]) continue;
+        // rounds used up with a chain still in front of an undecoded item (a stream whose blocks mostly follow blocks
+        // that are not on the thinned list): everything that was declined goes to the wave decoder in one launch —
+        // unless it is a piece's chain that got through half the piece (see above)
+        if (hres[k].status == 3 && hres[nb + k].out_len >= jobs[ids[k]].c * 4) continue;
+        chained = false;
+      }
   }
   if (!chained) {
     {
@@ -1390,7 +1413,7 @@ int inflate_segments_run(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, cons
     if ((rc = run_chains())) return rc;
   }
   std::vector<uint32_t> novf(hs, hs + nb);
-  std::vector<ZesRes> hr(hres, hres + nb);
+  std::vector<ZesRes> hr(hres, hres + 2 * nb);
   std::vector<char> go(nb, 0);
   bool any = false;
   for (uint32_t k = 0; k < nb; k++) {
@@ -1405,7 +1428,10 @@ int inflate_segments_run(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, cons
         fprintf(stderr, "   item %zu: end_bit %llu out_len %llu flags %u next %u\n", w, (unsigned long long)sr[w].end_bit,
                 (unsigned long long)sr[w].out_len, sr[w].flags, sr[w].next);
     }
+    if (hr[k].status == 3 && j.partial) hr[k].status = 0;  // a piece's chain, as far as it got
     if (hr[k].status != 0 || hr[k].aux == 0) continue;
+    j.end_bit = hr[nb + k].out_len;
+    j.final_seen = hr[nb + k].status != 0;
     if (hr[k].out_len > j.cap) {  // the caller learns the size without the output passes
       j.tier = 2;
       j.out_len = hr[k].out_len;
@@ -1419,6 +1445,22 @@ int inflate_segments_run(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, cons
   if (!any) return ZES_OK;
   if ((rc = ensure(g.wins, (size_t)work * ZES_WINDOW))) return rc;
   HIPCHK(hipMemcpyAsync(g.segjobs.p, hj, sizeof(ZesSegJob) * nb, hipMemcpyHostToDevice, g.stream));
+  // where every buffer's bytes go (and how much output exists in front: a later piece of a long stream)
+  if ((rc = ensure(g.segouts, sizeof(ZesSegOut) * nb))) return rc;
+  ZesSegOut* ho = (ZesSegOut*)((uint8_t*)g.pinned + 832 * 1024);  // (upload area)
+  uint32_t max_tr = 0, min_tr = 0xFFFFFFFFu;
+  for (uint32_t k = 0; k < nb; k++) {
+    const InfJob& j = jobs[ids[k]];
+    ho[k].out_off = j.out_off;
+    ho[k].cap = j.cap;
+    ho[k].nseg = (go[k] && novf[k] < hr[k].aux) ? hr[k].aux : 0u;
+    ho[k].hist = j.hist;
+    if (ho[k].nseg) {
+      max_tr = std::max(max_tr, ho[k].nseg);
+      min_tr = std::min(min_tr, ho[k].nseg);
+    }
+  }
+  HIPCHK(hipMemcpyAsync(g.segouts.p, ho, sizeof(ZesSegOut) * nb, hipMemcpyHostToDevice, g.stream));
   {
     // windows: groups of maps composed in parallel, the groups chained, every window finished in parallel
     uint32_t max_nseg = 0;
@@ -1430,28 +1472,13 @@ int inflate_segments_run(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, cons
     hipLaunchKernelGGL(k_inf_seg_win_group, dim3(max_groups, nb), dim3(1024), 0, g.stream, (const uint32_t*)g.maps.p,
                        (const uint32_t*)g.seglist.p, (const ZesSegJob*)g.segjobs.p, (uint32_t*)g.pw16.p);
     hipLaunchKernelGGL(k_inf_seg_win_top, dim3(nb), dim3(1024), 0, g.stream, (const uint32_t*)g.pw16.p, (const ZesSegJob*)g.segjobs.p,
-                       (uint8_t*)g.gwins.p);
+                       (uint8_t*)g.gwins.p, (const uint8_t*)d_out, (const ZesSegOut*)g.segouts.p);
     hipLaunchKernelGGL(k_inf_seg_win_fin, dim3(max_nseg, nb), dim3(1024), 0, g.stream, (const uint32_t*)g.pw16.p,
                        (const ZesSegJob*)g.segjobs.p, (const uint8_t*)g.gwins.p, (uint8_t*)g.wins.p);
   }
   {
     // symbols -> bytes: one launch over (segments, workgroups per segment, buffers)
-    if ((rc = ensure(g.segouts, sizeof(ZesSegOut) * nb))) return rc;
-    ZesSegOut* ho = (ZesSegOut*)((uint8_t*)g.pinned + 832 * 1024);  // (upload area)
-    uint32_t max_tr = 0, min_tr = 0xFFFFFFFFu;
-    for (uint32_t k = 0; k < nb; k++) {
-      const InfJob& j = jobs[ids[k]];
-      ho[k].out_off = j.out_off;
-      ho[k].cap = j.cap;
-      ho[k].nseg = (go[k] && novf[k] < hr[k].aux) ? hr[k].aux : 0u;
-      ho[k].pad = 0;
-      if (ho[k].nseg) {
-        max_tr = std::max(max_tr, ho[k].nseg);
-        min_tr = std::min(min_tr, ho[k].nseg);
-      }
-    }
     if (max_tr) {
-      HIPCHK(hipMemcpyAsync(g.segouts.p, ho, sizeof(ZesSegOut) * nb, hipMemcpyHostToDevice, g.stream));
       Timed t("k_inf_seg_translate");
       // few long segments: split each over several workgroups (by the buffer with the fewest)
       const uint32_t ny = std::max(1u, std::min(16u, 2048u / std::max(1u, min_tr * std::min(nb, 8u))));
@@ -1468,7 +1495,7 @@ int inflate_segments_run(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, cons
       Timed t("k_inf_seg_decode");
       hipLaunchKernelGGL(k_inf_seg_decode, dim3(nseg), dim3(64), 0, g.stream, d_in, j.in_off, j.c, d_out, j.out_off, j.cap, cs + cbase[k],
                          (const ZesSegRes*)g.sres.p + wf, (const uint32_t*)g.seglist.p + wf, (const uint64_t*)g.segprefix.p + wf,
-                         (const uint8_t*)g.wins.p + (size_t)wf * ZES_WINDOW, fail_d + k, novf[k] < nseg ? 1u : 0u);
+                         (const uint8_t*)g.wins.p + (size_t)wf * ZES_WINDOW, fail_d + k, novf[k] < nseg ? 1u : 0u, j.start0, j.hist);
     }
   }
   HIPCHK(hipMemcpyAsync(hs, fail_d, (size_t)nb * 4, hipMemcpyDeviceToHost, g.stream));
@@ -1529,6 +1556,7 @@ int inflate_segments(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const st
         hb[k].first_chunk = (uint32_t)chunks;
         hb[k].cand_base = cbase[k];
         hb[k].cand_cap = ccap[k];
+        hb[k].start_rel = j.start0 - 16u;  // (a piece of a longer stream: nothing in front of its first block is searched)
         chunks += (j.c + INF_SCAN_BYTES - 1) / INF_SCAN_BYTES;
         total_c += j.c;
       }
@@ -1573,6 +1601,7 @@ int inflate_segments(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const st
       b0.cap = j.cap;
       b0.cand_base = cbase[k];
       b0.cand_cap = ccap[k];
+      b0.start_rel = j.start0 - 16u;
       const uint32_t chunks = (uint32_t)((j.c + INF_SCAN_BYTES - 1) / INF_SCAN_BYTES);
       b1.first_chunk = chunks;
       hipLaunchKernelGGL(k_inf_set_table1, dim3(1), dim3(64), 0, g.stream, b0, b1, const_cast<ZesInfBuf*>(dbufs), counters, 4u);
@@ -1635,6 +1664,53 @@ int inflate_segments(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const st
 
 // A stream of stored blocks only (tier 2 as well: parallel, any encoder).  Leaves j.tier at 0 if it is anything else.
 constexpr uint64_t STORED_MIN_C = 65536;  // below this the serial wavefront is as quick
+// A stream too long for this tier's 32-bit bit positions (512 MiB of compressed data and more) goes through it piece by
+// piece: a piece starts at the block behind the last one decoded (work item 0 at that bit, the candidate search from
+// there), its chain is accepted as far as the piece holds whole blocks, and the 32 KiB in front of its first segment
+// are the output so far.  (src/inflate.ts:16-40 has no size limit; reference-made streams of this size take
+// inflate_pieces, the block-parallel tier's form of the same.)  ZES_SEG_PIECE_MB: piece size, for tests.
+int inflate_segments_pieces(const uint8_t* d_in, uint8_t* d_out, InfJob& j) {
+  static const uint64_t piece = [] {
+    const char* e = getenv("ZES_SEG_PIECE_MB");
+    const uint64_t mb = e ? strtoull(e, nullptr, 10) : 0;
+    return mb ? (mb << 20) : (32ull << 20);  // (a piece of 32 MiB has about as many blocks as the tier takes work items: no thinning)
+  }();
+  int rc;
+  uint64_t pos_bit = 16, out_base = 0;
+  for (int guard = 0; guard < (1 << 20); guard++) {
+    // the piece: from a 16-byte boundary at least two bytes in front of the block (work item 0 starts at bit >= 16 of it)
+    const uint64_t pb = pos_bit >> 3;
+    const uint64_t byte0 = pb >= 2 ? ((pb - 2) & ~15ull) : 0;
+    std::vector<InfJob> sub(1);
+    sub[0] = InfJob{j.in_off + byte0, std::min<uint64_t>(j.c - byte0, piece), j.out_off + out_base, j.cap > out_base ? j.cap - out_base : 0, 0, ZES_OK, 0};
+    sub[0].start0 = (uint32_t)(pos_bit - 8 * byte0);
+    sub[0].hist = (uint32_t)std::min<uint64_t>(out_base, ZES_WINDOW);
+    sub[0].partial = byte0 + sub[0].c < j.c;  // (the last piece must end with the stream's final block)
+    const std::vector<uint32_t> one(1, 0u);
+    if ((rc = inflate_segments(d_in, d_out, sub.data(), one))) return rc;
+    if (sub[0].tier != 2) return ZES_OK;  // not this way: the serial tiers decide
+    if (sub[0].status == ZES_E_NOSPACE) {
+      if (!sub[0].final_seen) return ZES_OK;  // (the size is only known at the end: the serial tiers report it)
+      j.tier = 2;
+      j.status = ZES_E_NOSPACE;
+      j.out_len = out_base + sub[0].out_len;
+      return ZES_OK;
+    }
+    if (sub[0].status != ZES_OK) return ZES_OK;
+    out_base += sub[0].out_len;
+    if (sub[0].final_seen) {
+      j.tier = 2;
+      j.status = ZES_OK;
+      j.out_len = out_base;
+      return ZES_OK;
+    }
+    const uint64_t next_bit = 8 * byte0 + sub[0].end_bit;
+    if (!sub[0].partial || next_bit <= pos_bit) return ZES_OK;  // no final block where the data ends, or no progress
+    pos_bit = next_bit;
+  }
+  return ZES_OK;
+}
+
 int inflate_stored(const uint8_t* d_in, uint8_t* d_out, InfJob& j) {
   int rc;
   const uint64_t cap_entries = std::min<uint64_t>(j.c / 5 + 1, 1ull << 22);
@@ -1879,10 +1955,20 @@ int inflate_jobs(const uint8_t* d_in, uint8_t* d_out, std::vector<InfJob>& jobs,
       for (size_t q = 0; q < st.size(); q++)
         if (want[q] && (rc = inflate_stored(d_in, d_out, jobs[st[q]]))) return rc;
     }
+    // (ZES_SEG_PIECE_MB set: every stream goes piece by piece, for tests)
+    static const bool force_pieces = getenv("ZES_SEG_PIECE_MB") != nullptr;
     std::vector<uint32_t> segs;
     for (uint32_t i : todo)
-      if (jobs[i].tier == 0 && jobs[i].status == ZES_OK && jobs[i].c >= SEG_MIN_C && jobs[i].c < (1ull << 29)) segs.push_back(i);
+      if (jobs[i].tier == 0 && jobs[i].status == ZES_OK && jobs[i].c >= SEG_MIN_C && jobs[i].c < SEG_PIECES_MIN_C && !force_pieces) segs.push_back(i);
     if (!segs.empty() && (rc = inflate_segments(d_in, d_out, jobs.data(), segs))) return rc;
+    // Longer streams: the same tier, piece by piece.  Not only the ones beyond 32-bit bit positions (512 MiB): the tier
+    // takes at most SEG_BUCKETS work items per buffer, so a long stream's candidates are thinned, every item is then
+    // several blocks long, and all but the first of them are decoded by a lone wave — 155 MiB of zlib -1 text
+    // (400 MiB): 88 ms in one go, 12.7 ms in five pieces.
+    for (uint32_t i : todo)
+      if (jobs[i].tier == 0 && jobs[i].status == ZES_OK && (jobs[i].c >= SEG_PIECES_MIN_C || (force_pieces && jobs[i].c >= SEG_MIN_C)) &&
+          (rc = inflate_segments_pieces(d_in, d_out, jobs[i])))
+        return rc;
   }
   int worst = 0;
   for (uint32_t i : todo) {

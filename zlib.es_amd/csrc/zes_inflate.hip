@@ -1639,10 +1639,10 @@ __global__ __launch_bounds__(1024) void k_inf_seg_order(const ZesSegJob* __restr
   for (uint32_t w = tid; w < nwork; w += 1024) {
     const uint32_t st = w ? cand[w - 1] : 0u;
     const uint32_t nx = w < ncand ? cand[w] : endbit;
-    s_span[w] = (w > 0 && st == 0) ? 0u : nx - st;  // the duplicate of work item 0 returns at once
+    s_span[w] = (w > 0 && st + 16u == jb.start0) ? 0u : nx - st;  // the duplicate of work item 0 returns at once
   }
   __syncthreads();
-  if (tid == 0 && ncand > 0 && cand[0] == 0) s_span[0] = ncand > 1 ? cand[1] : endbit;
+  if (tid == 0 && ncand > 0 && cand[0] + 16u == jb.start0) s_span[0] = ncand > 1 ? cand[1] : endbit;
   __syncthreads();
   for (uint32_t w = tid; w < nwork; w += 1024) {
     const uint32_t v = s_span[w];
@@ -1690,10 +1690,10 @@ __device__ __forceinline__ static void seg_scan_body(SM& S, const uint8_t* __res
   r.out_len = 0;
   r.flags = 0;
   r.next = 0;
-  uint64_t start = 16;
+  uint64_t start = jb.start0;
   if (w > 0) {
     const uint32_t c0 = cand[w - 1];
-    if (c0 == 0) {  // the stream start is work item 0 already
+    if (c0 + 16u == jb.start0) {  // the stream start is work item 0 already
       if (lane == 0) sres[w] = r;
       WD_JOIN();
       return;
@@ -1715,7 +1715,7 @@ __device__ __forceinline__ static void seg_scan_body(SM& S, const uint8_t* __res
   // the next work item (the end of the stream for the last one); a segment that outgrows its share is decoded twice
   {
     uint32_t nx = w;  // candidate that starts the next work item (candidate 0 at bit 16 duplicates work item 0)
-    if (w == 0 && ncand > 0 && cand[0] == 0) nx = 1;
+    if (w == 0 && ncand > 0 && cand[0] + 16u == jb.start0) nx = 1;
     const uint64_t b0 = (start - 16) / 8, b1 = nx < ncand ? (uint64_t)cand[nx] / 8 : c;
     d.sym = sym_ratio ? sym16 + b0 * sym_ratio / 2 : nullptr;
     if (lane == 0) symoff_all[jb.work_first + w] = jb.sym_base + b0 * sym_ratio / 2;  // (where k_inf_seg_translate finds the symbols)
@@ -1858,13 +1858,14 @@ __global__ __launch_bounds__(256) void k_inf_seg_chain(const ZesSegJob* __restri
   uint32_t* novf = novf_all + blockIdx.x;
   __shared__ uint32_t s_nf[SEGCHAIN_LDS];  // next | flags << 30
   __shared__ unsigned long long s_part[256];
-  __shared__ uint32_t s_nseg;
+  __shared__ uint32_t s_nseg, s_stuck;
   const uint32_t tid = threadIdx.x;
   const bool lds = nwork <= SEGCHAIN_LDS;
   if (lds)
     for (uint32_t i = tid; i < nwork; i += 256) s_nf[i] = (sres[i].next & 0x3FFFFFFFu) | (sres[i].flags << 30);
   if (tid == 0) {
     s_nseg = 0;
+    s_stuck = 0;
     res->status = 1;
     res->out_len = 0;
     res->aux = 0;
@@ -1875,7 +1876,11 @@ __global__ __launch_bounds__(256) void k_inf_seg_chain(const ZesSegJob* __restri
     for (;;) {
       const uint32_t nf = lds ? s_nf[w] : ((sres[w].next & 0x3FFFFFFFu) | (sres[w].flags << 30));
       if (!(nf >> 30 & 1u) || k >= nwork) {
-        if (k < nwork) res->out_len = (unsigned long long)w + 1ull;  // stuck on an undecoded (or failed) item
+        if (k < nwork) {
+          res->out_len = (unsigned long long)w + 1ull;  // stuck on an undecoded (or failed) item
+          s_stuck = w + 1u;
+          if ((jb.flags & ZES_SEG_PARTIAL) && k > 0) break;  // a piece of a longer stream: the chain as far as it got
+        }
         k = 0;
         break;
       }
@@ -1913,7 +1918,11 @@ __global__ __launch_bounds__(256) void k_inf_seg_chain(const ZesSegJob* __restri
     }
     res->out_len = run;
     res->aux = nseg;
-    res->status = 0;
+    res->status = s_stuck ? 3 : 0;  // 3: a partial chain (ZES_SEG_PARTIAL), the item it stands in front of in the second record
+    ZesRes* r2 = res_all + gridDim.x + blockIdx.x;  // second record: where the chain ends
+    r2->out_len = sres[seg[nseg - 1]].end_bit;
+    r2->aux = s_stuck;
+    r2->status = (int)((sres[seg[nseg - 1]].flags >> 1) & 1u);  // the stream's final block has passed
   }
   __syncthreads();
   unsigned long long run = s_part[tid];
@@ -1968,7 +1977,8 @@ __global__ __launch_bounds__(1024) void k_inf_seg_win_group(const uint32_t* __re
 }
 
 __global__ __launch_bounds__(1024) void k_inf_seg_win_top(const uint32_t* __restrict__ pw16_all, const ZesSegJob* __restrict__ jobs,
-                                                          uint8_t* __restrict__ gw_all) {
+                                                          uint8_t* __restrict__ gw_all, const uint8_t* __restrict__ d_out,
+                                                          const ZesSegOut* __restrict__ outs) {
   const ZesSegJob jb = jobs[blockIdx.x];
   const uint32_t nseg = jb.nseg, tid = threadIdx.x;
   if (nseg < 2) return;
@@ -1976,7 +1986,12 @@ __global__ __launch_bounds__(1024) void k_inf_seg_win_top(const uint32_t* __rest
   const uint32_t* pw16 = pw16_all + (size_t)jb.work_first * (ZES_WINDOW / 2);
   uint8_t* gw = gw_all + (size_t)jb.work_first / SEGWIN_GROUP * ZES_WINDOW + (size_t)blockIdx.x * ZES_WINDOW;  // see the host: room per buffer
   __shared__ __align__(16) uint8_t W[2][ZES_WINDOW];
-  for (uint32_t i = tid; i < ZES_WINDOW / 4; i += 1024) reinterpret_cast<uint32_t*>(W[0])[i] = 0;  // nothing in front of the stream
+  {
+    // in front of the stream: nothing — or, for a later piece of a long stream, the output so far (its last 32 KiB)
+    const ZesSegOut ob = outs[blockIdx.x];
+    const uint8_t* dst = d_out + ob.out_off;
+    for (uint32_t i = tid; i < ZES_WINDOW; i += 1024) W[0][i] = (ZES_WINDOW - i <= ob.hist) ? dst[(int64_t)i - (int64_t)ZES_WINDOW] : (uint8_t)0;
+  }
   for (uint32_t gi = 0; gi < ngroups; gi++) {
     __syncthreads();
     const uint8_t* Wo = W[gi & 1];
@@ -2060,9 +2075,13 @@ __global__ __launch_bounds__(256) void k_inf_seg_translate(uint8_t* __restrict__
   if (k > 0) {
     const uint4* wv = reinterpret_cast<const uint4*>(wins + (size_t)(k - 1) * ZES_WINDOW);
     for (uint32_t i = tid; i < ZES_WINDOW / 16; i += 256) reinterpret_cast<uint4*>(W)[i] = wv[i];
+  } else if (ob.hist) {  // a later piece of a long stream: the window in front of its first segment is output that exists
+    const uint8_t* hp = d_out + out_off;
+    for (uint32_t i = tid; i < ZES_WINDOW; i += 256) W[i] = (ZES_WINDOW - i <= ob.hist) ? hp[(int64_t)i - (int64_t)ZES_WINDOW] : (uint8_t)0;
   }
   __syncthreads();
-  const uint32_t first_ok = pre >= ZES_WINDOW ? 0u : ZES_WINDOW - (uint32_t)pre;  // window positions below this do not exist
+  const uint64_t front = pre + ob.hist;  // bytes that exist in front of the segment
+  const uint32_t first_ok = front >= ZES_WINDOW ? 0u : ZES_WINDOW - (uint32_t)front;  // window positions below this do not exist
   const uint16_t* sy = reinterpret_cast<const uint16_t*>(sym16_all + symoff[w]);  // (the buffer's part of symoff[])
   uint8_t* dst = d_out + out_off;
   const uint64_t end = min(pre + r.out_len, cap);
@@ -2099,7 +2118,7 @@ __global__ __launch_bounds__(64) void k_inf_seg_decode(const uint8_t* __restrict
                                                        const uint32_t* __restrict__ cand, const ZesSegRes* __restrict__ sres,
                                                        const uint32_t* __restrict__ seg, const uint64_t* __restrict__ prefix,
                                                        const uint8_t* __restrict__ wins, uint32_t* __restrict__ fail,
-                                                       uint32_t only_overflowed) {
+                                                       uint32_t only_overflowed, uint32_t start0, uint32_t hist) {
   __shared__ __align__(16) InfSmem S;
   const uint32_t k = blockIdx.x, lane = threadIdx.x;
   const uint32_t w = seg[k];
@@ -2115,9 +2134,16 @@ __global__ __launch_bounds__(64) void k_inf_seg_decode(const uint8_t* __restrict
   d.ostart = pre & 15u;
   d.o = d.ostart;
   d.flushed = 0;
-  d.reach = (uint32_t)min(pre, (uint64_t)ZES_WINDOW);
+  d.reach = (uint32_t)min(pre + hist, (uint64_t)ZES_WINDOW);
   d.unfl = (uint32_t)d.ostart;
   d.oi = 0;
+  if (k == 0 && hist) {  // a later piece of a long stream: the bytes in front of its first segment are output that exists
+    const uint8_t* hp = d_out + out_off;
+    for (uint32_t i = lane; i < ZES_WINDOW; i += 64) {
+      const uint32_t p = (uint32_t)d.ostart + ZES_WINDOW + i;  // == position mod 65536
+      S.ring[p & (RING - 1)] = (ZES_WINDOW - i <= hist) ? hp[(int64_t)i - (int64_t)ZES_WINDOW] : (uint8_t)0;
+    }
+  }
   if (k > 0) {  // window bytes in front of the segment: positions ostart - 32768 .. ostart - 1
     const uint32_t* wv = reinterpret_cast<const uint32_t*>(wins + (size_t)(k - 1) * ZES_WINDOW);
     for (uint32_t i = lane; i < ZES_WINDOW / 4; i += 64) {
@@ -2127,7 +2153,7 @@ __global__ __launch_bounds__(64) void k_inf_seg_decode(const uint8_t* __restrict
       for (uint32_t q = 0; q < 4; q++) S.ring[(p + q) & (RING - 1)] = (uint8_t)(v >> (8 * q));
     }
   }
-  wd_seek(d, w ? (uint64_t)cand[w - 1] + 16 : 16);
+  wd_seek(d, w ? (uint64_t)cand[w - 1] + 16 : (uint64_t)start0);
   uint32_t bfinal = 0;
   int rc;
   for (;;) {

@@ -2193,10 +2193,10 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_seg_block_par(const uint8_t
   const uint32_t* cand = cand_all + jb.cand_base;
   ZesSegRes* sres = sres_all + jb.work_first;
   const uint64_t c = jb.c;
-  uint64_t start = 16;
+  uint64_t start = jb.start0;
   if (w > 0) {
     const uint32_t c0 = cand[w - 1];
-    if (c0 == 0) {  // the stream start is work item 0 already
+    if (c0 + 16u == jb.start0) {  // the stream start is work item 0 already
       if (threadIdx.x == 0) {
         ZesSegRes r;
         r.end_bit = 0;
@@ -2210,7 +2210,7 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_seg_block_par(const uint8_t
     start = (uint64_t)c0 + 16;
   }
   uint32_t nx = w;  // candidate that starts the next work item (candidate 0 at bit 16 duplicates work item 0)
-  if (w == 0 && ncand > 0 && cand[0] == 0) nx = 1;
+  if (w == 0 && ncand > 0 && cand[0] + 16u == jb.start0) nx = 1;
   ParItem it;
   it.g32 = reinterpret_cast<const uint32_t*>(d_in + jb.in_off);
   it.lastdw = (uint32_t)((c - 1) >> 2);

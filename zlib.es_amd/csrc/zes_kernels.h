@@ -80,13 +80,19 @@ struct ZesSegJob {
   uint32_t ncand;
   uint32_t work_first;
   uint32_t nseg;       // length of the buffer's chain (0 = not decoded by this tier): k_inf_seg_windows
+  // a piece of a longer stream (streams of 512 MiB and more go through this tier piece by piece): work item 0 starts
+  // at bit start0 of the piece (16: right behind the zlib header), and a chain that ends in front of a block the piece
+  // does not hold whole is accepted as far as it got (ZES_SEG_PARTIAL)
+  uint32_t start0;
+  uint32_t flags;
 };
+#define ZES_SEG_PARTIAL 1u
 
 // where a buffer of a segment-parallel group goes (k_inf_seg_translate)
 struct ZesSegOut {
   uint64_t out_off, cap;
   uint32_t nseg;  // segments to translate (0: none)
-  uint32_t pad;
+  uint32_t hist;  // bytes of output in front of out_off that exist (a later piece of a long stream: up to 32768)
 };
 
 #ifdef __HIPCC__
@@ -115,10 +121,10 @@ __global__ void k_inf_seg_translate(uint8_t*, const ZesSegJob*, const ZesSegOut*
                                     const uint8_t*, const uint32_t*, const uint64_t*, uint32_t*);
 #define SEGWIN_GROUP 32u
 __global__ void k_inf_seg_win_group(const uint32_t*, const uint32_t*, const ZesSegJob*, uint32_t*);
-__global__ void k_inf_seg_win_top(const uint32_t*, const ZesSegJob*, uint8_t*);
+__global__ void k_inf_seg_win_top(const uint32_t*, const ZesSegJob*, uint8_t*, const uint8_t*, const ZesSegOut*);
 __global__ void k_inf_seg_win_fin(const uint32_t*, const ZesSegJob*, const uint8_t*, uint8_t*);
 __global__ void k_inf_seg_decode(const uint8_t*, uint64_t, uint64_t, uint8_t*, uint64_t, uint64_t, const uint32_t*, const ZesSegRes*,
-                                 const uint32_t*, const uint64_t*, const uint8_t*, uint32_t*, uint32_t);
+                                 const uint32_t*, const uint64_t*, const uint8_t*, uint32_t*, uint32_t, uint32_t, uint32_t);
 __global__ void k_inf_block_par(const uint8_t*, uint8_t*, const ZesInfBuf*, uint32_t, const uint32_t*, const uint32_t*, const uint32_t*,
                                 ZesCandRes*, unsigned long long*, const uint32_t*, const uint32_t*, uint32_t*);
 __global__ void k_inf_block_par2(const uint8_t*, uint8_t*, const ZesInfBuf*, uint32_t, const uint32_t*, const uint32_t*, const uint32_t*,
