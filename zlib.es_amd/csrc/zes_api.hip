@@ -1225,9 +1225,9 @@ int inflate_t1_range(const uint8_t* d_in, uint64_t in_off, uint64_t c, uint64_t 
 #endif
 constexpr uint64_t SEG_MIN_C = ZES_SEG_MIN_C;  // shorter streams go straight to the serial wavefront (round 3: 32768 -> 4096: 29 KB of zlib stream can be 4 MiB of periodic data — 12.5 ms by the serial wavefront, 2.8 ms here)
 constexpr size_t SERIAL_BATCH_MIN_JOBS = 16;        // this many left-over streams of a call: one serial wavefront each, side by side
-constexpr uint64_t SERIAL_BATCH_MAX_C = 128ull << 10;  // (longer ones go to the segment-parallel tier: its block decoder is ~15 times a lone wave)
+constexpr uint64_t SERIAL_BATCH_MAX_C = 8ull << 10;  // (round 3: 128 KiB -> 8 KiB)  // (longer ones go to the segment-parallel tier: its block decoder is ~15 times a lone wave)
 constexpr uint64_t SEG_PIECES_MIN_C = 48ull << 20;  // streams from this size on go through the tier in pieces of 32 MiB (inflate_segments_pieces)
-constexpr uint32_t SEG_GROUP_BUFS = 64;      // buffers whose candidates are searched before the first read-back
+constexpr uint32_t SEG_GROUP_BUFS = 512;     // (round 3: 64 -> 512: 2048 x 64 KiB of zlib text 7.4 -> 3.8 ms with single-block streams taken by the block decoder)     // buffers whose candidates are searched before the first read-back
 constexpr uint32_t SEG_GROUP_WORK = 8192;    // work items per segment launch (each owns a 64 KiB map)
 
 // One group: buffers ids[0..nb) with their sorted candidate lists at cand_sorted + cbase[k], ncand[k] entries.
@@ -1650,7 +1650,7 @@ int inflate_segments(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const st
       return r;
     };
     for (uint32_t k = 0; k < nb; k++) {
-      if (nc[k] < 2 || nc[k] > SEG_BUCKETS) continue;  // nothing to cut the stream with (or a poisoned count)
+      if (nc[k] > SEG_BUCKETS) continue;  // (a poisoned count; a stream without a second block start is still one block for the block decoder)
       if (work + nc[k] + 1 > SEG_GROUP_WORK && (rc = flush())) return rc;
       rid.push_back(ids[k]);
       rbase.push_back(cbase[k]);
