@@ -165,5 +165,10 @@ it('malformed-stream cases (every 7th)', () => {
       }
     });
   }
+  // extra: the pooled GPU scratch can be handed back, and the calls go on
+  it('trim(), then the same bytes again', () => {
+    zlibes.trim();
+    assert.strictEqual(hex(zlibes.deflate(RAW_BIN)), hex(outs[1]));
+  });
   console.log('all ' + n + ' host checks passed');
 })().catch((e) => { console.error(e); process.exit(1); });

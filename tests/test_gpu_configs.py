@@ -424,3 +424,22 @@ def test_inflate_size_keeps_nothing(z, oracle, gpu):
     need = C.c_uint64()
     assert z.lib().zes_inflate_size(c.ctypes.data, c.size, C.byref(need), 0) == 0 and need.value == a.size
     assert not hasattr(z.lib(), "zes_inflate_fetch")
+
+
+def test_trim_returns_the_scratch_and_calls_go_on(z, oracle, gpu):
+    import torch
+
+    a = z.gen("itext", 77, 6 << 20)
+    ref = oracle.deflate(a)
+    assert np.array_equal(z.deflate(a), ref)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    z.trim()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free1 - free0 >= 40 << 20  # (the deflate scratch of a 6 MiB input alone is ~14 bytes per byte)
+    # the pools grow again on demand: same results, both directions, device and host entry points
+    assert np.array_equal(z.deflate(a), ref)
+    assert np.array_equal(z.inflate(ref), a)
+    t = dev(a, gpu)
+    out = torch.empty(z.deflate_bound(a.size), dtype=torch.uint8, device=gpu)
+    assert np.array_equal(z.deflate_tensor(t, out).cpu().numpy(), ref)

@@ -129,6 +129,13 @@ def init(device=0):
         _raise(rc)
 
 
+def trim():
+    """zes_trim: the pooled device scratch of every context goes back to the driver (the next call allocates again)."""
+    rc = lib().zes_trim()
+    if rc:
+        _raise(rc)
+
+
 def init_devices(n=0):
     """One process, n GPUs (n <= 0: every visible one): the host batch forms then spread over all of them
     (zes_init_devices).  Returns the number of devices in use."""

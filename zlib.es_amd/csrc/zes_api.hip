@@ -2061,19 +2061,42 @@ int zes_shutdown(void) {
   return rc;
 }
 
-static int shutdown_one(void) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (!g.ready) return ZES_OK;
-  (void)hipSetDevice(g.device);
-  (void)hipStreamSynchronize(g.stream);
+// every pooled device buffer of the current context
+static void free_scratch_locked() {
   DevBuf* all[] = {&g.bufs, &g.blks, &g.idx_a, &g.idx_b, &g.inv, &g.sdelta, &g.tmask, &g.mlist, &g.hists, &g.codes, &g.hdrs, &g.adler, &g.res, &g.order, &g.surv, &g.vlong, &g.segfail, &g.symoff, &g.cand,
                    &g.cand_sorted, &g.counters, &g.cres, &g.map, &g.resume, &g.dbg, &g.ibufs, &g.ibufs2, &g.mvlist, &g.scratch, &g.st_in, &g.st_out,
-                   &g.sres, &g.maps, &g.seglist, &g.segprefix, &g.wins, &g.sym16, &g.segorder, &g.segjobs, &g.kraft, &g.pw16, &g.gwins, &g.seglive, &g.segouts};
+                   &g.sres, &g.maps, &g.seglist, &g.segprefix, &g.wins, &g.sym16, &g.segorder, &g.segjobs, &g.pw16, &g.gwins, &g.seglive, &g.segouts};
   for (DevBuf* b : all) {
     if (b->p) (void)hipFree(b->p);
     b->p = nullptr;
     b->cap = 0;
   }
+}
+
+int zes_trim(void) {
+  std::lock_guard<std::mutex> cfg(g_cfg_mu);
+  const int keep = t_dev;
+  for (int i = 0; i < ZES_MAX_DEV; i++) {
+    t_dev = i;  // (not a routed call: every context in turn)
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g.ready) continue;
+    (void)hipSetDevice(g.device);
+    (void)hipStreamSynchronize(g.stream);
+    free_scratch_locked();  // (the scan's constant table, g.kraft, stays)
+  }
+  t_dev = keep;
+  return ZES_OK;
+}
+
+static int shutdown_one(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g.ready) return ZES_OK;
+  (void)hipSetDevice(g.device);
+  (void)hipStreamSynchronize(g.stream);
+  free_scratch_locked();
+  if (g.kraft.p) (void)hipFree(g.kraft.p);
+  g.kraft.p = nullptr;
+  g.kraft.cap = 0;
   if (g.pinned) (void)hipHostFree(g.pinned);
   g.pinned = nullptr;
   g_side_up.shutdown();

@@ -232,6 +232,15 @@ napi_value InitDevices(napi_env env, napi_callback_info info) {
   return v;
 }
 
+// trim(): the library's pooled device scratch goes back to the driver (zes_trim); the next call allocates again
+napi_value Trim(napi_env env, napi_callback_info) {
+  const int rc = zes_trim();
+  if (rc) return throw_status(env, rc);
+  napi_value v;
+  napi_get_undefined(env, &v);
+  return v;
+}
+
 // ---- Promise-returning forms: the blocking C-ABI call runs on a libuv worker thread ----
 struct AsyncJob {
   napi_async_work work = nullptr;
@@ -545,6 +554,7 @@ napi_value ModuleInit(napi_env env, napi_value exports) {
       {"adler32", nullptr, Adler32, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"init", nullptr, Init, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"initDevices", nullptr, InitDevices, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"trim", nullptr, Trim, nullptr, nullptr, nullptr, napi_default, nullptr},
   };
   napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props);
   return exports;

@@ -14,3 +14,4 @@ export declare function allocPinned(n: number): Uint8Array;
 export declare function adler32(input: Uint8Array): number;
 export declare function init(device: number): void;
 export declare function initDevices(n?: number): number;
+export declare function trim(): void;

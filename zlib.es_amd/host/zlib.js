@@ -98,6 +98,11 @@ function initDevices(n) {
   return addon.initDevices(n);
 }
 
+/** Extra: give the library's pooled GPU scratch back to the driver (a long-lived process after one large call). */
+function trim() {
+  addon.trim();
+}
+
 exports.inflate = inflate;
 exports.deflate = deflate;
 exports.deflateRaw = deflateRaw;
@@ -112,3 +117,4 @@ exports.allocPinned = allocPinned;
 exports.adler32 = adler32;
 exports.init = init;
 exports.initDevices = initDevices;
+exports.trim = trim;

@@ -16,3 +16,4 @@ export const allocPinned = z.allocPinned;
 export const adler32 = z.adler32;
 export const init = z.init;
 export const initDevices = z.initDevices;
+export const trim = z.trim;

@@ -96,3 +96,8 @@ export function init(device: number): void {
 export function initDevices(n: number = 0): number {
   return addon.initDevices(n);
 }
+
+/** Extra: give the library's pooled GPU scratch back to the driver (a long-lived process after one large call). */
+export function trim(): void {
+  addon.trim();
+}
