@@ -19,3 +19,6 @@ def test_foreign_streams_in_pieces():
     # every stream went through the tier (tier 2), none fell to the serial wavefront
     lines = [ln for ln in p.stdout.splitlines() if " MiB level " in ln]
     assert len(lines) == 5 and all(" tier 2 " in ln for ln in lines), p.stdout[-2000:]
+    # room that runs out mid-stream: the size is still reported by this tier; a stream cut off: the serial tiers' error
+    assert "too little room: need 25165824 (expected 25165824) tier 2 ok" in p.stdout, p.stdout[-2000:]
+    assert "truncated stream: Lack of data length tier 4" in p.stdout, p.stdout[-2000:]

@@ -1677,30 +1677,26 @@ int inflate_segments_pieces(const uint8_t* d_in, uint8_t* d_out, InfJob& j) {
   }();
   int rc;
   uint64_t pos_bit = 16, out_base = 0;
+  bool nospace = false;  // the caller's room ran out: the pieces behind are only measured (the chain's lengths need no output)
   for (int guard = 0; guard < (1 << 20); guard++) {
     // the piece: from a 16-byte boundary at least two bytes in front of the block (work item 0 starts at bit >= 16 of it)
     const uint64_t pb = pos_bit >> 3;
     const uint64_t byte0 = pb >= 2 ? ((pb - 2) & ~15ull) : 0;
     std::vector<InfJob> sub(1);
-    sub[0] = InfJob{j.in_off + byte0, std::min<uint64_t>(j.c - byte0, piece), j.out_off + out_base, j.cap > out_base ? j.cap - out_base : 0, 0, ZES_OK, 0};
+    const uint64_t room = (nospace || j.cap <= out_base) ? 0 : j.cap - out_base;
+    sub[0] = InfJob{j.in_off + byte0, std::min<uint64_t>(j.c - byte0, piece), j.out_off + std::min(out_base, j.cap), room, 0, ZES_OK, 0};
     sub[0].start0 = (uint32_t)(pos_bit - 8 * byte0);
-    sub[0].hist = (uint32_t)std::min<uint64_t>(out_base, ZES_WINDOW);
+    sub[0].hist = nospace ? 0u : (uint32_t)std::min<uint64_t>(out_base, ZES_WINDOW);
     sub[0].partial = byte0 + sub[0].c < j.c;  // (the last piece must end with the stream's final block)
     const std::vector<uint32_t> one(1, 0u);
     if ((rc = inflate_segments(d_in, d_out, sub.data(), one))) return rc;
     if (sub[0].tier != 2) return ZES_OK;  // not this way: the serial tiers decide
-    if (sub[0].status == ZES_E_NOSPACE) {
-      if (!sub[0].final_seen) return ZES_OK;  // (the size is only known at the end: the serial tiers report it)
-      j.tier = 2;
-      j.status = ZES_E_NOSPACE;
-      j.out_len = out_base + sub[0].out_len;
-      return ZES_OK;
-    }
-    if (sub[0].status != ZES_OK) return ZES_OK;
+    if (sub[0].status == ZES_E_NOSPACE) nospace = true;
+    else if (sub[0].status != ZES_OK) return ZES_OK;
     out_base += sub[0].out_len;
     if (sub[0].final_seen) {
       j.tier = 2;
-      j.status = ZES_OK;
+      j.status = (nospace || out_base > j.cap) ? ZES_E_NOSPACE : ZES_OK;
       j.out_len = out_base;
       return ZES_OK;
     }
