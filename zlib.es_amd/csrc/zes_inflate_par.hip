@@ -105,6 +105,7 @@ struct LaneBits {
   uint64_t bb;
   uint32_t nb;
   uint32_t pos;  // bit offset of bb's bit 0 inside the buffer; (pos + nb) % 32 == 0
+  uint32_t pre;  // reading global memory: the dword behind bb's bits, dword (pos + nb) / 32, asked for one refill early
 };
 template <bool LDS>
 __device__ __forceinline__ static void lb_seek(LaneBits& b, const BitSrc& s, uint32_t bit) {
@@ -113,12 +114,22 @@ __device__ __forceinline__ static void lb_seek(LaneBits& b, const BitSrc& s, uin
   b.bb = w >> sh;
   b.nb = 64u - sh;
   b.pos = bit;
+  b.pre = LDS ? 0u : src_ldw<LDS>(s, i + 2);
 }
+// From global memory (the emit pass: the LDS holds the output image by then) a refill takes the dword that was asked for
+// at the refill before and asks for the next one: the wave does not sit out a trip to memory every 32 bits of its
+// slowest lane (the emit pass was 130k cycles per block on random data for ~40k cycles of instructions).
 template <bool LDS>
 __device__ __forceinline__ static void lb_refill(LaneBits& b, const BitSrc& s) {
   if (b.nb <= 32u) {
-    b.bb |= (uint64_t)src_ldw<LDS>(s, (b.pos + b.nb) >> 5) << b.nb;
-    b.nb += 32u;
+    if (LDS) {
+      b.bb |= (uint64_t)src_ldw<LDS>(s, (b.pos + b.nb) >> 5) << b.nb;
+      b.nb += 32u;
+    } else {
+      b.bb |= (uint64_t)b.pre << b.nb;
+      b.nb += 32u;
+      b.pre = src_ldw<LDS>(s, (b.pos + b.nb) >> 5);
+    }
   }
 }
 __device__ __forceinline__ static uint32_t lb_take(LaneBits& b, uint32_t k) {
@@ -1003,6 +1014,37 @@ __device__ __forceinline__ static void seg_run(ParSmem& S, const BitSrc& src, ui
   lb_seek<LDS>(b, src, live ? entry : 0u);
   uint32_t ob = 0, fl = 0;
   bool act = live;
+  // T1's emit pass: literals leave as whole dwords.  The lanes' output ranges lie ~128 bytes apart — one LDS bank for
+  // half the wave — so every store instruction of the wave costs ~32 turns of that bank, and a byte store per literal
+  // made the stores the pass's bottleneck (126k cycles per block of random data).  A lane collects its bytes and stores
+  // the aligned dwords that belong to it alone; bytes in front of its first dword boundary, behind its last one, and
+  // around a match record go one by one.
+  // (only where the fast path for 8-bit literals is on — incompressible data, the regular 128-byte stride: on text the
+  // lanes' ranges are irregular, the byte stores spread over the banks, and collecting cost more than it saved)
+  const bool ACC = EMIT && !HIST && f8.n != 0u;  // (uniform)
+  uint32_t pend = 0, pn = 0;  // bytes not stored yet (positions out_off + ob - pn .. out_off + ob - 1, the first one on a dword boundary)
+  auto put = [&](uint32_t v, uint32_t n) __attribute__((always_inline)) {  // n <= 4 bytes of v, lowest first, behind the ones so far
+    uint32_t P = out_off + ob;  // where the first of them goes
+    v &= n >= 4u ? ~0u : ((1u << (8u * n)) - 1u);
+    if (pn == 0u && (P & 3u) != 0u && n != 0u) {  // up to the lane's first dword boundary: byte by byte
+      const uint32_t k = min(n, 4u - (P & 3u));
+      for (uint32_t i = 0; i < k; i++) S.out[P + i] = (uint8_t)(v >> (8u * i));
+      v = k < 4u ? v >> (8u * k) : 0u;
+      n -= k;
+      P += k;
+    }
+    const uint64_t w = (uint64_t)pend | ((uint64_t)v << (8u * pn));
+    const uint32_t t = pn + n;
+    if (t >= 4u) *reinterpret_cast<uint32_t*>(S.out + (P - pn)) = (uint32_t)w;
+    pend = t >= 4u ? (uint32_t)(w >> 32) : (uint32_t)w;
+    pn = t >= 4u ? t - 4u : t;
+  };
+  auto flush = [&]() __attribute__((always_inline)) {  // the bytes in hand, one by one (a match record or the lane's end follows)
+    const uint32_t P = out_off + ob - pn;
+    for (uint32_t i = 0; i < pn; i++) S.out[P + i] = (uint8_t)(pend >> (8u * i));
+    pend = 0;
+    pn = 0;
+  };
   while (__ballot(act)) {
     if (f8.n) {  // uniform: four 8-bit literals at a time while they stay inside the segment
 #pragma unroll
@@ -1019,11 +1061,15 @@ __device__ __forceinline__ static void seg_run(ParSmem& S, const BitSrc& src, ui
           const uint32_t i0 = k0 + (r >> 24), i1 = k0 + ((r >> 16) & 255u), i2 = k0 + ((r >> 8) & 255u), i3 = k0 + (r & 255u);
           const uint32_t s0 = S.syms_l[i0], s1 = S.syms_l[nlit > 1u ? i1 : i0], s2 = S.syms_l[nlit > 2u ? i2 : i0],
                          s3 = S.syms_l[nlit > 3u ? i3 : i0];
-          uint8_t* o = S.out + out_off + ob;
-          o[0] = (uint8_t)s0;
-          if (nlit > 1u) o[1] = (uint8_t)s1;
-          if (nlit > 2u) o[2] = (uint8_t)s2;
-          if (nlit > 3u) o[3] = (uint8_t)s3;
+          if (ACC) {
+            put((s0 & 255u) | ((s1 & 255u) << 8) | ((s2 & 255u) << 16) | (s3 << 24), nlit);
+          } else {
+            uint8_t* o = S.out + out_off + ob;
+            o[0] = (uint8_t)s0;
+            if (nlit > 1u) o[1] = (uint8_t)s1;
+            if (nlit > 2u) o[2] = (uint8_t)s2;
+            if (nlit > 3u) o[3] = (uint8_t)s3;
+          }
         }
         const uint32_t adv = 8u * nlit;
         ob += nlit;
@@ -1071,12 +1117,15 @@ __device__ __forceinline__ static void seg_run(ParSmem& S, const BitSrc& src, ui
     }
     if (act) {
       if (kind == 0u) {
-        if (EMIT) {
+        if (ACC) {
+          put((e >> 16) & 255u, 1u);
+        } else if (EMIT) {
           const uint32_t q = out_off + ob - clo;
           if (!HIST || q < PAR_CHUNK) S.out[q] = (uint8_t)(e >> 16);
         }
         ob += 1u;
       } else {
+        if (ACC) flush();
         if (EMIT) {
           const uint32_t p = out_off + ob, q = p - clo;
           if (!HIST && dist > p) {
@@ -1099,6 +1148,7 @@ __device__ __forceinline__ static void seg_run(ParSmem& S, const BitSrc& src, ui
       }
     }
   }
+  if (ACC) flush();
   exit_pos = b.pos;
   outbytes = ob;
   flags = fl;
