@@ -1712,13 +1712,34 @@ int inflate_stored(const uint8_t* d_in, uint8_t* d_out, InfJob& j) {
   const uint64_t cap_entries = std::min<uint64_t>(j.c / 5 + 1, 1ull << 22);
   if ((rc = ensure(g.res, sizeof(ZesRes)))) return rc;
   if ((rc = ensure(g.scratch, (size_t)cap_entries * sizeof(ZesStoredBlk)))) return rc;
-  {
+  ZesRes hr;
+  hr.status = 1;
+  // up to 128 MiB: every byte position tested for a stored block's header, the chain from the first one marked by
+  // pointer doubling (k_inf_stored_find / k_inf_stored_rank); what that cannot settle, and longer streams: the walk
+  constexpr uint64_t STORED_PAR_MAX_C = 128ull << 20;
+  constexpr uint32_t STORED_CHUNK_H = 16384, STORED_SLOTS_H = 8;
+  if (j.c >= (2ull << 20) && j.c <= STORED_PAR_MAX_C && !getenv("ZES_NO_STORED_PAR")) {  // (a short stream's walk is quicker than two launches)
+    const uint32_t nchunks = (uint32_t)((j.c + STORED_CHUNK_H - 1) / STORED_CHUNK_H);
+    if ((rc = ensure(g.mvlist, (size_t)nchunks * (STORED_SLOTS_H + 1) * 4))) return rc;
+    uint32_t* slots = (uint32_t*)g.mvlist.p;
+    uint32_t* counts = slots + (size_t)nchunks * STORED_SLOTS_H;
+    {
+      Timed t("k_inf_stored_find");
+      hipLaunchKernelGGL(k_inf_stored_find, dim3(nchunks), dim3(256), 0, g.stream, d_in, j.in_off, (uint32_t)j.c, slots, counts);
+    }
+    {
+      Timed t("k_inf_stored_rank");
+      hipLaunchKernelGGL(k_inf_stored_rank, dim3(1), dim3(1024), 0, g.stream, d_in, j.in_off, (uint32_t)j.c, (const uint32_t*)slots,
+                         (const uint32_t*)counts, nchunks, cap_entries, (ZesStoredBlk*)g.scratch.p, (ZesRes*)g.res.p);
+    }
+    if ((rc = read_res(&hr))) return rc;
+  }
+  if (hr.status != 0) {
     Timed t("k_inf_stored_walk");
     hipLaunchKernelGGL(k_inf_stored_walk, dim3(1), dim3(64), 0, g.stream, d_in, j.in_off, j.c, cap_entries, (ZesStoredBlk*)g.scratch.p,
                        (ZesRes*)g.res.p);
+    if ((rc = read_res(&hr))) return rc;
   }
-  ZesRes hr;
-  if ((rc = read_res(&hr))) return rc;
   if (hr.status != 0) return ZES_OK;
   j.tier = 2;
   j.out_len = hr.out_len;

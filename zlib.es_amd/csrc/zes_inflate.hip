@@ -1514,33 +1514,255 @@ __global__ __launch_bounds__(64) void k_inf_decode(const uint8_t* __restrict__ d
 // LEN + NLEN == 65535), then one workgroup per block copies.  Anything else in the chain — another block type, a bad
 // NLEN, data that ends early — and the walk reports "not mine": the other tiers take the stream.
 // ------------------------------------------------------------------------------------------
-__global__ void k_inf_stored_walk(const uint8_t* __restrict__ d_in, uint64_t in_off, uint64_t c, uint64_t cap_entries,
-                                  ZesStoredBlk* __restrict__ list, ZesRes* __restrict__ res) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(64) void k_inf_stored_walk(const uint8_t* __restrict__ d_in, uint64_t in_off, uint64_t c, uint64_t cap_entries,
+                                                        ZesStoredBlk* __restrict__ list, ZesRes* __restrict__ res) {
+  // One wavefront; lane 0 walks.  Where a block starts is known only from the block before, so a step is a trip to
+  // memory (~1 us from HBM: 1.2 ms for the 3000 blocks of a 48 MiB zlib stream).  The other lanes shorten the trips:
+  // an encoder's stored blocks are all about one size, so while header k+1 is on its way the wave touches the lines
+  // around where headers k+2 .. k+5 will be if the sizes repeat (256 bytes each): by the time the walk gets there they
+  // sit in the cache.  (Looking 64 blocks ahead and taking the ones whose guess holds was slower: zlib's stored
+  // blocks differ by a few bytes.)
+  if (blockIdx.x != 0) return;
+  const uint32_t lane = threadIdx.x;
   const uint8_t* in = d_in + in_off;
-  res->status = 1;
-  res->out_len = 0;
-  res->aux = 0;
+  if (lane == 0) {
+    res->status = 1;
+    res->out_len = 0;
+    res->aux = 0;
+  }
   uint64_t pos = 2, dst = 0, n = 0;  // the first block header sits at bit 16, every later one behind a whole byte
+  uint32_t sink = 0;
   for (;;) {
-    if (pos + 5 > c || n >= cap_entries) return;
-    const uint32_t h = in[pos];
-    if ((h >> 1) & 3u) return;  // not a stored block
-    const uint32_t LEN = in[pos + 1] | ((uint32_t)in[pos + 2] << 8), NLEN = in[pos + 3] | ((uint32_t)in[pos + 4] << 8);
-    if (LEN + NLEN != 65535u || pos + 5 + LEN > c) return;
-    ZesStoredBlk b;
-    b.src = pos + 5;
-    b.dst = dst;
-    b.len = LEN;
-    b.pad = 0;
-    list[n++] = b;
+    if (pos + 5 > c || n >= cap_entries) break;
+    uint32_t h = 0, LEN = 0, NLEN = 0;
+    if (lane == 0) {
+      h = in[pos];
+      LEN = in[pos + 1] | ((uint32_t)in[pos + 2] << 8);
+      NLEN = in[pos + 3] | ((uint32_t)in[pos + 4] << 8);
+    }
+    h = (uint32_t)__builtin_amdgcn_readfirstlane((int)h);
+    LEN = (uint32_t)__builtin_amdgcn_readfirstlane((int)LEN);
+    NLEN = (uint32_t)__builtin_amdgcn_readfirstlane((int)NLEN);
+    if (((h >> 1) & 3u) || LEN + NLEN != 65535u || pos + 5 + LEN > c) break;  // not a stored block (or the data ends early)
+    {
+      // lanes 16q .. 16q+15: the 256 bytes around where header k + 2 + q is expected
+      const uint64_t guess = pos + (uint64_t)(2u + (lane >> 4)) * (5ull + LEN);
+      const uint64_t a = (guess & ~127ull) + 16ull * (lane & 15u) - 64ull;
+      if (a + 4 <= c && guess < c) sink += *reinterpret_cast<const uint32_t*>(in + (a & ~3ull));
+    }
+    if (lane == 0) {
+      ZesStoredBlk b;
+      b.src = pos + 5;
+      b.dst = dst;
+      b.len = LEN;
+      b.pad = 0;
+      list[n] = b;
+    }
+    n++;
     dst += LEN;
     pos += 5 + (uint64_t)LEN;
-    if (h & 1u) break;  // BFINAL
+    if (h & 1u) {  // BFINAL
+      if (lane == 0) {
+        res->out_len = dst;
+        res->aux = (uint32_t)n;
+        res->status = 0;
+      }
+      break;
+    }
   }
-  res->out_len = dst;
-  res->aux = (uint32_t)n;
-  res->status = 0;
+  if (sink == 0x9E3779B9u && lane == 63) res->aux ^= 0u;  // (keeps the touches alive)
+}
+
+// ------------------------------------------------------------------------------------------
+// The same walk in parallel, for streams of up to 128 MiB (round 3).  A stored block's header is recognisable on its
+// own — a byte with BTYPE 00 followed by LEN and its complement — so every byte position is tested (k_inf_stored_find:
+// per 16 KiB of stream up to STORED_SLOTS hits, in order; one in 2^18 positions passes by chance), and one workgroup
+// (k_inf_stored_rank) finds the hits that are on the chain from the first header: next[i] = the hit at position
+// P[i] + 5 + LEN[i] (binary search), reachability from hit 0 by pointer doubling, a block's number = reachable hits in
+// front of it, its place in the output = P - 2 - 5 * number.  Anything irregular (too many hits, no hit at bit 16, a
+// chain that does not end on a final block) and the serial walk decides.
+// ------------------------------------------------------------------------------------------
+#define STORED_CHUNK 16384u
+#define STORED_SLOTS 8u
+#define STORED_MAXN 8192u
+__global__ __launch_bounds__(256) void k_inf_stored_find(const uint8_t* __restrict__ d_in, uint64_t in_off, uint32_t c,
+                                                         uint32_t* __restrict__ slots, uint32_t* __restrict__ counts) {
+  __shared__ uint32_t s_hit[STORED_CHUNK / 32];
+  const uint32_t tid = threadIdx.x;
+  const uint8_t* in = d_in + in_off;
+  const uint32_t base = blockIdx.x * STORED_CHUNK;
+  // 64 positions per thread, from 17 dwords (the stream starts on a 16-byte boundary)
+  const uint32_t p0 = base + tid * 64u;
+  uint32_t w[18];
+#pragma unroll
+  for (uint32_t k = 0; k < 18; k++) {
+    const uint64_t a = (uint64_t)p0 + 4ull * k;
+    w[k] = a + 4 <= c ? *reinterpret_cast<const uint32_t*>(in + a) : 0u;
+    if (a < c && a + 4 > c)
+      for (uint32_t q = 0; q < 4u && a + q < c; q++) w[k] |= (uint32_t)in[a + q] << (8u * q);
+  }
+  uint32_t m0 = 0, m1 = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < 64; k++) {
+    const uint32_t i = k >> 2, sh = (k & 3u) * 8u;
+    const uint32_t hb = (w[i] >> sh) & 255u;
+    const uint32_t k1 = k + 1u;
+    const uint32_t v = __builtin_amdgcn_alignbyte(w[(k1 >> 2) + 1u], w[k1 >> 2], k1 & 3u);  // bytes p+1 .. p+4
+    const uint32_t LEN = v & 0xFFFFu;
+    const bool hit = (hb & 6u) == 0u && ((v >> 16) ^ LEN) == 0xFFFFu && (uint64_t)p0 + k >= 2u && (uint64_t)p0 + k + 5u + LEN <= c;
+    if (k < 32u) m0 |= hit ? 1u << k : 0u; else m1 |= hit ? 1u << (k - 32u) : 0u;
+  }
+  // hits are rare (a true header per stored block, one position in 2^18 by chance): a thread that has any counts the
+  // hits of the threads below it and writes its own behind them, in order
+  const uint32_t mycnt = (uint32_t)(__popc(m0) + __popc(m1));
+  s_hit[tid] = mycnt;
+  __syncthreads();
+  if (mycnt) {
+    uint32_t n = 0;
+    for (uint32_t t = 0; t < tid; t++) n += s_hit[t];
+    for (uint32_t half = 0; half < 2u; half++) {
+      uint32_t m = half ? m1 : m0;
+      while (m) {
+        if (n < STORED_SLOTS) slots[(size_t)blockIdx.x * STORED_SLOTS + n] = p0 + 32u * half + (uint32_t)__builtin_ctz(m);
+        n++;
+        m &= m - 1u;
+      }
+    }
+  }
+  if (tid == 255) {
+    uint32_t n = 0;
+    for (uint32_t t = 0; t < 256; t++) n += s_hit[t];
+    counts[blockIdx.x] = n;
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_inf_stored_rank(const uint8_t* __restrict__ d_in, uint64_t in_off, uint32_t c,
+                                                          const uint32_t* __restrict__ slots, const uint32_t* __restrict__ counts,
+                                                          uint32_t nchunks, uint64_t cap_entries, ZesStoredBlk* __restrict__ list,
+                                                          ZesRes* __restrict__ res) {
+  __shared__ uint32_t P[STORED_MAXN];      // positions of the hits, ascending
+  __shared__ uint16_t L[STORED_MAXN];      // their LEN
+  __shared__ uint16_t J[2][STORED_MAXN];   // 2^r-th successor (0xFFFF: none)
+  __shared__ uint32_t R[STORED_MAXN / 32], F[STORED_MAXN / 32];  // reachable from hit 0; final block
+  __shared__ uint32_t s_scan[1024];
+  __shared__ uint32_t s_n, s_bad;
+  const uint32_t tid = threadIdx.x;
+  const uint8_t* in = d_in + in_off;
+  if (tid == 0) {
+    res->status = 1;
+    res->out_len = 0;
+    res->aux = 0;
+    s_bad = 0;
+  }
+  // hits per chunk -> offsets (a chunk range per thread)
+  const uint32_t per = (nchunks + 1023u) / 1024u;
+  const uint32_t c0 = min(nchunks, tid * per), c1 = min(nchunks, c0 + per);
+  uint32_t mine = 0, over = 0;
+  for (uint32_t k = c0; k < c1; k++) {
+    const uint32_t n = counts[k];
+    over |= n > STORED_SLOTS ? 1u : 0u;
+    mine += min(n, STORED_SLOTS);
+  }
+  s_scan[tid] = mine;
+  __syncthreads();
+  if (over) atomicOr(&s_bad, 1u);
+  if (tid == 0) {
+    uint32_t run = 0;
+    for (uint32_t t = 0; t < 1024; t++) {
+      const uint32_t v = s_scan[t];
+      s_scan[t] = run;
+      run += v;
+    }
+    s_n = run;
+  }
+  __syncthreads();
+  const uint32_t n = s_n;
+  if (s_bad || n == 0 || n > STORED_MAXN || (uint64_t)n > cap_entries) return;
+  {
+    uint32_t o = s_scan[tid];
+    for (uint32_t k = c0; k < c1; k++) {
+      const uint32_t m = min(counts[k], STORED_SLOTS);
+      for (uint32_t q = 0; q < m; q++) {
+        const uint32_t p = slots[(size_t)k * STORED_SLOTS + q];
+        P[o] = p;
+        L[o] = (uint16_t)((uint32_t)in[p + 1] | ((uint32_t)in[p + 2] << 8));
+        o++;
+      }
+    }
+  }
+  for (uint32_t i = tid; i < STORED_MAXN / 32; i += 1024) {
+    R[i] = 0;
+    F[i] = 0;
+  }
+  __syncthreads();
+  if (P[0] != 2u) return;  // (uniform) the first block is not a stored one
+  // successor of every hit, final flags
+  for (uint32_t i = tid; i < n; i += 1024) {
+    const uint32_t want = P[i] + 5u + (uint32_t)L[i];
+    uint32_t lo = i + 1, hi = n;
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (P[mid] < want) lo = mid + 1; else hi = mid;
+    }
+    J[0][i] = (lo < n && P[lo] == want) ? (uint16_t)lo : (uint16_t)0xFFFFu;
+    if (in[P[i]] & 1u) atomicOr(&F[i >> 5], 1u << (i & 31u));
+  }
+  if (tid == 0) R[0] = 1u;
+  __syncthreads();
+  // a final block ends the chain: nothing behind it is reached through it
+  for (uint32_t i = tid; i < n; i += 1024)
+    if ((F[i >> 5] >> (i & 31u)) & 1u) J[0][i] = 0xFFFFu;
+  __syncthreads();
+  // reachability by doubling: after round r everything within 2^(r+1) - 1 steps of hit 0 is marked
+  uint32_t cur = 0;
+  for (uint32_t r = 0; (1u << r) < n; r++) {
+    for (uint32_t i = tid; i < n; i += 1024) {
+      const uint32_t j = J[cur][i];
+      if (j != 0xFFFFu && ((R[i >> 5] >> (i & 31u)) & 1u)) atomicOr(&R[j >> 5], 1u << (j & 31u));
+      J[cur ^ 1][i] = j != 0xFFFFu ? J[cur][j] : (uint16_t)0xFFFFu;
+    }
+    cur ^= 1;
+    __syncthreads();
+  }
+  // block numbers = reachable hits in front (eight hits per thread), the list, the result
+  const uint32_t i0 = tid * 8u;
+  uint32_t cnt = 0;
+  for (uint32_t q = 0; q < 8u; q++) {
+    const uint32_t i = i0 + q;
+    cnt += (i < n && ((R[i >> 5] >> (i & 31u)) & 1u)) ? 1u : 0u;
+  }
+  s_scan[tid] = cnt;
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t run = 0;
+    for (uint32_t t = 0; t < 1024; t++) {
+      const uint32_t v = s_scan[t];
+      s_scan[t] = run;
+      run += v;
+    }
+    s_n = run;  // blocks on the chain
+  }
+  __syncthreads();
+  const uint32_t nblk = s_n;
+  uint32_t rank = s_scan[tid];
+  for (uint32_t q = 0; q < 8u; q++) {
+    const uint32_t i = i0 + q;
+    if (i >= n || !((R[i >> 5] >> (i & 31u)) & 1u)) continue;
+    ZesStoredBlk b;
+    b.src = (uint64_t)P[i] + 5u;
+    b.dst = (uint64_t)P[i] - 2u - 5ull * rank;
+    b.len = L[i];
+    b.pad = 0;
+    list[rank] = b;
+    if (rank + 1u == nblk) {  // the last block of the chain must be the stream's final one
+      if ((F[i >> 5] >> (i & 31u)) & 1u) {
+        res->out_len = b.dst + b.len;
+        res->aux = nblk;
+        res->status = 0;
+      }
+    }
+    rank++;
+  }
 }
 
 __global__ __launch_bounds__(256) void k_inf_stored_copy(const uint8_t* __restrict__ d_in, uint64_t in_off, uint8_t* __restrict__ d_out,

@@ -107,6 +107,8 @@ __global__ void k_inf_ranksort(const ZesInfBuf*, const uint32_t*, const uint32_t
 __global__ void k_inf_decode(const uint8_t*, uint8_t*, const ZesInfBuf*, ZesRes*, uint64_t*);
 __global__ void k_inf_stored_walk(const uint8_t*, uint64_t, uint64_t, uint64_t, ZesStoredBlk*, ZesRes*);
 __global__ void k_inf_stored_copy(const uint8_t*, uint64_t, uint8_t*, uint64_t, const ZesStoredBlk*);
+__global__ void k_inf_stored_find(const uint8_t*, uint64_t, uint32_t, uint32_t*, uint32_t*);
+__global__ void k_inf_stored_rank(const uint8_t*, uint64_t, uint32_t, const uint32_t*, const uint32_t*, uint32_t, uint64_t, ZesStoredBlk*, ZesRes*);
 __global__ void k_inf_cand_bucket(const uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*);
 __global__ void k_inf_cand_compact(const uint32_t*, uint32_t*, uint32_t*);
 __global__ void k_inf_seg_order(const ZesSegJob*, const uint32_t*, uint32_t*);
