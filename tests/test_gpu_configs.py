@@ -443,3 +443,28 @@ def test_trim_returns_the_scratch_and_calls_go_on(z, oracle, gpu):
     t = dev(a, gpu)
     out = torch.empty(z.deflate_bound(a.size), dtype=torch.uint8, device=gpu)
     assert np.array_equal(z.deflate_tensor(t, out).cpu().numpy(), ref)
+
+
+def test_stored_streams_find_their_blocks_in_parallel(z, gpu):
+    """Another encoder's stored blocks (incompressible input): from 2 MiB on the headers are found by a parallel search
+    (k_inf_stored_find / k_inf_stored_rank); a stream that turns to dynamic blocks half way is left to the other tiers."""
+    import zlib as pz
+
+    import torch
+
+    rnd = z.gen("xorshift", 31, 5 << 20)
+    txt = z.gen("itext", 32, 3 << 20)
+    z.set_profiling(True)
+    try:
+        for level, data, want_rank in ((0, rnd, True), (6, rnd, True), (6, np.concatenate([rnd, txt]), False), (0, rnd[: 1 << 20], False)):
+            comp = np.frombuffer(pz.compress(data.tobytes(), level), dtype=np.uint8)
+            out = torch.empty(data.size, dtype=torch.uint8, device=gpu)
+            got = z.inflate_tensor(dev(comp, gpu), out)
+            assert got.numel() == data.size and np.array_equal(got.cpu().numpy(), data)
+            assert z.last_inflate_tier() == 2
+            names = [k for k, ms, n in z.last_kernel_times()]
+            assert ("k_inf_stored_copy" in names) == (want_rank or data.size == 1 << 20)  # (the mixed stream is not decoded by the stored path)
+            if want_rank:
+                assert "k_inf_stored_rank" in names and "k_inf_stored_walk" not in names
+    finally:
+        z.set_profiling(False)
