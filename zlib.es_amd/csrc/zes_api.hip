@@ -1677,6 +1677,7 @@ int inflate_segments_pieces(const uint8_t* d_in, uint8_t* d_out, InfJob& j) {
   }();
   int rc;
   uint64_t pos_bit = 16, out_base = 0;
+  uint64_t piece_now = piece;  // (grows when a piece does not hold its first block whole: an encoder with very long blocks)
   bool nospace = false;  // the caller's room ran out: the pieces behind are only measured (the chain's lengths need no output)
   for (int guard = 0; guard < (1 << 20); guard++) {
     // the piece: from a 16-byte boundary at least two bytes in front of the block (work item 0 starts at bit >= 16 of it)
@@ -1684,13 +1685,19 @@ int inflate_segments_pieces(const uint8_t* d_in, uint8_t* d_out, InfJob& j) {
     const uint64_t byte0 = pb >= 2 ? ((pb - 2) & ~15ull) : 0;
     std::vector<InfJob> sub(1);
     const uint64_t room = (nospace || j.cap <= out_base) ? 0 : j.cap - out_base;
-    sub[0] = InfJob{j.in_off + byte0, std::min<uint64_t>(j.c - byte0, piece), j.out_off + std::min(out_base, j.cap), room, 0, ZES_OK, 0};
+    sub[0] = InfJob{j.in_off + byte0, std::min<uint64_t>(j.c - byte0, piece_now), j.out_off + std::min(out_base, j.cap), room, 0, ZES_OK, 0};
     sub[0].start0 = (uint32_t)(pos_bit - 8 * byte0);
     sub[0].hist = nospace ? 0u : (uint32_t)std::min<uint64_t>(out_base, ZES_WINDOW);
     sub[0].partial = byte0 + sub[0].c < j.c;  // (the last piece must end with the stream's final block)
     const std::vector<uint32_t> one(1, 0u);
     if ((rc = inflate_segments(d_in, d_out, sub.data(), one))) return rc;
+    const bool stuck = sub[0].tier != 2 || (sub[0].status == ZES_OK && !sub[0].final_seen && 8 * byte0 + sub[0].end_bit <= pos_bit);
+    if (stuck && sub[0].partial && piece_now < (448ull << 20)) {  // no whole block in this piece: a longer one, same start
+      piece_now = std::min<uint64_t>(piece_now * 4, 448ull << 20);
+      continue;
+    }
     if (sub[0].tier != 2) return ZES_OK;  // not this way: the serial tiers decide
+    piece_now = piece;
     if (sub[0].status == ZES_E_NOSPACE) nospace = true;
     else if (sub[0].status != ZES_OK) return ZES_OK;
     out_base += sub[0].out_len;
