@@ -1254,6 +1254,30 @@ __device__ __forceinline__ static bool par_build(ParSmem& S, uint32_t base, uint
   return true;
 }
 
+// wave scans over 64 lanes (inclusive), DPP: four steps inside each row of 16, then the row totals carried over
+template <int CTRL, int ROWS>
+__device__ __forceinline__ static uint32_t ph_dpp(uint32_t old, uint32_t x) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)x, CTRL, ROWS, 0xf, false);
+}
+__device__ __forceinline__ static uint32_t ph_scan_add(uint32_t x) {
+  x += ph_dpp<0x111, 0xf>(0u, x);
+  x += ph_dpp<0x112, 0xf>(0u, x);
+  x += ph_dpp<0x114, 0xf>(0u, x);
+  x += ph_dpp<0x118, 0xf>(0u, x);
+  x += ph_dpp<0x142, 0xa>(0u, x);  // row_bcast:15 into rows 1 and 3
+  x += ph_dpp<0x143, 0xc>(0u, x);  // row_bcast:31 into rows 2 and 3
+  return x;
+}
+__device__ __forceinline__ static uint32_t ph_scan_max(uint32_t x) {
+  x = max(x, ph_dpp<0x111, 0xf>(0u, x));
+  x = max(x, ph_dpp<0x112, 0xf>(0u, x));
+  x = max(x, ph_dpp<0x114, 0xf>(0u, x));
+  x = max(x, ph_dpp<0x118, 0xf>(0u, x));
+  x = max(x, ph_dpp<0x142, 0xa>(0u, x));
+  x = max(x, ph_dpp<0x143, 0xc>(0u, x));
+  return x;
+}
+
 // ZES_DEBUG_PHASES: header-step stamps go to slots 16..21 of the block's row (pointer set by the kernel)
 #define HSTAMP(i)                                                          \
   do {                                                                     \
@@ -1299,11 +1323,16 @@ __device__ __forceinline__ static bool par_header(ParSmem& S, const BitSrc& src,
   for (uint32_t i = lane; i < 352; i += 64) S.lens[i] = 0;
   HSTAMP(1);
   const uint32_t total = HLIT + HDIST;
-  // The code-length symbols, 64 bit positions at a time: lane j decodes the symbol that would start at
-  // bit j of the window (one table lookup for all 64), then the real chain is followed through the
-  // lanes' results with lane reads — one LDS latency per window instead of one per symbol.
+  // The code-length symbols, 64 bit positions at a time: lane j decodes the symbol that would start at bit j of the
+  // window (one table lookup for all 64).  The real chain through them is only MARKED by a scalar walk (a lane read
+  // and a few scalar operations per symbol); the symbols on it are then moved into lanes 0.. in order and everything
+  // else happens for all of them at once: "repeat previous" takes its value through a max-scan of the last lane
+  // that is no repeat, a symbol's first entry is a prefix sum of the counts, and each lane stores its own (at most
+  // six) entries.  (Round 2 did the values, the bookkeeping and the stores inside the walk: ~270 cycles per symbol
+  // for the lone wave, 40k cycles per header; k_inf_verify_long has had this form since round 2.)
   uint32_t prev = 0;
   uint32_t wbase = b.pos & ~31u, off = b.pos & 31u;  // window start (dword aligned), offset of the next symbol in it
+  uint32_t* s_cl = S.lut_d;  // (64 words of scratch: the distance table is built later)
   for (uint32_t k = 0; k < total;) {
     const uint32_t d = wbase >> 5;
     const uint32_t w0 = src_ldw<LDS>(src, d), w1 = src_ldw<LDS>(src, d + 1), w2 = src_ldw<LDS>(src, d + 2);
@@ -1316,26 +1345,58 @@ __device__ __forceinline__ static bool par_header(ParSmem& S, const BitSrc& src,
     const uint32_t rep = sy == 16u ? 3u + xv : sy == 17u ? 3u + xv : sy == 18u ? 11u + xv : 1u;
     // packed per lane: [6:0] offset of the following symbol (up to 77), [14:7] repeat count, [19:15] symbol, [20] valid
     const uint32_t pk = (lane + l + xb) | (rep << 7) | (sy << 15) | ((l != 0u) << 20);
-    uint32_t bad = 0;  // errors are collected and looked at once per window: no branches inside the chain
-    while (off < 64u && k < total) {
-      const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)pk, (int)off);
-      const uint32_t s1 = (v >> 15) & 31u, r1 = (v >> 7) & 255u;
-      const uint32_t val = (s1 == 16u) ? prev : (s1 >= 17u ? 0u : s1);
-      const bool fits = k + r1 <= total;
-      bad |= (((v >> 20) & 1u) ^ 1u) | (uint32_t)(s1 == 16u && k == 0u) | (uint32_t)!fits;
-      if (val && lane < r1 && fits) {
-        const uint32_t idx = k + lane;
+    // the chain through the window: which lanes are on it
+    uint64_t m = 0;
+    uint32_t cur = off, nsym = 0, inval = 0;
+    while (cur < 64u) {
+      const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)pk, (int)cur);
+      if (!((v >> 20) & 1u)) {  // no code-length code matches here: the header is not one
+        inval = 1;
+        break;
+      }
+      m |= 1ull << cur;
+      nsym++;
+      cur = v & 127u;
+    }
+    if (inval) return false;
+    // into lanes 0 .. nsym-1, in order
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if ((m >> lane) & 1ull) s_cl[(uint32_t)__popcll(m & zes_lanemask_lt())] = pk;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const uint32_t t = s_cl[lane];
+    const bool on = lane < nsym;
+    const uint32_t s1 = on ? (t >> 15) & 31u : 0u, r1 = on ? (t >> 7) & 255u : 0u;
+    const uint32_t is16 = (uint32_t)(s1 == 16u);
+    const uint32_t valraw = s1 >= 16u ? 0u : s1;  // (17, 18: zeros; 16: the value of the symbol before, below)
+    // the last symbol at or before this lane that is no "repeat previous" (0: none in this window — the carry)
+    const uint32_t srcl = ph_scan_max((on && !is16) ? lane + 1u : 0u);
+    const uint32_t vsrc = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((srcl ? srcl - 1u : 0u) << 2), (int)valraw);
+    const uint32_t val = srcl ? vsrc : prev;
+    const uint32_t kin = ph_scan_add(r1);
+    const uint32_t kk = k + kin - r1;  // the symbol's first entry
+    const uint64_t endm = __ballot(on && kk + r1 >= total);  // the symbol that completes the sequence (the first such)
+    const uint32_t cut = endm ? (uint32_t)__builtin_ctzll(endm) : nsym - 1u;  // last symbol of this window that counts
+    const bool mine = on && lane <= cut;
+    const uint64_t badm = __ballot(mine && ((is16 && kk == 0u) || kk + r1 > total));
+    if (badm) return false;
+    if (mine && val) {
+      for (uint32_t q = 0; q < r1; q++) {  // (a non-zero value repeats at most six times)
+        const uint32_t idx = kk + q;
         S.lens[idx < HLIT ? idx : 288 + (idx - HLIT)] = (uint8_t)val;
       }
-      prev = val;
-      k += r1;
-      off = v & 127u;
     }
-    if (bad) return false;
-    if (off >= 64u) {
-      wbase += 64u;
-      off -= 64u;
+    prev = (uint32_t)__builtin_amdgcn_readlane((int)val, (int)cut);
+    k = (uint32_t)__builtin_amdgcn_readlane((int)(kk + r1), (int)cut);
+    if (endm) {  // the header ends behind that symbol
+      off = (uint32_t)__builtin_amdgcn_readlane((int)(t & 127u), (int)cut);
+      if (off >= 64u) {
+        wbase += 64u;
+        off -= 64u;
+      }
+      break;
     }
+    off = cur - 64u;
+    wbase += 64u;
   }
   b.pos = wbase + off;
   HSTAMP(2);
