@@ -1004,6 +1004,16 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
             hs[0] / cntd, hs[1] / cntd, hs[2] / cntd, hs[3] / cntd, hs[4] / cntd);
     fprintf(stderr, "zes resolve steps (avg cycles): carry+clear %.0f fill %.0f jumping %.0f copy %.0f | %.1f barrier rounds per block\n", p4[0] / cntd,
             p4[1] / cntd, p4[2] / cntd, p4[3] / cntd, p4[4] / cntd);
+    {
+      double c0 = 0, c15 = 0;
+      for (uint32_t i = 0; i < work; i++) {
+        const unsigned long long* r = &h[(size_t)i * ZES_PAR_DBG_ROW];
+        if (!r[7]) continue;
+        c0 += (double)(r[22] - r[3]);
+        c15 += (double)(r[23] - r[3]);
+      }
+      fprintf(stderr, "zes count pass, cycles since its start: first wave through %.0f, last wave %.0f\n", c0 / cntd, c15 / cntd);
+    }
     fprintf(stderr, "zes 8-bit table path: %.2f lanes in %.2f waves per block fell back to the generic construction (segment shape or list full %.2f, three positions under one token %.2f, look-back %.2f)\n", fb_lanes / cntd, fb_waves / cntd, why[0] / cntd, why[1] / cntd, why[2] / cntd);
   }
   if (getenv("ZES_DEBUG")) {

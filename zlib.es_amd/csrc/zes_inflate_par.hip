@@ -1650,6 +1650,8 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
   // ---- P2: count pass from the true entries, totals, end bit, output offsets ----
   uint32_t entry = base + ecode, exit_pos = 0, outbytes = 0, flags = 0;
   seg_run<false, true, FOREIGN>(S, src, plimit, entry, stop, ecode < 48u, f8, 0, exit_pos, outbytes, flags);
+  STAMP(22);  // (ZES_DEBUG_PHASES: wave 0 is through the count pass)
+  if (dbg && threadIdx.x == PAR_THREADS - 64) dbg[(size_t)blockIdx.x * ZES_PAR_DBG_ROW + 23] = (unsigned long long)clock64();
   if (ecode >= 48u) flags = F_VOID;
   if (tid == 0) {
     S.tail_bytes = 0;
