@@ -848,7 +848,9 @@ void zes_lazy_set_dbg(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBO
 #define LAZY_WIN 512u
 #endif
 #define LAZY_NWIN (ZES_BLK / LAZY_WIN)
-#define LAZY_TAIL 512u         // positions at the block end that are evaluated up front, one lane each
+#ifndef LAZY_TAIL
+#define LAZY_TAIL 272u         // positions at the block end that are evaluated up front, one row each: every position whose match can reach the last three bytes (258 + 3), rounded up
+#endif
 #define LAZY_EVAL_LIT 1u       // match word of an evaluated position that stays a literal (no match bit: k_lz_parse reads a literal)
 #define LAZY_MERGE_CAP 1024u   // a second chain that has met no window chain after this many bytes gives up
 struct LazySmem {
