@@ -2078,45 +2078,129 @@ __global__ __launch_bounds__(256) void k_inf_seg_chain(const ZesSegJob* __restri
   uint64_t* prefix = prefix_all + jb.work_first;
   ZesRes* res = res_all + blockIdx.x;
   uint32_t* novf = novf_all + blockIdx.x;
-  __shared__ uint32_t s_nf[SEGCHAIN_LDS];  // next | flags << 30
+  // The chain as a list ranking instead of one lane's walk (2000 items: 300k cycles, one LDS latency per item).  Every
+  // item points at its successor, or at itself where a chain would end on it (1: not decoded, 2: it holds the final
+  // block, 3: no successor); the items of the chain from item 0 are marked by pointer doubling (after round r every
+  // item less than 2^(r+1) steps from item 0 is marked; what is marked is always on the chain), and since a segment
+  // ends behind its start the chain's order is the items' order: the k-th marked item is seg[k].  The result is
+  // checked link by link; anything else (more items than the LDS holds, a link that points backwards) and one lane
+  // walks the chain as before.
+  __shared__ uint16_t s_j[2][SEGCHAIN_LDS];
+  __shared__ uint8_t s_m[SEGCHAIN_LDS];  // bit 0: on the chain; bits 1-2: how a chain ends here
   __shared__ unsigned long long s_part[256];
-  __shared__ uint32_t s_nseg, s_stuck;
+  __shared__ uint32_t s_nseg, s_stuck, s_last, s_bad;
   const uint32_t tid = threadIdx.x;
   const bool lds = nwork <= SEGCHAIN_LDS;
-  if (lds)
-    for (uint32_t i = tid; i < nwork; i += 256) s_nf[i] = (sres[i].next & 0x3FFFFFFFu) | (sres[i].flags << 30);
   if (tid == 0) {
     s_nseg = 0;
     s_stuck = 0;
+    s_last = 0;
+    s_bad = lds ? 0u : 1u;
     res->status = 1;
     res->out_len = 0;
     res->aux = 0;
   }
   __syncthreads();
-  if (tid == 0) {
-    uint32_t w = 0, k = 0;
-    for (;;) {
-      const uint32_t nf = lds ? s_nf[w] : ((sres[w].next & 0x3FFFFFFFu) | (sres[w].flags << 30));
-      if (!(nf >> 30 & 1u) || k >= nwork) {
-        if (k < nwork) {
-          res->out_len = (unsigned long long)w + 1ull;  // stuck on an undecoded (or failed) item
-          s_stuck = w + 1u;
-          if ((jb.flags & ZES_SEG_PARTIAL) && k > 0) break;  // a piece of a longer stream: the chain as far as it got
-        }
-        k = 0;
-        break;
+  if (lds) {
+    for (uint32_t i = tid; i < nwork; i += 256) {
+      const uint32_t nx = sres[i].next & 0x3FFFFFFFu, fl = sres[i].flags;
+      const uint32_t type = !(fl & 1u) ? 1u : (fl & 2u) ? 2u : (nx == 0u || nx >= nwork) ? 3u : 0u;
+      s_j[0][i] = (uint16_t)(type ? i : nx);
+      s_m[i] = (uint8_t)((type << 1) | (i == 0u ? 1u : 0u));
+    }
+    __syncthreads();
+    uint32_t cur = 0;
+    for (uint32_t span = 1; span < nwork; span <<= 1) {
+      for (uint32_t i = tid; i < nwork; i += 256) {
+        const uint32_t j = s_j[cur][i];
+        s_j[cur ^ 1u][i] = s_j[cur][j];
+        if ((s_m[i] & 1u) && !(s_m[j] & 1u)) s_m[j] |= 1u;  // (every writer of a byte writes the same value)
       }
-      seg[k++] = w;
-      if (nf >> 31) break;  // final block inside this segment
-      w = nf & 0x3FFFFFFFu;
-      if (w == 0 || w >= nwork) {
-        k = 0;
-        break;
+      cur ^= 1u;
+      __syncthreads();
+    }
+    // the marked items in order -> ord[] (the pointer array that is free now), the last of them -> s_last
+    uint16_t* ord = s_j[cur ^ 1u];
+    const uint32_t per = (nwork + 255u) / 256u;
+    const uint32_t i0 = min(nwork, tid * per), i1 = min(nwork, i0 + per);
+    uint32_t mine = 0, lastm = 0;
+    for (uint32_t i = i0; i < i1; i++)
+      if (s_m[i] & 1u) {
+        mine++;
+        lastm = i;
+      }
+    s_part[tid] = mine;
+    if (mine) atomicMax(&s_last, lastm);
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long run = 0;
+      for (uint32_t t = 0; t < 256; t++) {
+        const unsigned long long v = s_part[t];
+        s_part[t] = run;
+        run += v;
+      }
+      s_nseg = (uint32_t)run;  // (for now: every marked item, the one the chain ends on included)
+    }
+    __syncthreads();
+    {
+      uint32_t k = (uint32_t)s_part[tid];
+      for (uint32_t i = i0; i < i1; i++)
+        if (s_m[i] & 1u) ord[k++] = (uint16_t)i;
+    }
+    __syncthreads();
+    const uint32_t nm = s_nseg, last = s_last, ltype = (uint32_t)s_m[last] >> 1;
+    // every link: the successor of the k-th is the (k+1)-th, and only the last one ends a chain
+    for (uint32_t k = tid; k + 1u < nm; k += 256) {
+      const uint32_t i = ord[k];
+      if ((s_m[i] >> 1) != 0u || (sres[i].next & 0x3FFFFFFFu) != (uint32_t)ord[k + 1u]) s_bad = 1u;
+    }
+    if (tid == 0 && (ltype == 0u || nm == 0u || ord[nm - 1u] != last)) s_bad = 1u;
+    __syncthreads();
+    if (!s_bad) {
+      // 2: the chain is whole.  1: it stands in front of an item nobody has decoded.  3: it is broken.
+      const uint32_t napp = ltype == 2u ? nm : (ltype == 1u ? nm - 1u : 0u);
+      const bool partial = ltype == 1u && (jb.flags & ZES_SEG_PARTIAL) && napp > 0u;  // a piece of a longer stream: the chain as far as it got
+      const uint32_t nkeep = (ltype == 2u || partial) ? napp : 0u;
+      for (uint32_t k = tid; k < nkeep; k += 256) seg[k] = ord[k];
+      if (tid == 0) {
+        if (ltype == 1u) {
+          res->out_len = (unsigned long long)last + 1ull;  // stuck on an undecoded (or failed) item
+          s_stuck = last + 1u;
+        }
+        s_nseg = nkeep;
       }
     }
-    s_nseg = k;
+    // seg[] is read back below by other lanes than its writers
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
   }
-  __syncthreads();
+  if (s_bad) {  // (uniform)
+    if (tid == 0) {
+      uint32_t w = 0, k = 0;
+      for (;;) {
+        const uint32_t nf = (sres[w].next & 0x3FFFFFFFu) | (sres[w].flags << 30);
+        if (!(nf >> 30 & 1u) || k >= nwork) {
+          if (k < nwork) {
+            res->out_len = (unsigned long long)w + 1ull;  // stuck on an undecoded (or failed) item
+            s_stuck = w + 1u;
+            if ((jb.flags & ZES_SEG_PARTIAL) && k > 0) break;  // a piece of a longer stream: the chain as far as it got
+          }
+          k = 0;
+          break;
+        }
+        seg[k++] = w;
+        if (nf >> 31) break;  // final block inside this segment
+        w = nf & 0x3FFFFFFFu;
+        if (w == 0 || w >= nwork) {
+          k = 0;
+          break;
+        }
+      }
+      s_nseg = k;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
   const uint32_t nseg = s_nseg;
   if (nseg == 0) return;
   // output offsets: chunked sums, scan of the chunk totals, chunked prefixes
