@@ -793,6 +793,7 @@ struct InfJob {
   uint32_t start0 = 16, hist = 0;
   bool partial = false, final_seen = false;
   uint64_t end_bit = 0;
+  int btype0 = -1;  // BTYPE of the block at bit 16, when the block-parallel tier's scan has sent it along (-1: not known)
 };
 
 bool t1_eligible(const InfJob& j, uint32_t flags) { return !(flags & (ZES_F_NO_FASTPATH | ZES_F_PIECES)) && j.c >= 64 && j.c < (1ull << 29); }
@@ -911,6 +912,10 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
   if (!one) {
     HIPCHK(hipMemcpyAsync(hc, g.counters.p, cnt_bytes, hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));  // the table upload has completed too: hb may be rewritten
+    for (uint32_t i = 0; i < nbuf; i++) {
+      const uint8_t fb = ((const uint8_t*)(hc + 4 + nbuf))[i];
+      if (fb & 0x40u) jobs[ids[i]].btype0 = (fb >> 4) & 3;
+    }
     if (check_first) {  // CM nibble of the first byte (src/zlib.ts:13-16): the scan kernel sent it along
       const uint8_t* hfirst = (const uint8_t*)(hc + 4 + nbuf);
       for (uint32_t i = 0; i < nbuf; i++)
@@ -963,6 +968,7 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
   HIPCHK(hipStreamSynchronize(g.stream));
   const uint32_t nsurv = hc[0];
   if (one) {
+    if (((const uint8_t*)(hc + 5))[0] & 0x40u) jobs[ids[0]].btype0 = (((const uint8_t*)(hc + 5))[0] >> 4) & 3;
     if (check_first && (((const uint8_t*)(hc + 5))[0] & 15u) != 8u) {  // src/zlib.ts:13-16
       jobs[ids[0]].status = ZES_E_NOT_DEFLATE;
       jobs[ids[0]].tier = -1;
@@ -1968,9 +1974,10 @@ int inflate_jobs(const uint8_t* d_in, uint8_t* d_out, std::vector<InfJob>& jobs,
     {
       // the stored-blocks walk is a launch and a read-back per buffer: with several buffers left, only those whose first
       // block IS a stored one (BTYPE, bits 1-2 of the byte behind the zlib header; gathered by one launch per group) try it
+      // (a buffer the block-parallel tier has looked at comes with its first BTYPE: no attempt, and no launch to find out)
       std::vector<uint32_t> st;
       for (uint32_t i : todo)
-        if (jobs[i].tier == 0 && jobs[i].status == ZES_OK && jobs[i].c >= STORED_MIN_C) st.push_back(i);
+        if (jobs[i].tier == 0 && jobs[i].status == ZES_OK && jobs[i].c >= STORED_MIN_C && (jobs[i].btype0 < 0 || jobs[i].btype0 == 0)) st.push_back(i);
       std::vector<char> want(st.size(), 1);
       if (st.size() >= 2) {
         for (size_t g0 = 0; g0 < st.size(); g0 += INF_GROUP) {

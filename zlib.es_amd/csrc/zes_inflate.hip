@@ -137,7 +137,9 @@ __global__ __launch_bounds__(INF_SCAN_THREADS) void k_inf_scan(const uint8_t* __
   }
   __syncthreads();
   // the buffer's first byte rides back with the counters (CM nibble check on the host, src/zlib.ts:13)
-  if (tid == 0 && b0 == 0) first_bytes[bi] = (uint8_t)(s[0] & 0xffu);
+  // (low nibble: CM; bits 4-5: BTYPE of the block at bit 16, bit 6: "it is there" — the host skips the stored-blocks
+  // attempt for a stream that does not begin with one)
+  if (tid == 0 && b0 == 0) first_bytes[bi] = (uint8_t)((s[0] & 0x0fu) | (((s[0] >> 17) & 3u) << 4) | 0x40u);
   const uint64_t end_bits = c * 8;
   // Two passes at most.  The first stages the survivors in LDS; a chunk with more of them than the list holds (a
   // periodic stream: the bit pattern of one repeated match passes the test at every repetition) is walked again and
