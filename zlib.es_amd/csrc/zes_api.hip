@@ -894,7 +894,7 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
   {
     Timed t("k_inf_scan");
     hipLaunchKernelGGL(k_inf_scan, dim3((uint32_t)chunks), dim3(INF_SCAN_THREADS), 0, g.stream, d_in, dbufs, nbuf,
-                       (unsigned long long*)g.surv.p, surv_cap, counters, dfirst, (flags & ZES_F_LOOSE_CANDIDATES) ? 1u : 0u,
+                       (unsigned long long*)g.surv.p, surv_cap, counters, dfirst, (flags & ZES_F_LOOSE_CANDIDATES) ? 1u : 2u,
                        (const uint8_t*)g.kraft.p);
   }
   // (k_inf_verify, measured on 64 MiB: 8192 workgroups 0.33 ms, 2048 0.26 ms, 512 0.36 ms — about one survivor in 256 input
@@ -1186,7 +1186,7 @@ int inflate_t1_range(const uint8_t* d_in, uint64_t in_off, uint64_t c, uint64_t 
     // (the scan's rule that a BFINAL position far from the end is no block start uses the end of the piece: a piece in
     // the middle of a stream merely keeps a few more survivors near its own end)
     hipLaunchKernelGGL(k_inf_scan, dim3((uint32_t)chunks), dim3(INF_SCAN_THREADS), 0, g.stream, d_in, dbufs, 1u, (unsigned long long*)g.surv.p,
-                       surv_cap, counters, dfirst, (flags & ZES_F_LOOSE_CANDIDATES) ? 1u : 0u, (const uint8_t*)g.kraft.p);
+                       surv_cap, counters, dfirst, (flags & ZES_F_LOOSE_CANDIDATES) ? 1u : 2u, (const uint8_t*)g.kraft.p);
   }
   if ((rc = launch_verify(d_in, dbufs, surv_cap, counters, cnt, (flags & ZES_F_LOOSE_CANDIDATES) ? 1u : 0u, c, 32768))) return rc;
   uint32_t* hc = (uint32_t*)g.pinned;

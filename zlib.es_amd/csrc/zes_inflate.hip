@@ -95,8 +95,9 @@ __device__ __forceinline__ static uint32_t buf_of_chunk(const ZesInfBuf* bufs, u
 __global__ __launch_bounds__(INF_SCAN_THREADS) void k_inf_scan(const uint8_t* __restrict__ d_in, const ZesInfBuf* __restrict__ bufs,
                                                                uint32_t nbuf, unsigned long long* __restrict__ surv,
                                                                uint32_t surv_cap, uint32_t* __restrict__ counters,
-                                                               uint8_t* __restrict__ first_bytes, uint32_t loose,
+                                                               uint8_t* __restrict__ first_bytes, uint32_t mode,
                                                                const uint8_t* __restrict__ kraft_tab) {
+  const uint32_t loose = mode & 1u;  // bit 0: ZES_F_LOOSE_CANDIDATES; bit 1: see below
   // Each thread owns 32 consecutive bit positions at a time.  The fixed-field tests (BTYPE = 2,
   // HLIT <= 29, HDIST <= 29) run on all 32 positions at once as shifted word logic; only the
   // surviving positions (about one in five) pay for the Kraft sum of the code-length code.
@@ -116,6 +117,21 @@ __global__ __launch_bounds__(INF_SCAN_THREADS) void k_inf_scan(const uint8_t* __
   const uint64_t b0 = (uint64_t)(blockIdx.x - bufs[bi].first_chunk) * SCAN_BYTES;
   const uint32_t* in32 = reinterpret_cast<const uint32_t*>(d_in + in_off);
   const uint64_t ndw = (c + 3) >> 2;
+  // The chain of blocks this search serves has to start at bit 16 + start_rel with a dynamic block — the reference
+  // writes nothing else (src/deflate.ts:28).  A stream that begins with a stored or fixed block (zlib on incompressible
+  // data, level 0) is another encoder's: no survivors, the tier declines without the 0.3 ms per 64 MiB of this search.
+  // (mode bit 1: the block-parallel tier's own launches ask for this; the tier for other encoders' streams wants every
+  // block start of a stream, whatever it begins with.)
+  uint32_t hdr2 = 0;
+  bool hdr_known = false;
+  if ((mode & 2u) && !loose && !(bufs[bi].range_flags & ZES_START_ANY)) {
+    const uint64_t hbit = 16ull + bufs[bi].start_rel;
+    if (hbit + 3 <= c * 8) {
+      const uint64_t hb = hbit >> 3;
+      hdr2 = ((uint32_t)d_in[in_off + hb] | ((uint32_t)d_in[in_off + (hb + 1 < c ? hb + 1 : hb)] << 8)) >> (uint32_t)(hbit & 7u);
+      hdr_known = true;
+    }
+  }
   {
     // all loads first (clamped addresses, so they are unconditional and overlap), then the masking
     constexpr uint32_t NLD = (SCAN_BYTES / 4 + 8 + INF_SCAN_THREADS - 1) / INF_SCAN_THREADS;
@@ -140,6 +156,7 @@ __global__ __launch_bounds__(INF_SCAN_THREADS) void k_inf_scan(const uint8_t* __
   // (low nibble: CM; bits 4-5: BTYPE of the block at bit 16, bit 6: "it is there" — the host skips the stored-blocks
   // attempt for a stream that does not begin with one)
   if (tid == 0 && b0 == 0) first_bytes[bi] = (uint8_t)((s[0] & 0x0fu) | (((s[0] >> 17) & 3u) << 4) | 0x40u);
+  if (hdr_known && ((hdr2 >> 1) & 3u) != 2u) return;  // (uniform)
   const uint64_t end_bits = c * 8;
   // Two passes at most.  The first stages the survivors in LDS; a chunk with more of them than the list holds (a
   // periodic stream: the bit pattern of one repeated match passes the test at every repetition) is walked again and
