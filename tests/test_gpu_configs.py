@@ -398,6 +398,15 @@ def test_pipelined_host_calls(z, oracle, gpu):
     other = np.frombuffer(pyzlib.compress(src.tobytes(), 1), dtype=np.uint8).copy()
     assert len(other) >= 8 << 20
     assert sha(z.inflate(other)) == sha(src) and z.last_inflate_tier() != 1
+    # ... and one that begins like the reference's (a dynamic block): its first piece fails on the history the block
+    # decoder does not have, with the next piece enqueued already
+    src = z.gen("itext", 78, 40 << 20)
+    other = np.frombuffer(pyzlib.compress(src.tobytes(), 6), dtype=np.uint8).copy()
+    assert len(other) >= 8 << 20
+    assert sha(z.inflate(other)) == sha(src) and z.last_inflate_tier() == 2
+    back = np.zeros(len(src), dtype=np.uint8)
+    blen = C.c_uint64()
+    assert L.zes_inflate(other.ctypes.data, len(other), back.ctypes.data, len(src), C.byref(blen), 0) == 0 and sha(back) == sha(src)
 
 
 def test_unaligned_device_views_are_staged(z, oracle, gpu):

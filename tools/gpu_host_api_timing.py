@@ -18,7 +18,7 @@ import __graft_entry__ as ge  # noqa: E402
 z = ge.load()
 z.init(0)
 L = z.lib()
-n = 64 << 20
+n = int(os.environ.get("HOST_N_MB", "64")) << 20  # (HOST_N_MB: another size)
 cap = z.deflate_bound(n)
 
 
@@ -41,8 +41,8 @@ def run(kind, pinned):
         bi = min(bi, time.perf_counter() - t0)
         assert rc == 0 and blen.value == n
     ok = bool((back == src).all())
-    print("%-9s %-8s host API: deflate %.2f ms (%.2f GiB/s)  inflate %.2f ms (%.2f GiB/s)  ok=%s" % (
-        kind, "pinned" if pinned else "pageable", bd * 1e3, n / bd / 2**30, bi * 1e3, n / bi / 2**30, ok), flush=True)
+    print("%-9s %-8s c=%d host API: deflate %.2f ms (%.2f GiB/s)  inflate %.2f ms (%.2f GiB/s)  ok=%s" % (
+        kind, "pinned" if pinned else "pageable", clen.value, bd * 1e3, n / bd / 2**30, bi * 1e3, n / bi / 2**30, ok), flush=True)
     if pinned:
         for x in (a, comp, back):
             z.host_free(x)

@@ -42,6 +42,7 @@ struct Ctx {
   hipStream_t stream = nullptr;
   hipStream_t cs_in = nullptr, cs_out = nullptr;  // copy streams of the pipelined host calls (H2D / D2H beside the kernels)
   hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_k = nullptr;
+  hipEvent_t ev_rng[2] = {nullptr, nullptr};  // host inflate in pieces: the results of piece k have come back
   hipStream_t s_adler = nullptr;                     // the Adler-32 pass of a deflate call runs beside the LZ77 kernels
   hipEvent_t ev_a0 = nullptr, ev_a1 = nullptr;
   // deflate scratch
@@ -139,6 +140,7 @@ int init_locked(int device) {
   HIPCHK(hipStreamCreateWithFlags(&g.cs_in, hipStreamNonBlocking));
   HIPCHK(hipStreamCreateWithFlags(&g.cs_out, hipStreamNonBlocking));
   for (int k = 0; k < 2; k++) HIPCHK(hipEventCreateWithFlags(&g.ev_up[k], hipEventDisableTiming));
+  for (int k = 0; k < 2; k++) HIPCHK(hipEventCreateWithFlags(&g.ev_rng[k], hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&g.ev_k, hipEventDisableTiming));
   HIPCHK(hipStreamCreateWithFlags(&g.s_adler, hipStreamNonBlocking));
   HIPCHK(hipEventCreateWithFlags(&g.ev_a0, hipEventDisableTiming));
@@ -1206,7 +1208,7 @@ int inflate_t1_range(const uint8_t* d_in, uint64_t in_off, uint64_t c, uint64_t 
   {
     Timed t("k_inf_chain");
     hipLaunchKernelGGL(k_inf_chain_range, dim3(1), dim3(256), 0, g.stream, dbufs, (const uint32_t*)cnt, (const uint32_t*)g.cand_sorted.p,
-                       (const ZesCandRes*)g.cres.p, (ZesRes*)g.res.p);
+                       (const ZesCandRes*)g.cres.p, (ZesRes*)g.res.p, (unsigned long long*)nullptr);
   }
   ZesRes* hres = (ZesRes*)((uint8_t*)g.pinned + 128 * 1024);
   HIPCHK(hipMemcpyAsync(hres, g.res.p, sizeof(ZesRes) * 2, hipMemcpyDeviceToHost, g.stream));
@@ -1222,6 +1224,119 @@ int inflate_t1_range(const uint8_t* d_in, uint64_t in_off, uint64_t c, uint64_t 
       fprintf(stderr, "  cand[%u]=%u flags=%u out_len=%llu end_bit=%llu\n", k, hcand[k], hcr[k].flags, (unsigned long long)hcr[k].out_len,
               (unsigned long long)hcr[k].end_bit);
   }
+  if (hres[0].status != 0) return ZES_OK;
+  rr->handled = true;
+  rr->out_len = hres[0].out_len;
+  rr->nblocks = hres[0].aux & 0x7FFFFFFFu;
+  rr->final_block = (hres[0].aux >> 31) != 0;
+  rr->end_bit = hres[1].out_len;
+  rr->first_bit = hres[1].aux;
+  return ZES_OK;
+}
+
+// The same in two halves, for the host call that decodes a stream piece by piece while its neighbours are on the link
+// (inflate_host_pipelined): range_begin enqueues everything piece k needs — no look at a result in between: the
+// block decoder is launched over a bound and takes the candidate count from device memory (ZES_WORK_AUTO), the piece's
+// place in the output is the block count of the pieces before it, kept on the device (k_inf_chain_range adds to it,
+// k_inf_set_table_range reads it) — and range_finish waits for the read-backs of that piece only.  The host enqueues
+// piece k + 1 before it waits for piece k: the device never waits for the host between pieces.
+struct RangePend {
+  bool skip = false, nothing = false, exact = false;
+  uint64_t lo_bit = 0;
+  uint32_t surv_cap = 0, cand_cap = 0, bound = 0;
+};
+static uint32_t* range_hc(int slot) { return (uint32_t*)((uint8_t*)g.pinned + 96 * 1024 + slot * 64); }
+static ZesRes* range_hres(int slot) { return (ZesRes*)((uint8_t*)g.pinned + 96 * 1024 + 256 + slot * 64); }
+static unsigned long long* range_acc() { return (unsigned long long*)((uint8_t*)g.counters.p + 64); }
+// scratch for pieces of up to cmax bytes, before anything is in flight (growing a buffer frees the old one)
+int range_reserve(uint64_t cmax) {
+  int rc;
+  const uint32_t cands = (uint32_t)std::min<uint64_t>(cmax / 64 + 64, 1ull << 23);
+  const uint32_t surv_cap = (uint32_t)std::min<uint64_t>(cmax / 4 + 1024ull, 1ull << 30);
+  if ((rc = ensure(g.ibufs, sizeof(ZesInfBuf) * 2))) return rc;
+  if ((rc = ensure(g.surv, (size_t)surv_cap * 8))) return rc;
+  if ((rc = ensure(g.cand, (size_t)cands * 4))) return rc;
+  if ((rc = ensure(g.cand_sorted, (size_t)cands * 4))) return rc;
+  if ((rc = ensure(g.cres, sizeof(ZesCandRes) * cands))) return rc;
+  if ((rc = ensure(g.counters, 128))) return rc;
+  if ((rc = ensure(g.res, sizeof(ZesRes) * 2))) return rc;
+  if ((rc = ensure(g.vlong, (size_t)std::min<uint64_t>(cmax / 256 + 4096, surv_cap) * 24))) return rc;
+  HIPCHK(hipMemsetAsync(range_acc(), 0, 8, g.stream));
+  return ZES_OK;
+}
+int range_begin(int slot, RangePend& pd, const uint8_t* d_in, uint64_t in_off, uint64_t c, uint64_t lo_bit, uint64_t own_bit, bool exact,
+                uint8_t* d_out, uint64_t dcap, bool two, uint32_t flags) {
+  int rc;
+  pd = RangePend();
+  pd.exact = exact;
+  pd.lo_bit = lo_bit;
+  if (c >= (1ull << 29) || lo_bit < 16) pd.skip = true;
+  else if (c * 8 < lo_bit + 64) pd.nothing = true;
+  if (!pd.skip && !pd.nothing) {
+    ZesInfBuf b0, b1;
+    memset(&b0, 0, sizeof b0);
+    memset(&b1, 0, sizeof b1);
+    const uint64_t chunks = (c + INF_SCAN_BYTES - 1) / INF_SCAN_BYTES;
+    b0.in_off = in_off;
+    b0.c = c;
+    b0.cand_cap = (uint32_t)std::min<uint64_t>(c / 64 + 64, 1ull << 23);
+    b0.start_rel = (uint32_t)(lo_bit - 16);
+    b0.own_rel = (uint32_t)std::min<uint64_t>(own_bit >= 16 ? own_bit - 16 : 0, 0xFFFFFFFEull);
+    b0.range_flags = exact ? 0u : ZES_START_ANY;
+    pd.cand_cap = b0.cand_cap;
+    pd.surv_cap = (uint32_t)std::min<uint64_t>(c / 4 + 1024ull, 1ull << 30);
+    // the most blocks the output can hold, and room for false candidates
+    pd.bound = (uint32_t)std::min<uint64_t>(b0.cand_cap, dcap / ZES_BLK + 65);
+    b1.first_chunk = (uint32_t)chunks;
+    b1.cand_base = b0.cand_cap;
+    b1.cand_cap = pd.bound;
+    b1.work_first = ZES_WORK_AUTO;
+    const ZesInfBuf* dbufs = (const ZesInfBuf*)g.ibufs.p;
+    uint32_t* counters = (uint32_t*)g.counters.p;
+    uint32_t* cnt = counters + 4;
+    uint8_t* dfirst = (uint8_t*)(cnt + 1);
+    hipLaunchKernelGGL(k_inf_set_table_range, dim3(1), dim3(64), 0, g.stream, b0, b1, (ZesInfBuf*)g.ibufs.p, counters, 6u,
+                       (const unsigned long long*)range_acc(), (unsigned long long)dcap);
+    {
+      Timed t("k_inf_scan");
+      hipLaunchKernelGGL(k_inf_scan, dim3((uint32_t)chunks), dim3(INF_SCAN_THREADS), 0, g.stream, d_in, dbufs, 1u, (unsigned long long*)g.surv.p,
+                         pd.surv_cap, counters, dfirst, (flags & ZES_F_LOOSE_CANDIDATES) ? 1u : 2u, (const uint8_t*)g.kraft.p);
+    }
+    if ((rc = launch_verify(d_in, dbufs, pd.surv_cap, counters, cnt, (flags & ZES_F_LOOSE_CANDIDATES) ? 1u : 0u, c, 32768))) return rc;
+    {
+      Timed t("k_inf_block_par");
+      hipLaunchKernelGGL(two ? k_inf_block_par2 : k_inf_block_par, dim3(pd.bound), dim3(PAR_THREADS), 0, g.stream, d_in, d_out, dbufs, 1u,
+                         (const uint32_t*)cnt, (const uint32_t*)g.cand_sorted.p, (const uint32_t*)nullptr, (ZesCandRes*)g.cres.p,
+                         (unsigned long long*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)g.cand.p, (uint32_t*)g.cand_sorted.p);
+    }
+    {
+      Timed t("k_inf_chain");
+      hipLaunchKernelGGL(k_inf_chain_range, dim3(1), dim3(256), 0, g.stream, dbufs, (const uint32_t*)cnt, (const uint32_t*)g.cand_sorted.p,
+                         (const ZesCandRes*)g.cres.p, (ZesRes*)g.res.p, range_acc());
+    }
+    HIPCHK(hipMemcpyAsync(range_hc(slot), g.counters.p, 24, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipMemcpyAsync(range_hres(slot), g.res.p, sizeof(ZesRes) * 2, hipMemcpyDeviceToHost, g.stream));
+  }
+  HIPCHK(hipEventRecord(g.ev_rng[slot], g.stream));
+  return ZES_OK;
+}
+int range_finish(int slot, const RangePend& pd, RangeRes* rr) {
+  *rr = RangeRes();
+  HIPCHK(hipEventSynchronize(g.ev_rng[slot]));
+  if (pd.skip) return ZES_OK;
+  auto nothing_here = [&]() {  // a range without a block start (a piece in the middle of one block): nothing to decode, and that is an answer
+    if (pd.exact) return ZES_OK;
+    rr->handled = true;
+    rr->first_bit = rr->end_bit = pd.lo_bit;
+    return ZES_OK;
+  };
+  if (pd.nothing) return nothing_here();
+  const uint32_t* hc = range_hc(slot);
+  const ZesRes* hres = range_hres(slot);
+  const uint32_t nsurv = hc[0], ncand = hc[4];
+  if (nsurv > pd.surv_cap || ncand > pd.cand_cap) return ZES_OK;
+  if (nsurv == 0 || ncand == 0) return nothing_here();
+  if (ncand > pd.bound) return ZES_OK;  // (more candidates than work items were launched: not decoded this way)
   if (hres[0].status != 0) return ZES_OK;
   rr->handled = true;
   rr->out_len = hres[0].out_len;
@@ -2150,6 +2265,7 @@ static int shutdown_one(void) {
   (void)hipStreamDestroy(g.cs_in);
   (void)hipStreamDestroy(g.cs_out);
   for (int k = 0; k < 2; k++) (void)hipEventDestroy(g.ev_up[k]);
+  for (int k = 0; k < 2; k++) (void)hipEventDestroy(g.ev_rng[k]);
   (void)hipEventDestroy(g.ev_k);
   (void)hipStreamDestroy(g.s_adler);
   (void)hipEventDestroy(g.ev_a0);
@@ -2399,22 +2515,31 @@ static int inflate_host_pipelined(const uint8_t* in, uint64_t c, uint8_t* out, u
                                   zes_alloc_fn alloc, void* user, bool* done) {
   *done = false;
   int rc;
-  // Piece boundaries (multiples of 64 KiB).  A piece's decode is ~0.5 ms whatever its size (seven launches, two
-  // read-backs, one round of the block decoder), so pieces of up to 32 MiB keep pace with their uploads; what cannot
-  // overlap anything is the LAST piece's decode and download: from 48 MiB on the last piece is a small one
-  // (64 MiB: 28 + 28 + 8 instead of 32 + 32).
+  // Piece boundaries (multiples of 64 KiB).  A piece costs ~0.3 ms of launches and read-backs whatever its size, so
+  // pieces of up to 32 MiB keep pace with their uploads; what cannot overlap anything is the LAST piece's decode and
+  // download: from 48 MiB on the last piece is a small one (64 MiB of incompressible data: 8 + 24 + 24 + 8).
   std::vector<uint64_t> B;
   {
-    const uint64_t pb = std::min<uint64_t>(32ull << 20, std::max<uint64_t>(4ull << 20, ((c / 2 + 65535) >> 16) << 16));
+    uint64_t pb = std::min<uint64_t>(32ull << 20, std::max<uint64_t>(4ull << 20, ((c / 2 + 65535) >> 16) << 16));
+    if (const char* e = getenv("ZES_PIPE_PIECE_MB")) pb = std::max<uint64_t>(1, strtoull(e, nullptr, 10)) << 20;  // (measurements)
     uint64_t last = 0;
     if (c >= (48ull << 20)) last = std::min<uint64_t>(8ull << 20, ((c / 8) >> 16) << 16);
-    const uint64_t rest = c - last;
+    // ... and the FIRST piece's upload and decode, before the first byte can come down: a small one as well, when the
+    // output is long enough to pay for one piece more (measured, pinned memory, ms per call without / with it: 64 MiB of
+    // text 2.25 / 1.96, 128 MiB 4.02 / 3.45, 64 MiB of random bytes 2.36 / 2.28 — but 48 MiB of text 1.59 / 1.80, of
+    // random bytes 2.01 / 2.16: a piece costs ~0.3 ms of launches and read-backs)
+    const uint64_t est_out = (cap && !alloc) ? cap : c * 4;
+    uint64_t first = (est_out >= (56ull << 20) && c >= (12ull << 20)) ? std::min<uint64_t>(8ull << 20, ((c / 3) >> 16) << 16) : 0;
+    if (const char* e = getenv("ZES_PIPE_FIRST_MB")) first = strtoull(e, nullptr, 10) << 20;  // (measurements)
+    if (first + last + (4ull << 20) > c) first = 0;
+    const uint64_t rest = c - last - first;
     const uint64_t nr = std::max<uint64_t>(1, (rest + pb - 1) / pb);
     const uint64_t each = (((rest + nr - 1) / nr + 65535) >> 16) << 16;
     B.push_back(0);
+    if (first) B.push_back(first);
     for (uint64_t k = 1; k < nr; k++)
-      if (k * each < rest) B.push_back(k * each);
-    if (last && rest > B.back()) B.push_back(rest);
+      if (k * each < rest) B.push_back(first + k * each);
+    if (last && first + rest > B.back()) B.push_back(first + rest);
     B.push_back(c);
   }
   const uint32_t np = (uint32_t)B.size() - 1;
@@ -2431,29 +2556,41 @@ static int inflate_host_pipelined(const uint8_t* in, uint64_t c, uint8_t* out, u
     HIPCHK(hipEventRecord(g.ev_up[k & 1], g.cs_in));
     return ZES_OK;
   };
+  {
+    uint64_t cmax = 0;
+    for (uint32_t k = 0; k < np; k++) cmax = std::max<uint64_t>(cmax, B[k + 1] - B[k] + T1_PIECE_SLACK + 64);
+    if ((rc = range_reserve(cmax))) return rc;
+  }
   if ((rc = up(0))) return rc;
   uint64_t blocks = 0, total = 0, prev_end = 16, pend_lo = 0, pend_hi = 0;
   bool final_seen = false, chain = true;
   std::future<int> f_up, f_down;
   SettleGuard guard{f_up, f_down};
   auto settle = [&](std::future<int>& f) { return f.valid() ? f.get() : (int)ZES_OK; };
-  for (uint32_t k = 0; k < np && chain && !final_seen; k++) {
-    if ((rc = settle(f_up))) return rc;  // (range k is up, or on its way with its event recorded)
+  // compressible data or not (which form of the block decoder): by the whole call, not by a piece
+  const bool two = c * 10 < std::min<uint64_t>(dcap, cap ? cap : dcap) * 7;
+  RangePend pend[2];
+  uint64_t byte0s[2] = {0, 0};
+  auto begin = [&](uint32_t k) -> int {  // (range k is up, or on its way with its event recorded)
     HIPCHK(hipStreamWaitEvent(g.stream, g.ev_up[k & 1], 0));
-    if (k + 1 < np) f_up = g_side_up.submit([&up, k] { return up(k + 1); });
-    if (out && !alloc && pend_hi > pend_lo) {
-      if ((rc = settle(f_down))) return rc;
-      const uint64_t a = pend_lo, b = pend_hi;
-      f_down = g_side_down.submit([=] { return download(out + a, d_out + a, b - a, g.cs_out, false); });
-    }
     const uint64_t lo_bit = k == 0 ? 16 : B[k] * 8, own_bit = B[k + 1] * 8;
     uint64_t byte0 = (lo_bit >> 3) & ~15ull;
     if (byte0 >= 16) byte0 -= 16;
+    byte0s[k & 1] = byte0;
     const uint64_t pc = std::min<uint64_t>(c - byte0, (own_bit >> 3) - byte0 + T1_PIECE_SLACK);
-    const uint64_t o_off = std::min<uint64_t>(blocks * ZES_BLK, dcap);
+    return range_begin((int)(k & 1), pend[k & 1], d_in, byte0, pc, lo_bit - 8 * byte0, own_bit - 8 * byte0, k == 0, d_out, dcap, two, flags);
+  };
+  if (np > 1) f_up = g_side_up.submit([&up] { return up(1); });
+  if ((rc = begin(0))) return rc;
+  for (uint32_t k = 0; k < np && chain && !final_seen; k++) {
+    if (k + 1 < np) {  // the next piece is enqueued before this one's results are waited for
+      if ((rc = settle(f_up))) return rc;
+      if (k + 2 < np) f_up = g_side_up.submit([&up, k] { return up(k + 2); });
+      if ((rc = begin(k + 1))) return rc;
+    }
     RangeRes rr;
-    if ((rc = inflate_t1_range(d_in, byte0, pc, lo_bit - 8 * byte0, own_bit - 8 * byte0, k == 0, d_out, o_off, dcap - o_off, flags, &rr))) return rc;
-    pend_lo = pend_hi = 0;
+    if ((rc = range_finish((int)(k & 1), pend[k & 1], &rr))) return rc;
+    const uint64_t byte0 = byte0s[k & 1];
     if (!rr.handled) {
       chain = false;
     } else if (rr.nblocks) {
@@ -2466,12 +2603,19 @@ static int inflate_host_pipelined(const uint8_t* in, uint64_t c, uint8_t* out, u
         pend_hi = std::min(total, cap);
         blocks += rr.nblocks;
         final_seen = rr.final_block;
+        if (out && !alloc && pend_hi > pend_lo && !(final_seen || k + 1 == np)) {  // (the last piece's bytes go down below)
+          if ((rc = settle(f_down))) return rc;
+          const uint64_t a = pend_lo, b = pend_hi;
+          f_down = g_side_down.submit([=] { return download(out + a, d_out + a, b - a, g.cs_out, false); });
+          pend_lo = pend_hi = 0;
+        }
       }
     }
   }
   if ((rc = settle(f_up))) return rc;
   if ((rc = settle(f_down))) return rc;
   HIPCHK(hipStreamSynchronize(g.cs_in));
+  HIPCHK(hipStreamSynchronize(g.stream));  // (a piece enqueued ahead of a result that ended the loop)
   if (!chain || !final_seen || total > dcap) {
     HIPCHK(hipStreamSynchronize(g.cs_out));
     return ZES_OK;  // not this way: the one-pass path decides

@@ -74,6 +74,21 @@ __global__ void k_inf_set_table1(ZesInfBuf b0, ZesInfBuf sentinel, ZesInfBuf* __
   if (counters && threadIdx.x < nwords) counters[threadIdx.x] = 0;
 }
 
+// The same for a piece of a stream whose place in the output follows from the pieces before it (host inflate, pieces
+// enqueued ahead of the host's look at their predecessors' results): block k of the piece goes to slot acc[0] + k, the
+// blocks counted so far by k_inf_chain_range.
+__global__ void k_inf_set_table_range(ZesInfBuf b0, ZesInfBuf sentinel, ZesInfBuf* __restrict__ bufs, uint32_t* __restrict__ counters,
+                                      uint32_t nwords, const unsigned long long* __restrict__ acc, unsigned long long dcap) {
+  if (threadIdx.x == 0) {
+    const unsigned long long off = acc[0] * ZES_BLK;
+    b0.out_off += off < dcap ? off : dcap;
+    b0.cap = dcap - (off < dcap ? off : dcap);
+    bufs[0] = b0;
+    bufs[1] = sentinel;
+  }
+  if (counters && threadIdx.x < nwords) counters[threadIdx.x] = 0;
+}
+
 // first byte of every buffer of a batch (CM nibble check on the host, src/zlib.ts:13)
 __global__ void k_inf_first_bytes(const uint8_t* __restrict__ d_in, const uint64_t* __restrict__ offs, uint8_t* __restrict__ out,
                                   uint32_t n) {
@@ -2599,7 +2614,7 @@ __global__ __launch_bounds__(256) void k_inf_chain(const ZesInfBuf* __restrict__
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_inf_chain_range(const ZesInfBuf* __restrict__ bufs, const uint32_t* __restrict__ cnt,
                                                          const uint32_t* __restrict__ cand_all, const ZesCandRes* __restrict__ cres_all,
-                                                         ZesRes* __restrict__ res) {
+                                                         ZesRes* __restrict__ res, unsigned long long* __restrict__ acc) {
   __shared__ uint32_t s_bad, s_final;
   __shared__ unsigned long long s_total;
   const uint32_t tid = threadIdx.x;
@@ -2655,6 +2670,7 @@ __global__ __launch_bounds__(256) void k_inf_chain_range(const ZesInfBuf* __rest
   res[0].aux = nown | (s_final << 31);
   res[1].out_len = cres[nown - 1].end_bit;
   res[1].aux = cand[0] + 16u;
+  if (acc) acc[0] += nown;  // (the next piece's table is set from it: k_inf_set_table_range)
 }
 
 // ------------------------------------------------------------------------------------------
