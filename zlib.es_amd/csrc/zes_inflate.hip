@@ -253,8 +253,14 @@ __global__ __launch_bounds__(INF_SCAN_THREADS) void k_inf_scan(const uint8_t* __
 // entry = symbol | length << 5.  In that index space a canonical code is a run of consecutive entries, so the table is
 // filled front to back in (length, symbol) order.  Dword j of lane l lives at [j][l].
 // ------------------------------------------------------------------------------------------
-#define VERIFY_WIN 18u  // dwords per lane: VERIFY_STEPS symbols of at most 14 bits + alignment + read-ahead
-static_assert(VERIFY_STEPS * 14u + 31u + 64u <= VERIFY_WIN * 32u, "the capped pass does not reload its window");
+// dwords of the stream per lane.  VERIFY_STEPS symbols of at most 14 bits + alignment + read-ahead would be 18; the usual
+// 32 symbols take ~200 bits, and a lane that runs out reloads (one more load latency for its wave).  What the smaller
+// window buys is LDS: 8 KiB of tables + 3 KiB of windows per wave are 14 waves a CU instead of 12 — this kernel is one
+// batch's latency (~40 us) per round of resident waves, and the 3171 batches of 64 MiB of incompressible data were
+// 3072 + 99: two rounds, 84 us; now one.
+#ifndef VERIFY_WIN
+#define VERIFY_WIN 12u
+#endif
 #define VSTATE_WORDS 6u  // per listed survivor: index in surv[], bit position, k, kl, kd, (psym | prev << 5 | eob << 9 | dmaxlen << 10 | nd << 14)
 
 // the reference's run-length coding of the code lengths (src/deflate.ts:100-139) never produces these (another
