@@ -27,7 +27,9 @@
 #define PAR_THREADS 1024
 #define PAR_WAVES (PAR_THREADS / 64)
 #define INF_SCAN_THREADS 256
+#ifndef INF_SCAN_BYTES
 #define INF_SCAN_BYTES 8192u
+#endif
 #define SEG_BUCKETS 2048u  // T2: at most this many candidate block starts are kept (one per bucket of the compressed stream)
 
 // One entry per buffer of an inflate call (T1); entry [nbuf] is a sentinel carrying the totals.
