@@ -1,3 +1,6 @@
+"""The link between host and GPU by itself (not a pytest; run on the GPU box): 64 MiB of pinned memory up, down, and both
+ways at once on two torch streams.  (The library's own pipelines overlap the two directions better than the last line
+suggests: see DESIGN.md §6.)"""
 import torch, time
 n = 64 << 20
 h = torch.empty(n, dtype=torch.uint8).pin_memory()
