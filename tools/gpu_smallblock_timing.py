@@ -13,5 +13,5 @@ for level, mem in ((6, 1), (6, 3), (1, 1)):
     best = 1e9
     for it in range(3):
         torch.cuda.synchronize(); t0 = time.perf_counter(); b = z.inflate_tensor(comp, back); best = min(best, time.perf_counter() - t0)
-    kt = {k: round(ms, 3) for k, ms, nl in z.last_kernel_times()}
+    kt = {k: (round(ms, 3), nl) for k, ms, nl in z.last_kernel_times()}  # (ms, launches)
     print("level %d mem %d c=%d inflate %.2f ms %.3f GiB/s tier %d ok=%s %s" % (level, mem, comp.numel(), best * 1e3, n / best / 2**30, z.last_inflate_tier(), bool((b == t).all()), kt), flush=True)
