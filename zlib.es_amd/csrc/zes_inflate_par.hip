@@ -1522,6 +1522,47 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
     if (S.status) return 1u;
     STAMP(1);
     ds = S.hdr_end;
+    // The reference's match finder never looks in front of the block (src/lz77.ts:11-22: the index is built per block),
+    // so its blocks begin with a literal and an early match reaches back no further than the bytes before it.  Another
+    // encoder's blocks — which pass this tier's header rules more often than not — nearly always begin with matches
+    // into the block before.  The first wavefront decodes the token at each of the block's first 64 bit positions,
+    // walks the chain of real tokens through them (~10 of them) and declines the block here, in front of the table
+    // construction and the count pass, when one reaches in front of the block (before: all blocks of such a stream
+    // were decoded side by side up to the count pass, where their sizes gave them away: 0.48 of the 1.34 ms of 16 MiB of
+    // zlib -9 text, 1.9 of the 8.0 ms of 256 x 1 MiB).  (A lone lane decoding them one after the other: 15k cycles.)
+    // (The form of the decoder for compressible data only: incompressible data from another encoder comes in stored
+    // blocks, and the other form's blocks — 0.55 ms per 64 MiB — would pay 2 % for the test.)
+    if (!FOREIGN && TWO) {
+      if (wave == 0) {
+        LaneBits pb;
+        lb_seek<true>(pb, src, ds + lane);
+        uint32_t v = 0, len = 0, dist = 0;
+        const uint32_t kind = (ds + lane < plimit) ? tok_step<true>(S, pb, src, v, len, dist) : T_FAIL;
+        const uint32_t w0 = kind | ((pb.pos - (ds + lane)) << 2) | (len << 8);  // kind, bits of the token (<= 48), match length
+        uint32_t cur = 0, made = 0;
+        bool hist = false;
+        for (uint32_t k = 0; k < 16u && cur < 64u; k++) {
+          const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)w0, (int)cur);
+          const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)dist, (int)cur);
+          const uint32_t kd = a & 3u;
+          if (kd == T_LIT) {
+            made++;
+          } else if (kd == T_MATCH) {
+            if (d > made) {
+              hist = true;
+              break;
+            }
+            made += (a >> 8) & 511u;
+          } else {
+            break;  // (end of block, or a bad code: the passes below deal with it)
+          }
+          cur += (a >> 2) & 63u;
+        }
+        if (hist && lane == 0) S.status = 1u;
+      }
+      __syncthreads();
+      if (S.status) return 1u;
+    }
     f8.lo = S.f8lo;
     f8.n = S.f8n;
     f8.off = S.f8off;
