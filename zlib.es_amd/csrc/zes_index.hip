@@ -350,7 +350,10 @@ __global__ __launch_bounds__(IDX_THREADS) void k_lz_index(const uint8_t* __restr
     }
     if (lane == 63) S.wsum[wave] = incl;
     atomicMax(&S.maxc, max(a, b));
-    if (a > IDX_REGCAP || b > IDX_REGCAP) atomicAdd(&S.nheavy, (a > IDX_REGCAP ? a : 0u) + (b > IDX_REGCAP ? b : 0u));
+    // (what counts as heavy for the decision below scales with the block: a 64 KiB buffer's text has the same heavy keys
+    // at half the counts — its blocks stayed here and cost more than k_lz_sort takes for them: 2048 x 64 KiB of text)
+    const uint32_t hv = max(128u, (uint32_t)(((uint64_t)IDX_REGCAP * cnt + (ZES_BLK - 1u)) >> 17));
+    if (a > hv || b > hv) atomicAdd(&S.nheavy, (a > hv ? a : 0u) + (b > hv ? b : 0u));
     __syncthreads();
     uint32_t woff = 0;
 #pragma unroll
