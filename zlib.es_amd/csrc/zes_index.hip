@@ -65,7 +65,7 @@ struct IndexSmem {
   uint32_t bcnt[IDX_NGROUP * 4], bpos[IDX_NGROUP * 4];
   uint32_t gfill[IDX_NGROUP];
   uint32_t ccur[IDX_GCLASS];                // group stage: cursors of the group's classes
-  uint32_t catcnt[5], catpos[5];
+  uint32_t catcnt[2][5], catpos[2][5];  // two sets, used in turn by the groups: a set is cleared while the other one counts
   uint8_t order[IDX_GCLASS];
   uint32_t wsum[IDX_WAVES];
   uint32_t pcur[IDX_NSLICE];
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(IDX_THREADS) void k_lz_index(const uint8_t* __restr
 
   for (uint32_t i = tid; i < IDX_NCLASS + 64u; i += IDX_THREADS) cur[i] = 0;
   if (tid < IDX_NSLICE) S.pcur[tid] = 0;
-  if (tid < 5u) S.catcnt[tid] = S.catpos[tid] = 0;
+  if (tid < 10u) (&S.catcnt[0][0])[tid] = (&S.catpos[0][0])[tid] = 0;
   if (tid == 0) {
     S.nbig = 0;
     S.maxc = 0;
@@ -467,6 +467,7 @@ __global__ __launch_bounds__(IDX_THREADS) void k_lz_index(const uint8_t* __restr
   // ---- group by group: the group's words come back into LDS, each to its class's run (cursors from the class sizes of
   // sweep 1), and every class is sorted by one wavefront, in registers ----
   uint32_t* gbuf = S.scr + IDX_GCAP;
+  uint32_t cs = 0;  // which set of category counters this group uses (uniform)
 #pragma unroll 1
   for (uint32_t q = 0; q < IDX_NGROUP; q++) {
     const uint32_t gb = S.base[q * IDX_GCLASS], gn = S.base[(q + 1u) * IDX_GCLASS] - gb;
@@ -480,12 +481,16 @@ __global__ __launch_bounds__(IDX_THREADS) void k_lz_index(const uint8_t* __restr
       const uint32_t b0 = S.base[q * IDX_GCLASS + tid], n = S.base[q * IDX_GCLASS + tid + 1u] - b0;
       S.ccur[tid] = b0 - gb;
       mycat = n == 0u ? 4u : (n > 256u ? 0u : (n > 128u ? 1u : (n > 64u ? 2u : 3u)));
-      atomicAdd(&S.catcnt[mycat], 1u);
+      atomicAdd(&S.catcnt[cs][mycat], 1u);
     }
     __syncthreads();
+    // the other set, for the next group: its last readers (the group before: nact, in front of that group's last barrier)
+    // are behind the barrier above, its next writers behind this group's two barriers below.  (One set cleared at the
+    // loop's end by wave 0 raced with wave 1's adds at the top of the next turn: a lost count, a class sorted twice.)
+    if (tid < 5u) S.catcnt[cs ^ 1u][tid] = S.catpos[cs ^ 1u][tid] = 0;
     if (tid < IDX_GCLASS && mycat < 4u) {
-      uint32_t at = atomicAdd(&S.catpos[mycat], 1u);
-      for (uint32_t k = 0; k < mycat; k++) at += S.catcnt[k];
+      uint32_t at = atomicAdd(&S.catpos[cs][mycat], 1u);
+      for (uint32_t k = 0; k < mycat; k++) at += S.catcnt[cs][k];
       S.order[at] = (uint8_t)tid;
     }
 #ifdef IDX_PROF
@@ -517,7 +522,7 @@ __global__ __launch_bounds__(IDX_THREADS) void k_lz_index(const uint8_t* __restr
     const unsigned long long tg1 = clock64();
     tpart += tg1 - tg0;
 #endif
-    const uint32_t nact = IDX_GCLASS - S.catcnt[4];
+    const uint32_t nact = IDX_GCLASS - S.catcnt[cs][4];
     for (uint32_t k = wave; k < nact; k += IDX_WAVES) {
       const uint32_t j = S.order[k];
       const uint32_t c = q * IDX_GCLASS + j;
@@ -545,7 +550,7 @@ __global__ __launch_bounds__(IDX_THREADS) void k_lz_index(const uint8_t* __restr
 #ifdef IDX_PROF
     twait += clock64() - tg2;
 #endif
-    if (tid < 5u) S.catcnt[tid] = S.catpos[tid] = 0;  // (read again only behind the next group's first barrier)
+    cs ^= 1u;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the heavy classes' words)
   __syncthreads();
