@@ -4,6 +4,7 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --inproc            # ONE process driving N GPUs through the host batch API (row n1)
 
 One step = one pass of the hot path over one batch of synthetic input: every rank deflates its own
 HBM-resident 64 MiB buffer (BASELINE.json configs[1]: xorshift32 bytes, seed 12345+rank) and inflates
@@ -14,14 +15,22 @@ all_reduce of the sizes, one exact-length send per rank over xGMI), in flight wh
 kernels run and finished inside the timed region.
 
 Rank 0 prints ONE JSON line.  `value` is GiB/s of uncompressed bytes taken through
-deflate-then-inflate by the whole job (n * N * K / wall).  `roofline` prices the dominant kernel
-(by HIP-event time on the library's stream) against HBM; `cpu_baseline` is the CPU oracle (a port
-of the reference algorithm) timed on this box's host cores on the same buffer.
+deflate-then-inflate by the whole job (n * N * K / wall).  Every timed loop (exactly K steps between
+barrier + synchronize) runs REPS = 3 times: the line carries the median, and the minimum and maximum
+beside it, so that a slow box and a slow build can be told apart.  `roofline` prices the dominant
+kernel (by HIP-event time on the library's stream) against HBM; `cpu_baseline` is the CPU oracle (a
+port of the reference algorithm) timed on this box's host cores on a bounded sample of the same input.
 
-The same process then runs the north-star workload as a second leg, reported under "text64" in the
-same line: BASELINE.json configs[2], a 64 MiB text-like buffer per GPU — its deflate, and the
-inflate-only hot loop over the reference-format stream (the >= 200 GiB/s aggregate target), with its
-own roofline and cpu_baseline records.  `--workload X` makes X the main leg instead (no second leg).
+The same process then runs the other BASELINE.json configurations as further legs of the same line,
+each with its own golden flag, roofline and cpu_baseline:
+  "text64"     configs[2]: one 64 MiB text-like buffer per GPU — deflate loop, then the inflate-only hot loop
+  "batch1m"    configs[3]: this GPU's 128 of the 1024 x 1 MiB buffers through the batch entry points
+  "lowent256"  configs[4]: one of the 8 x 256 MiB low-entropy buffers
+  "zlibtext64" SURVEY §8f.1: a 64 MiB stream another encoder made (CPython zlib -6), inflate only
+  "host_api"   (N = 1) the host-pointer path deflate(Uint8Array) / inflate(Uint8Array) actually is
+               (reference src/zlib.ts:11,25): zes_deflate / zes_inflate_alloc on pageable and on pinned host
+               arrays, PCIe included, random64 + text64 — and the same through Node when `node` is on the box.
+`--workload X` makes X the only leg.
 """
 import argparse
 import hashlib
@@ -35,6 +44,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 GIB = float(1 << 30)
+REPS = 3               # every timed loop runs this often: median reported, min / max beside it
 
 WORKLOADS = {
     # name: (generator, seed, bytes per buffer[, buffers per GPU])
@@ -47,6 +57,25 @@ WORKLOADS = {
     "zlibtext64": ("itext", 12345, 64 << 20, 1, "zlib6"),
 }
 MIX = ("xorshift", "itext", "lowent4k")           # buffer i uses seed 12345+i, generators in turn
+EXTRA_LEGS = ("text64", "batch1m", "lowent256", "zlibtext64")
+LEG_TEXT = {
+    "text64": "one 64 MiB itext buffer per GPU (seed 12345+rank), BASELINE.json configs[2]; deflate loop, then the inflate-only hot loop over the reference-format stream, HBM-resident",
+    "batch1m": "this GPU's 128 of the 1024 x 1 MiB buffers of BASELINE.json configs[3] (buffer i: generator i % 3, seed 12345+i) through zes_deflate_batch_dev / zes_inflate_batch_dev, HBM-resident",
+    "lowent256": "one 256 MiB lowent4k buffer per GPU (seed 12345+rank), BASELINE.json configs[4]; deflate loop, inflate loop, HBM-resident",
+    "lowent64": "one 64 MiB lowent4k buffer per GPU; deflate loop, inflate loop, HBM-resident",
+    "random64": "one 64 MiB xorshift32 buffer per GPU (seed 12345+rank), BASELINE.json configs[1]; deflate loop, inflate loop, HBM-resident",
+    "zlibtext64": "64 MiB of itext compressed by CPython zlib level 6 (history across blocks, SURVEY §8f.1), inflate-only loop, HBM-resident",
+}
+
+
+def _median(xs):
+    s = sorted(xs)
+    return s[len(s) // 2]
+
+
+def _spread(xs, scale=1.0, nd=4):
+    """median / min / max of the repeats of one timed loop"""
+    return {"median": round(_median(xs) * scale, nd), "min": round(min(xs) * scale, nd), "max": round(max(xs) * scale, nd)}
 
 
 class Leg:
@@ -128,6 +157,7 @@ class Leg:
         self.c = self.csize(comp)
         ok = bool(back.numel() == self.n and bool((back == self.d_in).all()))
         golden = False
+        self.golden_note = None
         rank = self.env["rank"]
         gdir = os.path.join(ROOT, "tests", "golden")
         try:
@@ -138,6 +168,9 @@ class Leg:
                     digest = hashlib.sha256(back.cpu().numpy().tobytes()).hexdigest()
                     ok = ok and back.numel() == e["output_len"] and digest == e["output_sha256"]
                     golden = True
+                else:
+                    self.golden_note = ("this box's CPython zlib made a different stream than the one the golden was made for (zlib 1.2.11): "
+                                        "the output is checked against the input only (round trip)")
             elif self.nbuf == 1:  # every rank against the reference's output for ITS seed (rank 0: manifest.big)
                 man = json.load(open(os.path.join(gdir, "manifest.json")))["big"]
                 rk = os.path.join(gdir, "ranks_%s.json" % self.kind)
@@ -183,25 +216,25 @@ class Leg:
                 "traffic_source": None if traffic is None else "profiles/traffic.json: rocprofv3 --pmc passes of this workload (profiles/collect.sh), not collected in this run",
                 "algorithmic_bytes_per_launch": self.n + c, "avg_launch_ms": round(avg_s * 1e3, 4)}
 
-    def cpu_baseline(self):
+    def cpu_baseline(self, cap=64 << 20):
         """The oracle (port of the reference algorithm, 1 thread) on a bounded sample of this leg's input."""
         import numpy as np
 
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import _oracle  # CPU restatement of the reference algorithm: the checker, timed as the baseline
 
-        ns = min(self.n, 64 << 20)  # bounded sample: at most 64 MiB of this GPU's input
+        ns = min(self.n, cap)  # bounded sample of this GPU's input
         sample = self.host[:ns]
         t1 = time.perf_counter()
         oc = np.frombuffer(self.foreign_bytes, dtype=np.uint8) if self.foreign else _oracle.deflate(sample)
         t2 = time.perf_counter()
         ob = _oracle.inflate(oc)
         t3 = time.perf_counter()
-        assert len(ob) == ns
+        assert len(ob) == (self.n if self.foreign else ns)
         cores = os.cpu_count() or 0
         if self.foreign:
-            return {"value": round(ns / (t3 - t2) / GIB, 5), "unit": "GiB/s", "cores": 1, "kind": "port",
-                    "sample": "the whole %d MiB stream once: inflate %.2f s, 1 thread of %d host cores" % (ns >> 20, t3 - t2, cores)}
+            return {"value": round(self.n / (t3 - t2) / GIB, 5), "unit": "GiB/s", "cores": 1, "kind": "port",
+                    "sample": "the whole %d MiB stream once: inflate %.2f s, 1 thread of %d host cores" % (self.n >> 20, t3 - t2, cores)}
         return {"value": round(ns / (t3 - t1) / GIB, 5), "unit": "GiB/s", "cores": 1, "kind": "port",
                 "sample": "the first %d MiB of the %s input once: deflate %.2f s + inflate %.2f s, 1 thread of %d host cores"
                           % (ns >> 20, self.kind, t2 - t1, t3 - t2, cores),
@@ -228,8 +261,11 @@ def launch_ranks(args, argv, run=None):
     """Parent side of `--gpus N` without a launcher.  No GPU call is made in this process (no torch.cuda, no zes_init:
     a process that has initialised the GPU must not start the ranks by exec, and need not start them at all).
     The child's stdout is relayed; if the ranks fail with the gather on, they are started once more with
-    --no-gather so that a transport problem costs the gather's measurement, not the scaling point."""
+    --no-gather so that a transport problem costs the gather's measurement, not the scaling point — but the failure is
+    not hidden: the relayed line carries `first_launch_failed` (the first launch's exit code) and the tail of its
+    stderr, and the exit code of this process is then 3 whatever the second launch returned."""
     import subprocess
+    import tempfile
 
     run = run or subprocess.run
     env = dict(os.environ)
@@ -237,24 +273,274 @@ def launch_ranks(args, argv, run=None):
     env.setdefault("OMP_NUM_THREADS", "4")
     tries = [list(argv)] + ([] if args.no_gather else [list(argv) + ["--no-gather"]])
     rc = 1
+    first_rc, first_err = None, ""
     for k, av in enumerate(tries):
         cmd = launch_command(args.gpus, av, _free_port())
         print("bench.py: starting %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
-        res = run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+        with tempfile.TemporaryFile(mode="w+") as errf:
+            res = run(cmd, env=env, stdout=subprocess.PIPE, stderr=errf, text=True)
+            errf.seek(0)
+            err_text = errf.read()
+        sys.stderr.write(err_text)
         rc = res.returncode
         lines = [ln for ln in (res.stdout or "").splitlines() if ln.startswith("{") and '"metric"' in ln]
         if lines:
             line = lines[-1]
-            if k > 0:  # say so in the line itself
+            if k > 0:  # say so in the line itself, and in the exit code
                 rec = json.loads(line)
+                rec["first_launch_failed"] = first_rc
+                rec["first_launch_stderr_tail"] = first_err[-1500:]
                 rec["config"]["gather"] = "FAILED with the gather on (rc %d of the first launch); measured again with --no-gather" % first_rc
                 line = json.dumps(rec)
+                print(line, flush=True)
+                return 3
             print(line, flush=True)
             return rc
-        first_rc = rc
+        first_rc, first_err = rc, err_text
         print("bench.py: the ranks ended with rc %d and no result line%s" % (rc, "; once more without the gather" if k + 1 < len(tries) else ""),
               file=sys.stderr, flush=True)
     return rc or 1
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the host-pointer path (N = 1): what deflate(Uint8Array) / inflate(Uint8Array) of src/zlib.ts:11,25 are
+# ------------------------------------------------------------------------------------------------------------------
+def host_api_leg(z, dev, steps, hosts, goldens, cpu):
+    """zes_deflate / zes_inflate_alloc on host arrays: pageable (a caller's ordinary array) and pinned (zes_host_alloc),
+    the random64 and the text64 input, PCIe trips included; output arrays exist and have been touched before the clock
+    starts (a binding that allocates a fresh 128 MiB array per call pays that array's page faults, not the library's
+    time).  K calls per timed loop, REPS loops; then the same four rows through Node's deflate() / inflate() when `node`
+    and the addon are on the box."""
+    import ctypes as C
+
+    import numpy as np
+    import torch
+
+    L = z.lib()
+    rows = {}
+    ok_all = True
+    k = max(1, min(steps, 10))
+    # the link itself on this box: 64 MiB of pinned memory up and down
+    pin = torch.empty(64 << 20, dtype=torch.uint8).pin_memory()
+    dbuf = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+    up = down = 1e9
+    for _ in range(4):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dbuf.copy_(pin, non_blocking=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        pin.copy_(dbuf, non_blocking=True)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        up, down = min(up, t1 - t0), min(down, t2 - t1)
+    link = {"h2d_GBs": round((64 << 20) / up / 1e9, 1), "d2h_GBs": round((64 << 20) / down / 1e9, 1), "what": "64 MiB of pinned memory, torch copy, best of 4"}
+    del pin, dbuf
+    for wname, src in hosts.items():
+        n = int(src.size)
+        cap = z.deflate_bound(n)
+        gold = goldens.get(wname)
+        for pinned in (False, True):
+            if pinned:
+                a, comp, back = z.host_alloc(n), z.host_alloc(cap), z.host_alloc(n)
+                a[:] = src
+                comp[:] = 0
+                back[:] = 0
+            else:
+                a, comp, back = src, np.zeros(cap, dtype=np.uint8), np.zeros(n, dtype=np.uint8)
+            clen, blen = C.c_uint64(), C.c_uint64()
+
+            def alloc(_user, _index, need, back=back):  # the allocator callback of zes_inflate_alloc: the caller's (touched) array
+                return back.ctypes.data if int(need) <= back.size else None
+
+            cb = z.ALLOC_FN(alloc)
+            assert L.zes_deflate(a.ctypes.data, n, comp.ctypes.data, cap, C.byref(clen)) == 0  # warm-up: pools, staging ring
+            assert L.zes_inflate_alloc(comp.ctypes.data, clen.value, cb, None, C.byref(blen), 0) == 0 and blen.value == n
+            td, ti = [], []
+            for _ in range(REPS):
+                t0 = time.perf_counter()
+                for _ in range(k):
+                    rc = L.zes_deflate(a.ctypes.data, n, comp.ctypes.data, cap, C.byref(clen))
+                t1 = time.perf_counter()
+                assert rc == 0
+                for _ in range(k):
+                    rc = L.zes_inflate_alloc(comp.ctypes.data, clen.value, cb, None, C.byref(blen), 0)
+                t2 = time.perf_counter()
+                assert rc == 0 and blen.value == n
+                td.append((t1 - t0) / k)
+                ti.append((t2 - t1) / k)
+            c = int(clen.value)
+            ok = bool((back == src).all())
+            gchk = False
+            if gold:
+                ok = ok and c == gold["deflate_len"] and hashlib.sha256(comp[:c].tobytes()).hexdigest() == gold["deflate_sha256"]
+                gchk = True
+            ok_all = ok_all and ok
+            md, mi = _median(td), _median(ti)
+            rows["%s_%s" % (wname, "pinned" if pinned else "pageable")] = {
+                "deflate_gibs": round(n / md / GIB, 3), "inflate_gibs": round(n / mi / GIB, 3),
+                "deflate_ms": _spread(td, 1e3), "inflate_ms": _spread(ti, 1e3), "compressed_bytes": c,
+                "verified_bit_exact": ok, "golden_sha256_checked": gchk,
+                # bytes over the link per call: n up + c down (deflate), c up + n down (inflate); a full-duplex link's
+                # floor is max(up, down) per direction
+                "roofline": {"bound": "pcie", "unit": "GB/s", "peak": link["h2d_GBs"],
+                             "achieved_deflate": round((n + c) / md / 1e9, 2), "achieved_inflate": round((n + c) / mi / 1e9, 2),
+                             "frac_deflate": round(n / md / 1e9 / link["h2d_GBs"], 4), "frac_inflate": round(n / mi / 1e9 / link["d2h_GBs"], 4),
+                             "note": "frac = the larger of the two transfers of the call (n bytes) per second against the measured one-way link rate"},
+            }
+            if pinned:
+                for x in (a, comp, back):
+                    z.host_free(x)
+    out = {"workload": "host-pointer API, 64 MiB calls, PCIe included (never `value`): zes_deflate / zes_inflate_alloc on pageable and pinned host arrays, "
+                       "%d calls per timed loop, median of %d loops; reference src/zlib.ts:11,25" % (k, REPS),
+           "link": link, "rows": rows, "verified_bit_exact": ok_all,
+           "cpu_baseline": None if not cpu else {w: cpu.get(w) for w in hosts}}
+    out["node"] = node_host_leg(hosts, goldens, k)
+    if out["node"] and out["node"].get("verified_bit_exact") is False:
+        out["verified_bit_exact"] = False
+    return out
+
+
+def node_host_leg(hosts, goldens, k):
+    """deflate(Uint8Array) / inflate(Uint8Array) of the TypeScript façade under Node (zlib.es_amd/host/zlib.js over the
+    N-API addon): the same inputs from files, timed inside Node (zlib.es_amd/host/bench_host.js).  A child process."""
+    import shutil
+    import subprocess
+    import tempfile
+
+    node = shutil.which("node")
+    addon = os.path.join(ROOT, "zlib.es_amd", "host", "build", "zes_napi.node")
+    script = os.path.join(ROOT, "zlib.es_amd", "host", "bench_host.js")
+    if node is None or not os.path.exists(addon) or not os.path.exists(script):
+        return {"skipped": "node or the addon is not on this box"}
+    tmp = tempfile.mkdtemp(prefix="zes_bench_")
+    try:
+        spec = []
+        for w, src in hosts.items():
+            path = os.path.join(tmp, w + ".bin")
+            src.tofile(path)
+            g = goldens.get(w) or {}
+            spec.append({"name": w, "path": path, "deflate_len": g.get("deflate_len"), "deflate_sha256": g.get("deflate_sha256")})
+        res = subprocess.run([node, script, json.dumps({"inputs": spec, "calls": k, "reps": REPS})], capture_output=True, text=True, timeout=240)
+        lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+        if res.returncode != 0 or not lines:
+            return {"failed": "rc %d: %s" % (res.returncode, (res.stderr or res.stdout)[-400:]), "verified_bit_exact": False}
+        return json.loads(lines[-1])
+    except (OSError, subprocess.SubprocessError, ValueError) as e:
+        return {"failed": repr(e)[:300], "verified_bit_exact": False}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# one process, N GPUs (row n1: "host code stays TypeScript on Node ... shard across the 8 GPUs"): no RCCL on this road
+# ------------------------------------------------------------------------------------------------------------------
+def inproc_plan(ngpus, nbuf_per_gpu=128, n1=1 << 20):
+    """(generator, seed) of every buffer and the owner the library's partition rule gives it: BASELINE configs[3]'s
+    buffers, 128 per GPU (all 1024 at N = 8)."""
+    total = ngpus * nbuf_per_gpu
+    return [(MIX[i % 3], 12345 + i, n1) for i in range(total)]
+
+
+def main_inproc(args):
+    """`--gpus N --inproc`: ONE process, zes_init_devices(N), the configs[3] batch (128 x 1 MiB per GPU) through the host
+    batch forms zes_deflate_batch / zes_inflate_batch_alloc from pinned host arrays — the path a Node host takes — every
+    buffer against the reference-run golden.  Same JSON shape as the torchrun line."""
+    import ctypes as C
+
+    import numpy as np
+
+    import __graft_entry__ as ge
+
+    z = ge.load()
+    L = z.lib()
+    got = z.init_devices(args.gpus)
+    plan = inproc_plan(args.gpus)
+    cnt = len(plan)
+    n1 = plan[0][2]
+    cap1 = (z.deflate_bound(n1) + 15) // 16 * 16
+    src = z.host_alloc(cnt * n1)
+    comp = z.host_alloc(cnt * cap1)
+    back = z.host_alloc(cnt * n1)
+    for i, (kind, seed, n) in enumerate(plan):
+        src[i * n1:(i + 1) * n1] = z.gen(kind, seed, n)
+    comp[:] = 0
+    back[:] = 0
+    P = C.c_void_p * cnt
+    U = C.c_uint64 * cnt
+    in_ptr = P(*[src.ctypes.data + i * n1 for i in range(cnt)])
+    c_ptr = P(*[comp.ctypes.data + i * cap1 for i in range(cnt)])
+    lens = U(*([n1] * cnt))
+    caps = U(*([cap1] * cnt))
+    clen, olen = U(), U()
+    st = (C.c_int32 * cnt)()
+
+    def alloc(_user, index, need):
+        return back.ctypes.data + int(index) * n1 if int(need) <= n1 else None
+
+    cb = z.ALLOC_FN(alloc)
+
+    def deflate():
+        rc = L.zes_deflate_batch(in_ptr, lens, c_ptr, caps, clen, st, cnt)
+        assert rc == 0 and not any(st), (rc, list(st)[:8])
+
+    def inflate():
+        rc = L.zes_inflate_batch_alloc(c_ptr, clen, cb, None, olen, st, cnt, 0)
+        assert rc == 0 and not any(st) and all(o == n1 for o in olen), (rc, list(st)[:8])
+
+    deflate()
+    inflate()
+    ok = bool((back == src).all())
+    golden = False
+    try:
+        gold = json.load(open(os.path.join(ROOT, "tests", "golden", "batch1m.json")))[:cnt]
+        if len(gold) == cnt:
+            for i, e in enumerate(gold):
+                c = int(clen[i])
+                ok = ok and e["i"] == i and c == e["deflate_len"] and hashlib.sha256(comp[i * cap1:i * cap1 + c].tobytes()).hexdigest() == e["deflate_sha256"]
+            golden = True
+    except (OSError, KeyError, ValueError):
+        pass
+    owners = z.partition([n1] * cnt, got)
+    for _ in range(args.warmup):
+        deflate()
+        inflate()
+    td, ti = [], []
+    for _ in range(REPS):
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            deflate()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            inflate()
+        t2 = time.perf_counter()
+        td.append(t1 - t0)
+        ti.append(t2 - t1)
+    total = cnt * n1
+    md, mi = _median(td), _median(ti)
+    ctot = int(sum(clen))
+    line = {
+        "metric": "GiB/s deflate+inflate round trip, 1 MiB buffers through the host batch API of ONE process driving N GPUs (uncompressed bytes / wall, PCIe included), bit-exact vs reference",
+        "value": round(total * args.steps / (md + mi) / GIB, 4), "unit": "GiB/s", "n_gpus": got, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round((md + mi) / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+        "data": "synthetic",
+        "config": {"workload": "inproc batch1m: %d x 1 MiB buffers (BASELINE.json configs[3]: generator i %% 3, seed 12345+i; 128 per GPU) from pinned host arrays through "
+                               "zes_deflate_batch / zes_inflate_batch_alloc, one process, zes_init_devices(%d)" % (cnt, got),
+                   "buffers_per_step": cnt, "bytes_per_buffer": n1, "compressed_bytes": ctot,
+                   "parallelism": "one host process, %d device contexts, buffers partitioned by size (zes_partition), no collective" % got,
+                   "buffers_per_context": [owners.count(d) for d in range(got)],
+                   "oversubscribed": bool(os.environ.get("ZES_OVERSUBSCRIBE")), "gather": None},
+        "repeats": REPS,
+        "deflate_gibs": round(total * args.steps / md / GIB, 4), "inflate_gibs": round(total * args.steps / mi / GIB, 4),
+        "deflate_ms": _spread([t / args.steps for t in td], 1e3), "inflate_ms": _spread([t / args.steps for t in ti], 1e3),
+        "verified_bit_exact": ok, "golden_sha256_checked": golden,
+        "roofline": None, "cpu_baseline": None, "pool_bytes": z.pool_bytes(),
+    }
+    print(json.dumps(line), flush=True)
+    for x in (src, comp, back):
+        z.host_free(x)
+    if not ok:
+        sys.exit(1)
 
 
 def main():
@@ -265,8 +551,12 @@ def main():
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: leave the compressed shards where they are")
+    ap.add_argument("--no-extra-legs", action="store_true", help="only the main leg and text64")
+    ap.add_argument("--inproc", action="store_true", help="one process drives all N GPUs through the host batch API (no RCCL)")
     args = ap.parse_args()
 
+    if args.inproc:
+        return main_inproc(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: this process never touches the GPU — it starts the N ranks as a CHILD
         # (torch.distributed.run, one process per GPU) and relays rank 0's JSON line and the exit code.
@@ -301,7 +591,7 @@ def main():
     z.init(local_dev)
     env = {"z": z, "dev": dev, "rank": rank, "world": world}
     main_name = args.workload or "random64"
-    second_name = None if args.workload else "text64"
+    extra = [] if args.workload else (["text64"] if args.no_extra_legs else list(EXTRA_LEGS))
     shard = None
     if world > 1 and not args.no_gather:
         import importlib.util
@@ -332,6 +622,15 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             flag = bool(t.item())
         return bool(flag)
+
+    def minmax_over_ranks(x):
+        if world > 1:
+            lo = torch.tensor([x], dtype=torch.float64, device=cdev)
+            hi = lo.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            return float(lo.item()), float(hi.item())
+        return x, x
 
     # ------------------------------------------------------------------ main leg
     leg = Leg(main_name, env)
@@ -376,26 +675,35 @@ def main():
         pending, _, _ = step(k, pending, False)
     finish(pending)
     pending = None
-    gathered_bytes[0] = 0
 
     z.set_profiling(True)
-    t_def = t_inf = 0.0
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        pending, d, i = step(k, pending, True)
-        t_def += d
-        t_inf += i
-    finish(pending)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    reps = []  # (elapsed, deflate seconds, inflate seconds) of each repeat of the K timed steps
+    for _ in range(REPS):
+        gathered_bytes[0] = 0
+        t_def = t_inf = 0.0
+        pending = None
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            pending, d, i = step(k, pending, True)
+            t_def += d
+            t_inf += i
+        finish(pending)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        elapsed, verified = reduce_time(elapsed, verified)
+        reps.append((elapsed, t_def, t_inf))
     z.set_profiling(False)
-    elapsed, verified = reduce_time(elapsed, verified)
+    elapsed, t_def, t_inf = sorted(reps)[len(reps) // 2]
+    n_timed = REPS * args.steps  # launches the kernel-time sums cover
+    main_pool = z.pool_bytes()
+    d_lo, d_hi = (0.0, 0.0) if leg.foreign else minmax_over_ranks(leg.n * args.steps / t_def / GIB)
+    i_lo, i_hi = minmax_over_ranks(leg.n * args.steps / t_inf / GIB)
 
-    # ------------------------------------------------------------------ second leg: the north-star workload
-    text = None
-    if second_name:
-        tl = Leg(second_name, env)
+    # ------------------------------------------------------------------ the other legs: deflate loop, inflate loop
+    def run_extra(name):
+        nonlocal verified
+        tl = Leg(name, env)
         tok = tl.verify()
         tl.golden_checked = reduce_flag(tl.golden_checked)
         comp = tl.run_deflate()
@@ -403,45 +711,78 @@ def main():
             tl.run_deflate()
             tl.run_inflate(comp)
         z.set_profiling(True)
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            tl.run_deflate()
-            tl.note_times("deflate")
-        barrier()
-        t2 = time.perf_counter()
-        for _ in range(args.steps):  # the inflate-only hot loop of configs[2]
-            tl.run_inflate(comp)
-            tl.note_times("inflate")
-        barrier()
-        t3 = time.perf_counter()
+        tds, tis = [], []
+        for _ in range(REPS):
+            if not tl.foreign:
+                barrier()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    tl.run_deflate()
+                    tl.note_times("deflate")
+                barrier()
+                td, tok = reduce_time(time.perf_counter() - t1, tok)
+                tds.append(td)
+            barrier()
+            t2 = time.perf_counter()
+            for _ in range(args.steps):  # the inflate-only hot loop
+                tl.run_inflate(comp)
+                tl.note_times("inflate")
+            barrier()
+            ti, tok = reduce_time(time.perf_counter() - t2, tok)
+            tis.append(ti)
         z.set_profiling(False)
-        td, tok = reduce_time(t2 - t1, tok)
-        ti, tok = reduce_time(t3 - t2, tok)
         verified = verified and tok
+        rec = None
         if rank == 0:
-            text = {
-                "workload": "text64: one 64 MiB itext buffer per GPU (seed 12345+rank), BASELINE.json configs[2]; deflate loop, then the inflate-only hot loop over the reference-format stream, HBM-resident",
+            ti = _median(tis)
+            rec = {
+                "workload": "%s: %s" % (name, LEG_TEXT[name]),
                 "inflate_gibs": round(tl.n * world * args.steps / ti / GIB, 4),
                 "inflate_gibs_per_gpu": round(tl.n * args.steps / ti / GIB, 4),
                 "inflate_ms": round(ti / args.steps * 1e3, 4),
-                "deflate_gibs": round(tl.n * world * args.steps / td / GIB, 4),
-                "deflate_gibs_per_gpu": round(tl.n * args.steps / td / GIB, 4),
-                "deflate_ms": round(td / args.steps * 1e3, 4),
+                "inflate_ms_spread": _spread([t / args.steps for t in tis], 1e3),
+            }
+            if tds:
+                td = _median(tds)
+                rec.update({
+                    "deflate_gibs": round(tl.n * world * args.steps / td / GIB, 4),
+                    "deflate_gibs_per_gpu": round(tl.n * args.steps / td / GIB, 4),
+                    "deflate_ms": round(td / args.steps * 1e3, 4),
+                    "deflate_ms_spread": _spread([t / args.steps for t in tds], 1e3),
+                    "round_trip_gibs_per_gpu": round(tl.n * args.steps / (td + ti) / GIB, 4),
+                })
+            rec.update({
+                "repeats": REPS,
                 "compressed_bytes": tl.c,
                 "verified_bit_exact": tok,
                 "golden_sha256_checked": tl.golden_checked,
                 "roofline": tl.roofline("inflate", tl.c),
                 "roofline_deflate": tl.roofline("deflate", tl.c),
                 "cpu_baseline": None if (world > 1 or args.no_cpu_baseline) else tl.cpu_baseline(),
-                "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for d in ("deflate", "inflate")
+                "pool_bytes": z.pool_bytes(),
+                "kernels_ms_per_step": {k: round(v[0] / (REPS * args.steps), 4) for d in ("deflate", "inflate")
                                         for k, v in sorted(tl.ktimes[d].items(), key=lambda kv: -kv[1][0])},
-            }
+            })
+            if tl.golden_note:
+                rec["golden_note"] = tl.golden_note
+        host = tl.host if name == "text64" else None
         del tl
+        torch.cuda.empty_cache()
+        z.trim()  # the next leg's pooled bytes are its own
+        return rec, host
+
+    legs = {}
+    text_host = None
+    z.trim()
+    for name in extra:
+        legs[name], h = run_extra(name)
+        if h is not None:
+            text_host = h
 
     if rank == 0:
         n, c = leg.n, leg.c
         value = n * world * args.steps / elapsed / GIB
+        vals = [n * world * args.steps / r[0] / GIB for r in reps]
         both = dict(leg.ktimes["deflate"])
         both.update(leg.ktimes["inflate"])
         dom_dir = "inflate"
@@ -457,7 +798,7 @@ def main():
             leg.d_back.copy_(leg.d_in)
         torch.cuda.synchronize()
         copy_gbs = 2 * n * 20 / (time.perf_counter() - tcp) / 1e9
-        for r in (roofline, text and text["roofline"], text and text["roofline_deflate"]):
+        for r in [roofline] + [x for lg in legs.values() if lg for x in (lg["roofline"], lg["roofline_deflate"])]:
             if r:
                 r["measured_copy_GBs"] = round(copy_gbs, 1)
                 r["frac_of_measured_copy"] = round(r["achieved"] / copy_gbs, 5)
@@ -488,16 +829,52 @@ def main():
                                   "before's lengths, sizes all_reduce read behind it), overlapped with the next step, completed inside the timed "
                                   "region: %d result bytes on rank 0 per step"
                                   % (gathered_bytes[0] // max(args.steps, 1)))},
+            # every timed loop ran REPS times (exactly `steps` steps each): value / ms_per_step are the median repeat's
+            "repeats": REPS,
+            "value_spread": _spread(vals),
+            "ms_per_step_spread": _spread([r[0] / args.steps for r in reps], 1e3),
             "deflate_gibs_per_gpu": None if foreign else round(n * args.steps / t_def / GIB, 4),
             "inflate_gibs_per_gpu": round(n * args.steps / t_inf / GIB, 4),
+            "deflate_gibs_per_gpu_spread": None if foreign else _spread([n * args.steps / r[1] / GIB for r in reps]),
+            "inflate_gibs_per_gpu_spread": _spread([n * args.steps / r[2] / GIB for r in reps]),
+            # what a reader of an N > 1 line has to check: the process group's size, the devices the ranks saw, every rank's own rate
+            "ranks": {"world_size": dist.get_world_size() if world > 1 else 1, "backend": backend if world > 1 else None,
+                      "device_count": torch.cuda.device_count(), "device": torch.cuda.get_device_name(dev),
+                      "deflate_gibs_per_rank_min_max": None if foreign else [round(d_lo, 3), round(d_hi, 3)],
+                      "inflate_gibs_per_rank_min_max": [round(i_lo, 3), round(i_hi, 3)],
+                      "gathered_bytes_per_step": None if shard is None else gathered_bytes[0] // max(args.steps, 1)},
             "verified_bit_exact": verified,
             "golden_sha256_checked": leg.golden_checked,
             "roofline": roofline,
             "cpu_baseline": cpu,
-            "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(both.items(), key=lambda kv: -kv[1][0])},
+            "pool_bytes": main_pool,
+            "kernels_ms_per_step": {k: round(v[0] / n_timed, 4) for k, v in sorted(both.items(), key=lambda kv: -kv[1][0])},
         }
-        if text:
-            line["text64"] = text
+        for name in extra:
+            line[name] = legs[name]
+        if world == 1 and extra and not args.no_extra_legs:
+            # the host-pointer path: the same random64 / text64 inputs, PCIe included
+            man = {}
+            try:
+                for e in json.load(open(os.path.join(ROOT, "tests", "golden", "manifest.json")))["big"]:
+                    if e["n"] == 64 << 20 and e["seed"] == 12345:
+                        man[e["kind"]] = e
+            except (OSError, KeyError, ValueError):
+                pass
+            hosts = {"random64": leg.host}
+            if text_host is not None:
+                hosts["text64"] = text_host
+            cpus = {"random64": cpu, "text64": legs.get("text64") and legs["text64"]["cpu_baseline"]}
+            try:
+                line["host_api"] = host_api_leg(z, dev, args.steps, hosts, {"random64": man.get("xorshift"), "text64": man.get("itext")},
+                                                None if args.no_cpu_baseline else cpus)
+                if line["host_api"]["verified_bit_exact"] is False:
+                    verified = False
+                    line["verified_bit_exact"] = False
+            except AssertionError as e:  # a failed host call fails the run, and says where
+                line["host_api"] = {"failed": repr(e)[:300]}
+                verified = False
+                line["verified_bit_exact"] = False
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -67,6 +67,9 @@ int zes_shutdown(void);
  * allocates what it needs again.  For a long-lived host that has had one large call.  replaces: nothing (the
  * reference's buffers are garbage collected). */
 int zes_trim(void);
+/* Bytes of pooled device scratch the library holds right now, over all contexts (what zes_trim would give back;
+ * bench.py reports it per workload).  replaces: nothing. */
+uint64_t zes_pool_bytes(void);
 /* Several GPUs from ONE process (what a Node host is: SURVEY §8b `zes_init(int ngpus)`, "the batch API is where
  * multi-GPU concurrency lives").  zes_init_devices(n) gives the library n contexts, context i on device i (n <= 0: every
  * visible device) — its own stream, scratch pools, staging and lock each.  From then on the host-pointer entry points use
@@ -217,6 +220,8 @@ int zes_last_kernel_times(zes_ktime* out, int cap);
  * 2 segment-parallel (any valid stream), 3 sequential wavefront, 4 exact single-lane restatement
  * (DESIGN.md §4); 0 if the call failed before decoding. */
 int zes_last_inflate_tier(void);
+/* (After zes_init_devices: zes_last_inflate_tier / zes_last_kernel_times report on the context that served the calling
+ * thread's last call; zes_set_profiling switches every context.) */
 int zes_set_profiling(int on);
 
 /* Deterministic integer-only workload generators: host side, used by bench.py,

@@ -110,6 +110,8 @@ def lib():
         L.zes_stage_huff_lengths_dev.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.zes_last_kernel_times.argtypes = [C.POINTER(ZesKTime), C.c_int]
         L.zes_set_profiling.argtypes = [C.c_int]
+        L.zes_pool_bytes.restype = C.c_uint64
+        L.zes_pool_bytes.argtypes = []
         L.zes_gen.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32]
         _lib = L
     return _lib
@@ -134,6 +136,11 @@ def trim():
     rc = lib().zes_trim()
     if rc:
         _raise(rc)
+
+
+def pool_bytes():
+    """zes_pool_bytes: pooled device scratch held right now, all contexts."""
+    return int(lib().zes_pool_bytes())
 
 
 def init_devices(n=0):

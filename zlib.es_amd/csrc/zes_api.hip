@@ -80,6 +80,7 @@ std::atomic<int> g_nctx{1};     // contexts in use (written under g_cfg_mu; read
 std::mutex g_cfg_mu;             // guards g_nctx and the context -> device binding
 thread_local int t_dev = 0;      // the context of the call this thread is inside
 thread_local bool t_routed = false;
+thread_local int t_last = 0;     // the context that served this thread's last call (what zes_last_inflate_tier / zes_last_kernel_times report on)
 #define g (g_ctx[t_dev])
 #define g_mu (g_mus[t_dev])
 struct UseDev {                  // a call's context for its duration (nested entry points keep the outer one's)
@@ -88,6 +89,7 @@ struct UseDev {                  // a call's context for its duration (nested en
   explicit UseDev(int d) : prev(t_dev), prev_routed(t_routed) {
     if (!t_routed) t_dev = d;
     t_routed = true;
+    t_last = t_dev;
   }
   ~UseDev() {
     t_dev = prev;
@@ -172,18 +174,33 @@ int route_host() {  // host-pointer work: the contexts in turn
   static std::atomic<uint32_t> rr{0};
   return (int)(rr.fetch_add(1) % (uint32_t)n);
 }
-int route_dev(const void* p) {  // device-pointer work: the context of the device that holds the memory
+// -1: several contexts are bound and none of them drives the device that holds the memory (or the pointer is not device
+// memory at all, or the two pointers of a call sit on different devices) — the entry point answers ZES_E_ARG instead of
+// letting context 0's kernels touch memory of a device it does not drive
+int route_dev(const void* p, const void* p2 = nullptr) {  // device-pointer work: the context of the device that holds the memory
   if (t_routed) return t_dev;
   if (g_nctx.load() <= 1 || !p) return 0;
   hipPointerAttribute_t a;
   if (hipPointerGetAttributes(&a, p) != hipSuccess) {
     (void)hipGetLastError();
-    return 0;
+    return -1;
+  }
+  if (p2) {
+    hipPointerAttribute_t b;
+    if (hipPointerGetAttributes(&b, p2) != hipSuccess) {
+      (void)hipGetLastError();
+      return -1;
+    }
+    if (b.device != a.device) return -1;
   }
   for (int i = 0, n = g_nctx.load(); i < n; i++)
     if ((g_ctx[i].ready ? g_ctx[i].device : g_ctx[i].want) == a.device) return i;
-  return 0;
+  return -1;
 }
+#define ROUTE_DEV(...)                    \
+  const int rd_ = route_dev(__VA_ARGS__); \
+  if (rd_ < 0) return ZES_E_ARG;          \
+  UseDev ud(rd_)
 
 // ---- host <-> device staging of the host-pointer entry points ----
 // A caller's buffer (a JS Uint8Array, a numpy array) is pageable: the DMA engines cannot read it.  It crosses in
@@ -2319,7 +2336,7 @@ int zes_deflate_bound(uint64_t n, uint64_t* cap) {
 
 int zes_deflate_batch_dev(const uint8_t* d_in, const uint64_t* in_off, const uint64_t* in_len, uint8_t* d_out,
                           const uint64_t* out_off, const uint64_t* out_cap, uint64_t* out_len, int32_t* status, uint32_t count) {
-  UseDev ud(route_dev(d_in));
+  ROUTE_DEV(d_in, d_out);
   if (!in_off || !in_len || !out_off || !out_cap || !out_len || !status) return ZES_E_ARG;
   std::lock_guard<std::mutex> lk(g_mu);
   int rc = init_locked(-1);
@@ -2328,7 +2345,7 @@ int zes_deflate_batch_dev(const uint8_t* d_in, const uint64_t* in_off, const uin
 }
 
 int zes_deflate_dev(const uint8_t* d_in, uint64_t n, uint8_t* d_out, uint64_t cap, uint64_t* out_len) {
-  UseDev ud(route_dev(d_in));
+  ROUTE_DEV(d_in, d_out);
   if (!out_len) return ZES_E_ARG;
   uint64_t zero = 0;
   int32_t st = 0;
@@ -2478,7 +2495,7 @@ int zes_deflate(const uint8_t* in, uint64_t n, uint8_t* out, uint64_t cap, uint6
 }
 
 int zes_inflate_dev(const uint8_t* d_in, uint64_t c, uint8_t* d_out, uint64_t cap, uint64_t* out_len, uint32_t flags) {
-  UseDev ud(route_dev(d_in));
+  ROUTE_DEV(d_in, d_out);
   if (!out_len) return ZES_E_ARG;
   if ((((uintptr_t)d_in) & 15u) || (((uintptr_t)d_out) & 15u)) return ZES_E_ARG;
   std::lock_guard<std::mutex> lk(g_mu);
@@ -2490,7 +2507,7 @@ int zes_inflate_dev(const uint8_t* d_in, uint64_t c, uint8_t* d_out, uint64_t ca
 int zes_inflate_batch_dev(const uint8_t* d_in, const uint64_t* in_off, const uint64_t* in_len, uint8_t* d_out,
                           const uint64_t* out_off, const uint64_t* out_cap, uint64_t* out_len, int32_t* status, uint32_t count,
                           uint32_t flags) {
-  UseDev ud(route_dev(d_in));
+  ROUTE_DEV(d_in, d_out);
   if (!in_off || !in_len || !out_off || !out_cap || !out_len || !status) return ZES_E_ARG;
   if ((((uintptr_t)d_in) & 15u) || (((uintptr_t)d_out) & 15u)) return ZES_E_ARG;
   std::lock_guard<std::mutex> lk(g_mu);
@@ -2931,7 +2948,7 @@ static int adler32_locked(const uint8_t* d_in, uint64_t n, uint32_t* adler_out) 
 // ---- one buffer over several GPUs: block ranges and their join ----
 int zes_deflate_range_dev(const uint8_t* d_in, uint64_t n, uint64_t n_readable, int final_range, uint8_t* d_out, uint64_t cap,
                           uint64_t* out_bits, uint32_t* adler) {
-  UseDev ud(route_dev(d_in));
+  ROUTE_DEV(d_in, d_out);
   if (!out_bits || !d_in || !d_out || n == 0 || n_readable < n) return ZES_E_ARG;
   if (!final_range && (n % ZES_BLK)) return ZES_E_ARG;  // only the input's last range may end inside a block
   if ((n % ZES_BLK) == 1) return ZES_E_CORRUPT;         // the reference throws on a 1-byte last block
@@ -2955,7 +2972,7 @@ int zes_deflate_range_dev(const uint8_t* d_in, uint64_t n, uint64_t n_readable, 
 
 int zes_deflate_join_dev(const uint8_t* const* d_piece, const uint64_t* piece_bits, const uint32_t* piece_adler, const uint64_t* piece_len,
                          uint32_t count, uint8_t* d_out, uint64_t cap, uint64_t* out_len) {
-  UseDev ud(route_dev(d_out));
+  ROUTE_DEV(d_out, (d_piece && count) ? d_piece[0] : nullptr);
   if (!d_piece || !piece_bits || !piece_adler || !piece_len || !d_out || !out_len || count == 0) return ZES_E_ARG;
   if (((uintptr_t)d_out) & 15u) return ZES_E_ARG;
   uint64_t bits = 0;
@@ -3001,7 +3018,7 @@ int zes_deflate_join_dev(const uint8_t* const* d_piece, const uint64_t* piece_bi
 
 int zes_inflate_range_dev(const uint8_t* d_in, uint64_t c, uint64_t lo_bit, uint64_t own_bit, int exact_start, uint8_t* d_out, uint64_t cap,
                           uint64_t* out_len, uint64_t* first_bit, uint64_t* end_bit, uint32_t* nblocks, int* final_block) {
-  UseDev ud(route_dev(d_in));
+  ROUTE_DEV(d_in, d_out);
   if (!d_in || !out_len || !first_bit || !end_bit || !nblocks || !final_block || lo_bit < 16 || own_bit <= lo_bit) return ZES_E_ARG;
   if ((((uintptr_t)d_in) & 15u) || (((uintptr_t)d_out) & 15u) || c >= (1ull << 29)) return ZES_E_ARG;
   std::lock_guard<std::mutex> lk(g_mu);
@@ -3020,7 +3037,7 @@ int zes_inflate_range_dev(const uint8_t* d_in, uint64_t c, uint64_t lo_bit, uint
 }
 
 int zes_adler32_dev(const uint8_t* d_in, uint64_t n, uint32_t* adler_out) {
-  UseDev ud(route_dev(d_in));
+  ROUTE_DEV(d_in);
   if (!adler_out) return ZES_E_ARG;
   std::lock_guard<std::mutex> lk(g_mu);
   int rc = init_locked(-1);
@@ -3039,7 +3056,7 @@ static int inflate_raw_staged(uint64_t n, uint8_t* d_out, uint64_t cap, uint64_t
 
 int zes_inflate_raw_dev(const uint8_t* d_in, uint64_t c, uint64_t offset, uint8_t* d_out, uint64_t cap, uint64_t* out_len,
                         uint32_t flags) {
-  UseDev ud(route_dev(d_in));
+  ROUTE_DEV(d_in, d_out);
   if (!out_len || (!d_in && c)) return ZES_E_ARG;
   if ((((uintptr_t)d_out) & 15u)) return ZES_E_ARG;
   std::lock_guard<std::mutex> lk(g_mu);
@@ -3093,7 +3110,7 @@ static int deflate_raw_common(const uint8_t* d_in, uint64_t n, uint64_t* raw_len
 }
 
 int zes_deflate_raw_dev(const uint8_t* d_in, uint64_t n, uint8_t* d_out, uint64_t cap, uint64_t* out_len) {
-  UseDev ud(route_dev(d_in));
+  ROUTE_DEV(d_in, d_out);
   if (!out_len || !d_out) return ZES_E_ARG;
   *out_len = 0;
   if (deflate_throws(n)) return ZES_E_CORRUPT;
@@ -3138,7 +3155,7 @@ int zes_adler32(const uint8_t* in, uint64_t n, uint32_t* adler_out) {
 }
 
 int zes_stage_lz77_dev(const uint8_t* d_in, uint64_t n, uint64_t start, uint32_t len, uint32_t* h_tokens, uint32_t* ntokens) {
-  UseDev ud(route_dev(d_in));
+  ROUTE_DEV(d_in);
   if (!h_tokens || !ntokens || len < 2 || len > ZES_BLK || start + len > n || (start % ZES_BLK)) return ZES_E_ARG;
   std::lock_guard<std::mutex> lk(g_mu);
   int rc = init_locked(-1);
@@ -3223,17 +3240,35 @@ int zes_stage_huff_lengths_dev(const uint32_t* h_hist, uint32_t nsym, uint32_t m
 }
 
 int zes_last_inflate_tier(void) {
+  UseDev ud(t_last);  // the context that served this thread's last call (single host calls go round robin over the contexts)
   std::lock_guard<std::mutex> lk(g_mu);
   return g.last_tier;
 }
 
 int zes_set_profiling(int on) {
-  std::lock_guard<std::mutex> lk(g_mu);
-  g.profiling = on != 0;
+  std::lock_guard<std::mutex> cfg(g_cfg_mu);
+  for (int i = 0; i < ZES_MAX_DEV; i++) {  // every context: a call may be served by any of them
+    std::lock_guard<std::mutex> lk(g_mus[i]);
+    g_ctx[i].profiling = on != 0;
+  }
   return ZES_OK;
 }
 
+uint64_t zes_pool_bytes(void) {
+  uint64_t total = 0;
+  for (int i = 0; i < ZES_MAX_DEV; i++) {
+    std::lock_guard<std::mutex> lk(g_mus[i]);
+    Ctx& c = g_ctx[i];
+    const DevBuf* all[] = {&c.bufs, &c.blks, &c.idx_a, &c.idx_b, &c.inv, &c.sdelta, &c.tmask, &c.mlist, &c.hists, &c.codes, &c.hdrs, &c.adler, &c.res, &c.order, &c.surv, &c.vlong, &c.segfail, &c.symoff, &c.cand,
+                           &c.cand_sorted, &c.counters, &c.cres, &c.map, &c.resume, &c.dbg, &c.ibufs, &c.ibufs2, &c.mvlist, &c.scratch, &c.st_in, &c.st_out,
+                           &c.sres, &c.maps, &c.seglist, &c.segprefix, &c.wins, &c.sym16, &c.segorder, &c.segjobs, &c.pw16, &c.gwins, &c.seglive, &c.segouts};
+    for (const DevBuf* b : all) total += b->cap;
+  }
+  return total;
+}
+
 int zes_last_kernel_times(zes_ktime* out, int cap) {
+  UseDev ud(t_last);
   std::lock_guard<std::mutex> lk(g_mu);
   int n = 0;
   g.name_pool.clear();
