@@ -853,8 +853,9 @@ void zes_lazy_set_dbg(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBO
 #endif
 #define LAZY_EVAL_LIT 1u       // match word of an evaluated position that stays a literal (no match bit: k_lz_parse reads a literal)
 #define LAZY_MERGE_CAP 1024u   // a second chain that has met no window chain after this many bytes gives up
+#define LAZY_IN_BYTES (MATCH_IN_DWORDS * 4u)
 struct LazySmem {
-  uint32_t in[(MATCH_IN_DWORDS + 31) / 32 * 32];  // block + halo, swizzled like MatchSmem::in
+  uint8_t in[LAZY_IN_BYTES];                      // block + halo, zero padded, plain byte order: the compares read 8 bytes at any byte offset (ds_read_b64)
   uint32_t v1[ZES_BLK / 32];                      // positions on the window-start chains
   uint16_t xw[LAZY_NWIN];                         // chain of window w leaves it at 128 w + xw[w]
   uint16_t tail[LAZY_TAIL];                       // hop (1 or match length) of the block's last LAZY_TAIL keyed positions
@@ -865,6 +866,16 @@ struct LazySmem {
   uint8_t titem[LAZY_NWIN];                       // true chain: it leaves window w at that window's exit
 };
 #define LAZY_NOMERGE 0xFFFFFFFFu
+__device__ __forceinline__ static uint64_t lz_ld64(const uint8_t* s, uint32_t off) {  // 8 bytes at any byte offset
+  uint64_t v;
+  __builtin_memcpy(&v, s + off, 8);
+  return v;
+}
+__device__ __forceinline__ static uint32_t lz_ld32(const uint8_t* s, uint32_t off) {
+  uint32_t v;
+  __builtin_memcpy(&v, s + off, 4);
+  return v;
+}
 
 // Match at position p by the whole wavefront (p uniform): the candidates one after the other, every compare
 // shared by the 64 lanes (four bytes each).  Candidate order, early exits and tie rule of src/lz77.ts:49-95.
@@ -876,7 +887,7 @@ __device__ static uint32_t lazy_wave_eval(const LazySmem& S, uint32_t iv, const 
   uint32_t s = iv & 0x1FFFFu;  // slot whose sd entry leads from the current candidate to the next
   uint32_t dq = 0, dqv = sd[s];  // (the entry of p's own slot: the distance to its nearest candidate)
   bool pending = true;  // dqv (requested while the candidate before was compared) still has to be read
-  const uint32_t pd = m_ld32u(S.in, p + 4u * lane), pt = m_ld32u(S.in, p + 256u);
+  const uint32_t pd = lz_ld32(S.in, p + 4u * lane), pt = lz_ld32(S.in, p + 256u);
   for (;;) {
     if (check >= 128u || (best >= 8u && check >= 16u) || best >= maxl) break;  // :66-69, :89-91 (before the wait: a full match needs no further distance)
     if (pending) dq = (uint32_t)__builtin_amdgcn_readfirstlane((int)dqv);
@@ -888,7 +899,7 @@ __device__ static uint32_t lazy_wave_eval(const LazySmem& S, uint32_t iv, const 
     s--;
     dqv = sd[s];  // (slot 0 has nobody in front of it: sd[0] is 0)
     pending = true;
-    const uint32_t x = m_ld32u(S.in, q + 4u * lane) ^ pd;
+    const uint32_t x = lz_ld32(S.in, q + 4u * lane) ^ pd;
     const uint64_t mism = __ballot(x != 0u);
     uint32_t L;
     if (mism) {
@@ -896,7 +907,7 @@ __device__ static uint32_t lazy_wave_eval(const LazySmem& S, uint32_t iv, const 
       const uint32_t xf = (uint32_t)__builtin_amdgcn_readlane((int)x, (int)fl);
       L = 4u * fl + ((uint32_t)__builtin_ctz(xf) >> 3);
     } else {
-      const uint32_t t = (m_ld32u(S.in, q + 256u) ^ pt) & 0xffffu;  // bytes 256, 257
+      const uint32_t t = (lz_ld32(S.in, q + 256u) ^ pt) & 0xffffu;  // bytes 256, 257
       L = t ? 256u + ((uint32_t)__builtin_ctz(t) >> 3) : ZES_MAXMATCH;
     }
     L = min(L, maxl);
@@ -930,6 +941,27 @@ __device__ static uint32_t lazy_wave_eval(const LazySmem& S, uint32_t iv, const 
 template <int N>
 __device__ __forceinline__ static uint32_t row_shr(uint32_t x) {  // lane i of a row gets lane i-N's value, 0 for the first N lanes
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x110 + N, 0xf, 0xf, false);
+}
+
+template <int N>
+__device__ __forceinline__ static uint32_t row_ror(uint32_t x) {  // lane i of a row gets lane (i - N) mod 16's value
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x120 + N, 0xf, 0xf, false);
+}
+// maximum / minimum over a row of 16 lanes, in every lane of the row: four DPP steps on the vector unit instead of a lane
+// lookup through the LDS crossbar (ds_bpermute: a round trip of ~150 cycles with sixteen wavefronts at it, and the turn had eight)
+__device__ __forceinline__ static uint32_t row_allmax(uint32_t x) {
+  x = max(x, row_ror<8>(x));
+  x = max(x, row_ror<4>(x));
+  x = max(x, row_ror<2>(x));
+  x = max(x, row_ror<1>(x));
+  return x;
+}
+__device__ __forceinline__ static uint32_t row_allmin(uint32_t x) {
+  x = min(x, row_ror<8>(x));
+  x = min(x, row_ror<4>(x));
+  x = min(x, row_ror<2>(x));
+  x = min(x, row_ror<1>(x));
+  return x;
 }
 
 template <uint32_t PHASE>
@@ -1023,7 +1055,7 @@ __device__ __forceinline__ static uint32_t lazy_chains(LazySmem& S, const uint32
       uint32_t hop = 0;
       if (PHASE != 0u) {
         intail = go && !keyless && p >= tbase;  // evaluated in phase 0
-        hop = S.tail[intail ? p - tbase : 0u];
+        if (__ballot(intail)) hop = S.tail[intail ? p - tbase : 0u];  // (the block's end only: not an LDS round trip per turn)
       }
       ev = go && !keyless && !intail;
       p += keyless ? 1u : (intail ? hop : 0u);
@@ -1117,32 +1149,38 @@ __device__ __forceinline__ static uint32_t lazy_chains(LazySmem& S, const uint32
       uint32_t L = 3;
       LLAP(3);
       {
-        const uint32_t qo = (v ? qk : 0u) + 3u, po = p + 3u;
-        uint32_t qi = qo >> 2, pi = po >> 2;
-        const uint32_t qs = qo & 3u, ps2 = po & 3u;
-        uint32_t qlo = S.in[mswz(qi)], plo = S.in[mswz(pi)];
+        uint32_t qo = (v ? qk : 0u) + 3u, po = p + 3u;
         bool run = v;
-        auto step = [&]() {  // 8 bytes
-          const uint32_t qm = S.in[mswz(qi + 1)], pm = S.in[mswz(pi + 1)];
-          const uint32_t qhi = S.in[mswz(qi + 2)], phi = S.in[mswz(pi + 2)];
-          const uint32_t x1 = __builtin_amdgcn_alignbyte(qm, qlo, qs) ^ __builtin_amdgcn_alignbyte(pm, plo, ps2);
-          const uint32_t x2 = __builtin_amdgcn_alignbyte(qhi, qm, qs) ^ __builtin_amdgcn_alignbyte(phi, pm, ps2);
+        auto step = [&]() {  // 8 bytes: one unaligned read each side
+          const uint64_t x = lz_ld64(S.in, qo) ^ lz_ld64(S.in, po);
           const bool live = run && L < maxl;
-          const uint32_t f1 = ((uint32_t)__ffs((int)x1) - 1u) >> 3, f2 = ((uint32_t)__ffs((int)x2) - 1u) >> 3;
-          const uint32_t add = x1 ? f1 : (x2 ? 4u + f2 : 8u);
+          const uint32_t add = x ? ((uint32_t)__builtin_ctzll(x) >> 3) : 8u;
           L += live ? add : 0u;
-          run = run && !(live && (x1 | x2));
-          qi += 2;
-          pi += 2;
-          qlo = qhi;
-          plo = phi;
+          run = run && !(live && x != 0ull);
+          qo += 8u;
+          po += 8u;
 #ifdef LAZY_PROF
           nlcp++;
 #endif
         };
-        if (__ballot(run && L < maxl)) step();
+        {
+          // the first sixteen bytes of both sides in ONE round trip to the LDS (two steps of eight: text settles 99.5 % of its
+          // compares in the first, but with ~48 candidates a wavefront one of them nearly always goes on to the second)
+          const uint64_t q0 = lz_ld64(S.in, qo), q1 = lz_ld64(S.in, qo + 8u), p0 = lz_ld64(S.in, po), p1 = lz_ld64(S.in, po + 8u);
+          const uint64_t x0 = q0 ^ p0, x1 = q1 ^ p1;
+          const bool live0 = run && L < maxl;
+          L += live0 ? (x0 ? ((uint32_t)__builtin_ctzll(x0) >> 3) : 8u) : 0u;
+          run = run && !(live0 && x0 != 0ull);
+          const bool live1 = run && L < maxl;
+          L += live1 ? (x1 ? ((uint32_t)__builtin_ctzll(x1) >> 3) : 8u) : 0u;
+          run = run && !(live1 && x1 != 0ull);
+          qo += 16u;
+          po += 16u;
+#ifdef LAZY_PROF
+          nlcp += 2;
+#endif
+        }
         if (__ballot(run && L < maxl)) {
-          step();
           // (text hardly ever gets here: two steps settle nearly all of its compares)
           // The nearest candidate of a position's first round still going after sixteen bytes, with the full compare length ahead
           // of it (periodic data: every candidate matches to the end, 32 steps of 8 bytes for sixteen of them): it is tested
@@ -1154,8 +1192,8 @@ __device__ __forceinline__ static uint32_t lazy_chains(LazySmem& S, const uint32
             const uint32_t qa = (wide ? q0 : 0u) + 16u * sub, pa = (wide ? p : 0u) + 16u * sub;
             uint32_t x = 0;
 #pragma unroll
-            for (uint32_t t = 0; t < 4; t++) x |= m_ld32u(S.in, qa + 4u * t) ^ m_ld32u(S.in, pa + 4u * t);
-            if (sub == 0u) x |= (m_ld32u(S.in, qa + 256u) ^ m_ld32u(S.in, pa + 256u)) & 0xffffu;  // bytes 256, 257
+            for (uint32_t t = 0; t < 4; t++) x |= lz_ld32(S.in, qa + 4u * t) ^ lz_ld32(S.in, pa + 4u * t);
+            if (sub == 0u) x |= (lz_ld32(S.in, qa + 256u) ^ lz_ld32(S.in, pa + 256u)) & 0xffffu;  // bytes 256, 257
             const bool full = wide && ((uint32_t)(__ballot(wide && x != 0u) >> g0) & 0xffffu) == 0u;
             L = (full && sub == 0u) ? ZES_MAXMATCH : L;
             run = run && !full;
@@ -1176,24 +1214,22 @@ __device__ __forceinline__ static uint32_t lazy_chains(LazySmem& S, const uint32
       // ended the scan (:89-91); both tests only ever cut off a tail of the row
       const bool ex = v && (base == 0u || excl < 8u) && excl < maxl;
       const uint32_t xm = (uint32_t)(__ballot(ex) >> g0) & 0xffffu;  // a prefix of the valid ones
-      const uint32_t nx = (uint32_t)__popc(xm);
-      const uint32_t top = (uint32_t)__shfl((int)incl, (int)(g0 + (nx ? nx - 1u : 0u)));  // maximum over the candidates looked at
-      const uint32_t gmax = nx ? top : 0u;
+      const bool allex = xm == 0xffffu;                                // all sixteen were there and were looked at
+      const uint32_t gmax = row_allmax(ex ? L : 0u);                   // maximum over the candidates looked at
       if (__ballot(more && gmax > best)) {
-        // strictly longer only, and the nearest of the longest: the nearest candidate wins ties (:86-88)
-        const uint32_t who = (uint32_t)(__ballot(ex && L == gmax) >> g0) & 0xffffu;
-        const uint32_t kb = who ? (uint32_t)__builtin_ctz(who) : 0u;
-        const uint32_t qb = (uint32_t)__shfl((int)qk, (int)(g0 + kb));
+        // strictly longer only, and the nearest of the longest: the nearest candidate wins ties (:86-88) — the nearest is the
+        // one at the highest position
+        const uint32_t qb = row_allmax((ex && L == gmax) ? qk + 1u : 0u) - 1u;
         const bool up = more && gmax > best;
         bestq = up ? qb : bestq;
         best = up ? gmax : best;
       }
       // another round: all sixteen were there and were looked at, fewer than 128 so far, and the rule lets candidate
       // 16 (32, ...) be looked at: less than 8 bytes in hand, no full-length match
-      const uint32_t lq = (uint32_t)__shfl((int)qk, (int)(g0 + LAZY_G - 1u));
+      const uint32_t lq = row_allmin(v ? qk : 0xFFFFFFFFu);  // (the sixteenth candidate, when all sixteen are there: the farthest)
       lastq = more ? lq : lastq;
       base += more ? LAZY_G : 0u;
-      more = more && nx == LAZY_G && base < 128u && best < 8u && best < maxl;
+      more = more && allex && base < 128u && best < 8u && best < maxl;
       dfresh = more;
       fin = fin || (was && !more);
 #ifdef LAZY_PROF
@@ -1257,7 +1293,8 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match_lazy(const uint8_t* 
   __shared__ __align__(16) LazySmem S;
   // (a batch of unlike buffers: the blocks in the order k_lz_order dealt them, heaviest first)
   const uint32_t g = order ? order[blockIdx.x] : blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  if (!(idx_a[(uint64_t)g * ZES_BLK + ZES_BLK - 1] & ZES_SORT_LAZY)) return;  // this block belongs to k_lz_match
+  const uint32_t flagword = idx_a[(uint64_t)g * ZES_BLK + ZES_BLK - 1];
+  if (!(flagword & ZES_SORT_LAZY)) return;  // this block belongs to k_lz_match
   if (threadIdx.x == 0) mlist_all[(uint64_t)g * ZES_MLIST_WORDS] = 0xFFFFFFFFu;  // "no list: a block of this kernel" (k_lz_parse)
   const uint32_t* inv = inv_all + (uint64_t)g * ZES_BLK;
   const uint16_t* sd = sd_all + (uint64_t)g * ZES_BLK;
@@ -1273,10 +1310,11 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match_lazy(const uint8_t* 
   const uint32_t nwin = (T + LAZY_WIN - 1) / LAZY_WIN;
 
   LSTAMP(0);
-  // stage block + halo (zero padded), swizzled; clear the result words and the tables
+  // stage block + halo (zero padded), plain byte order
   if ((((uintptr_t)src) & 15u) == 0) {
     const uint4* g4 = reinterpret_cast<const uint4*>(src);
-    for (uint32_t i = tid; i < MATCH_IN_DWORDS / 4; i += MATCH_THREADS) {
+    uint4* s4 = reinterpret_cast<uint4*>(S.in);
+    for (uint32_t i = tid; i < LAZY_IN_BYTES / 16; i += MATCH_THREADS) {
       uint4 v = make_uint4(0, 0, 0, 0);
       const uint32_t b = i * 16u;
       if (b + 16u <= avail) {
@@ -1286,34 +1324,42 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match_lazy(const uint8_t* 
         for (uint32_t k = 0; k < 16u && b + k < avail; k++) t[k >> 2] |= (uint32_t)src[b + k] << (8u * (k & 3u));
         v = make_uint4(t[0], t[1], t[2], t[3]);
       }
-      S.in[mswz(4 * i + 0)] = v.x;
-      S.in[mswz(4 * i + 1)] = v.y;
-      S.in[mswz(4 * i + 2)] = v.z;
-      S.in[mswz(4 * i + 3)] = v.w;
+      s4[i] = v;
     }
   } else {
-    for (uint32_t i = tid; i < MATCH_IN_DWORDS; i += MATCH_THREADS) {
+    uint32_t* s1 = reinterpret_cast<uint32_t*>(S.in);
+    for (uint32_t i = tid; i < LAZY_IN_BYTES / 4; i += MATCH_THREADS) {
       uint32_t t = 0;
       for (uint32_t k = 0; k < 4u; k++)
         if (4 * i + k < avail) t |= (uint32_t)src[4 * i + k] << (8u * k);
-      S.in[mswz(i)] = t;
+      s1[i] = t;
     }
   }
-  {
-    uint4* mo4 = reinterpret_cast<uint4*>(mo);
-    const uint32_t n4 = (T + 3u) >> 2;
-    for (uint32_t i = tid; i < n4; i += MATCH_THREADS) mo4[i] = make_uint4(0, 0, 0, 0);
-  }
-  for (uint32_t i = tid; i < ZES_BLK / 32; i += MATCH_THREADS) S.v1[i] = 0;
-  if (tid == 0) {
-    S.wq = 0;
-    S.unmerged = 0;
-  }
-  __syncthreads();
-
-  LSTAMP(1);
+  // The result words are only ever read where this kernel has written them (the parse reads the chain's positions, the
+  // second chains' re-walk the positions those chains evaluated) — except by phase 3's walk, which asks "has anybody
+  // evaluated this position?" of words nobody may have touched.  Phase 3 is what periodic data needs (chains of maximal
+  // matches never merge), and periodic data is what k_lz_index takes: those blocks clear their 512 KiB of words up front.
+  // Any other block (text: 268 MB of stores per 64 MiB of input until round 3) clears them only if a second chain does give
+  // up, and then evaluates once more.
+  bool cleared = (flagword & ZES_SORT_INDEX) != 0u;  // (uniform)
   const uint32_t tbase = cnt > LAZY_TAIL ? cnt - LAZY_TAIL : 0u;  // first pre-evaluated position
-  {
+  for (;;) {
+    if (cleared) {
+      uint4* mo4 = reinterpret_cast<uint4*>(mo);
+      const uint32_t n4 = (T + 3u) >> 2;
+      for (uint32_t i = tid; i < n4; i += MATCH_THREADS) mo4[i] = make_uint4(0, 0, 0, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the zeros are in memory before another wave writes a result word
+    } else if (tid < 2u && cnt + tid < T) {
+      mo[cnt + tid] = LAZY_EVAL_LIT;  // the block's last two bytes: on every chain, evaluated by nobody (src/lz77.ts:116-117)
+    }
+    for (uint32_t i = tid; i < ZES_BLK / 32; i += MATCH_THREADS) S.v1[i] = 0;
+    if (tid == 0) {
+      S.wq = 0;
+      S.unmerged = 0;
+    }
+    __syncthreads();
+
+    LSTAMP(1);
     (void)lazy_chains<0u>(S, inv, sd, mo, T, cnt, avail, tbase, cnt - tbase);
     __syncthreads();
     LSTAMP(2);
@@ -1326,8 +1372,13 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match_lazy(const uint8_t* 
     if (tid == 0) S.wq = 0;
     __syncthreads();
     (void)lazy_chains<2u>(S, inv, sd, mo, T, cnt, avail, tbase, nwin);
+    // (result words another wave of this workgroup reads back — the second chains' re-walk, phase 3 — are in memory)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     LSTAMP(4);
+    if (!S.unmerged || cleared) break;  // (uniform)
+    cleared = true;
+    __syncthreads();  // everybody has read the flag before it is reset
   }
   // ---- the positions of the true chain as a bit mask, for k_lz_parse (which otherwise finds them again: exit maps
   // of all 2048 chunks, region tables, a walk per chunk — 343k of its 480k cycles per block on text).  The chain is
@@ -1431,8 +1482,8 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match_lazy(const uint8_t* 
             const uint32_t qj = has ? pj - dj : 0u, pp = has ? pj : 0u;
             bool full = has;
             for (uint32_t wv = 0; wv < 64u && __ballot(full); wv++)  // bytes 0..255, four at a time
-              full = full && m_ld32u(S.in, qj + 4u * wv) == m_ld32u(S.in, pp + 4u * wv);
-            full = full && ((m_ld32u(S.in, qj + 256u) ^ m_ld32u(S.in, pp + 256u)) & 0xffffu) == 0u;  // bytes 256, 257
+              full = full && lz_ld32(S.in, qj + 4u * wv) == lz_ld32(S.in, pp + 4u * wv);
+            full = full && ((lz_ld32(S.in, qj + 256u) ^ lz_ld32(S.in, pp + 256u)) & 0xffffu) == 0u;  // bytes 256, 257
             const uint64_t okm = __ballot(full);
             const uint32_t nk = (~okm) ? (uint32_t)__builtin_ctzll(~okm) : 64u;  // leading lanes that are settled
             if (lane < nk) {
