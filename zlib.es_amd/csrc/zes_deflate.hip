@@ -943,26 +943,49 @@ __device__ __forceinline__ static uint32_t row_shr(uint32_t x) {  // lane i of a
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x110 + N, 0xf, 0xf, false);
 }
 
+// maximum / minimum over a row of 16 lanes, in every lane of the row: four DPP rotations on the vector unit instead of a lane
+// lookup through the LDS crossbar (ds_bpermute: a round trip of ~150 cycles with sixteen wavefronts at it, and the turn had
+// eight).  (`old` is the operation's identity, so that the compiler folds the rotation into the max / min instruction itself;
+// every lane of a rotation has a source, the value is never used.)
 template <int N>
-__device__ __forceinline__ static uint32_t row_ror(uint32_t x) {  // lane i of a row gets lane (i - N) mod 16's value
-  return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x120 + N, 0xf, 0xf, false);
+__device__ __forceinline__ static uint32_t row_ror0(uint32_t x) {  // lane i of a row gets lane (i + N) mod 16's value
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x120 + N, 0xf, 0xf, false);
 }
-// maximum / minimum over a row of 16 lanes, in every lane of the row: four DPP steps on the vector unit instead of a lane
-// lookup through the LDS crossbar (ds_bpermute: a round trip of ~150 cycles with sixteen wavefronts at it, and the turn had eight)
+template <int N>
+__device__ __forceinline__ static uint32_t row_ror1(uint32_t x) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x120 + N, 0xf, 0xf, false);
+}
 __device__ __forceinline__ static uint32_t row_allmax(uint32_t x) {
-  x = max(x, row_ror<8>(x));
-  x = max(x, row_ror<4>(x));
-  x = max(x, row_ror<2>(x));
-  x = max(x, row_ror<1>(x));
+  x = max(x, row_ror0<8>(x));
+  x = max(x, row_ror0<4>(x));
+  x = max(x, row_ror0<2>(x));
+  x = max(x, row_ror0<1>(x));
   return x;
 }
 __device__ __forceinline__ static uint32_t row_allmin(uint32_t x) {
-  x = min(x, row_ror<8>(x));
-  x = min(x, row_ror<4>(x));
-  x = min(x, row_ror<2>(x));
-  x = min(x, row_ror<1>(x));
+  x = min(x, row_ror1<8>(x));
+  x = min(x, row_ror1<4>(x));
+  x = min(x, row_ror1<2>(x));
+  x = min(x, row_ror1<1>(x));
   return x;
 }
+
+// The loop's requests to memory.  Where loads and stores are both in flight the compiler waits for a load with
+// s_waitcnt vmcnt(0) — they share the counter on gfx9 and it keeps no order between the two kinds — i.e. at EVERY use in
+// this loop: each turn sat out the full latency of the request it had made a moment ago, twice (in-kernel laps of round 3:
+// 3.4k cycles a turn for ~450 instructions).  So the three requests a turn makes for later turns are issued by hand,
+// unconditionally (address 0 when no row asks) and always in the same order — W: a row's next window of inv entries,
+// D: the next round's sixteen distances, S: the first sixteen distances of the position a chain will stand on next — and
+// are waited for by count: vector memory operations complete in issue order, so "all but the N youngest are done"
+// covers a request once N younger ones have been issued; whatever else is issued in between only makes the wait longer,
+// never shorter.  The registers the requests land in are touched by nothing but the wait that covers them.
+// The requests land in three ACCUMULATION registers (a0: W, a1: D, a2: S — gfx90a and later load straight into them), which
+// this kernel has no other use for and the compiler none at all (it takes them for spills and matrix instructions only):
+// nothing can copy, reuse or reschedule a register whose data is still on its way — with ordinary registers as
+// destinations the register allocator did exactly that (a copy of the pending register at the loop's back edge).  The wait
+// that covers a request also moves its data into a vector register.  tools/check_lazy_isa.py looks at the generated code:
+// the three registers may appear in these statements only.
+#define LZ_REQ(areg, op, base, byteoff) asm volatile(op " " areg ", %0, %1" ::"v"(byteoff), "s"(base) : "memory", areg)
 
 template <uint32_t PHASE>
 __device__ __forceinline__ static uint32_t lazy_chains(LazySmem& S, const uint32_t* __restrict__ inv, const uint16_t* __restrict__ sd,
@@ -975,8 +998,7 @@ __device__ __forceinline__ static uint32_t lazy_chains(LazySmem& S, const uint32
   uint32_t sdp = 0, sdp_r = 0;                               // first sixteen distances requested ahead for slot sdp_r
   bool sdp_ok = false;
   // Requests made for a LATER turn stay in registers of their own (spend: the first sixteen distances of the chain's
-  // next position; dpend: the next round's sixteen) and are folded into sdp / dnext where that turn first needs them:
-  // a select on the loaded value right behind the load makes the wave wait for memory in the turn that asked.
+  // next position; dpend: the next round's sixteen) and are folded into sdp / dnext where that turn first needs them.
   uint32_t spend = 0, dpend = 0;
   bool sfresh = false, dfresh = false;
   // the position a row is on (rounds of sixteen candidates; a row whose position needs another round does not hold up
@@ -998,7 +1020,9 @@ __device__ __forceinline__ static uint32_t lazy_chains(LazySmem& S, const uint32
 #endif
   for (;;) {
     niter++;
-    wnxt = fw ? wpend : wnxt;  // the window requested in an earlier turn has arrived
+    // W of the turn before has landed: behind it that turn issued its D and its S
+    asm volatile("s_waitcnt vmcnt(2)\n\tv_accvgpr_read_b32 %0, a0" : "=v"(wpend)::"memory");
+    wnxt = fw ? wpend : wnxt;
     fw = false;
     // ---- hand out work items to rows without a chain ----
     {
@@ -1064,7 +1088,9 @@ __device__ __forceinline__ static uint32_t lazy_chains(LazySmem& S, const uint32
     LLAP(0);
     // ---- a position starts (src/lz77.ts:49-95): its sorted slot, the first sixteen distances ----
     bool fin = false;  // the match at p is known
-    if (__ballot(ev)) {
+    const bool anyev = __ballot(ev) != 0ull;
+    uint32_t wreq = 0, iv = ZES_INV_NONE;
+    if (anyev) {
       // sorted slot of p from the row's two windows of inv entries (sixteen positions each, lane k the k-th); a chain
       // moves on by a few bytes per position, so the window behind the current one was requested turns ago
       if (__ballot(ev && p - wb >= 2u * LAZY_G)) {  // far jump (or a new work item): both windows from memory
@@ -1079,16 +1105,30 @@ __device__ __forceinline__ static uint32_t lazy_chains(LazySmem& S, const uint32
         const bool step = ev && p - wb >= LAZY_G;  // into the window behind: it becomes the current one, the next is requested
         wcur = step ? wnxt : wcur;
         wb += step ? LAZY_G : 0u;
-        if (__ballot(step)) {
-          const uint32_t a1 = inv[step ? min(wb + LAZY_G + sub, ZES_BLK - 1u) : 0u];
-          wpend = a1;  // read at the top of a later turn (fw: this row's request)
-          fw = step;
-        }
+        wreq = step ? min(wb + LAZY_G + sub, ZES_BLK - 1u) : 0u;
+        fw = step;  // read at the top of the next turn (this row's request)
       }
-      const uint32_t iv = (uint32_t)__shfl((int)wcur, (int)(g0 + ((ev ? p - wb : 0u) & (LAZY_G - 1u))));
-      LLAP(1);
+      iv = (uint32_t)__shfl((int)wcur, (int)(g0 + ((ev ? p - wb : 0u) & (LAZY_G - 1u))));
+    }
+    LZ_REQ("a0", "global_load_dword", inv, wreq << 2);  // W
+    // S and D of the turn before have landed: behind them this turn's W has been issued
+    asm volatile("s_waitcnt vmcnt(1)\n\tv_accvgpr_read_b32 %0, a2\n\tv_accvgpr_read_b32 %1, a1" : "=v"(spend), "=v"(dpend)::"memory");
+    LLAP(1);
+    uint32_t sreq = 0;  // the slot whose first sixteen distances this row asks for with this turn's S (0: it does not ask)
+    bool sask = false;
+    if (anyev) {
       const bool has = ev && iv != ZES_INV_NONE;
-      r = ev ? (iv & 0x1FFFFu) : r;  // sorted slot of p: the distance to candidate k is the sum of sd[r], sd[r-1], ... sd[r-k]
+      const uint32_t rr = iv & 0x1FFFFu;  // sorted slot of p: the distance to candidate k is the sum of sd[r], sd[r-1], ... sd[r-k]
+      sdp = sfresh ? spend : sdp;  // what an earlier turn asked for
+      sfresh = false;
+      // the first sixteen distances were requested when the chain came to stand here — unless the position lay outside the
+      // row's windows then, or the window was still on its way (long matches, new work items): those are fetched now
+      const bool hit = has && sdp_ok && sdp_r == rr;
+      if (__ballot(has && !hit)) {
+        const uint32_t t = sd[(has && sub <= rr) ? rr - sub : 0u];
+        sdp = (has && !hit) ? t : sdp;
+      }
+      r = ev ? rr : r;
       maxl = ev ? min(ZES_MAXMATCH, avail - p) : maxl;  // = min(258, n - p)
       best = ev ? 0u : best;
       bestq = ev ? 0u : bestq;
@@ -1097,6 +1137,8 @@ __device__ __forceinline__ static uint32_t lazy_chains(LazySmem& S, const uint32
       more = ev ? has : more;
       fin = ev && !has;  // no candidate: a literal
       mode = has ? LZ_EVAL : mode;
+      dnext = has ? sdp : dnext;
+      dfresh = ev ? false : dfresh;
       // A literal like that is often one of a run (incompressible stretches, the first period of periodic data): the
       // positions behind it whose inv entries, in the row's current window, say "no candidate" too are settled with it
       // — window chains only: a second chain has to test every position it stands on for a merge.
@@ -1108,31 +1150,22 @@ __device__ __forceinline__ static uint32_t lazy_chains(LazySmem& S, const uint32
         const uint32_t lim = min(min(wend, cnt), tbase) - p;                                // stay inside the window, the keyed and the not pre-evaluated positions
         litrun = fin ? max(1u, min(min(inv_run, LAZY_G - off), lim)) : 1u;
       }
-      // the distances of a round are requested one round ahead (round 0: at the end of the turn before, when the chain's
-      // next position was known — sdp/sdp_r say for which slot)
-      {
-        sdp = sfresh ? spend : sdp;  // what the turn before asked for
-        sfresh = false;
-        const bool hit = has && sdp_ok && sdp_r == r;
-        if (__ballot(has && !hit)) {
-          const uint32_t t = sd[(has && sub <= r) ? r - sub : 0u];
-          sdp = (has && !hit) ? t : sdp;
-        }
-        dnext = has ? sdp : dnext;
-      }
     }
     // ---- one round of sixteen candidates for every row that is on a position ----
-    if (__ballot(more)) {
-      const bool was = more;
-      const uint32_t k = base + sub;
+    const bool anymore = __ballot(more) != 0ull;
+    const bool was = more;
+    const uint32_t k = base + sub;
+    uint32_t d = 0, dreq = 0;
+    if (anymore) {
       const bool inl = more && k <= r;  // (slot 0 has nobody in front of it: sd[0] is 0)
-      dnext = dfresh ? dpend : dnext;  // (a row that has just started a position took its sixteen from sdp: dfresh is off)
-      uint32_t d = inl ? dnext : 0u;
-      {
-        const uint32_t k2 = k + LAZY_G;
-        dpend = sd[(more && k2 <= r) ? r - k2 : 0u];  // next round's sixteen, in flight until the next turn's round
-      }
-      LLAP(2);
+      dnext = dfresh ? dpend : dnext;   // (a row that has just started a position took its sixteen from sdp: dfresh is off)
+      d = inl ? dnext : 0u;
+      const uint32_t k2 = k + LAZY_G;
+      dreq = (more && k2 <= r) ? r - k2 : 0u;  // next round's sixteen, in flight until the next turn's round
+    }
+    LZ_REQ("a1", "global_load_ushort", sd, dreq << 1);  // D
+    LLAP(2);
+    if (anymore) {
       // candidate positions: prefix sum of the distances over the row
       uint32_t ps = d;
       ps += row_shr<1>(ps);
@@ -1188,8 +1221,8 @@ __device__ __forceinline__ static uint32_t lazy_chains(LazySmem& S, const uint32
           // (src/lz77.ts:86-91: the first candidate examined, and no longer one exists) — whatever the others are.
           const bool wide = ((uint32_t)(__ballot(run && L < maxl && sub == 0u && base == 0u && maxl == ZES_MAXMATCH) >> g0) & 1u) != 0u;  // (the same in a row's lanes)
           if (__ballot(wide)) {
-            const uint32_t q0 = (uint32_t)__shfl((int)qk, (int)g0);
-            const uint32_t qa = (wide ? q0 : 0u) + 16u * sub, pa = (wide ? p : 0u) + 16u * sub;
+            const uint32_t qn = (uint32_t)__shfl((int)qk, (int)g0);
+            const uint32_t qa = (wide ? qn : 0u) + 16u * sub, pa = (wide ? p : 0u) + 16u * sub;
             uint32_t x = 0;
 #pragma unroll
             for (uint32_t t = 0; t < 4; t++) x |= lz_ld32(S.in, qa + 4u * t) ^ lz_ld32(S.in, pa + 4u * t);
@@ -1262,20 +1295,20 @@ __device__ __forceinline__ static uint32_t lazy_chains(LazySmem& S, const uint32
         const uint32_t ivn = off < LAZY_G ? e0 : e1;
         const bool want = in2 && ivn != ZES_INV_NONE && !(fw && off >= LAZY_G);  // (a window still on its way: not this time)
         const uint32_t rn = ivn & 0x1FFFFu;
-        // (a row in the middle of its rounds keeps what it has — it is not the one asking; a row whose request of the
-        // turn before was never folded in has moved on without evaluating: that request is dead)
-        if (__ballot(want)) {
-          sdp = sfresh ? spend : sdp;  // (the new request overwrites spend in every lane: another row's pending one is folded in first)
-          sfresh = false;
-          spend = sd[(want && sub <= rn) ? rn - sub : 0u];
-        }
-        sfresh = fin ? true : sfresh;
+        sask = fin ? want : sask;
+        sreq = fin ? (want ? rn : 0u) : sreq;
         sdp_ok = fin ? want : sdp_ok;
         sdp_r = fin ? rn : sdp_r;
       }
     }
+    // S: the new request overwrites spend in every lane — a row's landed one is folded in first (a row whose request was
+    // never folded has moved on without evaluating: that request is dead)
+    sdp = sfresh ? spend : sdp;
+    sfresh = sask;
+    LZ_REQ("a2", "global_load_ushort", sd, ((sask && sub <= sreq) ? sreq - sub : 0u) << 1);
     LLAP(5);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the last requests have landed before the next phase issues its own)
 #ifdef LAZY_PROF
   if (PHASE == 1u && blockIdx.x == 7 && threadIdx.x == 0)
     printf("lazy prof: turns %u rounds %llu | control %llu inv-wait %llu sd-wait %llu prefix %llu lcp %llu (%llu steps) rule+store %llu\n", niter, nrnd,
