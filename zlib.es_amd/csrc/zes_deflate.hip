@@ -987,7 +987,10 @@ __device__ __forceinline__ static uint32_t row_allmin(uint32_t x) {
 // the three registers may appear in these statements only.
 #define LZ_REQ(areg, op, base, byteoff) asm volatile(op " " areg ", %0, %1" ::"v"(byteoff), "s"(base) : "memory", areg)
 
-template <uint32_t PHASE>
+// GUARDED: every section of a turn sits behind "does any row need it?" — for blocks whose turns mostly need few of them
+// (periodic data: runs of literals, one position in 258 behind them); text needs all of them nearly every turn, and a guard
+// costs two vector instructions and a branch.
+template <uint32_t PHASE, bool GUARDED>
 __device__ __forceinline__ static uint32_t lazy_chains(LazySmem& S, const uint32_t* __restrict__ inv, const uint16_t* __restrict__ sd,
                                                        uint32_t* __restrict__ mo, uint32_t T, uint32_t cnt, uint32_t avail, uint32_t tbase,
                                                        uint32_t nitems) {
@@ -1079,7 +1082,7 @@ __device__ __forceinline__ static uint32_t lazy_chains(LazySmem& S, const uint32
       uint32_t hop = 0;
       if (PHASE != 0u) {
         intail = go && !keyless && p >= tbase;  // evaluated in phase 0
-        if (__ballot(intail)) hop = S.tail[intail ? p - tbase : 0u];  // (the block's end only: not an LDS round trip per turn)
+        if (__ballot(p >= tbase)) hop = S.tail[intail ? p - tbase : 0u];  // (the block's end only: not an LDS round trip per turn)
       }
       ev = go && !keyless && !intail;
       p += keyless ? 1u : (intail ? hop : 0u);
@@ -1088,8 +1091,10 @@ __device__ __forceinline__ static uint32_t lazy_chains(LazySmem& S, const uint32
     LLAP(0);
     // ---- a position starts (src/lz77.ts:49-95): its sorted slot, the first sixteen distances ----
     bool fin = false;  // the match at p is known
-    const bool anyev = __ballot(ev) != 0ull;
+    // (the sections below run in every turn: with four rows a wavefront there is nearly always one that needs them, and every
+    // guard "does any row?" costs two vector instructions and a branch)
     uint32_t wreq = 0, iv = ZES_INV_NONE;
+    const bool anyev = !GUARDED || __ballot(ev) != 0ull;
     if (anyev) {
       // sorted slot of p from the row's two windows of inv entries (sixteen positions each, lane k the k-th); a chain
       // moves on by a few bytes per position, so the window behind the current one was requested turns ago
@@ -1108,7 +1113,7 @@ __device__ __forceinline__ static uint32_t lazy_chains(LazySmem& S, const uint32
         wreq = step ? min(wb + LAZY_G + sub, ZES_BLK - 1u) : 0u;
         fw = step;  // read at the top of the next turn (this row's request)
       }
-      iv = (uint32_t)__shfl((int)wcur, (int)(g0 + ((ev ? p - wb : 0u) & (LAZY_G - 1u))));
+      iv = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * (g0 + ((p - wb) & (LAZY_G - 1u)))), (int)wcur);  // (a row that is not starting reads some lane of its own)
     }
     LZ_REQ("a0", "global_load_dword", inv, wreq << 2);  // W
     // S and D of the turn before have landed: behind them this turn's W has been issued
@@ -1134,11 +1139,11 @@ __device__ __forceinline__ static uint32_t lazy_chains(LazySmem& S, const uint32
       bestq = ev ? 0u : bestq;
       base = ev ? 0u : base;
       lastq = ev ? p : lastq;
-      more = ev ? has : more;
+      more = has || (!ev && more);  // (has implies ev; bools are lane masks: logic on them is scalar work, a select is not)
       fin = ev && !has;  // no candidate: a literal
       mode = has ? LZ_EVAL : mode;
       dnext = has ? sdp : dnext;
-      dfresh = ev ? false : dfresh;
+      dfresh = dfresh && !ev;
       // A literal like that is often one of a run (incompressible stretches, the first period of periodic data): the
       // positions behind it whose inv entries, in the row's current window, say "no candidate" too are settled with it
       // — window chains only: a second chain has to test every position it stands on for a merge.
@@ -1152,11 +1157,10 @@ __device__ __forceinline__ static uint32_t lazy_chains(LazySmem& S, const uint32
       }
     }
     // ---- one round of sixteen candidates for every row that is on a position ----
-    const bool anymore = __ballot(more) != 0ull;
     const bool was = more;
     const uint32_t k = base + sub;
     uint32_t d = 0, dreq = 0;
-    if (anymore) {
+    {
       const bool inl = more && k <= r;  // (slot 0 has nobody in front of it: sd[0] is 0)
       dnext = dfresh ? dpend : dnext;   // (a row that has just started a position took its sixteen from sdp: dfresh is off)
       d = inl ? dnext : 0u;
@@ -1165,7 +1169,10 @@ __device__ __forceinline__ static uint32_t lazy_chains(LazySmem& S, const uint32
     }
     LZ_REQ("a1", "global_load_ushort", sd, dreq << 1);  // D
     LLAP(2);
-    if (anymore) {
+    // (periodic data has turn after turn without a round — runs of literals, one position in 258 after that — so this one
+    // guard stays; a row has a round to do exactly when its mode says so, and a compare of that is a guard of one vector
+    // instruction, where a ballot over the flag takes two)
+    if (__ballot(mode == LZ_EVAL)) {
       // candidate positions: prefix sum of the distances over the row
       uint32_t ps = d;
       ps += row_shr<1>(ps);
@@ -1249,7 +1256,7 @@ __device__ __forceinline__ static uint32_t lazy_chains(LazySmem& S, const uint32
       const uint32_t xm = (uint32_t)(__ballot(ex) >> g0) & 0xffffu;  // a prefix of the valid ones
       const bool allex = xm == 0xffffu;                                // all sixteen were there and were looked at
       const uint32_t gmax = row_allmax(ex ? L : 0u);                   // maximum over the candidates looked at
-      if (__ballot(more && gmax > best)) {
+      if (!GUARDED || __ballot(more && gmax > best)) {
         // strictly longer only, and the nearest of the longest: the nearest candidate wins ties (:86-88) — the nearest is the
         // one at the highest position
         const uint32_t qb = row_allmax((ex && L == gmax) ? qk + 1u : 0u) - 1u;
@@ -1270,7 +1277,7 @@ __device__ __forceinline__ static uint32_t lazy_chains(LazySmem& S, const uint32
 #endif
     }
     // ---- a finished evaluation moves its chain on ----
-    if (__ballot(fin)) {
+    if (!GUARDED || __ballot(fin)) {
       const bool acc = best >= 3u && p + best + 3u <= T;  // src/lz77.ts:95
       if (fin && sub == 0u) mo[p] = acc ? (ZES_TOK_MATCH | ((best - 3u) << 16) | (p - bestq - 1u)) : LAZY_EVAL_LIT;
       if (PHASE == 0u) {
@@ -1290,14 +1297,15 @@ __device__ __forceinline__ static uint32_t lazy_chains(LazySmem& S, const uint32
       {
         const uint32_t off = p - wb;
         const bool in2 = fin && off < 2u * LAZY_G && p < cnt;
-        const uint32_t e0 = (uint32_t)__shfl((int)wcur, (int)(g0 + (off & (LAZY_G - 1u))));
-        const uint32_t e1 = (uint32_t)__shfl((int)wnxt, (int)(g0 + (off & (LAZY_G - 1u))));
+        const int from = (int)(4u * (g0 + (off & (LAZY_G - 1u))));
+        const uint32_t e0 = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)wcur);
+        const uint32_t e1 = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)wnxt);
         const uint32_t ivn = off < LAZY_G ? e0 : e1;
         const bool want = in2 && ivn != ZES_INV_NONE && !(fw && off >= LAZY_G);  // (a window still on its way: not this time)
         const uint32_t rn = ivn & 0x1FFFFu;
-        sask = fin ? want : sask;
+        sask = want || (!fin && sask);  // (want implies fin)
         sreq = fin ? (want ? rn : 0u) : sreq;
-        sdp_ok = fin ? want : sdp_ok;
+        sdp_ok = want || (!fin && sdp_ok);
         sdp_r = fin ? rn : sdp_r;
       }
     }
@@ -1375,6 +1383,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match_lazy(const uint8_t* 
   // Any other block (text: 268 MB of stores per 64 MiB of input until round 3) clears them only if a second chain does give
   // up, and then evaluates once more.
   bool cleared = (flagword & ZES_SORT_INDEX) != 0u;  // (uniform)
+  const bool guarded = cleared;  // the same kind of block: its turns are mostly runs of literals (see lazy_chains)
   const uint32_t tbase = cnt > LAZY_TAIL ? cnt - LAZY_TAIL : 0u;  // first pre-evaluated position
   for (;;) {
     if (cleared) {
@@ -1393,18 +1402,20 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match_lazy(const uint8_t* 
     __syncthreads();
 
     LSTAMP(1);
-    (void)lazy_chains<0u>(S, inv, sd, mo, T, cnt, avail, tbase, cnt - tbase);
+    if (guarded) (void)lazy_chains<0u, true>(S, inv, sd, mo, T, cnt, avail, tbase, cnt - tbase);
+    else (void)lazy_chains<0u, false>(S, inv, sd, mo, T, cnt, avail, tbase, cnt - tbase);
     __syncthreads();
     LSTAMP(2);
     if (tid == 0) S.wq = 0;
     __syncthreads();
-    const uint32_t niter = lazy_chains<1u>(S, inv, sd, mo, T, cnt, avail, tbase, nwin);
+    const uint32_t niter = guarded ? lazy_chains<1u, true>(S, inv, sd, mo, T, cnt, avail, tbase, nwin) : lazy_chains<1u, false>(S, inv, sd, mo, T, cnt, avail, tbase, nwin);
     if (g_lazy_dbg && tid == 0) g_lazy_dbg[(size_t)blockIdx.x * 8 + 6] = niter;
     __syncthreads();
     LSTAMP(3);
     if (tid == 0) S.wq = 0;
     __syncthreads();
-    (void)lazy_chains<2u>(S, inv, sd, mo, T, cnt, avail, tbase, nwin);
+    if (guarded) (void)lazy_chains<2u, true>(S, inv, sd, mo, T, cnt, avail, tbase, nwin);
+    else (void)lazy_chains<2u, false>(S, inv, sd, mo, T, cnt, avail, tbase, nwin);
     // (result words another wave of this workgroup reads back — the second chains' re-walk, phase 3 — are in memory)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
