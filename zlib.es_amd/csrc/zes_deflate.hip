@@ -86,6 +86,7 @@ struct SortSmem {
   uint16_t whist[2][SORT_WAVES][256];
   uint32_t wsum[SORT_WAVES];
   uint32_t nsat;             // filter: positions that found their key already counted twice
+  uint32_t heavy;            // dense blocks: sampled positions whose key's class is a heavy one
 };
 static_assert((1u << SORT_HASH_BITS) * 2u / 8u <= ZES_BLK, "counter table must fit the block area");
 static_assert(SORT_OWN * SORT_THREADS == ZES_BLK, "one thread per 128 positions");
@@ -131,7 +132,10 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
     uint4* t4 = reinterpret_cast<uint4*>(S.in);
     for (uint32_t i = tid; i < ZES_BLK / 16; i += SORT_THREADS) t4[i] = make_uint4(0, 0, 0, 0);
     for (uint32_t i = tid; i < 4 * 3 * 256; i += SORT_THREADS) reinterpret_cast<uint32_t*>(&S.whist[0][0][0])[i] = 0;
-    if (tid == 0) S.nsat = 0;
+    if (tid == 0) {
+      S.nsat = 0;
+      S.heavy = 0;
+    }
   }
   __syncthreads();
   SSTAMP(1);
@@ -189,8 +193,47 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
   const bool dense = redo || (S.nsat & 0xFFFFu) * 4u >= (S.nsat >> 16) * 3u;
 #ifndef NO_LAZY
   if (dense && !redo && (mode & ZES_SORT_USE_INDEX) && inv_all != nullptr) {  // (uniform) k_lz_index builds this block's index inside LDS
-    if (tid == 0) A[ZES_BLK - 1] = cnt | ZES_SORT_LAZY | ZES_SORT_INDEX;
-    return;
+    // ... unless much of the block's weight sits in a few heavy keys (text: " th", "he "): k_lz_index would count its classes
+    // and hand the block back (a second launch of this kernel; text paid 0.08 ms for this launch's filter pass, 0.04 ms for
+    // that count and the second launch's start on top of its sort).  The same verdict from this launch's sample, one
+    // position in sixteen: the samples are counted per hash class (2048 of them), a class with more than its share of 512
+    // positions is heavy, and with a sixteenth of the positions in such classes the block is sorted HERE, now.  The sample
+    // only picks the kernel that builds the index — either builds the same candidate lists — so it need not agree with
+    // k_lz_index's own count on a block near the line (that kernel still hands back what it cannot take).
+    uint32_t* cc = reinterpret_cast<uint32_t*>(&S.whist[0][0][0]);  // [2048], zeroed at the start
+    // (fresh samples, at an offset inside each run of sixteen that differs from run to run: the density test's samples sit
+    // on multiples of sixteen, and data whose period is one — the 4 KiB pattern — shows them the same 256 keys over and over)
+    {
+      uint32_t ky[SORT_OWN / 16];
+#pragma unroll
+      for (uint32_t c = 0; c < SORT_OWN / 16; c++) {
+        const uint32_t sp = min(p0 + 16u * c + (((tid * 8u + c) * 0x9E3779B1u) >> 28), T >= 8u ? T - 8u : 0u);  // (the eight bytes read stay inside the block)
+        uint32_t w = 0, w2 = 0;
+        if (T >= 8u) {
+          __builtin_memcpy(&w, src + (sp & ~3u), 4);
+          __builtin_memcpy(&w2, src + (sp & ~3u) + 4u, 4);
+        }
+        ky[c] = __builtin_amdgcn_alignbyte(w2, w, sp & 3u) & 0xffffffu;
+      }
+#pragma unroll
+      for (uint32_t c = 0; c < SORT_OWN / 16; c++)
+        if (p0 + 16u * c < cnt) atomicAdd(&cc[sort_hash(ky[c]) >> (SORT_HASH_BITS - 11u)], 1u);
+    }
+    __syncthreads();
+    {
+      const uint32_t thr = max(2u, (32u * cnt + (ZES_BLK - 1u)) >> 17);  // a class's share of samples when it holds 512 positions of a full block
+      const uint32_t a = cc[2u * tid], b = cc[2u * tid + 1u];
+      const uint32_t w = (a > thr ? a : 0u) + (b > thr ? b : 0u);
+      if (w) atomicAdd(&S.heavy, w);
+    }
+    __syncthreads();
+    if (S.heavy * 256u <= cnt) {  // (uniform) samples are a sixteenth of the positions, heavy classes below a sixteenth of those
+      if (tid == 0) A[ZES_BLK - 1] = cnt | ZES_SORT_LAZY | ZES_SORT_INDEX;
+      return;
+    }
+    cc[2u * tid] = 0;  // (the dense path's byte histograms expect the area as it was)
+    cc[2u * tid + 1u] = 0;
+    __syncthreads();
   }
 #endif
   // Few kept (incompressible data: a fifth, nearly all of them collisions of the hash, not repeats of a key): a second
@@ -955,6 +998,10 @@ template <int N>
 __device__ __forceinline__ static uint32_t row_ror1(uint32_t x) {
   return (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x120 + N, 0xf, 0xf, false);
 }
+template <int N>
+__device__ __forceinline__ static uint32_t row_lane(uint32_t x) {  // lane N of the row, in every lane of the row (row_newbcast: gfx90a and later)
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x150 + N, 0xf, 0xf, false);
+}
 __device__ __forceinline__ static uint32_t row_allmax(uint32_t x) {
   x = max(x, row_ror0<8>(x));
   x = max(x, row_ror0<4>(x));
@@ -1204,16 +1251,20 @@ __device__ __forceinline__ static uint32_t lazy_chains(LazySmem& S, const uint32
 #endif
         };
         {
-          // the first sixteen bytes of both sides in ONE round trip to the LDS (two steps of eight: text settles 99.5 % of its
-          // compares in the first, but with ~48 candidates a wavefront one of them nearly always goes on to the second)
+          // The first sixteen bytes of both sides in ONE round trip to the LDS (text settles 99.5 % of its compares in the first
+          // eight, but with ~48 candidates a wavefront one of them nearly always needs the second eight).  Equal bytes from the
+          // front: per dword of the difference its low zero bytes (a dword without a difference: a huge number), the first
+          // dword that has one decides.  The cap at maxl comes behind the compare, so nothing has to stop adding on the way.
           const uint64_t q0 = lz_ld64(S.in, qo), q1 = lz_ld64(S.in, qo + 8u), p0 = lz_ld64(S.in, po), p1 = lz_ld64(S.in, po + 8u);
           const uint64_t x0 = q0 ^ p0, x1 = q1 ^ p1;
-          const bool live0 = run && L < maxl;
-          L += live0 ? (x0 ? ((uint32_t)__builtin_ctzll(x0) >> 3) : 8u) : 0u;
-          run = run && !(live0 && x0 != 0ull);
-          const bool live1 = run && L < maxl;
-          L += live1 ? (x1 ? ((uint32_t)__builtin_ctzll(x1) >> 3) : 8u) : 0u;
-          run = run && !(live1 && x1 != 0ull);
+          auto zb = [](uint32_t dw) {  // (v_ffbl_b32 of 0 is 0xFFFFFFFF; __ffs / __builtin_ctz make the compiler add a compare and a select)
+            uint32_t f;
+            asm("v_ffbl_b32 %0, %1" : "=v"(f) : "v"(dw));
+            return f >> 3;
+          };
+          const uint32_t n16 = min(min(min(zb((uint32_t)x0), zb((uint32_t)(x0 >> 32)) + 4u), zb((uint32_t)x1) + 8u), min(zb((uint32_t)(x1 >> 32)) + 12u, 16u));
+          L = 3u + n16;
+          run = v && n16 == 16u;
           qo += 16u;
           po += 16u;
 #ifdef LAZY_PROF
@@ -1253,8 +1304,7 @@ __device__ __forceinline__ static uint32_t lazy_chains(LazySmem& S, const uint32
       // candidate k is looked at unless 8 bytes are in hand after 16 candidates (:66-69) or a full-length match has
       // ended the scan (:89-91); both tests only ever cut off a tail of the row
       const bool ex = v && (base == 0u || excl < 8u) && excl < maxl;
-      const uint32_t xm = (uint32_t)(__ballot(ex) >> g0) & 0xffffu;  // a prefix of the valid ones
-      const bool allex = xm == 0xffffu;                                // all sixteen were there and were looked at
+      const bool allex = row_lane<15>(ex ? 1u : 0u) != 0u;            // all sixteen were there and were looked at (ex is a prefix of the row)
       const uint32_t gmax = row_allmax(ex ? L : 0u);                   // maximum over the candidates looked at
       if (!GUARDED || __ballot(more && gmax > best)) {
         // strictly longer only, and the nearest of the longest: the nearest candidate wins ties (:86-88) — the nearest is the
@@ -1266,7 +1316,7 @@ __device__ __forceinline__ static uint32_t lazy_chains(LazySmem& S, const uint32
       }
       // another round: all sixteen were there and were looked at, fewer than 128 so far, and the rule lets candidate
       // 16 (32, ...) be looked at: less than 8 bytes in hand, no full-length match
-      const uint32_t lq = row_allmin(v ? qk : 0xFFFFFFFFu);  // (the sixteenth candidate, when all sixteen are there: the farthest)
+      const uint32_t lq = row_lane<15>(qk);  // the sixteenth candidate (only a row that had all sixteen goes on from it)
       lastq = more ? lq : lastq;
       base += more ? LAZY_G : 0u;
       more = more && allex && base < 128u && best < 8u && best < maxl;
