@@ -8,6 +8,8 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <vector>
 
 #include "../../include/zes.h"
 
@@ -45,36 +47,172 @@ bool get_bytes(napi_env env, napi_value v, const uint8_t** data, size_t* len) {
   return false;
 }
 
-void free_external(napi_env, void* data, void*);
-// the library's output buffer becomes the result's ArrayBuffer (shrunk to the exact length: `buffer.byteLength === length`
-// like src/zlib.ts:42): no second copy of the result on the JS thread.  Takes the buffer over (frees it on failure).
-napi_value take_u8(napi_env env, uint8_t* buf, size_t n) {
-  void* shrunk = realloc(buf, n ? n : 1);
-  if (shrunk) buf = static_cast<uint8_t*>(shrunk);
+// ---- result memory ----
+// A result is a fresh Uint8Array with its own exact-length ArrayBuffer (src/zlib.ts:42).  Fresh memory is what a large call
+// pays most for on the host side: 64 MiB of untouched pages are 16 384 page faults under the copy that fills them, ~30 ms
+// where the GPU's work and both trips over PCIe take 2.5.  So results of 1 MiB and more live in blocks of page-locked memory
+// (zes_host_alloc: no faults, and the copy engines write them directly) that come back to a small pool when the ArrayBuffer is
+// collected and are handed out again.  Node runs the finalizers of external ArrayBuffers between event-loop turns, not
+// inside a synchronous loop: a host that awaits (deflateAsync / inflateAsync, any server) gets its blocks back and runs at
+// the library's pace; a tight synchronous loop over 64 MiB calls gets fresh blocks until BIG_OUTSTANDING_MAX are out, then
+// plain malloc as before.  trim() empties the pool.
+constexpr size_t BIG_MIN = 1u << 20;                 // smaller results: malloc, as before
+constexpr size_t BIG_KEEP_MAX = 512u << 20;          // bytes the pool keeps for reuse
+constexpr size_t BIG_OUTSTANDING_MAX = 512u << 20;   // pooled bytes in the hands of JS beyond which new results are not pooled
+struct BigPool {
+  struct Blk {
+    uint8_t* p;
+    size_t cap;
+  };
+  std::mutex mu;
+  std::vector<Blk> free_;
+  size_t kept = 0, out = 0;
+  size_t want = 0;  // a request the pool could not serve from inside the library (see take): the next top_up() gets such a block
+  // a block of at least n bytes, or nullptr (the caller falls back to malloc).  fresh = false: from inside one of the
+  // library's allocator callbacks — they run under the library's lock, and a new page-locked block comes from the library
+  // (zes_host_alloc takes that lock): only what the pool holds; the miss is noted and made good after the call.
+  uint8_t* take(size_t n, size_t* cap, bool fresh) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      size_t best = free_.size();
+      for (size_t i = 0; i < free_.size(); i++)
+        if (free_[i].cap >= n && free_[i].cap <= 2 * n + (8u << 20) && (best == free_.size() || free_[i].cap < free_[best].cap)) best = i;
+      if (best != free_.size()) {
+        Blk b = free_[best];
+        free_.erase(free_.begin() + (long)best);
+        kept -= b.cap;
+        out += b.cap;
+        *cap = b.cap;
+        return b.p;
+      }
+      if (out + n > BIG_OUTSTANDING_MAX) return nullptr;
+      if (!fresh) {
+        want = n > want ? n : want;
+        return nullptr;
+      }
+    }
+    void* p = nullptr;
+    const size_t want = (n + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
+    if (zes_host_alloc(want, &p) != 0 || !p) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    out += want;
+    *cap = want;
+    return static_cast<uint8_t*>(p);
+  }
+  void give(uint8_t* p, size_t cap) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      out -= cap < out ? cap : out;
+      if (kept + cap <= BIG_KEEP_MAX) {
+        free_.push_back({p, cap});
+        kept += cap;
+        return;
+      }
+    }
+    zes_host_free(p);
+  }
+  // after a library call whose callback missed: one block of the size it asked for, for the next call of that kind
+  void top_up() {
+    size_t n = 0;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      n = want;
+      want = 0;
+      if (!n || out + kept + n > BIG_OUTSTANDING_MAX) return;
+    }
+    void* p = nullptr;
+    const size_t cap = (n + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
+    if (zes_host_alloc(cap, &p) != 0 || !p) return;
+    std::lock_guard<std::mutex> lk(mu);
+    if (kept + cap <= BIG_KEEP_MAX) {
+      free_.push_back({static_cast<uint8_t*>(p), cap});
+      kept += cap;
+      return;
+    }
+    zes_host_free(p);  // (cannot happen under the limits above; never keep more than the budget)
+  }
+  void clear() {
+    std::vector<Blk> all;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      all.swap(free_);
+      kept = 0;
+    }
+    for (Blk& b : all) zes_host_free(b.p);
+  }
+};
+BigPool g_big;
+
+// memory for a result of up to n bytes: pooled (cap > 0) or malloc'd (cap == 0)
+struct ResultMem {
+  uint8_t* p = nullptr;
+  size_t cap = 0;
+};
+ResultMem result_alloc(size_t n, bool fresh = true) {
+  ResultMem m;
+  if (n >= BIG_MIN) m.p = g_big.take(n, &m.cap, fresh);
+  if (!m.p) {
+    m.cap = 0;
+    m.p = static_cast<uint8_t*>(malloc(n ? n : 1));
+  }
+  return m;
+}
+void result_free(ResultMem m) {
+  if (!m.p) return;
+  if (m.cap)
+    g_big.give(m.p, m.cap);
+  else
+    free(m.p);
+}
+// what the finalizer of a result's ArrayBuffer needs: where the memory goes back to, and how much V8 was told about
+struct ResultTag {
+  size_t cap;     // capacity of the pooled block, or 0 for malloc'd memory
+  int64_t told;   // bytes reported with napi_adjust_external_memory
+};
+void free_external(napi_env env, void* data, void* hint) {
+  ResultTag* t = static_cast<ResultTag*>(hint);
+  ResultMem m;
+  m.p = static_cast<uint8_t*>(data);
+  m.cap = t ? t->cap : 0;
+  if (t && t->told) {
+    int64_t now = 0;
+    napi_adjust_external_memory(env, -t->told, &now);
+  }
+  delete t;
+  result_free(m);
+}
+// the result's memory becomes its ArrayBuffer (exact length: `buffer.byteLength === length` like src/zlib.ts:42; a pooled
+// block is longer than what the ArrayBuffer shows of it): no second copy of the result on the JS thread.  Takes the
+// memory over (gives it back on failure).  V8 is told how much memory hangs on the object — it does not count an external
+// ArrayBuffer's bytes by itself — so that a loop over large calls makes it collect, and the blocks come back to the pool.
+napi_value take_u8(napi_env env, ResultMem m, size_t n) {
+  if (!m.cap) {
+    void* shrunk = realloc(m.p, n ? n : 1);
+    if (shrunk) m.p = static_cast<uint8_t*>(shrunk);
+  }
+  ResultTag* tag = new ResultTag{m.cap, (int64_t)(m.cap ? m.cap : n)};
   napi_value ab, ta;
-  if (napi_create_external_arraybuffer(env, buf, n, free_external, nullptr, &ab) != napi_ok) {
-    free(buf);
+  if (napi_create_external_arraybuffer(env, m.p, n, free_external, tag, &ab) != napi_ok) {
+    delete tag;
+    result_free(m);
     return nullptr;
   }
-  if (napi_create_typedarray(env, napi_uint8_array, n, ab, 0, &ta) != napi_ok) return nullptr;  // (the ArrayBuffer's finalizer owns buf)
+  int64_t now = 0;
+  if (napi_adjust_external_memory(env, tag->told, &now) != napi_ok) tag->told = 0;
+  if (napi_create_typedarray(env, napi_uint8_array, n, ab, 0, &ta) != napi_ok) return nullptr;  // (the ArrayBuffer's finalizer owns the memory)
   return ta;
 }
 
 // zes_alloc_fn of the synchronous inflate: runs on the JS thread, inside zes_inflate_alloc
 struct SyncAlloc {
-  napi_env env;
-  napi_value ab;
+  ResultMem m;
   bool failed;
 };
 uint8_t* sync_alloc(void* user, uint32_t, uint64_t n) {
   SyncAlloc* a = static_cast<SyncAlloc*>(user);
-  void* dst = nullptr;
-  if (napi_create_arraybuffer(a->env, (size_t)n, &dst, &a->ab) != napi_ok) {
-    a->failed = true;
-    return nullptr;
-  }
-  static uint8_t empty;
-  return n ? static_cast<uint8_t*>(dst) : &empty;
+  a->m = result_alloc((size_t)n, false);  // (inside the library's call)
+  if (!a->m.p) a->failed = true;
+  return a->m.p;
 }
 
 napi_value Deflate(napi_env env, napi_callback_info info) {
@@ -89,11 +227,11 @@ napi_value Deflate(napi_env env, napi_callback_info info) {
   }
   uint64_t cap = 0, out_len = 0;
   zes_deflate_bound(n, &cap);
-  uint8_t* tmp = static_cast<uint8_t*>(malloc(cap));
-  if (!tmp) return throw_status(env, ZES_E_ARG);
-  const int rc = zes_deflate(in, n, tmp, cap, &out_len);
+  ResultMem tmp = result_alloc(cap);
+  if (!tmp.p) return throw_status(env, ZES_E_ARG);
+  const int rc = zes_deflate(in, n, tmp.p, cap, &out_len);
   if (rc) {
-    free(tmp);
+    result_free(tmp);
     return throw_status(env, rc);
   }
   return take_u8(env, tmp, out_len);
@@ -112,13 +250,15 @@ napi_value Inflate(napi_env env, napi_callback_info info) {
   // one call, one lock: the library decodes, then asks for the exact ArrayBuffer (the reference grows a
   // Uint8WriteStream instead, src/inflate.ts:17) and copies straight into it — nothing is kept between calls,
   // so an inflateAsync() in flight on a worker thread cannot get in between
-  SyncAlloc sa{env, nullptr, false};
+  SyncAlloc sa{ResultMem(), false};
   uint64_t out_len = 0;
   const int rc = zes_inflate_alloc(in, c, sync_alloc, &sa, &out_len, ZES_F_DEFAULT);
-  if (rc) return sa.failed ? nullptr : throw_status(env, rc);  // (a failed napi allocation has its own pending exception)
-  napi_value ta;
-  if (napi_create_typedarray(env, napi_uint8_array, out_len, sa.ab, 0, &ta) != napi_ok) return nullptr;
-  return ta;
+  g_big.top_up();
+  if (rc) {
+    result_free(sa.m);
+    return throw_status(env, sa.failed ? ZES_E_ARG : rc);
+  }
+  return take_u8(env, sa.m, out_len);
 }
 
 // deflateRaw(input): the raw stream of the reference's src/deflate.ts:14 (no zlib wrapper)
@@ -134,11 +274,11 @@ napi_value DeflateRaw(napi_env env, napi_callback_info info) {
   }
   uint64_t cap = 0, out_len = 0;
   zes_deflate_bound(n, &cap);
-  uint8_t* tmp = static_cast<uint8_t*>(malloc(cap));
-  if (!tmp) return throw_status(env, ZES_E_ARG);
-  const int rc = zes_deflate_raw(in, n, tmp, cap, &out_len);
+  ResultMem tmp = result_alloc(cap);
+  if (!tmp.p) return throw_status(env, ZES_E_ARG);
+  const int rc = zes_deflate_raw(in, n, tmp.p, cap, &out_len);
   if (rc) {
-    free(tmp);
+    result_free(tmp);
     return throw_status(env, rc);
   }
   return take_u8(env, tmp, out_len);
@@ -169,16 +309,16 @@ napi_value InflateRaw(napi_env env, napi_callback_info info) {
   // grow-and-retry like the reference's Uint8WriteStream (src/utils/Uint8WriteStream.ts:13-21)
   uint64_t cap = c * 4 + 65536, out_len = 0;
   for (int attempt = 0; attempt < 8; attempt++) {
-    uint8_t* tmp = static_cast<uint8_t*>(malloc(cap));
-    if (!tmp) return throw_status(env, ZES_E_ARG);
-    const int rc = zes_inflate_raw(in, c, offset, tmp, cap, &out_len, ZES_F_DEFAULT);
+    ResultMem tmp = result_alloc(cap);
+    if (!tmp.p) return throw_status(env, ZES_E_ARG);
+    const int rc = zes_inflate_raw(in, c, offset, tmp.p, cap, &out_len, ZES_F_DEFAULT);
     if (rc == ZES_E_NOSPACE && out_len > cap) {
-      free(tmp);
+      result_free(tmp);
       cap = out_len;
       continue;
     }
     if (rc) {
-      free(tmp);
+      result_free(tmp);
       return throw_status(env, rc);
     }
     return take_u8(env, tmp, out_len);
@@ -234,6 +374,7 @@ napi_value InitDevices(napi_env env, napi_callback_info info) {
 
 // trim(): the library's pooled device scratch goes back to the driver (zes_trim); the next call allocates again
 napi_value Trim(napi_env env, napi_callback_info) {
+  g_big.clear();
   const int rc = zes_trim();
   if (rc) return throw_status(env, rc);
   napi_value v;
@@ -249,54 +390,41 @@ struct AsyncJob {
   const uint8_t* in = nullptr;
   size_t n = 0;
   bool inflate = false;
-  uint8_t* out = nullptr;
+  ResultMem out;
   uint64_t out_len = 0;
   int rc = 0;
 };
+
+uint8_t* async_alloc(void* user, uint32_t, uint64_t n) {  // zes_alloc_fn on the worker thread: pool or malloc, no N-API calls
+  AsyncJob* j = static_cast<AsyncJob*>(user);
+  j->out = result_alloc((size_t)n, false);  // (inside the library's call)
+  return j->out.p;
+}
 
 void async_execute(napi_env, void* data) {  // worker thread: no N-API calls here
   AsyncJob* j = static_cast<AsyncJob*>(data);
   if (!j->inflate) {
     uint64_t cap = 0;
     zes_deflate_bound(j->n, &cap);
-    j->out = static_cast<uint8_t*>(malloc(cap ? cap : 1));
-    j->rc = j->out ? zes_deflate(j->in, j->n, j->out, cap, &j->out_len) : ZES_E_ARG;
+    j->out = result_alloc(cap ? cap : 1);
+    j->rc = j->out.p ? zes_deflate(j->in, j->n, j->out.p, cap, &j->out_len) : ZES_E_ARG;
     return;
   }
-  // grow-and-retry (the size/fetch pair of the synchronous form keeps state in the library between two calls,
-  // which another thread's call could replace)
-  uint64_t cap = (uint64_t)j->n * 4 + 65536;
-  for (int attempt = 0; attempt < 8; attempt++) {
-    j->out = static_cast<uint8_t*>(malloc(cap));
-    if (!j->out) {
-      j->rc = ZES_E_ARG;
-      return;
-    }
-    j->rc = zes_inflate(j->in, j->n, j->out, cap, &j->out_len, ZES_F_DEFAULT);
-    if (j->rc == ZES_E_NOSPACE && j->out_len > cap) {
-      free(j->out);
-      j->out = nullptr;
-      cap = j->out_len;
-      continue;
-    }
-    return;
-  }
-  j->rc = ZES_E_DEVICE;
+  // one call: the library decodes, then asks for memory of the exact size (no state is kept in the library between calls)
+  j->rc = zes_inflate_alloc(j->in, j->n, async_alloc, j, &j->out_len, ZES_F_DEFAULT);
+  g_big.top_up();
 }
 
-void free_external(napi_env, void* data, void*) { free(data); }
 
 void async_complete(napi_env env, napi_status, void* data) {  // JS thread again
   AsyncJob* j = static_cast<AsyncJob*>(data);
   napi_value result = nullptr;
   bool ok = j->rc == 0;
   if (ok) {
-    napi_value ab;
-    // the worker's buffer becomes the result's ArrayBuffer (exact length, no copy on the JS thread)
-    if (napi_create_external_arraybuffer(env, j->out, (size_t)j->out_len, free_external, nullptr, &ab) == napi_ok &&
-        napi_create_typedarray(env, napi_uint8_array, (size_t)j->out_len, ab, 0, &result) == napi_ok) {
-      j->out = nullptr;  // owned by the ArrayBuffer now
-    } else {
+    // the worker's memory becomes the result's ArrayBuffer (exact length, no copy on the JS thread)
+    result = take_u8(env, j->out, (size_t)j->out_len);
+    j->out = ResultMem();  // owned by the ArrayBuffer now (or given back by take_u8)
+    if (!result) {
       ok = false;
       j->rc = ZES_E_ARG;
     }
@@ -309,7 +437,7 @@ void async_complete(napi_env env, napi_status, void* data) {  // JS thread again
     napi_create_error(env, nullptr, msg, &err);  // plain Error with the reference's message, as a rejection
     napi_reject_deferred(env, j->deferred, err);
   }
-  free(j->out);
+  result_free(j->out);
   napi_delete_reference(env, j->input_ref);
   napi_delete_async_work(env, j->work);
   delete j;
@@ -369,13 +497,20 @@ struct BatchJob {
   const uint8_t** in = nullptr;
   uint64_t* in_len = nullptr;
   uint8_t** out = nullptr;
+  size_t* out_pool = nullptr;  // capacity of the pooled block behind out[i], or 0: malloc'd
   uint64_t* out_cap = nullptr;
   uint64_t* out_len = nullptr;
   int32_t* status = nullptr;
   int rc = 0;
   ~BatchJob() {
     if (out)
-      for (uint32_t i = 0; i < count; i++) free(out[i]);
+      for (uint32_t i = 0; i < count; i++) {
+        ResultMem m;
+        m.p = out[i];
+        m.cap = out_pool ? out_pool[i] : 0;
+        result_free(m);
+      }
+    delete[] out_pool;
     delete[] in;
     delete[] in_len;
     delete[] out;
@@ -387,7 +522,9 @@ struct BatchJob {
 
 uint8_t* batch_alloc(void* user, uint32_t i, uint64_t n) {  // any thread: plain malloc, wrapped into an ArrayBuffer later
   BatchJob* j = static_cast<BatchJob*>(user);
-  j->out[i] = static_cast<uint8_t*>(malloc(n ? n : 1));
+  const ResultMem m = result_alloc((size_t)n, false);  // (inside the library's call, possibly on one of its threads)
+  j->out[i] = m.p;
+  j->out_pool[i] = m.cap;
   return j->out[i];
 }
 
@@ -399,7 +536,9 @@ void batch_execute(napi_env, void* data) {
   }
   for (uint32_t i = 0; i < j->count; i++) {
     zes_deflate_bound(j->in_len[i], &j->out_cap[i]);
-    j->out[i] = static_cast<uint8_t*>(malloc(j->out_cap[i]));
+    const ResultMem m = result_alloc((size_t)j->out_cap[i]);
+    j->out[i] = m.p;
+    j->out_pool[i] = m.cap;
     if (!j->out[i]) {
       j->rc = ZES_E_ARG;
       return;
@@ -416,12 +555,13 @@ napi_value batch_results(napi_env env, BatchJob* j) {
   for (uint32_t i = 0; i < j->count; i++) {
     napi_value v = nullptr;
     if (j->status[i] == 0) {
-      napi_value ab;
-      void* shrunk = realloc(j->out[i], j->out_len[i] ? (size_t)j->out_len[i] : 1);  // exact-size backing store
-      if (shrunk) j->out[i] = static_cast<uint8_t*>(shrunk);
-      if (napi_create_external_arraybuffer(env, j->out[i], (size_t)j->out_len[i], free_external, nullptr, &ab) != napi_ok) return nullptr;
-      j->out[i] = nullptr;  // owned by the ArrayBuffer now
-      if (napi_create_typedarray(env, napi_uint8_array, (size_t)j->out_len[i], ab, 0, &v) != napi_ok) return nullptr;
+      ResultMem m;
+      m.p = j->out[i];
+      m.cap = j->out_pool[i];
+      j->out[i] = nullptr;  // owned by the ArrayBuffer from here on (or given back by take_u8)
+      j->out_pool[i] = 0;
+      v = take_u8(env, m, (size_t)j->out_len[i]);
+      if (!v) return nullptr;
     } else {
       napi_value msg;
       napi_create_string_utf8(env, zes_strerror(j->status[i]), NAPI_AUTO_LENGTH, &msg);
@@ -464,6 +604,7 @@ napi_value start_batch(napi_env env, napi_callback_info info, bool inflate, bool
   j->in = new const uint8_t*[count + 1]();
   j->in_len = new uint64_t[count + 1]();
   j->out = new uint8_t*[count + 1]();
+  j->out_pool = new size_t[count + 1]();
   j->out_cap = new uint64_t[count + 1]();
   j->out_len = new uint64_t[count + 1]();
   j->status = new int32_t[count + 1]();
