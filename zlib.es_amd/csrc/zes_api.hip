@@ -2633,10 +2633,14 @@ static int inflate_host_pipelined(const uint8_t* in, uint64_t c, uint8_t* out, u
       }
     }
   }
+  const bool dbgp = getenv("ZES_DEBUG_PIPE") != nullptr;
+  auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double tp0 = dbgp ? tnow() : 0;
   if ((rc = settle(f_up))) return rc;
   if ((rc = settle(f_down))) return rc;
   HIPCHK(hipStreamSynchronize(g.cs_in));
   HIPCHK(hipStreamSynchronize(g.stream));  // (a piece enqueued ahead of a result that ended the loop)
+  if (dbgp) fprintf(stderr, "zes pipe: loop done, settle+sync %.3f ms, np %u total %llu\n", tnow() - tp0, np, (unsigned long long)total);
   if (!chain || !final_seen || total > dcap) {
     HIPCHK(hipStreamSynchronize(g.cs_out));
     return ZES_OK;  // not this way: the one-pass path decides
@@ -2645,9 +2649,13 @@ static int inflate_host_pipelined(const uint8_t* in, uint64_t c, uint8_t* out, u
   g.last_tier = 1;
   *out_len = total;
   if (alloc) {  // the caller allocates the exact result now that its size is known
+    const double ta = dbgp ? tnow() : 0;
     out = alloc(user, 0, total);
     if (!out) return ZES_E_ARG;
-    return download(out, d_out, total, g.cs_out, true);
+    const double tb = dbgp ? tnow() : 0;
+    rc = download(out, d_out, total, g.cs_out, true);
+    if (dbgp) fprintf(stderr, "zes pipe: alloc %.3f ms, download %.3f ms\n", tb - ta, tnow() - tb);
+    return rc;
   }
   if (total > cap) {
     HIPCHK(hipStreamSynchronize(g.cs_out));

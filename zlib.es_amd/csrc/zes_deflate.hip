@@ -907,6 +907,8 @@ struct LazySmem {
   uint32_t mp[LAZY_NWIN];                         // where the second chain from window w's exit met a window chain (LAZY_NOMERGE: it ran to the block's end)
   uint32_t tfrom[LAZY_NWIN];                      // true chain: the first position of window w's own chain that is on it (LAZY_NOMERGE: none)
   uint8_t titem[LAZY_NWIN];                       // true chain: it leaves window w at that window's exit
+  uint16_t tj[LAZY_NWIN];                         // true chain: the window reached from w by 2^round links
+  uint8_t tmark[LAZY_NWIN];                       // true chain: window w is on it
 };
 #define LAZY_NOMERGE 0xFFFFFFFFu
 __device__ __forceinline__ static uint64_t lz_ld64(const uint8_t* s, uint32_t off) {  // 8 bytes at any byte offset
@@ -1485,18 +1487,50 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match_lazy(const uint8_t* 
       S.titem[i] = 0;
     }
     __syncthreads();
-    if (tid == 0) {  // (at most one step per window)
-      uint32_t w = 0, from = 0;
-      for (uint32_t guard = 0; guard < LAZY_NWIN && w < nwin; guard++) {
-        S.tfrom[w] = from;
-        const uint32_t e = w * LAZY_WIN + S.xw[w];
-        if (e >= T) break;  // the chain ended with the block
-        S.titem[w] = 1;
-        const uint32_t m = S.mp[w];
-        if (m == LAZY_NOMERGE || m / LAZY_WIN <= w) break;  // (ran to the block's end; the second test cannot fail: a chain moves forward)
-        w = m / LAZY_WIN;
-        from = m;
+    // Which windows the true chain passes through: window 0, then the window its second chain met (mp[0] / LAZY_WIN), and so
+    // on — a linked list of up to 256 windows that one lane used to walk (three LDS round trips a link: 77k of this kernel's
+    // 2.5M cycles per block of text).  Marked by pointer doubling instead: after round r every window less than 2^(r+1)
+    // links from window 0 is marked, and only windows on the chain ever are.
+    constexpr uint32_t TJ_END = 0xFFFFu;
+    uint32_t mynext = TJ_END, myentry = 0;  // (threads below nwin: the link out of window tid, and where it lands)
+    if (tid < LAZY_NWIN) {
+      bool leaves = false;
+      if (tid < nwin) {
+        const uint32_t e = tid * LAZY_WIN + S.xw[tid];
+        leaves = e < T;  // (else the chain ended with the block)
+        const uint32_t m = S.mp[tid];
+        if (leaves && m != LAZY_NOMERGE && m / LAZY_WIN > tid) {  // (else it ran to the block's end; a chain moves forward)
+          mynext = m / LAZY_WIN;
+          myentry = m;
+        }
       }
+      S.tj[tid] = (uint16_t)mynext;
+      S.tmark[tid] = tid == 0u ? 1 : 0;
+      S.titem[tid] = leaves ? 1 : 0;  // (kept only for marked windows, below)
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (uint32_t r = 0; r < 8u; r++) {  // 2^8 = LAZY_NWIN
+      uint32_t j = TJ_END, jj = TJ_END;
+      bool mk = false;
+      if (tid < LAZY_NWIN) {
+        j = S.tj[tid];
+        mk = S.tmark[tid] != 0;
+        if (j != TJ_END) jj = S.tj[j];
+      }
+      __syncthreads();
+      if (tid < LAZY_NWIN) {
+        if (mk && j != TJ_END) S.tmark[j] = 1;
+        S.tj[tid] = (uint16_t)jj;
+      }
+      __syncthreads();
+    }
+    static_assert(LAZY_NWIN <= 256u, "eight rounds of pointer doubling");
+    if (tid < LAZY_NWIN) {
+      const bool on = S.tmark[tid] != 0;
+      if (!on) S.titem[tid] = 0;
+      if (tid == 0u) S.tfrom[0] = 0;
+      if (on && mynext != TJ_END) S.tfrom[mynext] = myentry;  // (a window on the chain has one predecessor on it)
     }
     __syncthreads();
     for (uint32_t i = tid; i < ZES_BLK / 32; i += MATCH_THREADS) {  // a window's chain in front of the meeting point, and windows the chain skips: not on it
