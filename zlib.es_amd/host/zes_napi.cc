@@ -57,8 +57,8 @@ bool get_bytes(napi_env env, napi_value v, const uint8_t** data, size_t* len) {
 // the library's pace; a tight synchronous loop over 64 MiB calls gets fresh blocks until BIG_OUTSTANDING_MAX are out, then
 // plain malloc as before.  trim() empties the pool.
 constexpr size_t BIG_MIN = 1u << 20;                 // smaller results: malloc, as before
-constexpr size_t BIG_KEEP_MAX = 512u << 20;          // bytes the pool keeps for reuse
-constexpr size_t BIG_OUTSTANDING_MAX = 512u << 20;   // pooled bytes in the hands of JS beyond which new results are not pooled
+constexpr size_t BIG_KEEP_MAX = 768u << 20;          // bytes the pool keeps for reuse
+constexpr size_t BIG_OUTSTANDING_MAX = 1024u << 20;  // (V8 collects a few calls behind: 64 MiB calls in an awaited loop hold ~0.5 GiB at any time)  // pooled bytes in the hands of JS beyond which new results are not pooled
 struct BigPool {
   struct Blk {
     uint8_t* p;
