@@ -341,13 +341,14 @@ def host_api_leg(z, dev, steps, hosts, goldens, cpu):
         cap = z.deflate_bound(n)
         gold = goldens.get(wname)
         for pinned in (False, True):
+            nb = n + n // 8 + (1 << 20)  # room for the early upper estimate of ZES_F_ALLOC_BOUND (the result is its first n bytes)
             if pinned:
-                a, comp, back = z.host_alloc(n), z.host_alloc(cap), z.host_alloc(n)
+                a, comp, back = z.host_alloc(n), z.host_alloc(cap), z.host_alloc(nb)
                 a[:] = src
                 comp[:] = 0
                 back[:] = 0
             else:
-                a, comp, back = src, np.zeros(cap, dtype=np.uint8), np.zeros(n, dtype=np.uint8)
+                a, comp, back = src, np.zeros(cap, dtype=np.uint8), np.zeros(nb, dtype=np.uint8)
             clen, blen = C.c_uint64(), C.c_uint64()
 
             def alloc(_user, _index, need, back=back):  # the allocator callback of zes_inflate_alloc: the caller's (touched) array
@@ -356,21 +357,26 @@ def host_api_leg(z, dev, steps, hosts, goldens, cpu):
             cb = z.ALLOC_FN(alloc)
             assert L.zes_deflate(a.ctypes.data, n, comp.ctypes.data, cap, C.byref(clen)) == 0  # warm-up: pools, staging ring
             assert L.zes_inflate_alloc(comp.ctypes.data, clen.value, cb, None, C.byref(blen), 0) == 0 and blen.value == n
-            td, ti = [], []
+            td, ti, tx = [], [], []
             for _ in range(REPS):
                 t0 = time.perf_counter()
                 for _ in range(k):
                     rc = L.zes_deflate(a.ctypes.data, n, comp.ctypes.data, cap, C.byref(clen))
                 t1 = time.perf_counter()
                 assert rc == 0
-                for _ in range(k):
-                    rc = L.zes_inflate_alloc(comp.ctypes.data, clen.value, cb, None, C.byref(blen), 0)
+                for _ in range(k):  # the allocator may be asked early for an upper estimate: what the N-API addon does
+                    rc = L.zes_inflate_alloc(comp.ctypes.data, clen.value, cb, None, C.byref(blen), z.ZES_F_ALLOC_BOUND)
                 t2 = time.perf_counter()
+                assert rc == 0 and blen.value == n
+                for _ in range(k):  # the allocator is asked once, for the exact size (known last: the download cannot overlap the decode)
+                    rc = L.zes_inflate_alloc(comp.ctypes.data, clen.value, cb, None, C.byref(blen), 0)
+                t3 = time.perf_counter()
                 assert rc == 0 and blen.value == n
                 td.append((t1 - t0) / k)
                 ti.append((t2 - t1) / k)
+                tx.append((t3 - t2) / k)
             c = int(clen.value)
-            ok = bool((back == src).all())
+            ok = bool((back[:n] == src).all())
             gchk = False
             if gold:
                 ok = ok and c == gold["deflate_len"] and hashlib.sha256(comp[:c].tobytes()).hexdigest() == gold["deflate_sha256"]
@@ -379,7 +385,8 @@ def host_api_leg(z, dev, steps, hosts, goldens, cpu):
             md, mi = _median(td), _median(ti)
             rows["%s_%s" % (wname, "pinned" if pinned else "pageable")] = {
                 "deflate_gibs": round(n / md / GIB, 3), "inflate_gibs": round(n / mi / GIB, 3),
-                "deflate_ms": _spread(td, 1e3), "inflate_ms": _spread(ti, 1e3), "compressed_bytes": c,
+                "inflate_exact_alloc_gibs": round(n / _median(tx) / GIB, 3),
+                "deflate_ms": _spread(td, 1e3), "inflate_ms": _spread(ti, 1e3), "inflate_exact_alloc_ms": _spread(tx, 1e3), "compressed_bytes": c,
                 "verified_bit_exact": ok, "golden_sha256_checked": gchk,
                 # bytes over the link per call: n up + c down (deflate), c up + n down (inflate); a full-duplex link's
                 # floor is max(up, down) per direction
@@ -391,7 +398,7 @@ def host_api_leg(z, dev, steps, hosts, goldens, cpu):
             if pinned:
                 for x in (a, comp, back):
                     z.host_free(x)
-    out = {"workload": "host-pointer API, 64 MiB calls, PCIe included (never `value`): zes_deflate / zes_inflate_alloc on pageable and pinned host arrays, "
+    out = {"workload": "host-pointer API, 64 MiB calls, PCIe included (never `value`): zes_deflate / zes_inflate_alloc (ZES_F_ALLOC_BOUND, and the exact-size protocol beside it) on pageable and pinned host arrays, "
                        "%d calls per timed loop, median of %d loops; reference src/zlib.ts:11,25" % (k, REPS),
            "link": link, "rows": rows, "verified_bit_exact": ok_all,
            "cpu_baseline": None if not cpu else {w: cpu.get(w) for w in hosts}}

@@ -49,6 +49,11 @@ typedef enum zes_status {
 #define ZES_F_NO_FASTPATH 1u   /* force the general (serial, any-stream) decoder: testing aid */
 #define ZES_F_PIECES 4u        /* decode a reference-made stream piece by piece (1 MiB pieces) as streams of 512 MiB and more are
                                   * (256 MiB pieces): testing aid for that path; same results */
+#define ZES_F_ALLOC_BOUND 8u   /* zes_inflate_alloc: the allocator may be asked EARLY for an upper estimate of the result's size (the
+                                 result is then a prefix of what it returned: *out_len says how long), and a second time for the exact
+                                 size if the estimate fell short — the last pointer it returned holds the result.  For callers whose
+                                 memory can show a prefix (the N-API addon's pooled blocks): the download then runs beside the decode
+                                 instead of behind it (64 MiB of random bytes: 18 -> 25 GiB/s) */
 #define ZES_F_LOOSE_CANDIDATES 2u /* block-start search without the reference's run-length-coding rules: more false
                                   * candidates reach the block decoder (testing aid for that path; same results) */
 

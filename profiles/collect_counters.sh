@@ -5,7 +5,7 @@ set -e -o pipefail
 TAG=${1:-rXX}
 KIND=${2:-itext}
 ROOT=$(pwd)
-OUT=$ROOT/gpurun_out/prof_${TAG}_counters_$KIND
+OUT=$ROOT/gpurun_out/prof_${TAG}_counters_${TOOL:+inf_}$KIND
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
@@ -14,7 +14,7 @@ for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_INSTS_VMEM_RD
            "SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM" \
            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d "$OUT/p$i" -o c -- python3 "$ROOT/tools/gpu_deflate_kernels.py" $KIND > "$OUT/p$i.log" 2>&1 || echo "[collect_counters] pass $i failed"
+  rocprofv3 --pmc $set --output-format csv -d "$OUT/p$i" -o c -- python3 "$ROOT/tools/${TOOL:-gpu_deflate_kernels.py}" $KIND > "$OUT/p$i.log" 2>&1 || echo "[collect_counters] pass $i failed"
   echo "[collect_counters] pass $i done"
 done
 cd "$ROOT"
@@ -33,6 +33,6 @@ for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive
 res = {"_note": "rocprofv3 --pmc passes of tools/gpu_deflate_kernels.py %s (4 deflate calls of 64 MiB each): sums over all launches of a kernel; _n_* = dispatches summed" % kind}
 for k, v in acc.items():
     res[k] = {c: x for c, x in v.items()}
-json.dump(res, open(os.path.join(os.path.dirname(out), "%s_counters_%s.json" % (tag, kind)), "w"), indent=1)
+json.dump(res, open(os.path.join(os.path.dirname(out), "%s_counters_%s%s.json" % (tag, "inf_" if os.environ.get("TOOL") else "", kind)), "w"), indent=1)
 print("[collect_counters] %d kernels" % (len(res) - 1))
 PY

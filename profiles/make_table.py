@@ -33,9 +33,9 @@ out = ["| workload | c / n | deflate GiB/s | inflate GiB/s | round trip | domina
 h = d.get("host_api")
 if h and "rows" in h:
     out += ["", "Host-pointer API, 64 MiB calls, PCIe included (never `value`); link measured on the same box: %.0f GB/s up, %.0f down:" % (h["link"]["h2d_GBs"], h["link"]["d2h_GBs"]), "",
-            "| | deflate GiB/s | inflate (`zes_inflate_alloc`) GiB/s |", "|---|---|---|"]
+            "| | deflate GiB/s | inflate (`zes_inflate_alloc`, early estimate / exact size) GiB/s |", "|---|---|---|"]
     for k, v in h["rows"].items():
-        out.append("| C-ABI, %s | %.1f | %.1f |" % (k.replace("_", ", "), v["deflate_gibs"], v["inflate_gibs"]))
+        out.append("| C-ABI, %s | %.1f | %.1f / %.1f |" % (k.replace("_", ", "), v["deflate_gibs"], v["inflate_gibs"], v.get("inflate_exact_alloc_gibs", 0)))
     nd = h.get("node") or {}
     for k, v in (nd.get("rows") or {}).items():
         out.append("| Node façade, %s | %.1f | %.1f |" % (k.replace("_", ", "), v["deflate_gibs"], v["inflate_gibs"]))

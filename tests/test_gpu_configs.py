@@ -477,3 +477,41 @@ def test_stored_streams_find_their_blocks_in_parallel(z, gpu):
                 assert "k_inf_stored_rank" in names and "k_inf_stored_walk" not in names
     finally:
         z.set_profiling(False)
+
+
+def test_allocator_asked_early_for_an_upper_estimate(z, gpu):
+    """zes_inflate_alloc with ZES_F_ALLOC_BOUND (include/zes.h; what the N-API addon passes): the allocator is asked after the
+    first piece for an upper estimate, the result is a prefix of what it returned — or, when the stream's first piece is far
+    more compressible than the rest and the estimate falls short, it is asked a second time for the exact size and the last
+    pointer holds the result.  Same bytes as the exact-size protocol either way; a foreign stream takes the one-pass path."""
+    import zlib as pyzlib
+
+    L = z.lib()
+    n = 40 << 20
+    mixed = np.concatenate([z.gen("xorshift", 6, 12 << 20), z.gen("lowent4k", 5, n - (12 << 20))])  # the estimate from piece 0 (random bytes) falls short
+    for name, src in (("itext", z.gen("itext", 99, n)), ("xorshift", z.gen("xorshift", 98, n)), ("mixed", mixed)):
+        comp = z.deflate(src)
+        calls, bufs = [], []
+
+        def alloc(_user, _index, need):
+            calls.append(int(need))
+            bufs.append(np.zeros(max(int(need), 1), dtype=np.uint8))
+            return bufs[-1].ctypes.data
+
+        cb = z.ALLOC_FN(alloc)
+        blen = C.c_uint64()
+        assert L.zes_inflate_alloc(comp.ctypes.data, comp.size, cb, None, C.byref(blen), z.ZES_F_ALLOC_BOUND) == 0
+        assert blen.value == n and 1 <= len(calls) <= 2 and calls[-1] >= n, (name, calls)
+        assert sha(bufs[-1][:n]) == sha(src), name
+        if name == "mixed":
+            assert len(calls) == 2 and calls[0] < n and calls[1] == n, calls  # short estimate, then the exact size
+        else:
+            assert len(calls) == 1 and n <= calls[0] <= n + n // 8 + (1 << 20), (name, calls)  # (5 % and two blocks on top of the first piece's ratio)
+    # another encoder's stream: the pieces do not chain, the call starts over on the one-pass path and asks once, exactly
+    src = z.gen("itext", 7, 24 << 20)
+    foreign = np.frombuffer(pyzlib.compress(src.tobytes(), 6), dtype=np.uint8)
+    calls, bufs = [], []
+    cb = z.ALLOC_FN(lambda u, i, need: (calls.append(int(need)), bufs.append(np.zeros(int(need), dtype=np.uint8)), bufs[-1].ctypes.data)[2])
+    blen = C.c_uint64()
+    assert L.zes_inflate_alloc(foreign.ctypes.data, foreign.size, cb, None, C.byref(blen), z.ZES_F_ALLOC_BOUND) == 0
+    assert blen.value == src.size and calls[-1] == src.size and sha(bufs[-1][: src.size]) == sha(src)

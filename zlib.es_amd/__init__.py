@@ -38,6 +38,7 @@ ZES_E_ARG = -18
 ZES_F_NO_FASTPATH = 1
 ZES_F_LOOSE_CANDIDATES = 2
 ZES_F_PIECES = 4
+ZES_F_ALLOC_BOUND = 8
 ZES_E_NOTRANGE = -19
 
 GEN_KINDS = {"xorshift": 0, "lowent4k": 1, "itext": 2}

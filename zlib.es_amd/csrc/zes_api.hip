@@ -2590,6 +2590,7 @@ static int inflate_host_pipelined(const uint8_t* in, uint64_t c, uint8_t* out, u
   auto settle = [&](std::future<int>& f) { return f.valid() ? f.get() : (int)ZES_OK; };
   // compressible data or not (which form of the block decoder): by the whole call, not by a piece
   const bool two = c * 10 < std::min<uint64_t>(dcap, cap ? cap : dcap) * 7;
+  const bool early = alloc && (flags & ZES_F_ALLOC_BOUND);  // the allocator takes an upper estimate (include/zes.h)
   RangePend pend[2];
   uint64_t byte0s[2] = {0, 0};
   auto begin = [&](uint32_t k) -> int {  // (range k is up, or on its way with its event recorded)
@@ -2624,7 +2625,19 @@ static int inflate_host_pipelined(const uint8_t* in, uint64_t c, uint8_t* out, u
         pend_hi = std::min(total, cap);
         blocks += rr.nblocks;
         final_seen = rr.final_block;
-        if (out && !alloc && pend_hi > pend_lo && !(final_seen || k + 1 == np)) {  // (the last piece's bytes go down below)
+        if (early && !out) {
+          // the first piece is decoded: from its blocks' ratio an upper estimate of the whole result (5 % and two blocks on
+          // top), asked for now, so that every piece's bytes can go down while the ones behind it are decoded
+          const uint64_t in0 = std::max<uint64_t>(1, (prev_end + 7) / 8);
+          const long double ratio = (long double)total / (long double)in0;
+          uint64_t est = (uint64_t)((long double)c * ratio * 1.05L) + 2 * ZES_BLK;
+          est = std::min<uint64_t>(std::max<uint64_t>(est, total), dcap);
+          out = alloc(user, 0, est);
+          if (!out) return ZES_E_ARG;
+          cap = est;
+          pend_hi = std::min(total, cap);
+        }
+        if (out && (!alloc || early) && pend_hi > pend_lo && !(final_seen || k + 1 == np)) {  // (the last piece's bytes go down below)
           if ((rc = settle(f_down))) return rc;
           const uint64_t a = pend_lo, b = pend_hi;
           f_down = g_side_down.submit([=] { return download(out + a, d_out + a, b - a, g.cs_out, false); });
@@ -2648,7 +2661,13 @@ static int inflate_host_pipelined(const uint8_t* in, uint64_t c, uint8_t* out, u
   *done = true;
   g.last_tier = 1;
   *out_len = total;
-  if (alloc) {  // the caller allocates the exact result now that its size is known
+  if (alloc && early && out && total <= cap) {  // the estimate held: what is left to go down is the last piece
+    if (pend_hi > pend_lo && (rc = download(out + pend_lo, d_out + pend_lo, pend_hi - pend_lo, g.cs_out, false))) return rc;
+    HIPCHK(hipStreamSynchronize(g.cs_out));
+    return ZES_OK;
+  }
+  if (alloc) {  // the caller allocates the exact result now that its size is known (or: the early estimate fell short)
+    HIPCHK(hipStreamSynchronize(g.cs_out));
     const double ta = dbgp ? tnow() : 0;
     out = alloc(user, 0, total);
     if (!out) return ZES_E_ARG;

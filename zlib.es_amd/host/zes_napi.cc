@@ -210,6 +210,7 @@ struct SyncAlloc {
 };
 uint8_t* sync_alloc(void* user, uint32_t, uint64_t n) {
   SyncAlloc* a = static_cast<SyncAlloc*>(user);
+  result_free(a->m);  // (ZES_F_ALLOC_BOUND: a second call when the first one's estimate fell short, or the call started over)
   a->m = result_alloc((size_t)n, false);  // (inside the library's call)
   if (!a->m.p) a->failed = true;
   return a->m.p;
@@ -252,7 +253,9 @@ napi_value Inflate(napi_env env, napi_callback_info info) {
   // so an inflateAsync() in flight on a worker thread cannot get in between
   SyncAlloc sa{ResultMem(), false};
   uint64_t out_len = 0;
-  const int rc = zes_inflate_alloc(in, c, sync_alloc, &sa, &out_len, ZES_F_DEFAULT);
+  // (the pooled block is longer than the ArrayBuffer shows of it anyway: the library may ask early for an upper estimate and
+  // send the bytes down while it is still decoding)
+  const int rc = zes_inflate_alloc(in, c, sync_alloc, &sa, &out_len, ZES_F_ALLOC_BOUND);
   g_big.top_up();
   if (rc) {
     result_free(sa.m);
@@ -397,6 +400,7 @@ struct AsyncJob {
 
 uint8_t* async_alloc(void* user, uint32_t, uint64_t n) {  // zes_alloc_fn on the worker thread: pool or malloc, no N-API calls
   AsyncJob* j = static_cast<AsyncJob*>(user);
+  result_free(j->out);  // (ZES_F_ALLOC_BOUND: see sync_alloc)
   j->out = result_alloc((size_t)n, false);  // (inside the library's call)
   return j->out.p;
 }
@@ -411,7 +415,7 @@ void async_execute(napi_env, void* data) {  // worker thread: no N-API calls her
     return;
   }
   // one call: the library decodes, then asks for memory of the exact size (no state is kept in the library between calls)
-  j->rc = zes_inflate_alloc(j->in, j->n, async_alloc, j, &j->out_len, ZES_F_DEFAULT);
+  j->rc = zes_inflate_alloc(j->in, j->n, async_alloc, j, &j->out_len, ZES_F_ALLOC_BOUND);
   g_big.top_up();
 }
 
