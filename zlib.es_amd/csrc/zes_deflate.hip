@@ -904,6 +904,8 @@ struct LazySmem {
   uint16_t tail[LAZY_TAIL];                       // hop (1 or match length) of the block's last LAZY_TAIL keyed positions
   uint32_t wq;                                    // next work item to hand out
   uint32_t unmerged;                              // a second chain gave up: the true chain may hold unevaluated positions
+  uint32_t ngave;                                 // how many gave up (the probe of a block that may be periodic counts them)
+  uint32_t abort3;                                // phase 3 ran out of its budget of single evaluations: the block is not periodic after all
   uint32_t mp[LAZY_NWIN];                         // where the second chain from window w's exit met a window chain (LAZY_NOMERGE: it ran to the block's end)
   uint32_t tfrom[LAZY_NWIN];                      // true chain: the first position of window w's own chain that is on it (LAZY_NOMERGE: none)
   uint8_t titem[LAZY_NWIN];                       // true chain: it leaves window w at that window's exit
@@ -1036,13 +1038,34 @@ __device__ __forceinline__ static uint32_t row_allmin(uint32_t x) {
 // the three registers may appear in these statements only.
 #define LZ_REQ(areg, op, base, byteoff) asm volatile(op " " areg ", %0, %1" ::"v"(byteoff), "s"(base) : "memory", areg)
 
+// Which windows a launch of the chains takes (work item k -> window):
+#define LZ_MAP_ALL 0u     // every window
+#define LZ_MAP_PROBE 1u   // three windows in sixteen (16 g, 16 g + 1, 16 g + 2): the probe of a block that may be periodic
+#define LZ_MAP_REST 2u    // the other thirteen
+#define LZ_MAP_PROBE2 3u  // the second chains of the probe: from the exits of windows 16 g (they meet V1 inside 16 g + 1, 16 g + 2 or give up)
+#define LAZY_PROBE_STRIDE 16u
+#define LAZY_PROBE_SPAN 3u
+__device__ __forceinline__ static uint32_t lz_map_window(uint32_t map, uint32_t k) {
+  if (map == LZ_MAP_PROBE) return (k / LAZY_PROBE_SPAN) * LAZY_PROBE_STRIDE + k % LAZY_PROBE_SPAN;
+  if (map == LZ_MAP_REST) return (k / (LAZY_PROBE_STRIDE - LAZY_PROBE_SPAN)) * LAZY_PROBE_STRIDE + LAZY_PROBE_SPAN + k % (LAZY_PROBE_STRIDE - LAZY_PROBE_SPAN);
+  if (map == LZ_MAP_PROBE2) return k * LAZY_PROBE_STRIDE;
+  return k;
+}
+__host__ __device__ static inline uint32_t lz_map_count(uint32_t map, uint32_t nwin) {  // (the items are numbered so that k < count names windows below nwin only)
+  const uint32_t full = nwin / LAZY_PROBE_STRIDE, part = nwin % LAZY_PROBE_STRIDE;
+  if (map == LZ_MAP_PROBE) return full * LAZY_PROBE_SPAN + (part < LAZY_PROBE_SPAN ? part : LAZY_PROBE_SPAN);
+  if (map == LZ_MAP_REST) return full * (LAZY_PROBE_STRIDE - LAZY_PROBE_SPAN) + (part > LAZY_PROBE_SPAN ? part - LAZY_PROBE_SPAN : 0u);
+  if (map == LZ_MAP_PROBE2) return full + (part ? 1u : 0u);
+  return nwin;
+}
+
 // GUARDED: every section of a turn sits behind "does any row need it?" — for blocks whose turns mostly need few of them
 // (periodic data: runs of literals, one position in 258 behind them); text needs all of them nearly every turn, and a guard
 // costs two vector instructions and a branch.
 template <uint32_t PHASE, bool GUARDED>
 __device__ __forceinline__ static uint32_t lazy_chains(LazySmem& S, const uint32_t* __restrict__ inv, const uint16_t* __restrict__ sd,
                                                        uint32_t* __restrict__ mo, uint32_t T, uint32_t cnt, uint32_t avail, uint32_t tbase,
-                                                       uint32_t nitems) {
+                                                       uint32_t nitems, uint32_t map = LZ_MAP_ALL) {
   const uint32_t lane = zes_lane(), sub = lane & (LAZY_G - 1u), g0 = lane & ~(LAZY_G - 1u);  // g0: first lane of this row
   uint32_t mode = LZ_IDLE, item = 0, p = 0, wend = 0, cstart = 0;  // the same in the 16 lanes of a row
   uint32_t wcur = 0, wnxt = 0, wpend = 0, wb = 0x40000000u;  // inv entries of positions [wb, wb+16) and [wb+16, wb+32), lane k the k-th
@@ -1087,16 +1110,17 @@ __device__ __forceinline__ static uint32_t lazy_chains(LazySmem& S, const uint32
         if (firsti >= nitems) drained = true;
         const uint32_t mine = firsti + (uint32_t)__popcll(idle & ((1ull << g0) - 1ull));
         const bool take = mode == LZ_IDLE && mine < nitems;
-        item = take ? mine : item;
+        const uint32_t wid = PHASE == 0u ? mine : lz_map_window(map, mine);  // the window (phase 0: the position) the item stands for
+        item = take ? wid : item;
         uint32_t np, nw;
         if (PHASE == 0u) {
           np = tbase + mine;
           nw = np + 1u;
         } else if (PHASE == 1u) {
-          np = mine * LAZY_WIN;
+          np = wid * LAZY_WIN;
           nw = min(np + LAZY_WIN, T);
         } else {
-          np = mine * LAZY_WIN + S.xw[take ? mine : 0u];
+          np = wid * LAZY_WIN + S.xw[take ? wid : 0u];
           nw = T;  // (np >= T: the chain ended with the block)
         }
         p = take ? np : p;
@@ -1117,7 +1141,10 @@ __device__ __forceinline__ static uint32_t lazy_chains(LazySmem& S, const uint32
         const uint32_t vb = (S.v1[pc >> 5] >> (pc & 31u)) & 1u;
         merged = st && !leave && vb != 0u;  // from here on it is a window's own chain
         gaveup = st && !leave && !merged && p - cstart >= LAZY_MERGE_CAP;
-        if (gaveup && sub == 0u) S.unmerged = 1u;
+        if (gaveup && sub == 0u) {
+          S.unmerged = 1u;
+          atomicAdd(&S.ngave, 1u);
+        }
         if (merged && sub == 0u) S.mp[item] = p;
         if (leave && sub == 0u) S.mp[item] = LAZY_NOMERGE;
       }
@@ -1436,7 +1463,16 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match_lazy(const uint8_t* 
   // up, and then evaluates once more.
   bool cleared = (flagword & ZES_SORT_INDEX) != 0u;  // (uniform)
   const bool guarded = cleared;  // the same kind of block: its turns are mostly runs of literals (see lazy_chains)
+  // Periodic data — what k_lz_index's blocks mostly are — gets nothing from its window chains: the true chain stands on
+  // p0 + 258 k, the windows start on multiples of 512, the second chains give up, and phase 3 evaluates the whole true
+  // chain itself, 64 maximal matches at a time (lowent4k: window and second chains 400k of the kernel's 770k cycles per
+  // block).  So such a block is PROBED first: three windows in sixteen get their chains, the second chains from every
+  // sixteenth window's exit look for them; when three quarters of those give up the block goes straight to phase 3, with a
+  // budget of single evaluations (a block that only looked periodic runs out of it and gets all its chains after all);
+  // otherwise the other thirteen windows in sixteen get theirs and every second chain runs, as for any block.
+  bool probe = guarded && nwin >= 4u * LAZY_PROBE_STRIDE;
   const uint32_t tbase = cnt > LAZY_TAIL ? cnt - LAZY_TAIL : 0u;  // first pre-evaluated position
+  uint32_t* tm = tmask_all + (uint64_t)g * ZES_TMASK_WORDS;
   for (;;) {
     if (cleared) {
       uint4* mo4 = reinterpret_cast<uint4*>(mo);
@@ -1450,6 +1486,8 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match_lazy(const uint8_t* 
     if (tid == 0) {
       S.wq = 0;
       S.unmerged = 0;
+      S.ngave = 0;
+      S.abort3 = 0;
     }
     __syncthreads();
 
@@ -1458,29 +1496,64 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match_lazy(const uint8_t* 
     else (void)lazy_chains<0u, false>(S, inv, sd, mo, T, cnt, avail, tbase, cnt - tbase);
     __syncthreads();
     LSTAMP(2);
-    if (tid == 0) S.wq = 0;
-    __syncthreads();
-    const uint32_t niter = guarded ? lazy_chains<1u, true>(S, inv, sd, mo, T, cnt, avail, tbase, nwin) : lazy_chains<1u, false>(S, inv, sd, mo, T, cnt, avail, tbase, nwin);
-    if (g_lazy_dbg && tid == 0) g_lazy_dbg[(size_t)blockIdx.x * 8 + 6] = niter;
-    __syncthreads();
-    LSTAMP(3);
-    if (tid == 0) S.wq = 0;
-    __syncthreads();
-    if (guarded) (void)lazy_chains<2u, true>(S, inv, sd, mo, T, cnt, avail, tbase, nwin);
-    else (void)lazy_chains<2u, false>(S, inv, sd, mo, T, cnt, avail, tbase, nwin);
-    // (result words another wave of this workgroup reads back — the second chains' re-walk, phase 3 — are in memory)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    LSTAMP(4);
-    if (!S.unmerged || cleared) break;  // (uniform)
-    cleared = true;
-    __syncthreads();  // everybody has read the flag before it is reset
-  }
+    uint32_t budget3 = 0xFFFFFFFFu;
+    if (probe) {  // (blocks of k_lz_index: the guarded form)
+      if (tid == 0) S.wq = 0;
+      __syncthreads();
+      (void)lazy_chains<1u, true>(S, inv, sd, mo, T, cnt, avail, tbase, lz_map_count(LZ_MAP_PROBE, nwin), LZ_MAP_PROBE);
+      __syncthreads();
+      if (tid == 0) S.wq = 0;
+      __syncthreads();
+      const uint32_t n2 = lz_map_count(LZ_MAP_PROBE2, nwin);
+      (void)lazy_chains<2u, true>(S, inv, sd, mo, T, cnt, avail, tbase, n2, LZ_MAP_PROBE2);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      const bool periodic = S.ngave * 4u >= n2 * 3u;  // (uniform)
+      __syncthreads();
+      if (periodic) {
+        budget3 = 64u + T / 1024u;  // (periodic data: one single evaluation per 64 maximal matches, ~10 a block)
+        if (tid == 0) S.unmerged = 1u;
+      } else {
+        if (tid == 0) {
+          S.wq = 0;
+          S.unmerged = 0;
+        }
+        __syncthreads();
+        (void)lazy_chains<1u, true>(S, inv, sd, mo, T, cnt, avail, tbase, lz_map_count(LZ_MAP_REST, nwin), LZ_MAP_REST);
+        __syncthreads();
+        if (tid == 0) S.wq = 0;
+        __syncthreads();
+        (void)lazy_chains<2u, true>(S, inv, sd, mo, T, cnt, avail, tbase, nwin);  // every second chain (the probe's once more: their windows are all there now)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __syncthreads();
+      LSTAMP(3);
+      LSTAMP(4);
+    } else {
+      if (tid == 0) S.wq = 0;
+      __syncthreads();
+      const uint32_t niter = guarded ? lazy_chains<1u, true>(S, inv, sd, mo, T, cnt, avail, tbase, nwin) : lazy_chains<1u, false>(S, inv, sd, mo, T, cnt, avail, tbase, nwin);
+      if (g_lazy_dbg && tid == 0) g_lazy_dbg[(size_t)blockIdx.x * 8 + 6] = niter;
+      __syncthreads();
+      LSTAMP(3);
+      if (tid == 0) S.wq = 0;
+      __syncthreads();
+      if (guarded) (void)lazy_chains<2u, true>(S, inv, sd, mo, T, cnt, avail, tbase, nwin);
+      else (void)lazy_chains<2u, false>(S, inv, sd, mo, T, cnt, avail, tbase, nwin);
+      // (result words another wave of this workgroup reads back — the second chains' re-walk, phase 3 — are in memory)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      LSTAMP(4);
+    }
+    if (S.unmerged && !cleared) {  // (uniform) phase 3 asks "has anybody evaluated this position?": the words are cleared first, and everything is evaluated once more
+      cleared = true;
+      __syncthreads();  // everybody has read the flag before it is reset
+      continue;
+    }
   // ---- the positions of the true chain as a bit mask, for k_lz_parse (which otherwise finds them again: exit maps
   // of all 2048 chunks, region tables, a walk per chunk — 343k of its 480k cycles per block on text).  The chain is
   // window 0's own chain up to its exit, the second chain from there up to where it met a window chain, that window's
   // chain from there to its exit, and so on: the windows' parts are in V1 already. ----
-  uint32_t* tm = tmask_all + (uint64_t)g * ZES_TMASK_WORDS;
   if (!S.unmerged) {
     for (uint32_t i = tid; i < LAZY_NWIN; i += MATCH_THREADS) {
       S.tfrom[i] = LAZY_NOMERGE;
@@ -1563,7 +1636,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match_lazy(const uint8_t* 
     __syncthreads();
   }
   if (walk3 && wave == 0) {
-    uint32_t p = 0;
+    uint32_t p = 0, nev = 0;  // nev: positions this walk had to evaluate itself, one at a time
     // The words of the chain's positions come 64 at a time (lane k: the word of position cb + k; the chunk behind is
     // requested while this one is walked); runs of evaluated literals are stepped over at once.
     // (Words written by the other waves of this workgroup: read past this CU's L1.)
@@ -1592,7 +1665,25 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match_lazy(const uint8_t* 
         if (p >= tbase) {
           m = LAZY_EVAL_LIT;  // (cannot happen: phase 0 evaluated the tail; keeps a corrupted table from hanging the wavefront)
         } else {
-          const uint32_t iv = (uint32_t)__builtin_amdgcn_readfirstlane((int)inv[p]);
+          // the inv entries of the 64 positions from p on: a run of positions without any candidate (the first period of
+          // periodic data, when no window chain has been there) is settled at once
+          const uint32_t ivs = inv[min(p + lane, ZES_BLK - 1u)];
+          const uint64_t none = __ballot(ivs == ZES_INV_NONE && p + lane < tbase);
+          const uint32_t nrun = (~none) ? (uint32_t)__builtin_ctzll(~none) : 64u;
+          if (nrun > 1u) {
+            if (lane < nrun) {
+              mo[p + lane] = LAZY_EVAL_LIT;
+              atomicOr(&S.v1[(p + lane) >> 5], 1u << ((p + lane) & 31u));
+            }
+            p += nrun;
+            cb = 0xFFFFFFFFu;  // (the chunk in hand does not know these words)
+            continue;
+          }
+          if (++nev > budget3) {  // not the periodic block the probe took it for: the windows get their chains after all
+            if (lane == 0) S.abort3 = 1u;
+            break;
+          }
+          const uint32_t iv = (uint32_t)__builtin_amdgcn_readfirstlane((int)ivs);
           m = lazy_wave_eval(S, iv, sd, p, T, avail);
           if (lane == 0) mo[p] = m;
           if ((m & ZES_TOK_MATCH) && zes_tok_len(m) == ZES_MAXMATCH) {
@@ -1609,8 +1700,8 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match_lazy(const uint8_t* 
             const uint32_t dj = sd[has ? (ivj & 0x1FFFFu) : 0u];  // distance to the nearest candidate
             const uint32_t qj = has ? pj - dj : 0u, pp = has ? pj : 0u;
             bool full = has;
-            for (uint32_t wv = 0; wv < 64u && __ballot(full); wv++)  // bytes 0..255, four at a time
-              full = full && lz_ld32(S.in, qj + 4u * wv) == lz_ld32(S.in, pp + 4u * wv);
+            for (uint32_t wv = 0; wv < 32u && __ballot(full); wv++)  // bytes 0..255, eight at a time
+              full = full && lz_ld64(S.in, qj + 8u * wv) == lz_ld64(S.in, pp + 8u * wv);
             full = full && ((lz_ld32(S.in, qj + 256u) ^ lz_ld32(S.in, pp + 256u)) & 0xffffu) == 0u;  // bytes 256, 257
             const uint64_t okm = __ballot(full);
             const uint32_t nk = (~okm) ? (uint32_t)__builtin_ctzll(~okm) : 64u;  // leading lanes that are settled
@@ -1629,9 +1720,16 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match_lazy(const uint8_t* 
   }
   if (walk3) {
     __syncthreads();
+    if (S.abort3) {  // (uniform) the probe was wrong about this block: once more, every window with its chain
+      probe = false;
+      __syncthreads();
+      continue;
+    }
     for (uint32_t i = tid; i < ZES_BLK / 32; i += MATCH_THREADS) tm[4u + i] = S.v1[i];
     __syncthreads();
     if (tid == 0) tm[0] = 1u;
+  }
+  break;
   }
   LSTAMP(5);
 }
