@@ -53,7 +53,10 @@ typedef enum zes_status {
                                  result is then a prefix of what it returned: *out_len says how long), and a second time for the exact
                                  size if the estimate fell short — the last pointer it returned holds the result.  For callers whose
                                  memory can show a prefix (the N-API addon's pooled blocks): the download then runs beside the decode
-                                 instead of behind it (64 MiB of random bytes: 18 -> 25 GiB/s) */
+                                 instead of behind it (64 MiB of random bytes: 18 -> 25 GiB/s).  The early request carries
+                                 ZES_ALLOC_EARLY in its index argument; the allocator may answer it with NULL ("not now": no block of
+                                 that size at hand) and is then asked once, later, for the exact size as without the flag */
+#define ZES_ALLOC_EARLY 0x80000000u
 #define ZES_F_LOOSE_CANDIDATES 2u /* block-start search without the reference's run-length-coding rules: more false
                                   * candidates reach the block decoder (testing aid for that path; same results) */
 

@@ -507,6 +507,22 @@ def test_allocator_asked_early_for_an_upper_estimate(z, gpu):
             assert len(calls) == 2 and calls[0] < n and calls[1] == n, calls  # short estimate, then the exact size
         else:
             assert len(calls) == 1 and n <= calls[0] <= n + n // 8 + (1 << 20), (name, calls)  # (5 % and two blocks on top of the first piece's ratio)
+    # an allocator that declines the early request ("not now") is asked once, for the exact size
+    src = z.gen("itext", 99, n)
+    comp = z.deflate(src)
+    calls, bufs = [], []
+
+    def picky(_user, index, need):
+        calls.append((int(index), int(need)))
+        if index & z.ZES_ALLOC_EARLY:
+            return None
+        bufs.append(np.zeros(int(need), dtype=np.uint8))
+        return bufs[-1].ctypes.data
+
+    cb = z.ALLOC_FN(picky)
+    blen = C.c_uint64()
+    assert L.zes_inflate_alloc(comp.ctypes.data, comp.size, cb, None, C.byref(blen), z.ZES_F_ALLOC_BOUND) == 0
+    assert blen.value == n and len(calls) == 2 and calls[0][0] & z.ZES_ALLOC_EARLY and calls[1] == (0, n) and sha(bufs[-1]) == sha(src), calls
     # another encoder's stream: the pieces do not chain, the call starts over on the one-pass path and asks once, exactly
     src = z.gen("itext", 7, 24 << 20)
     foreign = np.frombuffer(pyzlib.compress(src.tobytes(), 6), dtype=np.uint8)

@@ -39,6 +39,7 @@ ZES_F_NO_FASTPATH = 1
 ZES_F_LOOSE_CANDIDATES = 2
 ZES_F_PIECES = 4
 ZES_F_ALLOC_BOUND = 8
+ZES_ALLOC_EARLY = 0x80000000  # in the allocator's index argument: an early request for an upper estimate (may be declined with NULL)
 ZES_E_NOTRANGE = -19
 
 GEN_KINDS = {"xorshift": 0, "lowent4k": 1, "itext": 2}

@@ -2590,7 +2590,7 @@ static int inflate_host_pipelined(const uint8_t* in, uint64_t c, uint8_t* out, u
   auto settle = [&](std::future<int>& f) { return f.valid() ? f.get() : (int)ZES_OK; };
   // compressible data or not (which form of the block decoder): by the whole call, not by a piece
   const bool two = c * 10 < std::min<uint64_t>(dcap, cap ? cap : dcap) * 7;
-  const bool early = alloc && (flags & ZES_F_ALLOC_BOUND);  // the allocator takes an upper estimate (include/zes.h)
+  bool early = alloc && (flags & ZES_F_ALLOC_BOUND);  // the allocator takes an upper estimate (include/zes.h)
   RangePend pend[2];
   uint64_t byte0s[2] = {0, 0};
   auto begin = [&](uint32_t k) -> int {  // (range k is up, or on its way with its event recorded)
@@ -2632,10 +2632,13 @@ static int inflate_host_pipelined(const uint8_t* in, uint64_t c, uint8_t* out, u
           const long double ratio = (long double)total / (long double)in0;
           uint64_t est = (uint64_t)((long double)c * ratio * 1.05L) + 2 * ZES_BLK;
           est = std::min<uint64_t>(std::max<uint64_t>(est, total), dcap);
-          out = alloc(user, 0, est);
-          if (!out) return ZES_E_ARG;
-          cap = est;
-          pend_hi = std::min(total, cap);
+          out = alloc(user, ZES_ALLOC_EARLY, est);
+          if (out) {
+            cap = est;
+            pend_hi = std::min(total, cap);
+          } else {
+            early = false;  // "not now": the exact size, once, when it is known
+          }
         }
         if (out && (!alloc || early) && pend_hi > pend_lo && !(final_seen || k + 1 == np)) {  // (the last piece's bytes go down below)
           if ((rc = settle(f_down))) return rc;

@@ -208,9 +208,21 @@ struct SyncAlloc {
   ResultMem m;
   bool failed;
 };
-uint8_t* sync_alloc(void* user, uint32_t, uint64_t n) {
+// an early request (ZES_F_ALLOC_BOUND: an upper estimate, the bytes then come down beside the decode) is only worth
+// taking with a pooled block: downloads piece by piece into fresh malloc'd memory pay its page faults the slow way
+ResultMem early_alloc(size_t n) {
+  ResultMem m;
+  if (n >= BIG_MIN) m.p = g_big.take(n, &m.cap, false);
+  if (!m.p) m.cap = 0;
+  return m;
+}
+uint8_t* sync_alloc(void* user, uint32_t index, uint64_t n) {
   SyncAlloc* a = static_cast<SyncAlloc*>(user);
   result_free(a->m);  // (ZES_F_ALLOC_BOUND: a second call when the first one's estimate fell short, or the call started over)
+  if (index & ZES_ALLOC_EARLY) {
+    a->m = early_alloc((size_t)n);
+    return a->m.p;  // (NULL: "not now" — the exact size is asked for once, later)
+  }
   a->m = result_alloc((size_t)n, false);  // (inside the library's call)
   if (!a->m.p) a->failed = true;
   return a->m.p;
@@ -398,9 +410,13 @@ struct AsyncJob {
   int rc = 0;
 };
 
-uint8_t* async_alloc(void* user, uint32_t, uint64_t n) {  // zes_alloc_fn on the worker thread: pool or malloc, no N-API calls
+uint8_t* async_alloc(void* user, uint32_t index, uint64_t n) {  // zes_alloc_fn on the worker thread: pool or malloc, no N-API calls
   AsyncJob* j = static_cast<AsyncJob*>(user);
   result_free(j->out);  // (ZES_F_ALLOC_BOUND: see sync_alloc)
+  if (index & ZES_ALLOC_EARLY) {
+    j->out = early_alloc((size_t)n);
+    return j->out.p;
+  }
   j->out = result_alloc((size_t)n, false);  // (inside the library's call)
   return j->out.p;
 }
