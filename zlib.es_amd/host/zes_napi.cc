@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/zes.h"
@@ -203,6 +204,49 @@ napi_value take_u8(napi_env env, ResultMem m, size_t n) {
   return ta;
 }
 
+// A synchronous deflate() that finds no pooled block (a tight loop: Node runs no finalizer inside it) would hand the
+// library ~64 MiB of untouched malloc'd memory to download into piece by piece — every page faulted under the copy
+// engine's hands, ~40 ms.  Instead the library writes into ONE page-locked scratch block the addon keeps for this purpose,
+// and the exact-length result is copied out of it by a few threads (the faults of the fresh result spread over them).
+struct SyncScratch {
+  uint8_t* p = nullptr;
+  size_t cap = 0;
+  uint8_t* get(size_t n) {
+    if (n <= cap) return p;
+    if (p) zes_host_free(p);
+    p = nullptr;
+    cap = 0;
+    void* q = nullptr;
+    const size_t want = (n + (4u << 20) - 1) & ~(size_t)((4u << 20) - 1);
+    if (zes_host_alloc(want, &q) != 0 || !q) return nullptr;
+    p = static_cast<uint8_t*>(q);
+    cap = want;
+    return p;
+  }
+  void clear() {
+    if (p) zes_host_free(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+SyncScratch g_sync_scratch;  // (JS thread only)
+void copy_parallel(uint8_t* dst, const uint8_t* src, size_t n) {
+  const unsigned hw = std::thread::hardware_concurrency();
+  const unsigned nt = n < (8u << 20) ? 1u : (hw >= 8 ? 4u : 2u);
+  if (nt == 1) {
+    memcpy(dst, src, n);
+    return;
+  }
+  std::vector<std::thread> th;
+  const size_t part = ((n / nt) + 4095) & ~(size_t)4095;
+  for (unsigned i = 1; i < nt; i++) {
+    const size_t o = i * part;
+    if (o < n) th.emplace_back([=] { memcpy(dst + o, src + o, (o + part < n) ? part : n - o); });
+  }
+  memcpy(dst, src, part < n ? part : n);
+  for (auto& t : th) t.join();
+}
+
 // zes_alloc_fn of the synchronous inflate: runs on the JS thread, inside zes_inflate_alloc
 struct SyncAlloc {
   ResultMem m;
@@ -240,7 +284,22 @@ napi_value Deflate(napi_env env, napi_callback_info info) {
   }
   uint64_t cap = 0, out_len = 0;
   zes_deflate_bound(n, &cap);
-  ResultMem tmp = result_alloc(cap);
+  ResultMem tmp;
+  if (cap >= BIG_MIN) tmp.p = g_big.take(cap, &tmp.cap, false);  // a block the pool holds, if any
+  if (!tmp.p && cap >= (4u << 20)) {  // none (a tight synchronous loop): through the scratch block, see above
+    tmp.cap = 0;
+    uint8_t* sc = g_sync_scratch.get(cap);
+    if (sc) {
+      const int rc = zes_deflate(in, n, sc, cap, &out_len);
+      if (rc) return throw_status(env, rc);
+      ResultMem m;
+      m.p = static_cast<uint8_t*>(malloc(out_len ? out_len : 1));
+      if (!m.p) return throw_status(env, ZES_E_ARG);
+      copy_parallel(m.p, sc, (size_t)out_len);
+      return take_u8(env, m, out_len);
+    }
+  }
+  if (!tmp.p) tmp = result_alloc(cap, false);
   if (!tmp.p) return throw_status(env, ZES_E_ARG);
   const int rc = zes_deflate(in, n, tmp.p, cap, &out_len);
   if (rc) {
@@ -390,6 +449,7 @@ napi_value InitDevices(napi_env env, napi_callback_info info) {
 // trim(): the library's pooled device scratch goes back to the driver (zes_trim); the next call allocates again
 napi_value Trim(napi_env env, napi_callback_info) {
   g_big.clear();
+  g_sync_scratch.clear();
   const int rc = zes_trim();
   if (rc) return throw_status(env, rc);
   napi_value v;
