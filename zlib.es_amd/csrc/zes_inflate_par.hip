@@ -1477,6 +1477,7 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
   uint32_t ds = 0, seg0 = 0, seglen = 0, base = 0, stop = 0, ecode = 0, tail_code = 0;  // (seg0: first bit of segment 0)
   uint32_t plimit = limit;  // end of what the phases that read the staged copy may look at: the data's end, or the staged copy's
   Lit8 f8 = {0, 0, 0};
+  bool p2_global = false;  // the count pass reads its bits from global memory (the tables were parked over the staged block)
   STAMP(0);
   // P0 + P1 for one estimate of the block's end.  Returns 0 = go on, 1 = not decodable here.
   auto stage_and_tables = [&](const uint32_t de_est) __attribute__((always_inline)) -> uint32_t {
@@ -1600,13 +1601,23 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
     // staging area) every lane parks its table in LDS, 52 bytes apart (the sweep's tables are there already, 68 apart),
     // and a step of the walks below is one byte read; otherwise (incompressible data) the tables stay in registers and
     // a step broadcasts a lane's table.
-    const bool lds_tabs = dp || tab_off + PAR_THREADS * 52u <= STAGE_DW * 4u;  // uniform
+    // Round 4: incompressible data has no room behind its staged block (131 KB of the 144 KB area) and kept the tables in
+    // registers — a step of the walks broadcast a lane's table, sixteen readlanes and a select chain: 155k of the kernel's
+    // 450k cycles per block of random data.  The tables are parked OVER the staged block instead: once every lane has built
+    // its table nothing reads the staged copy any more but the count pass, which then takes its bits from global memory
+    // like the emit pass does anyway.
+    const bool room = dp || tab_off + PAR_THREADS * 52u <= STAGE_DW * 4u;  // uniform
+    const bool over = !room && !FOREIGN;
+    const bool lds_tabs = room || over;
+    const uint32_t toff = over ? 0u : tab_off;
+    p2_global = over;
     const uint32_t tstride = dp ? DP_ROW : 52u;
-    const uint8_t* tb = S.out + tab_off + wave * 64u * tstride;  // this wave's 64 tables
+    const uint8_t* tb = S.out + toff + wave * 64u * tstride;  // this wave's 64 tables
+    if (over) __syncthreads();  // every lane is done with the staged copy
     if (dp) {
       __syncthreads();
     } else if (lds_tabs) {
-      uint32_t* tw = reinterpret_cast<uint32_t*>(S.out + tab_off) + tid * 13u;
+      uint32_t* tw = reinterpret_cast<uint32_t*>(S.out + toff) + tid * 13u;
       tw[0] = (uint32_t)tab.a;
       tw[1] = (uint32_t)(tab.a >> 32);
       tw[2] = (uint32_t)tab.b;
@@ -1690,7 +1701,10 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
 
   // ---- P2: count pass from the true entries, totals, end bit, output offsets ----
   uint32_t entry = base + ecode, exit_pos = 0, outbytes = 0, flags = 0;
-  seg_run<false, true, FOREIGN>(S, src, plimit, entry, stop, ecode < 48u, f8, 0, exit_pos, outbytes, flags);
+  if (!FOREIGN && p2_global)  // (uniform; the same bound as the staged form: behind plimit every position fails)
+    seg_run<false, false, FOREIGN>(S, src, plimit, entry, stop, ecode < 48u, f8, 0, exit_pos, outbytes, flags);
+  else
+    seg_run<false, true, FOREIGN>(S, src, plimit, entry, stop, ecode < 48u, f8, 0, exit_pos, outbytes, flags);
   STAMP(22);  // (ZES_DEBUG_PHASES: wave 0 is through the count pass)
   if (dbg && threadIdx.x == PAR_THREADS - 64) dbg[(size_t)blockIdx.x * ZES_PAR_DBG_ROW + 23] = (unsigned long long)clock64();
   if (ecode >= 48u) flags = F_VOID;
