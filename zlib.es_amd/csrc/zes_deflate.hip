@@ -1641,13 +1641,20 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match_lazy(const uint8_t* 
     // requested while this one is walked); runs of evaluated literals are stepped over at once.
     // (Words written by the other waves of this workgroup: read past this CU's L1.)
     uint32_t cb = 0xFFFFFFFFu, cw = 0, nb = 0xFFFFFFFFu, nw = 0;  // current chunk, next sequential chunk
+    uint32_t ciw = 0, niw = 0;  // ... and the inv entries of the same positions, in the same batch of loads (a walk through a stretch
+                                // nobody has evaluated needs them at every stop: one memory latency per chunk instead of two per stop)
     while (p < cnt) {
       const uint32_t base = p & ~63u;
       if (base != cb) {
-        cw = (base == nb) ? nw : __hip_atomic_load(&mo[min(base + lane, ZES_BLK - 1u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool seq = base == nb;
+        const uint32_t cw2 = seq ? nw : __hip_atomic_load(&mo[min(base + lane, ZES_BLK - 1u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t ciw2 = seq ? niw : inv[min(base + lane, ZES_BLK - 1u)];
         cb = base;
         nb = base + 64u;
         nw = __hip_atomic_load(&mo[min(nb + lane, ZES_BLK - 1u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        niw = inv[min(nb + lane, ZES_BLK - 1u)];
+        cw = cw2;
+        ciw = ciw2;
       }
       {
         const uint64_t lit = __ballot(cw == LAZY_EVAL_LIT) >> (p - base);
@@ -1667,23 +1674,22 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match_lazy(const uint8_t* 
         } else {
           // the inv entries of the 64 positions from p on: a run of positions without any candidate (the first period of
           // periodic data, when no window chain has been there) is settled at once
-          const uint32_t ivs = inv[min(p + lane, ZES_BLK - 1u)];
-          const uint64_t none = __ballot(ivs == ZES_INV_NONE && p + lane < tbase);
-          const uint32_t nrun = (~none) ? (uint32_t)__builtin_ctzll(~none) : 64u;
+          const uint32_t po = p - base;  // (lane k of ciw: the inv entry of position base + k)
+          const uint64_t none = __ballot(ciw == ZES_INV_NONE && base + lane < tbase) >> po;
+          const uint32_t nrun = min((~none) ? (uint32_t)__builtin_ctzll(~none) : 64u, 64u - po);
           if (nrun > 1u) {
-            if (lane < nrun) {
-              mo[p + lane] = LAZY_EVAL_LIT;
-              atomicOr(&S.v1[(p + lane) >> 5], 1u << ((p + lane) & 31u));
+            if (lane >= po && lane < po + nrun) {
+              mo[base + lane] = LAZY_EVAL_LIT;
+              atomicOr(&S.v1[(base + lane) >> 5], 1u << ((base + lane) & 31u));
             }
-            p += nrun;
-            cb = 0xFFFFFFFFu;  // (the chunk in hand does not know these words)
+            p += nrun;  // (the chunk in hand stays: its words of the positions behind p are all it is asked for)
             continue;
           }
           if (++nev > budget3) {  // not the periodic block the probe took it for: the windows get their chains after all
             if (lane == 0) S.abort3 = 1u;
             break;
           }
-          const uint32_t iv = (uint32_t)__builtin_amdgcn_readfirstlane((int)ivs);
+          const uint32_t iv = (uint32_t)__builtin_amdgcn_readlane((int)ciw, (int)po);
           m = lazy_wave_eval(S, iv, sd, p, T, avail);
           if (lane == 0) mo[p] = m;
           if ((m & ZES_TOK_MATCH) && zes_tok_len(m) == ZES_MAXMATCH) {
@@ -1700,8 +1706,12 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_lz_match_lazy(const uint8_t* 
             const uint32_t dj = sd[has ? (ivj & 0x1FFFFu) : 0u];  // distance to the nearest candidate
             const uint32_t qj = has ? pj - dj : 0u, pp = has ? pj : 0u;
             bool full = has;
-            for (uint32_t wv = 0; wv < 32u && __ballot(full); wv++)  // bytes 0..255, eight at a time
-              full = full && lz_ld64(S.in, qj + 8u * wv) == lz_ld64(S.in, pp + 8u * wv);
+            for (uint32_t wv = 0; wv < 32u && __ballot(full); wv += 4u) {  // bytes 0..255, 32 at a time (eight reads in flight)
+              uint64_t x = 0;
+#pragma unroll
+              for (uint32_t t = 0; t < 4u; t++) x |= lz_ld64(S.in, qj + 8u * (wv + t)) ^ lz_ld64(S.in, pp + 8u * (wv + t));
+              full = full && x == 0ull;
+            }
             full = full && ((lz_ld32(S.in, qj + 256u) ^ lz_ld32(S.in, pp + 256u)) & 0xffffu) == 0u;  // bytes 256, 257
             const uint64_t okm = __ballot(full);
             const uint32_t nk = (~okm) ? (uint32_t)__builtin_ctzll(~okm) : 64u;  // leading lanes that are settled
