@@ -220,6 +220,13 @@ int zes_stage_lz77_dev(const uint8_t* d_in, uint64_t n, uint64_t start, uint32_t
  * hist[nsym] symbol counts → lens[nsym] code lengths (0 = unused), limit maxlen (15 or 7). */
 int zes_stage_huff_lengths_dev(const uint32_t* h_hist, uint32_t nsym, uint32_t maxlen, uint8_t* h_lens);
 
+/* Checks, on the device this context drives, the hardware behaviour k_lz_sort's stable ranks rest on: lanes of one
+ * wavefront whose returning LDS add (ds_add_rtn_u32) meets in one word receive their old values in ascending lane order.
+ * 256 workgroups x 16 wavefronts x iters rounds x 4 adds over six digit patterns; *bad = values that differ from the rank
+ * computed with ballots (0 on gfx950), *checked = values compared.  A diagnostic for tests/test_gpu_hw_props.py.
+ * replaces: nothing. */
+int zes_selftest_lds_order(uint32_t iters, uint32_t seed, uint64_t* bad, uint64_t* checked);
+
 /* Timing of the last *_dev call's kernels, measured with HIP events on the library's own
  * stream: name/ms pairs for bench.py's roofline leg.  Returns the number of entries. */
 typedef struct zes_ktime { const char* name; float ms; uint32_t launches; } zes_ktime;

@@ -110,6 +110,7 @@ def lib():
         L.zes_deflate_join_dev.argtypes = [C.POINTER(C.c_void_p), u64p, u32p, u64p, C.c_uint32, C.c_void_p, C.c_uint64, u64p]
         L.zes_stage_lz77_dev.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, u32p]
         L.zes_stage_huff_lengths_dev.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.zes_selftest_lds_order.argtypes = [C.c_uint32, C.c_uint32, u64p, u64p]
         L.zes_last_kernel_times.argtypes = [C.POINTER(ZesKTime), C.c_int]
         L.zes_set_profiling.argtypes = [C.c_int]
         L.zes_pool_bytes.restype = C.c_uint64
@@ -483,6 +484,15 @@ def stage_lz77_tensor(t, start, length):
     if rc:
         _raise(rc)
     return tok[: nt.value].copy()
+
+
+def selftest_lds_order(iters=200, seed=1):
+    """zes_selftest_lds_order: (values out of lane order, values checked) of returning LDS adds on this device."""
+    bad, n = C.c_uint64(0), C.c_uint64(0)
+    rc = lib().zes_selftest_lds_order(iters, seed, C.byref(bad), C.byref(n))
+    if rc:
+        _raise(rc)
+    return int(bad.value), int(n.value)
 
 
 def stage_huff_lengths(hist, maxlen):

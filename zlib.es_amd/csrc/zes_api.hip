@@ -3269,6 +3269,23 @@ int zes_stage_huff_lengths_dev(const uint32_t* h_hist, uint32_t nsym, uint32_t m
   return ZES_OK;
 }
 
+int zes_selftest_lds_order(uint32_t iters, uint32_t seed, uint64_t* bad, uint64_t* checked) {
+  if (!bad || !checked || iters == 0 || iters > 100000u) return ZES_E_ARG;
+  std::lock_guard<std::mutex> lk(g_mu);
+  int rc = init_locked(-1);
+  if (rc) return rc;
+  if ((rc = ensure(g.hists, 320 * 4))) return rc;
+  HIPCHK(hipMemsetAsync(g.hists.p, 0, 16, g.stream));
+  hipLaunchKernelGGL(k_selftest_lds_order, dim3(256), dim3(SORT_THREADS), 0, g.stream, (unsigned long long*)g.hists.p, iters, seed);
+  HIPCHK(hipGetLastError());
+  unsigned long long h[2] = {0, 0};
+  HIPCHK(hipMemcpyAsync(h, g.hists.p, 16, hipMemcpyDeviceToHost, g.stream));
+  HIPCHK(hipStreamSynchronize(g.stream));
+  *bad = h[0];
+  *checked = h[1];
+  return ZES_OK;
+}
+
 int zes_last_inflate_tier(void) {
   UseDev ud(t_last);  // the context that served this thread's last call (single host calls go round robin over the contexts)
   std::lock_guard<std::mutex> lk(g_mu);

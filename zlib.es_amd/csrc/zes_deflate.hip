@@ -442,6 +442,11 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
     const uint32_t off = 2u - (uint32_t)pass;  // least significant key byte first
     const uint32_t* from = (pass == 1) ? A : B;
     uint32_t* to = (pass == 1) ? B : A;
+    {  // the first tile's counter row of this wave (the last pass may have left its offsets there; the dense path its histograms)
+      uint32_t* w0 = reinterpret_cast<uint32_t*>(&S.whist[0][wave][0]);
+      w0[lane] = 0;
+      w0[lane + 64u] = 0;
+    }
     // exclusive scan of this pass's digit histogram
     if (wave == 0) {
       uint32_t c[4];
@@ -465,20 +470,18 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
       }
     }
     __syncthreads();
-    // Tiles of 4096 elements: wave w takes elements [256 w, 256 w + 256) of the tile in four rounds of
-    // 64, so the three workgroup barriers and the cross-wave scan are paid once per 4096 elements.
+    // Tiles of 8192 elements: wave w takes elements [512 w, 512 w + 512) of the tile in eight rounds of
+    // 64, so the two workgroup barriers and the cross-wave scan are paid once per 8192 elements.
     const uint32_t ntiles = (ns + SORT_TILE - 1) / SORT_TILE;
     uint32_t pn[SORT_ROUNDS];
 #pragma unroll
     for (uint32_t r = 0; r < SORT_ROUNDS; r++) pn[r] = from[min(wave * (SORT_TILE / SORT_WAVES) + lane + 64u * r, ns - 1u)];
     for (uint32_t t = 0; t < ntiles; t++) {
       uint16_t(*wh)[256] = S.whist[t & 1];
-      // zero this tile's per-wave counters: 16 waves x 256 x u16 = 8 KiB = 1024 x 8 B
-      reinterpret_cast<uint64_t*>(&wh[0][0])[tid] = 0ull;
       const uint32_t i0 = t * SORT_TILE + wave * (SORT_TILE / SORT_WAVES) + lane;
       uint32_t p[SORT_ROUNDS], d[SORT_ROUNDS], rk[SORT_ROUNDS];
       // The tile's indices were requested before the previous tile's scatter (unconditional loads with
-      // clamped addresses).  One wait for all four here: a load or store under a branch makes the
+      // clamped addresses).  One wait for all of them here: a load or store under a branch makes the
       // compiler wait for every outstanding memory operation, the scatter stores included, and those
       // would then run one at a time.
 #pragma unroll
@@ -489,33 +492,20 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
 #endif
 #pragma unroll
       for (uint32_t r = 0; r < SORT_ROUNDS; r++) d[r] = (i0 + 64u * r < ns) ? S.in[p[r] + off] : 0u;
-      __syncthreads();  // (A) counters zeroed
+      // Rank of an element among the wave's elements of its digit, this round's lower lanes and all earlier rounds: the old
+      // value of ONE returning LDS add on the wave's own counter row (two 16-bit counters per word: a wave counts at most
+      // 512 per tile).  Lanes of one instruction that meet in a word are served in ascending lane order on this hardware
+      // (tools/micro/lds_atomic_order.hip: 0 of 3.3e10 values out of order; tests/test_gpu_hw_props.py checks the box it runs
+      // on), and a wave's LDS instructions execute in program order: the ranks are the stable ones.  (Before: eight ballots
+      // and sixteen mask updates per round to find the lanes of the same digit.)  The row is this wave's own until the
+      // barrier: it was zeroed by this wave, behind its own last read of it (below).
+      uint32_t* wrow = reinterpret_cast<uint32_t*>(&wh[wave][0]);
 #pragma unroll
       for (uint32_t r = 0; r < SORT_ROUNDS; r++) {
         const bool valid = i0 + 64u * r < ns;
-        // lanes of this wave holding the same digit (stable rank = lower lanes first)
-        // per bit: lanes whose bit differs from mine drop out of the mask; written on 32-bit halves with
-        // the bit spread to a full word so that each half is one three-input logic op
-        const uint64_t m0 = __ballot(valid);
-        uint32_t mlo = (uint32_t)m0, mhi = (uint32_t)(m0 >> 32);
-#pragma unroll
-        for (int b = 0; b < 8; b++) {
-          const uint32_t nb = (uint32_t)((int32_t)(d[r] << (31 - b)) >> 31);  // 0 or ~0
-          const uint64_t bal = __ballot(nb != 0u);
-          mlo &= ~((uint32_t)bal ^ nb);
-          mhi &= ~((uint32_t)(bal >> 32) ^ nb);
-        }
-        const uint64_t m = (uint64_t)mlo | ((uint64_t)mhi << 32);
-        const uint32_t rank = (uint32_t)__popcll(m & zes_lanemask_lt());
-        // running count of this digit in the wave's earlier rounds: kept in the wave's own counter row
-        // (one writer per digit and round: the group's first lane)
-        uint32_t prev = 0;
-        if (valid && rank == 0) {
-          prev = wh[wave][d[r]];
-          wh[wave][d[r]] = (uint16_t)(prev + (uint32_t)__popcll(m));
-        }
-        prev = (uint32_t)__shfl((int)prev, valid ? (int)__builtin_ctzll(m) : 0);
-        rk[r] = prev + rank;
+        const uint32_t sh = 16u * (d[r] & 1u);
+        const uint32_t old = valid ? atomicAdd(&wrow[d[r] >> 1], 1u << sh) : 0u;
+        rk[r] = (old >> sh) & 0xffffu;
       }
       __syncthreads();  // (B) counts visible
       if (tid < 256) {
@@ -531,6 +521,11 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
         S.base[bsel ^ 1][tid] = S.base[bsel][tid] + o;
       }
       __syncthreads();  // (C) offsets visible
+      {  // the next tile's row of this wave: read last by the tile before this one (its scan, this wave's scatter)
+        uint32_t* wnext = reinterpret_cast<uint32_t*>(&S.whist[(t + 1u) & 1u][wave][0]);
+        wnext[lane] = 0;
+        wnext[lane + 64u] = 0;
+      }
 #pragma unroll
       for (uint32_t r = 0; r < SORT_ROUNDS; r++) pn[r] = from[min(i0 + SORT_TILE + 64u * r, ns - 1u)];  // next tile
       // unconditional stores for the same reason (slot ZES_BLK-2 of either array is never used:
@@ -542,8 +537,8 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
         to[valid ? dst : ZES_BLK - 2u] = p[r];
       }
       bsel ^= 1;
-      // no barrier here: the next tile writes whist[other] and base[other-other] only after
-      // its own barriers (A)/(B), which every thread reaches after this scatter
+      // no barrier here: the next tile's adds go to whist[other], rows this wave zeroed itself; the scan writes
+      // whist[other] and base[other-other] behind barrier (B), which every thread reaches after this scatter
     }
     __syncthreads();
     SSTAMP(6 + (pass == 2));
@@ -3027,6 +3022,62 @@ __global__ __launch_bounds__(256) void k_bits_place(uint32_t* __restrict__ dst, 
 }
 
 // small utility kernels ---------------------------------------------------------------------
+// The hardware property k_lz_sort's ranks rest on (see its scatter passes): lanes of one wavefront whose returning LDS add
+// meets in one word are handed their old values in ascending lane order, and a wave's LDS instructions execute in program
+// order.  Sixteen wavefronts, a counter row each (two 16-bit counters per word, as the sort packs them), digit patterns from
+// uniform to a single digit, four adds back to back; every value is checked against the rank found with ballots.
+// out[0] += values out of order, out[1] += values checked.
+__global__ __launch_bounds__(SORT_THREADS) void k_selftest_lds_order(unsigned long long* __restrict__ out, uint32_t iters, uint32_t seed) {
+  __shared__ uint32_t row[SORT_WAVES][128];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  unsigned long long bad = 0, n = 0;
+  for (uint32_t it = 0; it < iters; it++) {
+    row[wave][lane] = 0;
+    row[wave][lane + 64u] = 0;
+    const uint32_t pat = (it + wave) % 6u;
+    uint32_t h = seed ^ (blockIdx.x * 0x9E3779B1u) ^ (it * SORT_THREADS + tid);
+    h = (h ^ (h >> 16)) * 0x7feb352du;
+    h = (h ^ (h >> 15)) * 0x846ca68bu;
+    h ^= h >> 16;
+    uint32_t d;
+    if (pat == 0) d = h & 255u;
+    else if (pat == 1) d = h & 3u;
+    else if (pat == 2) d = 77u + (lane >> 6);  // one digit (not a compile-time uniform address)
+    else if (pat == 3) d = 32u + ((h >> 3) % 27u);
+    else if (pat == 4) d = (h & 1u) + 2u * ((h >> 8) & 7u);  // pairs that share a word
+    else d = (lane * 4u + (h & 3u)) & 255u;
+    const bool valid = pat != 3u || (h >> 20) % 9u != 0u;
+    uint32_t dd[4], rk[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) dd[r] = (d + (pat == 0u ? 17u * r : 0u)) & 255u;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const uint32_t sh = 16u * (dd[r] & 1u);
+      const uint32_t old = valid ? atomicAdd(&row[wave][dd[r] >> 1], 1u << sh) : 0u;
+      rk[r] = (old >> sh) & 0xffffu;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      uint32_t expect = 0;
+      for (int q = 0; q <= r; q++) {  // lanes holding my round-r digit in round q: all of them for q < r, the lower ones for q == r
+        uint64_t m = __ballot(valid);
+        for (int b = 0; b < 8; b++) {
+          const bool bit = (dd[r] >> b) & 1u;
+          const uint64_t bal = __ballot((dd[q] >> b) & 1u);
+          m &= bit ? bal : ~bal;
+        }
+        expect += (uint32_t)__popcll(q < r ? m : (m & zes_lanemask_lt()));
+      }
+      if (valid) {
+        n++;
+        bad += rk[r] != expect;
+      }
+    }
+  }
+  atomicAdd(&out[0], bad);
+  atomicAdd(&out[1], n);
+}
+
 __global__ void k_zero_u64(unsigned long long* p, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = 0ull;

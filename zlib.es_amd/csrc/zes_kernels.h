@@ -160,6 +160,7 @@ __global__ void k_lz_parse(const uint8_t*, const ZesBuf*, ZesBlk*, const uint32_
 __global__ void k_lz_parse_small(const uint8_t*, const ZesBuf*, ZesBlk*, const uint32_t*, uint32_t*, uint32_t*, const uint32_t*, const uint32_t*);
 __global__ void k_huff(ZesBlk*, const uint32_t*, uint32_t*, uint32_t*);
 __global__ void k_huff_lengths_only(const uint32_t*, uint32_t, uint32_t, uint8_t*);
+__global__ void k_selftest_lds_order(unsigned long long*, uint32_t, uint32_t);
 __global__ void k_adler(const uint8_t*, uint64_t, uint64_t, unsigned long long*);
 __global__ void k_adler_blocks(const uint8_t*, const ZesBuf*, const ZesBlk*, unsigned long long*);
 __global__ void k_layout(uint8_t*, const ZesBuf*, ZesBlk*, const unsigned long long*, ZesRes*);
