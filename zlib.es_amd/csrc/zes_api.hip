@@ -660,7 +660,7 @@ int deflate_batch_core(const uint8_t* d_in, const uint64_t* in_off, const uint64
       for (int k = 1; k < 8; k++) acc[k] += (double)(h[(size_t)i * 8 + k] - h[(size_t)i * 8 + k - 1]);
     }
     if (n)
-      fprintf(stderr, "zes sort steps (avg cycles over %u blocks): zero %.0f count %.0f flag %.0f compact %.0f stage %.0f pass0+1 %.0f pass2 %.0f\n", n,
+      fprintf(stderr, "zes sort steps (avg cycles over %u blocks): zero %.0f count %.0f flag %.0f compact %.0f stage %.0f three passes %.0f sd/inv %.0f\n", n,
               acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[5] / n, acc[6] / n, acc[7] / n);
   }
   {

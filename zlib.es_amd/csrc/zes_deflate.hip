@@ -78,7 +78,7 @@ void zes_sort_set_dbg(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBO
 #define SORT_ROUNDS 8u
 #endif
 #define SORT_TILE (SORT_THREADS * SORT_ROUNDS)
-static_assert(SORT_ROUNDS == 4u || SORT_ROUNDS == 8u, "the arrival wait names four or eight registers");
+static_assert(SORT_ROUNDS == 4u || SORT_ROUNDS == 8u || SORT_ROUNDS == 16u, "the arrival wait names four, eight or sixteen registers");
 struct SortSmem {
   uint8_t in[ZES_BLK + 16];  // filter phase: the counter table; then the staged block
   uint32_t hist[3][256];     // digit histograms of the kept positions, one per pass
@@ -487,8 +487,12 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
 #pragma unroll
       for (uint32_t r = 0; r < SORT_ROUNDS; r++) p[r] = (dense && pass == 0) ? min(i0 + 64u * r, ns - 1u) : pn[r];  // dense: the list is 0, 1, 2, ...
       asm volatile("" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]));
-#if SORT_ROUNDS == 8u
+#if SORT_ROUNDS >= 8u
       asm volatile("" : "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]));
+#endif
+#if SORT_ROUNDS == 16u
+      asm volatile("" : "+v"(p[8]), "+v"(p[9]), "+v"(p[10]), "+v"(p[11]));
+      asm volatile("" : "+v"(p[12]), "+v"(p[13]), "+v"(p[14]), "+v"(p[15]));
 #endif
 #pragma unroll
       for (uint32_t r = 0; r < SORT_ROUNDS; r++) d[r] = (i0 + 64u * r < ns) ? S.in[p[r] + off] : 0u;
@@ -541,7 +545,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
       // whist[other] and base[other-other] behind barrier (B), which every thread reaches after this scatter
     }
     __syncthreads();
-    SSTAMP(6 + (pass == 2));
+    SSTAMP(6);
   }
   // For the lazy match finder, which walks the candidates of a position most recent first (src/lz77.ts:65):
   //   sd[r]   distance from the position in sorted slot r to the one in slot r-1 when both hold the same key and lie
@@ -580,14 +584,31 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
       asm volatile("" : "+v"(prv[0]), "+v"(prv[1]), "+v"(prv[2]), "+v"(prv[3]), "+v"(prv[4]), "+v"(prv[5]), "+v"(prv[6]), "+v"(prv[7]));
 #pragma unroll
       for (uint32_t k = 0; k < 8; k++) {
-        const uint32_t r = rb + k * SORT_THREADS;
-        if (r < ns) {
-          const bool sm = r != 0u && ((lds_ld32u(S.in, prv[k]) ^ lds_ld32u(S.in, pos[k])) & 0xffffffu) == 0u;  // slot r holds the key of slot r-1
-          const uint32_t delta = pos[k] - prv[k];  // > 0: equal keys are in ascending position order
-          const bool has = sm && delta <= ZES_WINDOW;
+        const uint32_t r = rb + k * SORT_THREADS;  // (lanes of a wave: 64 consecutive slots)
+        const bool valid = r < ns;
+        // the key of slot r-1 comes from the lane below; lane 0 reads it
+        const uint32_t key = valid ? (lds_ld32u(S.in, pos[k]) & 0xffffffu) : 0u;
+        uint32_t kprev = (uint32_t)__shfl_up((int)key, 1);
+        if (lane == 0 && valid) kprev = lds_ld32u(S.in, prv[k]) & 0xffffffu;
+        const bool sm = valid && r != 0u && key == kprev;  // slot r holds the key of slot r-1
+        const uint32_t delta = pos[k] - prv[k];  // > 0: equal keys are in ascending position order
+        const bool has = sm && delta <= ZES_WINDOW;
+        const uint32_t sl = pos[k] >> 14;
+        // One cursor add per slice and round, by the first lane of the slice's lanes (found with three ballots): 64 returning
+        // adds on eight cursors were served one lane at a time, ~130k of the kernel's 1.1M cycles on text.
+        uint64_t m = __ballot(valid);
+#pragma unroll
+        for (int bb = 0; bb < 3; bb++) {
+          const bool bit = (sl >> bb) & 1u;
+          const uint64_t bal = __ballot(bit);
+          m &= bit ? bal : ~bal;
+        }
+        const uint32_t rank = (uint32_t)__popcll(m & zes_lanemask_lt());
+        uint32_t at = 0;
+        if (valid && rank == 0u) at = atomicAdd(&pcur[sl], (uint32_t)__popcll(m));
+        at = (uint32_t)__shfl((int)at, valid ? (int)__builtin_ctzll(m) : 0) + rank;
+        if (valid) {
           sd[r] = (uint16_t)(has ? delta : 0u);  // (lanes of a wave write 64 consecutive entries)
-          const uint32_t sl = pos[k] >> 14;
-          const uint32_t at = atomicAdd(&pcur[sl], 1u);
           P[sl * 16384u + at] = (pos[k] & 16383u) | (r << 14) | (has ? 0x80000000u : 0u);
         }
       }
@@ -619,6 +640,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
       __syncthreads();
     }
   }
+  SSTAMP(7);
 }
 
 // ------------------------------------------------------------------------------------------
