@@ -70,7 +70,7 @@ const char* zes_strerror(int status);
  * replaces: nothing (the reference has no state); required because device scratch is pooled across calls. */
 int zes_init(int device);
 int zes_shutdown(void);
-/* Gives the pooled device scratch back to the driver (every context's; ~14 bytes per input byte after a deflate call,
+/* Gives the pooled device scratch back to the driver (every context's; ~10 bytes per input byte after a deflate call,
  * ~3 GB after another encoder's long stream) and keeps the contexts, streams and pinned staging: the next call
  * allocates what it needs again.  For a long-lived host that has had one large call.  replaces: nothing (the
  * reference's buffers are garbage collected). */

@@ -46,7 +46,7 @@ struct Ctx {
   hipStream_t s_adler = nullptr;                     // the Adler-32 pass of a deflate call runs beside the LZ77 kernels
   hipEvent_t ev_a0 = nullptr, ev_a1 = nullptr;
   // deflate scratch
-  DevBuf bufs, blks, idx_a, idx_b, inv, sdelta, tmask, mlist, hists, codes, hdrs, adler, res, order;
+  DevBuf bufs, blks, idx_a, idx_b, sdelta, tmask, mlist, hists, codes, hdrs, adler, res, order;
   // inflate scratch
   DevBuf surv, vlong, segfail, symoff, cand, cand_sorted, counters, cres, map, resume, dbg, ibufs, ibufs2, mvlist, scratch, sres, maps, seglist, segprefix, wins, sym16, segorder, segjobs, pw16, gwins, seglive, segouts;
   // staging for the host-pointer API
@@ -578,7 +578,6 @@ int deflate_batch_core(const uint8_t* d_in, const uint64_t* in_off, const uint64
   if ((rc = ensure(g.blks, sizeof(ZesBlk) * nblk))) return rc;
   if ((rc = ensure(g.idx_a, (size_t)nblk * ZES_BLK * 4))) return rc;
   if ((rc = ensure(g.idx_b, (size_t)nblk * ZES_BLK * 4))) return rc;
-  if ((rc = ensure(g.inv, (size_t)nblk * ZES_BLK * 4))) return rc;
   if ((rc = ensure(g.sdelta, (size_t)nblk * ZES_BLK * 2 + 64))) return rc;
   if ((rc = ensure(g.tmask, (size_t)nblk * ZES_TMASK_WORDS * 4))) return rc;  // k_lz_match_lazy -> k_lz_parse: the chain's positions
   if ((rc = ensure(g.mlist, (size_t)nblk * ZES_MLIST_WORDS * 4))) return rc;  // k_lz_match -> k_lz_parse: the matches of a match-poor block
@@ -635,16 +634,16 @@ int deflate_batch_core(const uint8_t* d_in, const uint64_t* in_off, const uint64
   static const bool use_index = getenv("ZES_NO_INDEX") == nullptr;
   {
     Timed t("k_lz_sort");
-    hipLaunchKernelGGL(k_lz_sort, dim3(nblk), dim3(SORT_THREADS), 0, g.stream, d_in, dbufs, dblks, idx_a, idx_b, (uint32_t*)g.inv.p, (uint16_t*)g.sdelta.p,
+    hipLaunchKernelGGL(k_lz_sort, dim3(nblk), dim3(SORT_THREADS), 0, g.stream, d_in, dbufs, dblks, idx_a, idx_b, (uint32_t*)g.idx_a.p, (uint16_t*)g.sdelta.p,
                        ZES_SORT_MODE_FIRST | (use_index ? ZES_SORT_USE_INDEX : 0u));
   }
   if (use_index) {
     {
       Timed t("k_lz_index");
-      hipLaunchKernelGGL(k_lz_index, dim3(nblk), dim3(IDX_THREADS), 0, g.stream, d_in, dbufs, dblks, idx_a, idx_b, (uint32_t*)g.inv.p, (uint16_t*)g.sdelta.p);
+      hipLaunchKernelGGL(k_lz_index, dim3(nblk), dim3(IDX_THREADS), 0, g.stream, d_in, dbufs, dblks, idx_a, idx_b, (uint32_t*)g.idx_a.p, (uint16_t*)g.sdelta.p);
     }
     Timed t("k_lz_sort_redo");
-    hipLaunchKernelGGL(k_lz_sort, dim3(nblk), dim3(SORT_THREADS), 0, g.stream, d_in, dbufs, dblks, idx_a, idx_b, (uint32_t*)g.inv.p, (uint16_t*)g.sdelta.p,
+    hipLaunchKernelGGL(k_lz_sort, dim3(nblk), dim3(SORT_THREADS), 0, g.stream, d_in, dbufs, dblks, idx_a, idx_b, (uint32_t*)g.idx_a.p, (uint16_t*)g.sdelta.p,
                        ZES_SORT_MODE_REDO);
   }
   if (sort_dbg) {  // average shader-clock cycles per step of k_lz_sort
@@ -683,7 +682,7 @@ int deflate_batch_core(const uint8_t* d_in, const uint64_t* in_off, const uint64
     }
     Timed t("k_lz_match_lazy");  // the blocks k_lz_sort flagged (most positions kept); the others return at once
     hipLaunchKernelGGL(k_lz_match_lazy, dim3(nblk), dim3(MATCH_THREADS), 0, g.stream, d_in, dbufs, dblks, idx_a,
-                       (const uint32_t*)g.inv.p, (const uint16_t*)g.sdelta.p, idx_b, (uint32_t*)g.tmask.p, (uint32_t*)g.mlist.p, order);
+                       (const uint32_t*)g.idx_a.p, (const uint16_t*)g.sdelta.p, idx_b, (uint32_t*)g.tmask.p, (uint32_t*)g.mlist.p, order);
   }
   if (sort_dbg) {  // average shader-clock cycles per phase of k_lz_match_lazy
     HIPCHK(hipStreamSynchronize(g.stream));
@@ -2240,7 +2239,7 @@ int zes_shutdown(void) {
 
 // every pooled device buffer of the current context
 static void free_scratch_locked() {
-  DevBuf* all[] = {&g.bufs, &g.blks, &g.idx_a, &g.idx_b, &g.inv, &g.sdelta, &g.tmask, &g.mlist, &g.hists, &g.codes, &g.hdrs, &g.adler, &g.res, &g.order, &g.surv, &g.vlong, &g.segfail, &g.symoff, &g.cand,
+  DevBuf* all[] = {&g.bufs, &g.blks, &g.idx_a, &g.idx_b, &g.sdelta, &g.tmask, &g.mlist, &g.hists, &g.codes, &g.hdrs, &g.adler, &g.res, &g.order, &g.surv, &g.vlong, &g.segfail, &g.symoff, &g.cand,
                    &g.cand_sorted, &g.counters, &g.cres, &g.map, &g.resume, &g.dbg, &g.ibufs, &g.ibufs2, &g.mvlist, &g.scratch, &g.st_in, &g.st_out,
                    &g.sres, &g.maps, &g.seglist, &g.segprefix, &g.wins, &g.sym16, &g.segorder, &g.segjobs, &g.pw16, &g.gwins, &g.seglive, &g.segouts};
   for (DevBuf* b : all) {
@@ -3205,7 +3204,6 @@ int zes_stage_lz77_dev(const uint8_t* d_in, uint64_t n, uint64_t start, uint32_t
   if ((rc = ensure(g.blks, sizeof z))) return rc;
   if ((rc = ensure(g.idx_a, (size_t)ZES_BLK * 4))) return rc;
   if ((rc = ensure(g.idx_b, (size_t)ZES_BLK * 4))) return rc;
-  if ((rc = ensure(g.inv, (size_t)ZES_BLK * 4))) return rc;
   if ((rc = ensure(g.sdelta, (size_t)ZES_BLK * 2 + 64))) return rc;
   if ((rc = ensure(g.hists, 320 * 4))) return rc;
   if ((rc = ensure(g.tmask, ZES_TMASK_WORDS * 4))) return rc;
@@ -3214,19 +3212,19 @@ int zes_stage_lz77_dev(const uint8_t* d_in, uint64_t n, uint64_t start, uint32_t
   HIPCHK(hipMemcpyAsync(g.blks.p, &z, sizeof z, hipMemcpyHostToDevice, g.stream));
   const bool use_index = getenv("ZES_NO_INDEX") == nullptr;  // the same three launches as the whole pipeline
   hipLaunchKernelGGL(k_lz_sort, dim3(1), dim3(SORT_THREADS), 0, g.stream, d_in, (const ZesBuf*)g.bufs.p, (const ZesBlk*)g.blks.p,
-                     (uint32_t*)g.idx_a.p, (uint32_t*)g.idx_b.p, (uint32_t*)g.inv.p, (uint16_t*)g.sdelta.p,
+                     (uint32_t*)g.idx_a.p, (uint32_t*)g.idx_b.p, (uint32_t*)g.idx_a.p, (uint16_t*)g.sdelta.p,
                      ZES_SORT_MODE_FIRST | (use_index ? ZES_SORT_USE_INDEX : 0u));
   if (use_index) {
     hipLaunchKernelGGL(k_lz_index, dim3(1), dim3(IDX_THREADS), 0, g.stream, d_in, (const ZesBuf*)g.bufs.p, (const ZesBlk*)g.blks.p,
-                       (uint32_t*)g.idx_a.p, (uint32_t*)g.idx_b.p, (uint32_t*)g.inv.p, (uint16_t*)g.sdelta.p);
+                       (uint32_t*)g.idx_a.p, (uint32_t*)g.idx_b.p, (uint32_t*)g.idx_a.p, (uint16_t*)g.sdelta.p);
     hipLaunchKernelGGL(k_lz_sort, dim3(1), dim3(SORT_THREADS), 0, g.stream, d_in, (const ZesBuf*)g.bufs.p, (const ZesBlk*)g.blks.p,
-                       (uint32_t*)g.idx_a.p, (uint32_t*)g.idx_b.p, (uint32_t*)g.inv.p, (uint16_t*)g.sdelta.p, ZES_SORT_MODE_REDO);
+                       (uint32_t*)g.idx_a.p, (uint32_t*)g.idx_b.p, (uint32_t*)g.idx_a.p, (uint16_t*)g.sdelta.p, ZES_SORT_MODE_REDO);
   }
   if (const char* dump = getenv("ZES_DUMP_INDEX")) {  // development: the block's index as the match finders will see it
     HIPCHK(hipStreamSynchronize(g.stream));
     std::vector<uint32_t> hinv(ZES_BLK), hflag(1);
     std::vector<uint16_t> hsd(ZES_BLK);
-    HIPCHK(hipMemcpy(hinv.data(), g.inv.p, ZES_BLK * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hinv.data(), g.idx_a.p, ZES_BLK * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(hsd.data(), g.sdelta.p, ZES_BLK * 2, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(hflag.data(), (uint32_t*)g.idx_a.p + ZES_BLK - 1, 4, hipMemcpyDeviceToHost));
     if (FILE* f = fopen(dump, "wb")) {
@@ -3239,7 +3237,7 @@ int zes_stage_lz77_dev(const uint8_t* d_in, uint64_t n, uint64_t start, uint32_t
   hipLaunchKernelGGL(k_lz_match, dim3(1), dim3(MATCH_THREADS), 0, g.stream, d_in, (const ZesBuf*)g.bufs.p,
                      (const ZesBlk*)g.blks.p, (const uint32_t*)g.idx_a.p, (uint32_t*)g.idx_b.p, (uint32_t*)g.mlist.p);
   hipLaunchKernelGGL(k_lz_match_lazy, dim3(1), dim3(MATCH_THREADS), 0, g.stream, d_in, (const ZesBuf*)g.bufs.p,
-                     (const ZesBlk*)g.blks.p, (const uint32_t*)g.idx_a.p, (const uint32_t*)g.inv.p, (const uint16_t*)g.sdelta.p, (uint32_t*)g.idx_b.p,
+                     (const ZesBlk*)g.blks.p, (const uint32_t*)g.idx_a.p, (const uint32_t*)g.idx_a.p, (const uint16_t*)g.sdelta.p, (uint32_t*)g.idx_b.p,
                      (uint32_t*)g.tmask.p, (uint32_t*)g.mlist.p, (const uint32_t*)nullptr);
   hipLaunchKernelGGL(k_lz_parse_small, dim3(1), dim3(PARSE_THREADS), 0, g.stream, d_in, (const ZesBuf*)g.bufs.p, (ZesBlk*)g.blks.p,
                      (const uint32_t*)g.idx_b.p, (uint32_t*)g.idx_a.p, (uint32_t*)g.hists.p, (const uint32_t*)g.tmask.p, (const uint32_t*)g.mlist.p);
@@ -3306,7 +3304,7 @@ uint64_t zes_pool_bytes(void) {
   for (int i = 0; i < ZES_MAX_DEV; i++) {
     std::lock_guard<std::mutex> lk(g_mus[i]);
     Ctx& c = g_ctx[i];
-    const DevBuf* all[] = {&c.bufs, &c.blks, &c.idx_a, &c.idx_b, &c.inv, &c.sdelta, &c.tmask, &c.mlist, &c.hists, &c.codes, &c.hdrs, &c.adler, &c.res, &c.order, &c.surv, &c.vlong, &c.segfail, &c.symoff, &c.cand,
+    const DevBuf* all[] = {&c.bufs, &c.blks, &c.idx_a, &c.idx_b, &c.sdelta, &c.tmask, &c.mlist, &c.hists, &c.codes, &c.hdrs, &c.adler, &c.res, &c.order, &c.surv, &c.vlong, &c.segfail, &c.symoff, &c.cand,
                            &c.cand_sorted, &c.counters, &c.cres, &c.map, &c.resume, &c.dbg, &c.ibufs, &c.ibufs2, &c.mvlist, &c.scratch, &c.st_in, &c.st_out,
                            &c.sres, &c.maps, &c.seglist, &c.segprefix, &c.wins, &c.sym16, &c.segorder, &c.segjobs, &c.pw16, &c.gwins, &c.seglive, &c.segouts};
     for (const DevBuf* b : all) total += b->cap;

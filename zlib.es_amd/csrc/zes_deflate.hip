@@ -105,8 +105,8 @@ __device__ __forceinline__ static uint4 sort_ld16(const uint8_t* __restrict__ sr
 }
 
 __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restrict__ d_in, const ZesBuf* __restrict__ bufs,
-                                                          const ZesBlk* __restrict__ blks, uint32_t* __restrict__ idx_a,
-                                                          uint32_t* __restrict__ idx_b, uint32_t* __restrict__ inv_all, uint16_t* __restrict__ sd_all,
+                                                          const ZesBlk* __restrict__ blks, uint32_t* idx_a,
+                                                          uint32_t* __restrict__ idx_b, uint32_t* inv_all, uint16_t* __restrict__ sd_all,
                                                           uint32_t mode) {
   __shared__ __align__(16) SortSmem S;
   const uint32_t g = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -634,6 +634,9 @@ __global__ __launch_bounds__(SORT_THREADS) void k_lz_sort(const uint8_t* __restr
         for (uint32_t k = 0; k < 16; k++)
           if (k * SORT_THREADS + tid < have && (e[k] >> 31)) stage[e[k] & 16383u] = (e[k] >> 14) & 0x1FFFFu;
       }
+      // (inv_all may BE idx_a — the library passes one array for both: the sorted list is dead by now, eager blocks have no
+      // inv[] — so the block's flag word, slot ZES_BLK-1, travels with the last slice; no position has that number)
+      if (tid == 0 && lo + 16384u == ZES_BLK) stage[16383] = ns | ZES_SORT_LAZY;
       __syncthreads();
       uint4* o4 = reinterpret_cast<uint4*>(inv + lo);
       for (uint32_t i = tid; i < 4096u; i += SORT_THREADS) o4[i] = st4[i];

@@ -288,8 +288,8 @@ __device__ static void idx_class_heavy(IndexSmem& S, uint32_t b0, uint32_t n, ui
 }
 
 __global__ __launch_bounds__(IDX_THREADS) void k_lz_index(const uint8_t* __restrict__ d_in, const ZesBuf* __restrict__ bufs,
-                                                          const ZesBlk* __restrict__ blks, uint32_t* __restrict__ idx_a,
-                                                          uint32_t* __restrict__ idx_b, uint32_t* __restrict__ inv_all, uint16_t* __restrict__ sd_all) {
+                                                          const ZesBlk* __restrict__ blks, uint32_t* idx_a,
+                                                          uint32_t* __restrict__ idx_b, uint32_t* inv_all, uint16_t* __restrict__ sd_all) {
   __shared__ __align__(16) IndexSmem S;
   const uint32_t g = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 #ifdef IDX_PROF
@@ -582,6 +582,9 @@ __global__ __launch_bounds__(IDX_THREADS) void k_lz_index(const uint8_t* __restr
       for (uint32_t k = 0; k < IDX_SLICE / IDX_THREADS; k++)
         if (k * IDX_THREADS + tid < have) stage[e[k] & (IDX_SLICE - 1u)] = (e[k] >> 31) ? ((e[k] >> 14) & 0x1FFFFu) : ZES_INV_NONE;
     }
+    // (inv_all may BE idx_a, the library passes one array for both: slice s of inv[] then lands on bucket s, whose words are
+    // all in registers or in the image by now; the block's flag word, slot ZES_BLK-1, travels with the last slice)
+    if (tid == 0 && lo + IDX_SLICE == ZES_BLK) stage[IDX_SLICE - 1u] = cnt | ZES_SORT_LAZY | ZES_SORT_INDEX;
     __syncthreads();
     const uint4* st4 = reinterpret_cast<const uint4*>(stage);
     uint4* o4 = reinterpret_cast<uint4*>(inv + lo);
