@@ -60,6 +60,7 @@ struct ParSmem {
   uint8_t wtab[PAR_WAVES][48];   // composed transfer table of each wave
   uint8_t wentry[PAR_WAVES];      // entry code of each wave's first segment
   uint32_t hdr_end, status, tail_entry, bfinal, tail_bytes, tail_end;
+  uint32_t h_hlit, h_total, h_wbase, h_off, h_k, h_prev, h_done;  // the header's second part: what its rounds hand on
   uint32_t res_flag[3];       // P4: "a pointer moved in this step"
   uint32_t res_lastw[RES_W / 32];  // P4: last match start (+1) at or before each 32 positions of the window
   uint32_t res_strad[4];      // P4: end and distance of the match that runs into the window from the one before; the next one's
@@ -1154,22 +1155,28 @@ __device__ __forceinline__ static void seg_run(ParSmem& S, const BitSrc& src, ui
   flags = fl;
 }
 
-// root table + canonical arrays of one alphabet (wave 0 only; lens at S.lens[base..base+nsym))
-__device__ __forceinline__ static bool par_build(ParSmem& S, uint32_t base, uint32_t nsym, uint32_t root, bool is_dist, uint32_t* lut,
-                                                 uint16_t* syms, uint32_t* first, uint16_t* cnt, uint16_t* offs) {
+// Canonical arrays of one alphabet (lens at S.lens[base..base+nsym)): the symbols in (length, symbol) order, first code,
+// count and offset per length.  One WAVE per chunk of 64 symbols (lit/len: five waves, distances: one): every wave counts
+// all chunks' lengths itself (ballots over S.lens: nothing to wait for), ranks its own chunk's symbols and stores them;
+// chunk 0's wave also writes the per-length arrays.  The root tables are filled afterwards, one thread per ENTRY
+// (par_fill).  (Rounds 2-3: one wave per alphabet, chunk after chunk, each symbol's lane filling its 2^(root-len) entries
+// in a loop — 64 turns for a 4-bit code: 12k cycles on text with fourteen waves waiting.)
+__device__ __forceinline__ static bool par_build(ParSmem& S, uint32_t base, uint32_t nsym, uint32_t chunk, bool is_dist, uint16_t* syms, uint32_t* first,
+                                                 uint16_t* cnt, uint16_t* offs) {
   const uint32_t lane = zes_lane();
   const uint8_t* lens = S.lens + base;
-  uint8_t* blut = is_dist ? S.len_d : S.len_l;
-  for (uint32_t i = lane; i < (1u << root); i += 64) {
-    lut[i] = 0;
-    blut[i] = 0x80u;  // default: long code or no code -> the full tables decide
-  }
-  uint32_t c[16];
+  uint32_t c[16], before[16];
 #pragma unroll
-  for (int l = 0; l < 16; l++) c[l] = 0;
+  for (int l = 0; l < 16; l++) c[l] = before[l] = 0;
+  uint32_t myl = 0;
   for (uint32_t s0 = 0; s0 < nsym; s0 += 64) {
     const uint32_t s = s0 + lane;
     const uint32_t l = s < nsym ? lens[s] : 0u;
+    if (s0 == 64u * chunk) {  // (uniform)
+      myl = l;
+#pragma unroll
+      for (int k = 1; k < 16; k++) before[k] = c[k];
+    }
 #pragma unroll
     for (int k = 1; k < 16; k++) c[k] += (uint32_t)__popcll(__ballot(l == (uint32_t)k));
   }
@@ -1184,74 +1191,81 @@ __device__ __forceinline__ static bool par_build(ParSmem& S, uint32_t base, uint
     kraft += c[l] << (15 - l);
   }
   if (kraft > 32768u) return false;
-  if (!is_dist) {
-    uint32_t n8 = 0;  // literals with an 8-bit code
-    for (uint32_t s0 = 0; s0 < 256u; s0 += 64) n8 += (uint32_t)__popcll(__ballot(lens[s0 + lane] == 8u));
-    if (lane == 0) {
-      S.f8lo = fst[8];
-      S.f8n = n8 >= 128u ? n8 : 0u;  // worth testing for only when most literals are 8 bits long
-      S.f8off = ofs[8];
-    }
-  }
-  if (lane < 16) {
-    uint32_t f = 0, o2 = 0, cc = 0;
-#pragma unroll
-    for (int l = 1; l < 16; l++)
-      if ((int)lane == l) {
-        f = fst[l];
-        o2 = ofs[l];
-        cc = c[l];
-      }
-    first[lane] = f;
-    offs[lane] = (uint16_t)o2;
-    cnt[lane] = (uint16_t)cc;
-  }
-  uint32_t run[16];  // symbols of each length seen in the chunks before this one (uniform)
-#pragma unroll
-  for (int k = 0; k < 16; k++) run[k] = 0;
-  for (uint32_t s0 = 0; s0 < nsym; s0 += 64) {
-    const uint32_t s = s0 + lane;
-    const uint32_t l = s < nsym ? lens[s] : 0u;
-    // rank of s among the symbols of its length = those in earlier chunks + lower lanes of this chunk with
-    // the same length (four ballots match the 4-bit length)
-    uint64_t same = ~0ull;
-#pragma unroll
-    for (int bt = 0; bt < 4; bt++) {
-      const bool bit = (l >> bt) & 1u;
-      const uint64_t bal = __ballot(bit);
-      same &= bit ? bal : ~bal;
-    }
-    uint32_t before = 0;
-#pragma unroll
-    for (int k = 1; k < 16; k++) {
-      before = ((int)l == k) ? run[k] : before;
-      run[k] += (uint32_t)__popcll(__ballot(l == (uint32_t)k));
-    }
-    if (l) {
-      const uint32_t rank = before + (uint32_t)__popcll(same & zes_lanemask_lt());
-      uint32_t f = 0, o2 = 0;
-#pragma unroll
-      for (int k = 1; k < 16; k++)
-        if ((int)l == k) {
-          f = fst[k];
-          o2 = ofs[k];
-        }
-      syms[o2 + rank] = (uint16_t)s;
-      if (l <= root) {
-        const uint32_t rev = __brev(f + rank) >> (32u - l);
-        const uint32_t ent = is_dist ? entry_d(s, l) : entry_l(s, l);
-        const uint32_t kind = (ent >> 8) & 3u;
-        uint32_t bl = (ent & 15u) + ((ent >> 4) & 15u);  // code bits + extra bits
-        if (is_dist) bl = (kind == 2u) ? bl : 0x80u;
-        else bl = (kind == 0u) ? bl : (kind == 2u) ? (bl | 0x40u) : 0x80u;  // EOB and 286/287 go the long way
-        for (uint32_t e = rev; e < (1u << root); e += 1u << l) {
-          lut[e] = ent;
-          blut[e] = (uint8_t)bl;
-        }
+  if (chunk == 0u) {
+    if (!is_dist) {
+      uint32_t n8 = 0;  // literals with an 8-bit code
+      for (uint32_t s0 = 0; s0 < 256u; s0 += 64) n8 += (uint32_t)__popcll(__ballot(lens[s0 + lane] == 8u));
+      if (lane == 0) {
+        S.f8lo = fst[8];
+        S.f8n = n8 >= 128u ? n8 : 0u;  // worth testing for only when most literals are 8 bits long
+        S.f8off = ofs[8];
       }
     }
+    if (lane < 16) {
+      uint32_t f = 0, o2 = 0, cc = 0;
+#pragma unroll
+      for (int l = 1; l < 16; l++)
+        if ((int)lane == l) {
+          f = fst[l];
+          o2 = ofs[l];
+          cc = c[l];
+        }
+      first[lane] = f;
+      offs[lane] = (uint16_t)o2;
+      cnt[lane] = (uint16_t)cc;
+    }
+  }
+  // rank of a symbol among the symbols of its length = those in earlier chunks + lower lanes of this chunk with the same
+  // length (four ballots match the 4-bit length)
+  uint64_t same = ~0ull;
+#pragma unroll
+  for (int bt = 0; bt < 4; bt++) {
+    const bool bit = (myl >> bt) & 1u;
+    const uint64_t bal = __ballot(bit);
+    same &= bit ? bal : ~bal;
+  }
+  if (myl) {
+    uint32_t o2 = 0;
+#pragma unroll
+    for (int k = 1; k < 16; k++)
+      if ((int)myl == k) o2 = ofs[k] + before[k];
+    syms[o2 + (uint32_t)__popcll(same & zes_lanemask_lt())] = (uint16_t)(64u * chunk + lane);
   }
   return true;
+}
+// One root-table entry: the symbol whose code is a prefix of the entry's index (bits in stream order), if one of at most
+// ROOT bits is.  (The per-length arrays are read up front, all reads in flight; the symbol and the entry's fields once.)
+template <uint32_t ROOT, bool IS_DIST>
+__device__ __forceinline__ static void par_fill(uint32_t i, const uint16_t* syms, const uint32_t* first, const uint16_t* cnt, const uint16_t* offs,
+                                                uint32_t* lut, uint8_t* blut) {
+  uint32_t fst[ROOT + 1], cn[ROOT + 1], ofs[ROOT + 1];
+#pragma unroll
+  for (uint32_t l = 1; l <= ROOT; l++) {
+    fst[l] = first[l];
+    cn[l] = cnt[l];
+    ofs[l] = offs[l];
+  }
+  const uint32_t msb = __brev(i) >> (32u - ROOT);  // the index as a code reads it
+  uint32_t at = 0, len = 0;
+#pragma unroll
+  for (uint32_t l = 1; l <= ROOT; l++) {
+    const uint32_t r = (msb >> (ROOT - l)) - fst[l];
+    if (r < cn[l]) {
+      at = ofs[l] + r;
+      len = l;
+    }
+  }
+  uint32_t ent = 0, bl = 0x80u;  // default: long code or no code -> the full tables decide
+  if (len) {
+    const uint32_t sym = syms[at];
+    ent = IS_DIST ? entry_d(sym, len) : entry_l(sym, len);
+    const uint32_t kind = (ent >> 8) & 3u;
+    bl = (ent & 15u) + ((ent >> 4) & 15u);  // code bits + extra bits
+    if (IS_DIST) bl = (kind == 2u) ? bl : 0x80u;
+    else bl = (kind == 0u) ? bl : (kind == 2u) ? (bl | 0x40u) : 0x80u;  // EOB and 286/287 go the long way
+  }
+  lut[i] = ent;
+  blut[i] = (uint8_t)bl;
 }
 
 // wave scans over 64 lanes (inclusive), DPP: four steps inside each row of 16, then the row totals carried over
@@ -1283,58 +1297,123 @@ __device__ __forceinline__ static uint32_t ph_scan_max(uint32_t x) {
   do {                                                                     \
     if (hdbg && zes_lane() == 0) hdbg[16 + (i)] = (unsigned long long)clock64(); \
   } while (0)
-// dynamic header by wave 0 (uniform): returns false on anything T2/T3 should look at
+// Dynamic header, first part, by wave 0 (uniform): the fixed fields and the code-length code's table; leaves what the
+// second part needs in S.h_*.  Returns false on anything T2/T3 should look at.
 template <bool LDS>
-__device__ __forceinline__ static bool par_header(ParSmem& S, const BitSrc& src, uint32_t limit, uint32_t start, unsigned long long* hdbg) {
+__device__ __forceinline__ static bool par_header_fixed(ParSmem& S, const BitSrc& src, uint32_t limit, uint32_t start, unsigned long long* hdbg) {
   const uint32_t lane = zes_lane();
   HSTAMP(0);
-  LaneBits b;
-  lb_seek<LDS>(b, src, start);
-  lb_refill<LDS>(b, src);
-  const uint32_t bfinal = lb_take(b, 1);
-  if (lb_take(b, 2) != 2u) return false;
-  const uint32_t HLIT = lb_take(b, 5) + 257u;
-  const uint32_t HDIST = lb_take(b, 5) + 1u;
-  const uint32_t HCLEN = lb_take(b, 4) + 4u;
-  uint32_t mycl = 0;
-  for (uint32_t k = 0; k < HCLEN; k++) {
-    lb_refill<LDS>(b, src);
-    const uint32_t v = lb_take(b, 3);
-    if (lane == kClOrder[k]) mycl = v;
+  uint32_t bfinal, HLIT, HDIST, HCLEN;
+  {
+    const uint32_t i = start >> 5, sh = start & 31u;
+    const uint64_t w = (uint64_t)src_ldw<LDS>(src, i) | ((uint64_t)src_ldw<LDS>(src, i + 1u) << 32);
+    const uint32_t f = (uint32_t)(w >> sh);  // 32 bits from the block's first
+    bfinal = f & 1u;
+    if (((f >> 1) & 3u) != 2u) return false;
+    HLIT = ((f >> 3) & 31u) + 257u;
+    HDIST = ((f >> 8) & 31u) + 1u;
+    HCLEN = ((f >> 13) & 15u) + 4u;
   }
-  for (uint32_t i = lane; i < 128; i += 64) S.cl_lut[i] = 0;
+  // lane k reads the k-th 3-bit length; lane s then takes the one of symbol s (kClOrder[k] == s)
+  uint32_t mycl;
+  {
+    const uint32_t bp = start + 17u + 3u * (lane < 19u ? lane : 0u);
+    const uint32_t j = bp >> 5, s2 = bp & 31u;
+    const uint64_t w = (uint64_t)src_ldw<LDS>(src, j) | ((uint64_t)src_ldw<LDS>(src, j + 1u) << 32);
+    const uint32_t v = lane < HCLEN ? ((uint32_t)(w >> s2) & 7u) : 0u;
+    // position of symbol s in the order 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15 (src/const.ts:31-35), five bits each
+    constexpr uint64_t inv_lo = 3ull | (17ull << 5) | (15ull << 10) | (13ull << 15) | (11ull << 20) | (9ull << 25) | (7ull << 30) | (5ull << 35) | (4ull << 40) |
+                                (6ull << 45) | (8ull << 50) | (10ull << 55);                                                        // symbols 0..11
+    constexpr uint64_t inv_hi = 12ull | (14ull << 5) | (16ull << 10) | (18ull << 15) | (0ull << 20) | (1ull << 25) | (2ull << 30);  // symbols 12..18
+    const uint32_t from = lane < 12u ? (uint32_t)(inv_lo >> (5u * lane)) & 31u : lane < 19u ? (uint32_t)(inv_hi >> (5u * (lane - 12u))) & 31u : 63u;
+    mycl = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(from << 2), (int)v);
+    if (lane >= 19u) mycl = 0;
+  }
+  // the 128-entry table, two entries per lane: the symbols go to LDS in (length, symbol) order, and an entry takes the one
+  // whose code is a prefix of its index (bits in stream order).  (Before: every symbol's lane filled its 2^(7-len) entries in
+  // a loop; the 1-bit and 2-bit codes of incompressible data's headers made that 64 + 32 turns.)
   uint32_t kraft = 0;
   {
-    uint32_t code = 0;
+    uint32_t code = 0, off = 0, e0 = 0, e1 = 0;
+    const uint32_t i0 = __brev(lane) >> 25, i1 = __brev(lane + 64u) >> 25;  // the entries' indices as a code reads them
+    uint8_t* sorted = reinterpret_cast<uint8_t*>(S.wave_sum);  // [19] (nobody else's until P2)
+    static_assert(sizeof(S.wave_sum) >= 20, "room for the code-length code's symbols");
+    uint32_t fst[8], cn[8], ofs[8];
+#pragma unroll
     for (uint32_t l = 1; l <= 7; l++) {
       const bool mine = lane < 19 && mycl == l;
       const uint64_t m = __ballot(mine);
-      if (mine) {
-        const uint32_t rank = (uint32_t)__popcll(m & zes_lanemask_lt());
-        const uint32_t rev = __brev(code + rank) >> (32u - l);
-        for (uint32_t e = rev; e < 128; e += 1u << l) S.cl_lut[e] = (uint8_t)(lane | (l << 5));
-      }
       const uint32_t n = (uint32_t)__popcll(m);
+      if (mine) sorted[off + (uint32_t)__popcll(m & zes_lanemask_lt())] = (uint8_t)lane;
+      fst[l] = code;
+      cn[l] = n;
+      ofs[l] = off;
       kraft += n << (7 - l);
       code = (code + n) << 1;
+      off += n;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    uint32_t a0 = 0, l0 = 0, a1 = 0, l1 = 0;  // where in sorted[], which length
+#pragma unroll
+    for (uint32_t l = 1; l <= 7; l++) {
+      const uint32_t r0 = (i0 >> (7u - l)) - fst[l], r1 = (i1 >> (7u - l)) - fst[l];
+      if (r0 < cn[l]) {
+        a0 = ofs[l] + r0;
+        l0 = l;
+      }
+      if (r1 < cn[l]) {
+        a1 = ofs[l] + r1;
+        l1 = l;
+      }
+    }
+    e0 = l0 ? (uint32_t)sorted[a0] | (l0 << 5) : 0u;
+    e1 = l1 ? (uint32_t)sorted[a1] | (l1 << 5) : 0u;
+    if (kraft <= 128u) {  // (an over-subscribed code has no prefix property: declined below)
+      S.cl_lut[lane] = (uint8_t)e0;
+      S.cl_lut[lane + 64u] = (uint8_t)e1;
     }
   }
   if (kraft > 128u) return false;
   for (uint32_t i = lane; i < 352; i += 64) S.lens[i] = 0;
+  if (lane == 0) {
+    const uint32_t p = start + 17u + 3u * HCLEN;  // the first code-length symbol
+    S.bfinal = bfinal;
+    S.h_hlit = HLIT;
+    S.h_total = HLIT + HDIST;
+    S.h_wbase = p & ~31u;
+    S.h_off = p & 31u;
+    S.h_done = 0;
+  }
+  (void)limit;
   HSTAMP(1);
-  const uint32_t total = HLIT + HDIST;
-  // The code-length symbols, 64 bit positions at a time: lane j decodes the symbol that would start at bit j of the
-  // window (one table lookup for all 64).  The real chain through them is only MARKED by a scalar walk (a lane read
-  // and a few scalar operations per symbol); the symbols on it are then moved into lanes 0.. in order and everything
-  // else happens for all of them at once: "repeat previous" takes its value through a max-scan of the last lane
-  // that is no repeat, a symbol's first entry is a prefix sum of the counts, and each lane stores its own (at most
-  // six) entries.  (Round 2 did the values, the bookkeeping and the stores inside the walk: ~270 cycles per symbol
-  // for the lone wave, 40k cycles per header; k_inf_verify_long has had this form since round 2.)
-  uint32_t prev = 0;
-  uint32_t wbase = b.pos & ~31u, off = b.pos & 31u;  // window start (dword aligned), offset of the next symbol in it
-  uint32_t* s_cl = S.lut_d;  // (64 words of scratch: the distance table is built later)
-  for (uint32_t k = 0; k < total;) {
-    const uint32_t d = wbase >> 5;
+  return true;
+}
+
+// Dynamic header, second part, by ALL waves (uniform for the workgroup): the HLIT + HDIST code lengths into S.lens, the
+// header's end into S.hdr_end; anything T2/T3 should look at sets S.status.  (src/inflate.ts:140-204.)
+//   Rounds of 1024 bits, wave w on the 64 bit positions [64 w, 64 w + 64) of the round: lane j decodes the code-length symbol
+//   that would start at bit j (one table lookup for all 64).  A symbol that starts in the window before can end at most 13
+//   bits into this one, so the window has at most 14 entry offsets: pointer doubling (six lane permutes) gives every offset
+//   the offset its chain leaves the window at, the code lengths the chain produces, whether it meets a hole of the code,
+//   and the last plain length on it ("repeat previous" at the head of the next window takes that).  The waves' tables go
+//   to LDS; every wave composes the windows before its own (<= 15 lookups) and knows its entry offset, the index of its
+//   first length and the value in front — the rest is the lone wave's step of rounds 2-3 for all windows at once: the
+//   real chain through the window is marked by a scalar walk, its symbols are moved into lanes 0.. in order, "repeat
+//   previous" takes its value through a max-scan, a symbol's first entry is a prefix sum of the counts, and each lane
+//   stores its own (at most six non-zero) entries.  (One wave, window after window: 27k cycles of the 60k a block's
+//   header took, with fifteen waves waiting.)
+template <bool LDS>
+__device__ __forceinline__ static void par_header_lens(ParSmem& S, const BitSrc& src, uint32_t limit, unsigned long long* hdbg) {
+  const uint32_t lane = zes_lane(), wave = threadIdx.x >> 6;
+  constexpr uint32_t LP_NONE = 31u;
+  uint32_t* s_tab = S.lut_d;             // [PAR_WAVES][32] (the first window of all is entered up to 31 bits in): the distance table is built later
+  uint32_t* s_cl = S.lut_l + wave * 64u;  // this wave's 64 words: so is the lit/len table
+  static_assert(PAR_WAVES * 32u <= (1u << PD_ROOT) && PAR_WAVES * 64u <= (1u << PL_ROOT), "header scratch lies over the tables");
+  const uint32_t HLIT = S.h_hlit, total = S.h_total;
+  uint32_t wbase0 = S.h_wbase, off0 = S.h_off, k0 = 0, prev0 = 0;
+  for (;;) {  // (uniform for the workgroup)
+    const uint32_t wb = wbase0 + 64u * wave;
+    const uint32_t d = wb >> 5;
     const uint32_t w0 = src_ldw<LDS>(src, d), w1 = src_ldw<LDS>(src, d + 1), w2 = src_ldw<LDS>(src, d + 2);
     const uint64_t lo64 = (uint64_t)w0 | ((uint64_t)w1 << 32), hi64 = (uint64_t)w1 | ((uint64_t)w2 << 32);
     const uint32_t bits = lane < 32u ? (uint32_t)(lo64 >> lane) : (uint32_t)(hi64 >> (lane - 32u));  // >= 32 bits from bit `lane` on
@@ -1342,70 +1421,102 @@ __device__ __forceinline__ static bool par_header(ParSmem& S, const BitSrc& src,
     const uint32_t l = e >> 5, sy = e & 31u;
     const uint32_t xb = sy == 16u ? 2u : sy == 17u ? 3u : sy == 18u ? 7u : 0u;
     const uint32_t xv = (bits >> l) & ((1u << xb) - 1u);
-    const uint32_t rep = sy == 16u ? 3u + xv : sy == 17u ? 3u + xv : sy == 18u ? 11u + xv : 1u;
-    // packed per lane: [6:0] offset of the following symbol (up to 77), [14:7] repeat count, [19:15] symbol, [20] valid
-    const uint32_t pk = (lane + l + xb) | (rep << 7) | (sy << 15) | ((l != 0u) << 20);
-    // the chain through the window: which lanes are on it
-    uint64_t m = 0;
-    uint32_t cur = off, nsym = 0, inval = 0;
-    while (cur < 64u) {
-      const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)pk, (int)cur);
-      if (!((v >> 20) & 1u)) {  // no code-length code matches here: the header is not one
-        inval = 1;
+    const bool valid = l != 0u && (uint64_t)wb + lane + l + xb <= (uint64_t)limit;  // a code-length code matches here, inside the data
+    const uint32_t rep = !valid ? 0u : sy == 16u ? 3u + xv : sy == 17u ? 3u + xv : sy == 18u ? 11u + xv : 1u;
+    // packed per lane: [6:0] offset of the following symbol (up to 77; a hole: out of the window), [14:7] repeat count, [19:15] symbol, [20] valid
+    const uint32_t pk = (valid ? lane + l + xb : 64u) | (rep << 7) | (sy << 15) | ((uint32_t)valid << 20);
+    // the window's transfer table: [6:0] where the chain from here goes on (>= 64: out), [20:7] lengths it produces,
+    // [21] it meets a hole, [26:22] the last plain length on it (LP_NONE: only "repeat previous" so far)
+    uint32_t t = (pk & 127u) | (rep << 7) | ((uint32_t)!valid << 21) | ((!valid || sy == 16u ? LP_NONE : sy >= 17u ? 0u : sy) << 22);
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+      const uint32_t J = t & 127u;
+      const uint32_t u = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(min(J, 63u) << 2), (int)t);
+      if (J < 64u) {
+        const uint32_t lpu = (u >> 22) & 31u;
+        t = (u & 127u) | ((((t >> 7) & 0x3FFFu) + ((u >> 7) & 0x3FFFu)) << 7) | ((t | u) & (1u << 21)) | ((lpu != LP_NONE ? lpu : (t >> 22) & 31u) << 22);
+      }
+    }
+    if (lane < 32u) s_tab[wave * 32u + lane] = t;
+    __syncthreads();
+    // this wave's entry: through the windows before it
+    uint32_t en = off0, k = k0, prev = prev0;
+    bool past = false, bad = false;
+    for (uint32_t v = 0; v < wave; v++) {
+      const uint32_t tt = s_tab[v * 32u + en];
+      k += (tt >> 7) & 0x3FFFu;
+      if (k >= total) {  // the sequence ends in window v: that wave's business
+        past = true;
         break;
       }
-      m |= 1ull << cur;
-      nsym++;
-      cur = v & 127u;
+      bad = bad || ((tt >> 21) & 1u);  // (all of window v's chain lies inside the sequence)
+      const uint32_t lpv = (tt >> 22) & 31u;
+      prev = lpv != LP_NONE ? lpv : prev;
+      en = (tt & 127u) - 64u;
     }
-    if (inval) return false;
-    // into lanes 0 .. nsym-1, in order
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if ((m >> lane) & 1ull) s_cl[(uint32_t)__popcll(m & zes_lanemask_lt())] = pk;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const uint32_t t = s_cl[lane];
-    const bool on = lane < nsym;
-    const uint32_t s1 = on ? (t >> 15) & 31u : 0u, r1 = on ? (t >> 7) & 255u : 0u;
-    const uint32_t is16 = (uint32_t)(s1 == 16u);
-    const uint32_t valraw = s1 >= 16u ? 0u : s1;  // (17, 18: zeros; 16: the value of the symbol before, below)
-    // the last symbol at or before this lane that is no "repeat previous" (0: none in this window — the carry)
-    const uint32_t srcl = ph_scan_max((on && !is16) ? lane + 1u : 0u);
-    const uint32_t vsrc = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((srcl ? srcl - 1u : 0u) << 2), (int)valraw);
-    const uint32_t val = srcl ? vsrc : prev;
-    const uint32_t kin = ph_scan_add(r1);
-    const uint32_t kk = k + kin - r1;  // the symbol's first entry
-    const uint64_t endm = __ballot(on && kk + r1 >= total);  // the symbol that completes the sequence (the first such)
-    const uint32_t cut = endm ? (uint32_t)__builtin_ctzll(endm) : nsym - 1u;  // last symbol of this window that counts
-    const bool mine = on && lane <= cut;
-    const uint64_t badm = __ballot(mine && ((is16 && kk == 0u) || kk + r1 > total));
-    if (badm) return false;
-    if (mine && val) {
-      for (uint32_t q = 0; q < r1; q++) {  // (a non-zero value repeats at most six times)
-        const uint32_t idx = kk + q;
-        S.lens[idx < HLIT ? idx : 288 + (idx - HLIT)] = (uint8_t)val;
+    if (bad && lane == 0) atomicOr(&S.status, 1u);
+    if (!past && !bad) {
+      // the chain through the window: which lanes are on it
+      uint64_t m = 0;
+      uint32_t cur = en, nsym = 0;
+      while (cur < 64u) {
+        const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)pk, (int)cur);
+        m |= 1ull << cur;
+        nsym++;
+        cur = v & 127u;
+      }
+      // into lanes 0 .. nsym-1, in order
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if ((m >> lane) & 1ull) s_cl[(uint32_t)__popcll(m & zes_lanemask_lt())] = pk;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const uint32_t tc = s_cl[lane];
+      const bool on = lane < nsym;
+      const uint32_t s1 = on ? (tc >> 15) & 31u : 0u, r1 = on ? (tc >> 7) & 255u : 0u;
+      const bool hole = on && !((tc >> 20) & 1u);
+      const uint32_t is16 = (uint32_t)(on && !hole && s1 == 16u);
+      const uint32_t valraw = s1 >= 16u ? 0u : s1;  // (17, 18: zeros; 16: the value of the symbol before, below)
+      // the last symbol at or before this lane that is no "repeat previous" (0: none in this window — the carry)
+      const uint32_t srcl = ph_scan_max((on && !is16) ? lane + 1u : 0u);
+      const uint32_t vsrc = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((srcl ? srcl - 1u : 0u) << 2), (int)valraw);
+      const uint32_t val = srcl ? vsrc : prev;
+      const uint32_t kin = ph_scan_add(r1);
+      const uint32_t kk = k + kin - r1;  // the symbol's first entry
+      const uint64_t endm = __ballot(on && !hole && kk + r1 >= total);  // the symbol that completes the sequence (the first such)
+      const uint32_t cut = endm ? (uint32_t)__builtin_ctzll(endm) : nsym - 1u;  // last symbol of this window that counts
+      const bool mine = on && lane <= cut;
+      const uint64_t badm = __ballot(mine && (hole || (is16 && kk == 0u) || kk + r1 > total));
+      if (badm) {
+        if (lane == 0) atomicOr(&S.status, 1u);
+      } else {
+        if (mine && val) {
+          for (uint32_t q = 0; q < r1; q++) {  // (a non-zero value repeats at most six times)
+            const uint32_t idx = kk + q;
+            S.lens[idx < HLIT ? idx : 288 + (idx - HLIT)] = (uint8_t)val;
+          }
+        }
+        if (endm) {  // the header ends behind that symbol
+          const uint32_t nx = (uint32_t)__builtin_amdgcn_readlane((int)(tc & 127u), (int)cut);
+          if (lane == 0) {
+            S.hdr_end = wb + nx;
+            S.h_done = 1;
+          }
+        } else if (wave == PAR_WAVES - 1u && lane == 0) {  // the next round's entry
+          S.h_off = cur - 64u;
+          S.h_k = (uint32_t)__builtin_amdgcn_readlane((int)(kk + r1), (int)cut);
+          S.h_prev = (uint32_t)__builtin_amdgcn_readlane((int)val, (int)cut);
+        }
       }
     }
-    prev = (uint32_t)__builtin_amdgcn_readlane((int)val, (int)cut);
-    k = (uint32_t)__builtin_amdgcn_readlane((int)(kk + r1), (int)cut);
-    if (endm) {  // the header ends behind that symbol
-      off = (uint32_t)__builtin_amdgcn_readlane((int)(t & 127u), (int)cut);
-      if (off >= 64u) {
-        wbase += 64u;
-        off -= 64u;
-      }
-      break;
-    }
-    off = cur - 64u;
-    wbase += 64u;
+    __syncthreads();
+    if (S.status || S.h_done) break;
+    off0 = S.h_off;
+    k0 = S.h_k;
+    prev0 = S.h_prev;
+    wbase0 += 64u * PAR_WAVES;
+    __syncthreads();  // (the carry is read before the next round's last wave writes it again)
   }
-  b.pos = wbase + off;
-  HSTAMP(2);
-  if (b.pos > limit) return false;
-  if (lane == 0) {
-    S.hdr_end = b.pos;
-    S.bfinal = bfinal;
-  }
-  return true;  // the tables: par_build, by two waves side by side (the caller)
+  if (wave == 0) HSTAMP(2);
+  if (!S.status && S.hdr_end > limit && threadIdx.x == 0) S.status = 1;
 }
 
 // What a work item is and where its results go.  T1 (k_inf_block_par): candidate ci of a reference-made stream, output
@@ -1506,21 +1617,28 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
     __syncthreads();
     unsigned long long* hdbg = dbg ? dbg + (size_t)blockIdx.x * ZES_PAR_DBG_ROW : nullptr;
     if (wave == 0 && use_lds) {
-      const bool ok = par_header<true>(S, src, plimit, start, hdbg);
+      const bool ok = par_header_fixed<true>(S, src, plimit, start, hdbg);
       if (!ok && lane == 0) S.status = 1;
     }
     __syncthreads();
     if (S.status) return 1u;
-    // the two alphabets' tables side by side: lit/len by wave 0, distances by wave 1
-    if (wave == 0) {
-      if (!par_build(S, 0, 288, PL_ROOT, false, S.lut_l, S.syms_l, S.first_l, S.cnt_l, S.offs_l) && lane == 0) atomicOr(&S.status, 1u);
-      HSTAMP(3);
-    } else if (wave == 1) {
-      if (!par_build(S, 288, 32, PD_ROOT, true, S.lut_d, S.syms_d, S.first_d, S.cnt_d, S.offs_d) && lane == 0) atomicOr(&S.status, 1u);
+    par_header_lens<true>(S, src, plimit, hdbg);
+    __syncthreads();
+    if (S.status) return 1u;
+    // the two alphabets' canonical arrays, a wave per 64 symbols; then the root tables, a thread per entry
+    if (wave < 5u) {
+      if (!par_build(S, 0, 288, wave, false, S.syms_l, S.first_l, S.cnt_l, S.offs_l) && lane == 0) atomicOr(&S.status, 1u);
+    } else if (wave == 5u) {
+      if (!par_build(S, 288, 32, 0, true, S.syms_d, S.first_d, S.cnt_d, S.offs_d) && lane == 0) atomicOr(&S.status, 1u);
     }
     __syncthreads();
-    if (wave == 0) HSTAMP(4);
+    if (wave == 0) HSTAMP(3);
     if (S.status) return 1u;
+    static_assert(PAR_THREADS == (1u << PL_ROOT) && PAR_THREADS >= (1u << PD_ROOT), "one thread per root-table entry");
+    par_fill<PL_ROOT, false>(tid, S.syms_l, S.first_l, S.cnt_l, S.offs_l, S.lut_l, S.len_l);
+    if (tid < (1u << PD_ROOT)) par_fill<PD_ROOT, true>(tid, S.syms_d, S.first_d, S.cnt_d, S.offs_d, S.lut_d, S.len_d);
+    __syncthreads();
+    if (wave == 0) HSTAMP(4);
     STAMP(1);
     ds = S.hdr_end;
     // The reference's match finder never looks in front of the block (src/lz77.ts:11-22: the index is built per block),

@@ -8,6 +8,10 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <csignal>
+#include <execinfo.h>
+#include <unistd.h>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -57,6 +61,12 @@ bool get_bytes(napi_env env, napi_value v, const uint8_t** data, size_t* len) {
 // inside a synchronous loop: a host that awaits (deflateAsync / inflateAsync, any server) gets its blocks back and runs at
 // the library's pace; a tight synchronous loop over 64 MiB calls gets fresh blocks until BIG_OUTSTANDING_MAX are out, then
 // plain malloc as before.  trim() empties the pool.
+// Set when the last environment (or the process) goes down: from then on nothing here calls into the library or the HIP
+// runtime any more — page-locked blocks are left to the process's end.
+std::atomic<bool> g_exiting{false};
+std::atomic<int> g_envs{0};
+void mark_exiting_atexit() { g_exiting.store(true); }
+
 constexpr size_t BIG_MIN = 1u << 20;                 // smaller results: malloc, as before
 constexpr size_t BIG_KEEP_MAX = 768u << 20;          // bytes the pool keeps for reuse
 constexpr size_t BIG_OUTSTANDING_MAX = 1024u << 20;  // (V8 collects a few calls behind: 64 MiB calls in an awaited loop hold ~0.5 GiB at any time)  // pooled bytes in the hands of JS beyond which new results are not pooled
@@ -101,6 +111,7 @@ struct BigPool {
     return static_cast<uint8_t*>(p);
   }
   void give(uint8_t* p, size_t cap) {
+    if (g_exiting.load()) return;
     {
       std::lock_guard<std::mutex> lk(mu);
       out -= cap < out ? cap : out;
@@ -133,6 +144,7 @@ struct BigPool {
     zes_host_free(p);  // (cannot happen under the limits above; never keep more than the budget)
   }
   void clear() {
+    if (g_exiting.load()) return;
     std::vector<Blk> all;
     {
       std::lock_guard<std::mutex> lk(mu);
@@ -142,7 +154,7 @@ struct BigPool {
     for (Blk& b : all) zes_host_free(b.p);
   }
 };
-BigPool g_big;
+BigPool& g_big = *new BigPool;  // (never destroyed: an environment's cleanup may still come by during exit())
 
 // memory for a result of up to n bytes: pooled (cap > 0) or malloc'd (cap == 0)
 struct ResultMem {
@@ -165,22 +177,115 @@ void result_free(ResultMem m) {
   else
     free(m.p);
 }
-// what the finalizer of a result's ArrayBuffer needs: where the memory goes back to, and how much V8 was told about
-struct ResultTag {
-  size_t cap;     // capacity of the pooled block, or 0 for malloc'd memory
+// ---- whose memory is still in use: no finalizers ----
+// The memory behind an array handed to JS (a result, an allocPinned() array) is an external ArrayBuffer WITHOUT a finalizer;
+// the addon keeps a weak reference to it and looks, at the start of every call, which of them the collector has cleared:
+// those blocks go back (to the pool, to the library, to free()).  Why not a finalizer: Node 12 hands an N-API finalizer to
+// the environment's immediate queue without keeping the N-API environment alive, frees that environment in a cleanup hook
+// when the process ends, and runs the queue afterwards — v8::HandleScope on freed memory: seven of ten bench_host.js runs
+// ended in SIGSEGV behind their last line (any array alive at exit has its finalizer queued there).  And a finalizer only
+// ever runs between two turns of the event loop, so a synchronous loop over deflate() got fresh memory for every result,
+// page by page; a weak reference is cleared by the collection itself, and the next call of the loop has the block again.
+struct Track {
+  napi_ref ref;   // weak: to the ArrayBuffer
+  uint8_t* p;
+  size_t cap;     // pooled block: its capacity; 0: malloc'd (results) — or page-locked by allocPinned (pinned)
   int64_t told;   // bytes reported with napi_adjust_external_memory
+  bool pinned;    // allocPinned(): goes back with zes_host_free
 };
-void free_external(napi_env env, void* data, void* hint) {
-  ResultTag* t = static_cast<ResultTag*>(hint);
-  ResultMem m;
-  m.p = static_cast<uint8_t*>(data);
-  m.cap = t ? t->cap : 0;
-  if (t && t->told) {
-    int64_t now = 0;
-    napi_adjust_external_memory(env, -t->told, &now);
+struct EnvTracks {
+  napi_env env;
+  std::vector<Track> v;
+  size_t cursor = 0;
+};
+std::mutex g_tracks_mu;
+std::vector<EnvTracks*> g_tracks;  // one per environment (a Worker has its own); an entry is used by its environment's thread only
+EnvTracks* tracks_of(napi_env env) {
+  std::lock_guard<std::mutex> lk(g_tracks_mu);
+  for (EnvTracks* t : g_tracks)
+    if (t->env == env) return t;
+  return nullptr;
+}
+void release_memory(const Track& t) {
+  if (t.pinned) {
+    if (!g_exiting.load()) zes_host_free(t.p);
+  } else {
+    ResultMem m;
+    m.p = t.p;
+    m.cap = t.cap;
+    result_free(m);
   }
-  delete t;
-  result_free(m);
+}
+constexpr size_t SWEEP_MAX = 4096;  // references looked at per call (a host that keeps more arrays alive is swept in turns)
+void sweep(napi_env env) {
+  EnvTracks* et = tracks_of(env);
+  if (!et || et->v.empty()) return;
+  size_t todo = et->v.size() < SWEEP_MAX ? et->v.size() : SWEEP_MAX;
+  size_t i = et->cursor < et->v.size() ? et->cursor : 0;
+  while (todo--) {
+    if (i >= et->v.size()) i = 0;
+    if (et->v.empty()) break;
+    napi_value val = nullptr;
+    if (napi_get_reference_value(env, et->v[i].ref, &val) == napi_ok && val == nullptr) {
+      const Track t = et->v[i];
+      et->v[i] = et->v.back();
+      et->v.pop_back();
+      napi_delete_reference(env, t.ref);
+      if (t.told) {
+        int64_t now = 0;
+        napi_adjust_external_memory(env, -t.told, &now);
+      }
+      release_memory(t);
+    } else {
+      i++;
+    }
+  }
+  et->cursor = i;
+}
+// the environment goes down: its arrays with it (no N-API call from here; pooled blocks stay pooled for other environments)
+void env_cleanup(void* arg) {
+  napi_env env = static_cast<napi_env>(arg);
+  EnvTracks* mine = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_tracks_mu);
+    for (size_t i = 0; i < g_tracks.size(); i++)
+      if (g_tracks[i]->env == env) {
+        mine = g_tracks[i];
+        g_tracks.erase(g_tracks.begin() + (long)i);
+        break;
+      }
+  }
+  const bool last = g_envs.fetch_sub(1) == 1;
+  if (last) g_exiting.store(true);
+  if (mine) {
+    if (!last)
+      for (const Track& t : mine->v) release_memory(t);
+    delete mine;
+  }
+}
+// hands p[0, n) to JS as the ArrayBuffer of a fresh Uint8Array and starts tracking it; on failure the memory is released
+napi_value adopt(napi_env env, uint8_t* p, size_t n, size_t cap, bool pinned) {
+  Track t;
+  t.ref = nullptr;
+  t.p = p;
+  t.cap = cap;
+  t.told = (int64_t)(cap ? cap : n);
+  t.pinned = pinned;
+  EnvTracks* et = tracks_of(env);
+  napi_value ab, ta;
+  if (!et || napi_create_external_arraybuffer(env, p, n, nullptr, nullptr, &ab) != napi_ok) {
+    release_memory(t);
+    return nullptr;
+  }
+  if (napi_create_reference(env, ab, 0, &t.ref) != napi_ok) {  // (the ArrayBuffer is garbage from here; its memory must outlive it: kept)
+    napi_throw_error(env, nullptr, "zes: out of memory");
+    return nullptr;
+  }
+  int64_t now = 0;
+  if (napi_adjust_external_memory(env, t.told, &now) != napi_ok) t.told = 0;
+  et->v.push_back(t);
+  if (napi_create_typedarray(env, napi_uint8_array, n, ab, 0, &ta) != napi_ok) return nullptr;  // (tracked: released once collected)
+  return ta;
 }
 // the result's memory becomes its ArrayBuffer (exact length: `buffer.byteLength === length` like src/zlib.ts:42; a pooled
 // block is longer than what the ArrayBuffer shows of it): no second copy of the result on the JS thread.  Takes the
@@ -191,17 +296,7 @@ napi_value take_u8(napi_env env, ResultMem m, size_t n) {
     void* shrunk = realloc(m.p, n ? n : 1);
     if (shrunk) m.p = static_cast<uint8_t*>(shrunk);
   }
-  ResultTag* tag = new ResultTag{m.cap, (int64_t)(m.cap ? m.cap : n)};
-  napi_value ab, ta;
-  if (napi_create_external_arraybuffer(env, m.p, n, free_external, tag, &ab) != napi_ok) {
-    delete tag;
-    result_free(m);
-    return nullptr;
-  }
-  int64_t now = 0;
-  if (napi_adjust_external_memory(env, tag->told, &now) != napi_ok) tag->told = 0;
-  if (napi_create_typedarray(env, napi_uint8_array, n, ab, 0, &ta) != napi_ok) return nullptr;  // (the ArrayBuffer's finalizer owns the memory)
-  return ta;
+  return adopt(env, m.p, n, m.cap, false);
 }
 
 // A synchronous deflate() that finds no pooled block (a tight loop: Node runs no finalizer inside it) would hand the
@@ -736,7 +831,6 @@ napi_value InflateBatchAsync(napi_env env, napi_callback_info info) { return sta
 // library's staging copy; released when the array is collected.  The finalizer runs on the JS thread and takes
 // the library's lock for a moment (no stream is waited for: hipHostFree itself waits for work that uses the block), so
 // it can stall behind a call that is holding the lock; zes_host_free also works after zes_shutdown.
-void free_pinned(napi_env, void* data, void*) { zes_host_free(data); }
 napi_value AllocPinned(napi_env env, napi_callback_info info) {
   size_t argc = 1;
   napi_value argv[1];
@@ -749,35 +843,57 @@ napi_value AllocPinned(napi_env env, napi_callback_info info) {
   void* p = nullptr;
   const int rc = zes_host_alloc((uint64_t)d, &p);
   if (rc) return throw_status(env, rc);
-  napi_value ab, ta;
-  if (napi_create_external_arraybuffer(env, p, (size_t)d, free_pinned, nullptr, &ab) != napi_ok) {
-    zes_host_free(p);  // no ArrayBuffer took the block over
-    return nullptr;
-  }
-  // from here on the ArrayBuffer's finalizer (free_pinned) owns the block, whatever happens to the view
-  if (napi_create_typedarray(env, napi_uint8_array, (size_t)d, ab, 0, &ta) != napi_ok) return nullptr;
-  return ta;
+  return adopt(env, static_cast<uint8_t*>(p), (size_t)d, 0, true);  // (released by a later call's sweep once the array is collected)
+}
+
+// every entry point first looks which arrays the collector has taken since the last call
+template <napi_callback F>
+napi_value swept(napi_env env, napi_callback_info info) {
+  sweep(env);
+  return F(env, info);
 }
 
 napi_value ModuleInit(napi_env env, napi_value exports) {
   napi_property_descriptor props[] = {
-      {"deflate", nullptr, Deflate, nullptr, nullptr, nullptr, napi_default, nullptr},
-      {"inflate", nullptr, Inflate, nullptr, nullptr, nullptr, napi_default, nullptr},
-      {"deflateRaw", nullptr, DeflateRaw, nullptr, nullptr, nullptr, napi_default, nullptr},
-      {"inflateRaw", nullptr, InflateRaw, nullptr, nullptr, nullptr, napi_default, nullptr},
-      {"deflateAsync", nullptr, DeflateAsync, nullptr, nullptr, nullptr, napi_default, nullptr},
-      {"inflateAsync", nullptr, InflateAsync, nullptr, nullptr, nullptr, napi_default, nullptr},
-      {"deflateBatch", nullptr, DeflateBatch, nullptr, nullptr, nullptr, napi_default, nullptr},
-      {"inflateBatch", nullptr, InflateBatch, nullptr, nullptr, nullptr, napi_default, nullptr},
-      {"deflateBatchAsync", nullptr, DeflateBatchAsync, nullptr, nullptr, nullptr, napi_default, nullptr},
-      {"inflateBatchAsync", nullptr, InflateBatchAsync, nullptr, nullptr, nullptr, napi_default, nullptr},
-      {"allocPinned", nullptr, AllocPinned, nullptr, nullptr, nullptr, napi_default, nullptr},
-      {"adler32", nullptr, Adler32, nullptr, nullptr, nullptr, napi_default, nullptr},
-      {"init", nullptr, Init, nullptr, nullptr, nullptr, napi_default, nullptr},
-      {"initDevices", nullptr, InitDevices, nullptr, nullptr, nullptr, napi_default, nullptr},
-      {"trim", nullptr, Trim, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"deflate", nullptr, swept<Deflate>, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"inflate", nullptr, swept<Inflate>, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"deflateRaw", nullptr, swept<DeflateRaw>, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"inflateRaw", nullptr, swept<InflateRaw>, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"deflateAsync", nullptr, swept<DeflateAsync>, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"inflateAsync", nullptr, swept<InflateAsync>, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"deflateBatch", nullptr, swept<DeflateBatch>, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"inflateBatch", nullptr, swept<InflateBatch>, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"deflateBatchAsync", nullptr, swept<DeflateBatchAsync>, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"inflateBatchAsync", nullptr, swept<InflateBatchAsync>, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"allocPinned", nullptr, swept<AllocPinned>, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"adler32", nullptr, swept<Adler32>, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"init", nullptr, swept<Init>, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"initDevices", nullptr, swept<InitDevices>, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"trim", nullptr, swept<Trim>, nullptr, nullptr, nullptr, napi_default, nullptr},
   };
   napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props);
+  if (getenv("ZES_NAPI_SEGV_TRACE")) {  // development: where a SIGSEGV comes from
+    signal(SIGSEGV, [](int) {
+      void* bt[64];
+      const int n = backtrace(bt, 64);
+      backtrace_symbols_fd(bt, n, 2);
+      _exit(139);
+    });
+  }
+  g_envs.fetch_add(1);
+  g_exiting.store(false);
+  {
+    EnvTracks* et = new EnvTracks;
+    et->env = env;
+    std::lock_guard<std::mutex> lk(g_tracks_mu);
+    g_tracks.push_back(et);
+  }
+  napi_add_env_cleanup_hook(env, env_cleanup, env);
+  static bool once = false;
+  if (!once) {
+    once = true;
+    atexit(mark_exiting_atexit);
+  }
   return exports;
 }
 
