@@ -3,9 +3,9 @@
 //   node bench_host.js '{"inputs":[{"name":..,"path":..,"deflate_len":..,"deflate_sha256":..}],"calls":K,"reps":R}'
 // Every call returns a fresh exact-size Uint8Array, as the reference does (src/zlib.ts:42): its allocation is inside the
 // time.  Rows: the input in an ordinary Uint8Array (pageable) and in an allocPinned() one; each as a tight synchronous loop
-// over deflate() / inflate() (the reference's own calling pattern: Node runs no finalizer inside such a loop, so every
+// over deflate() / inflate() (the reference's own calling pattern: V8 collects eight to ten results behind in such a loop, so nearly every
 // result is fresh memory) and as an awaited loop over deflateAsync() / inflateAsync() (a host that yields to the event loop:
-// collected results give their page-locked blocks back to the addon's pool).  Prints ONE JSON line.
+// collected results' page-locked blocks are back in the addon's pool a few calls later).  Prints ONE JSON line.
 'use strict';
 const fs = require('fs');
 const crypto = require('crypto');
@@ -60,7 +60,7 @@ async function main() {
           deflate_ms: spread(td), inflate_ms: spread(ti), compressed_bytes: comp.length, verified_bit_exact: ok, golden_sha256_checked: golden,
         };
         comp = back = null;
-        await new Promise((res) => setImmediate(res));  // let the finalizers of this row's results run
+        await new Promise((res) => setImmediate(res));  // a turn of the event loop between rows
       }
     }
   }

@@ -6,6 +6,7 @@
 #include <node_api.h>
 
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
@@ -64,6 +65,7 @@ bool get_bytes(napi_env env, napi_value v, const uint8_t** data, size_t* len) {
 // Set when the last environment (or the process) goes down: from then on nothing here calls into the library or the HIP
 // runtime any more — page-locked blocks are left to the process's end.
 std::atomic<bool> g_exiting{false};
+std::atomic<long> g_dbg_hit{0}, g_dbg_miss{0}, g_dbg_released{0}, g_dbg_fresh{0};
 std::atomic<int> g_envs{0};
 void mark_exiting_atexit() { g_exiting.store(true); }
 
@@ -89,6 +91,7 @@ struct BigPool {
       for (size_t i = 0; i < free_.size(); i++)
         if (free_[i].cap >= n && free_[i].cap <= 2 * n + (8u << 20) && (best == free_.size() || free_[i].cap < free_[best].cap)) best = i;
       if (best != free_.size()) {
+        g_dbg_hit++;
         Blk b = free_[best];
         free_.erase(free_.begin() + (long)best);
         kept -= b.cap;
@@ -96,6 +99,7 @@ struct BigPool {
         *cap = b.cap;
         return b.p;
       }
+      g_dbg_miss++;
       if (out + n > BIG_OUTSTANDING_MAX) return nullptr;
       if (!fresh) {
         want = n > want ? n : want;
@@ -236,6 +240,7 @@ void sweep(napi_env env) {
         napi_adjust_external_memory(env, -t.told, &now);
       }
       release_memory(t);
+      g_dbg_released++;
     } else {
       i++;
     }
@@ -255,6 +260,9 @@ void env_cleanup(void* arg) {
         break;
       }
   }
+  if (getenv("ZES_NAPI_DEBUG"))
+    fprintf(stderr, "zes_napi: pool hits %ld misses %ld, arrays released by sweeps %ld, still tracked %zu\n", g_dbg_hit.load(), g_dbg_miss.load(),
+            g_dbg_released.load(), mine ? mine->v.size() : 0);
   const bool last = g_envs.fetch_sub(1) == 1;
   if (last) g_exiting.store(true);
   if (mine) {
