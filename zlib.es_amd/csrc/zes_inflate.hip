@@ -2522,10 +2522,15 @@ __global__ __launch_bounds__(64) void k_inf_seg_decode(const uint8_t* __restrict
 __global__ __launch_bounds__(256) void k_inf_chain(const ZesInfBuf* __restrict__ bufs, const uint32_t* __restrict__ cnt,
                                                    const uint32_t* __restrict__ cand_all, const ZesCandRes* __restrict__ cres_all,
                                                    const uint32_t* __restrict__ map_in_all, uint32_t* __restrict__ map_out_all,
-                                                   ZesRes* __restrict__ res_all) {
+                                                   ZesRes* __restrict__ res_all, const uint32_t* __restrict__ counters, uint32_t counter_words,
+                                                   uint32_t* __restrict__ counters_host) {
   __shared__ uint32_t s_bad, s_final;
   __shared__ unsigned long long s_total;
   const uint32_t tid = threadIdx.x;
+  // (one buffer: res_all and counters_host point into the host's page-locked read-back area; the counters — final since
+  // the verify kernels — go there with this kernel, the host reads both after one synchronisation, no copy command)
+  if (counters_host && blockIdx.x == 0)
+    for (uint32_t i = tid; i < counter_words; i += blockDim.x) counters_host[i] = counters[i];
   const ZesInfBuf bf = bufs[blockIdx.x];
   const uint32_t ncand = min(cnt[blockIdx.x], bf.cand_cap);
   uint32_t nwork = bufs[blockIdx.x + 1].work_first - bf.work_first;

@@ -134,7 +134,7 @@ __global__ void k_inf_block_par(const uint8_t*, uint8_t*, const ZesInfBuf*, uint
 __global__ void k_inf_block_par2(const uint8_t*, uint8_t*, const ZesInfBuf*, uint32_t, const uint32_t*, const uint32_t*, const uint32_t*,
                                 ZesCandRes*, unsigned long long*, const uint32_t*, const uint32_t*, uint32_t*);
 __global__ void k_inf_move_slots(uint8_t*, const uint8_t*, const uint32_t*, const uint32_t*, uint32_t);
-__global__ void k_inf_chain(const ZesInfBuf*, const uint32_t*, const uint32_t*, const ZesCandRes*, const uint32_t*, uint32_t*, ZesRes*);
+__global__ void k_inf_chain(const ZesInfBuf*, const uint32_t*, const uint32_t*, const ZesCandRes*, const uint32_t*, uint32_t*, ZesRes*, const uint32_t*, uint32_t, uint32_t*);
 __global__ void k_inf_chain_range(const ZesInfBuf*, const uint32_t*, const uint32_t*, const ZesCandRes*, ZesRes*, unsigned long long*);
 __global__ void k_inf_set_table_range(ZesInfBuf, ZesInfBuf, ZesInfBuf*, uint32_t*, uint32_t, const unsigned long long*, unsigned long long);
 __global__ void k_inf_exact(const uint8_t*, uint64_t, uint64_t, uint8_t*, uint64_t, uint64_t, const uint64_t*, ZesRes*);
