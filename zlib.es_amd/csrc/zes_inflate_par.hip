@@ -704,28 +704,56 @@ __device__ __forceinline__ static void seg_table_dp(ParSmem& S, const BitSrc& sr
   // (uniform) some lane's segment ends within 64 bits of the data's end, or behind it: tokens are checked against it
   const bool near = __ballot((uint64_t)base + seglen + 64u > (uint64_t)limit) != 0ull;
   uint32_t mid = src_ldw<true>(src, d0 + nd), hi = src_ldw<true>(src, d0 + nd + 1u);
+  // Three positions in flight inside a dword (the sweep goes from bit 31 down to bit 0): A(q) asks for position q's lit/len
+  // entry, B(q) takes it, finds the distance part's place and asks for that entry, C(q) finishes the token and moves the
+  // ring.  An iteration runs A(bb-2), B(bb-1), C(bb): both table reads of a position are on their way one and two turns
+  // before they are used, and only the ring's read-then-write is waited for.  (Before: three dependent LDS round trips per
+  // position, ~300 of its ~700 cycles.)  The pipeline drains at the dword's end: two positions in 32 without the overlap.
+  uint32_t w_b = 0, a_b = 0;                              // A -> B: the window, the lit/len entry
+  uint32_t n_c = 0, ovr_c = 0, dd_c = 0, t_c = 0;         // B -> C
+  bool m_c = false;
+  auto stage_a = [&](uint32_t lo, uint32_t q) {
+    w_b = __builtin_amdgcn_alignbit(mid, lo, q);
+    a_b = T13[w_b & ((1u << DP_LROOT) - 1u)];
+  };
+  auto stage_b = [&](uint32_t q) {
+    const uint32_t w32 = w_b, a = a_b;
+    const uint32_t wh = __builtin_amdgcn_alignbit(hi, mid, q);
+    uint32_t n = a & 63u, ovr = 0;
+    bool m = (a & 0x40u) != 0u;
+    const bool sp = (a & 0x80u) != 0u;
+    if (__ballot(sp)) {  // end of block, a code longer than 13 bits, no code
+      const uint32_t e = lut_l_entry(S, w32);
+      const uint32_t kind = (e >> 8) & 3u;
+      if (sp) {
+        ovr = (kind == 1u) ? C_EOB : ((kind == 3u) || ((e & 15u) == 0u)) ? C_FAIL : 0u;
+        n = (e & 15u) + ((e >> 4) & 15u);
+        m = kind == 2u;
+      }
+    }
+    const uint32_t t = __builtin_amdgcn_alignbit(wh, w32, n);  // n <= 20
+    n_c = n;
+    ovr_c = ovr;
+    m_c = m;
+    t_c = t;
+    dd_c = D12[t & ((1u << DP_DROOT) - 1u)];
+  };
 #pragma unroll 1
   for (uint32_t j = nd; j-- > 0u;) {
     const uint32_t lo = src_ldw<true>(src, d0 + j);
+    stage_a(lo, 31u);
+    stage_b(31u);
+    stage_a(lo, 30u);
 #pragma unroll 2
     for (uint32_t bb = 32u; bb-- > 0u;) {
       const uint32_t p = 32u * j + bb;
-      const uint32_t w32 = __builtin_amdgcn_alignbit(mid, lo, bb), wh = __builtin_amdgcn_alignbit(hi, mid, bb);
-      const uint32_t a = T13[w32 & ((1u << DP_LROOT) - 1u)];
-      uint32_t n = a & 63u, ovr = 0;
-      bool m = (a & 0x40u) != 0u;
-      const bool sp = (a & 0x80u) != 0u;
-      if (__ballot(sp)) {  // end of block, a code longer than 13 bits, no code
-        const uint32_t e = lut_l_entry(S, w32);
-        const uint32_t kind = (e >> 8) & 3u;
-        if (sp) {
-          ovr = (kind == 1u) ? C_EOB : ((kind == 3u) || ((e & 15u) == 0u)) ? C_FAIL : 0u;
-          n = (e & 15u) + ((e >> 4) & 15u);
-          m = kind == 2u;
-        }
-      }
-      const uint32_t t = (uint32_t)(((((uint64_t)wh) << 32) | w32) >> (n & 31u));  // n <= 20
-      const uint32_t dd = D12[t & ((1u << DP_DROOT) - 1u)];
+      // C(bb): what B(bb) left
+      uint32_t n = n_c, ovr = ovr_c;
+      const bool m = m_c;
+      const uint32_t dd = dd_c, t = t_c;
+      // B(bb-1) (its entry was asked for a turn ago), then A(bb-2)
+      if (bb >= 1u) stage_b(bb - 1u);
+      if (bb >= 2u) stage_a(lo, bb - 2u);
       uint32_t n2 = dd & 63u;
       const bool dsp = m && (dd & 0x80u) != 0u;
       if (__ballot(dsp)) {
