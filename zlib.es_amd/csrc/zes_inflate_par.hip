@@ -2106,23 +2106,76 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
         const uint32_t wlen = min(RES_W, clen - ws);
         // (a) per 32 positions of the window: the last match start at or before them (matches do not overlap each
         // other, so the nearest start in front of a byte is the only match that can cover it)
-        if (tid < RES_W / 32u) {
-          const uint32_t w = S.bitmap[(ws >> 5) + tid];
-          uint32_t hs = w ? 32u * tid + 32u - (uint32_t)__clz(w) : 0u;  // start + 1 (window-relative), 0: none
+        // (T1 looks the start up in the bitmap itself, below: a match is at most 258 bytes long, so the start that covers a
+        // byte is in its own word of the bitmap or one of the nine before it — no running maxima, no barrier, and no
+        // carry from window to window.  T2 overwrites the words of resolved windows with its marker flags.)
+        if (FOREIGN) {
+          if (tid < RES_W / 32u) {
+            const uint32_t w = S.bitmap[(ws >> 5) + tid];
+            uint32_t hs = w ? 32u * tid + 32u - (uint32_t)__clz(w) : 0u;  // start + 1 (window-relative), 0: none
 #pragma unroll
-          for (int dlt = 1; dlt < 64; dlt <<= 1) {
-            const uint32_t t = __shfl_up(hs, dlt);
-            if ((int)lane >= dlt) hs = max(hs, t);
+            for (int dlt = 1; dlt < 64; dlt <<= 1) {
+              const uint32_t t = __shfl_up(hs, dlt);
+              if ((int)lane >= dlt) hs = max(hs, t);
+            }
+            S.res_lastw[tid] = hs;
           }
-          S.res_lastw[tid] = hs;
+          __syncthreads();
         }
-        __syncthreads();
         P4LAP(0);
         // (b) every byte of the window looks up the match that covers it — the nearest start in its own 32 positions,
         // else the last one of the words before (a match that began in the window before is in res_strad) — and takes
         // that match's distance, or 0 for a literal byte.  The lane keeps its four entries in registers.
         uint32_t d[RES_W / PAR_THREADS];
-        {
+        if (!FOREIGN) {
+          // (the records of the windows before are gone — their bytes have been copied over them: the one match that can
+          // reach in from there, the last one to start before this window, is carried in res_strad)
+          const uint32_t sEnd = S.res_strad[0], sD = S.res_strad[1];
+          const uint32_t* out32 = reinterpret_cast<const uint32_t*>(S.out);
+          uint32_t w0[RES_W / PAR_THREADS], w1[RES_W / PAR_THREADS];  // the byte's own word of the bitmap and the one before: all reads in flight
+#pragma unroll
+          for (uint32_t k = 0; k < RES_W / PAR_THREADS; k++) {
+            const uint32_t wi = (ws + tid + k * PAR_THREADS) >> 5;
+            w0[k] = S.bitmap[wi];
+            w1[k] = S.bitmap[wi ? wi - 1u : 0u];
+          }
+#pragma unroll
+          for (uint32_t k = 0; k < RES_W / PAR_THREADS; k++) {
+            const uint32_t bpos = tid + k * PAR_THREADS, P = ws + bpos, wi = P >> 5;
+            uint32_t w = w0[k] & (0xFFFFFFFFu >> (31u - (P & 31u)));  // starts at or before this byte, in its word
+            uint32_t bk = 0;
+            if (!w && wi) {  // (text: a start every few bytes — the own word or the one before)
+              w = w1[k];
+              bk = 1;
+            }
+            while (!w && bk < 9u && bk < wi) {
+              bk++;
+              w = S.bitmap[wi - bk];
+            }
+            uint32_t dv = 0, e = 0, dd = 0;
+            if (w) {
+              const uint32_t s = 32u * (wi - bk) + 31u - (uint32_t)__clz(w);
+              if (s >= ws) {
+                const uint32_t lo = out32[s >> 2], hi = out32[(s >> 2) + 1u];
+                const uint32_t rec = __builtin_amdgcn_alignbyte(hi, lo, s & 3u);  // distance - 1 (16 bits), length - 3 (8 bits)
+                const uint32_t D = (rec & 0xffffu) + 1u, L = ((rec >> 16) & 0xffu) + 3u;
+                dv = P < s + L ? D : 0u;
+                e = s + L;
+                dd = D;
+              } else {
+                dv = P < sEnd ? sD : 0u;
+              }
+            }
+            // the match that runs past this window's end, for the next window: what the window's last byte has found
+            if (bpos == RES_W - 1u) {
+              S.res_strad[2] = e > ws + RES_W ? e : 0u;
+              S.res_strad[3] = dd;
+            }
+            dv = bpos < wlen ? dv : 0u;
+            d[k] = dv;
+            dist[bpos] = (uint16_t)dv;
+          }
+        } else {
           const uint32_t sEnd = S.res_strad[0], sD = S.res_strad[1];  // absolute end and distance of the match that straddles in
           const uint32_t* out32 = reinterpret_cast<const uint32_t*>(S.out);
 #pragma unroll
@@ -2190,8 +2243,13 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
               live[k] = mv && d[k] <= tid + k * PAR_THREADS;  // an ancestor that is final stays final
             }
           }
-          // "did anything move": three flags in rotation, so that clearing one never meets a wave that is a step ahead
-          if (__ballot(moved) && lane == 0) S.res_flag[rnd % 3u] = 1u;
+          // "is any entry still on its way" (an entry whose ancestor is final is done: no round just to see that nothing
+          // moves any more): three flags in rotation, so that clearing one never meets a wave that is a step ahead
+          bool unsettled = false;
+#pragma unroll
+          for (uint32_t k = 0; k < RES_W / PAR_THREADS; k++) unsettled = unsettled || live[k];
+          (void)moved;
+          if (__ballot(unsettled) && lane == 0) S.res_flag[rnd % 3u] = 1u;
           __syncthreads();
           const bool any = S.res_flag[rnd % 3u] != 0u;
           if (tid == 0) S.res_flag[(rnd + 2u) % 3u] = 0u;
