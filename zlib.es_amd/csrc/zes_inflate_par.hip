@@ -58,6 +58,7 @@ struct ParSmem {
   uint8_t cl_lut[128];
   uint32_t wave_sum[PAR_WAVES];
   uint8_t wtab[PAR_WAVES][48];   // composed transfer table of each wave
+  uint8_t gtab[PAR_WAVES][4][48];  // ... of each wave's four groups of sixteen segments
   uint8_t wentry[PAR_WAVES];      // entry code of each wave's first segment
   uint32_t hdr_end, status, tail_entry, bfinal, tail_bytes, tail_end;
   uint32_t h_hlit, h_total, h_wbase, h_off, h_k, h_prev, h_done;  // the header's second part: what its rounds hand on
@@ -1782,9 +1783,26 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
       // over the 64 segments of this wave: lane j (< 48) carries input offset j
       uint32_t cur = lane;
       if (lds_tabs) {
-        for (uint32_t sgm = 0; sgm < 64u; sgm++) {
-          const uint32_t v = tb[sgm * tstride + (cur < 48u ? cur : 0u)];
-          cur = cur < 48u ? v : cur;  // (end of block / fail stay what they are)
+        // A walk through 64 tables is 64 dependent LDS reads, ~350 cycles each with sixteen waves at it: the two walks of
+        // this step were 45k of a block's cycles (text), 60k (incompressible data).  In four groups of 16 segments: the
+        // 4 x 48 group tables first (three chains per lane, side by side: 16 reads deep), then the wave's table through
+        // the four of them; the true entries below walk the groups side by side as well.  20 + 20 reads deep, not 128.
+        uint8_t* gt = &S.gtab[wave][0][0];
+#pragma unroll
+        for (uint32_t q = 0; q < 3u; q++) {
+          const uint32_t idx = lane + 64u * q, grp = idx / 48u, j = idx - 48u * grp;  // (idx < 192)
+          uint32_t c = j;
+          for (uint32_t sgm = 0; sgm < 16u; sgm++) {
+            const uint32_t v = tb[(16u * grp + sgm) * tstride + (c < 48u ? c : 0u)];
+            c = c < 48u ? v : c;  // (end of block / fail stay what they are)
+          }
+          gt[idx] = (uint8_t)c;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (this wave's own writes, read back by its other lanes)
+#pragma unroll
+        for (uint32_t grp = 0; grp < 4u; grp++) {
+          const uint32_t v = gt[48u * grp + (cur < 48u ? cur : 0u)];
+          cur = cur < 48u ? v : cur;
         }
       } else {
         for (uint32_t sgm = 0; sgm < 64u; sgm++) {
@@ -1808,10 +1826,20 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
     uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.wentry[wave]);
     uint32_t mine = C_FAIL;
     if (lds_tabs) {
-      for (uint32_t sgm = 0; sgm < 64u; sgm++) {
-        if (lane == sgm) mine = e;
-        if (e < 48u) e = (uint32_t)__builtin_amdgcn_readfirstlane((int)tb[sgm * tstride + e]);
+      // the entries of the four groups (three lookups), then every lane walks its own group up to its own segment
+      const uint8_t* gt = &S.gtab[wave][0][0];
+      const uint32_t grp = lane >> 4, upto = lane & 15u;
+      uint32_t eg = e, c = e;
+#pragma unroll
+      for (uint32_t k = 0; k < 3u; k++) {
+        eg = eg < 48u ? (uint32_t)gt[48u * k + eg] : eg;
+        c = grp == k + 1u ? eg : c;
       }
+      for (uint32_t sgm = 0; sgm < 15u; sgm++) {
+        const uint32_t v = tb[(16u * grp + sgm) * tstride + (c < 48u ? c : 0u)];
+        c = (sgm < upto && c < 48u) ? v : c;
+      }
+      mine = c;
     } else {
       // every lane looks the (uniform) entry up in its own table and the owning lane's answer is broadcast
       for (uint32_t sgm = 0; sgm < 64u; sgm++) {
