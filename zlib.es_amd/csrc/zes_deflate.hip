@@ -2846,7 +2846,9 @@ __global__ __launch_bounds__(256) void k_layout(uint8_t* __restrict__ d_out, con
 // whole dwords.  Only the first and last dword of a block (shared with its neighbours) use
 // global atomics.
 // ------------------------------------------------------------------------------------------
+#ifndef EMIT_ITEMS
 #define EMIT_ITEMS 4  // tokens per thread per tile (a multiple of 4: 16-byte loads)
+#endif
 #define EMIT_TILE (EMIT_THREADS * EMIT_ITEMS)
 #define EMIT_STAGE_WORDS (EMIT_TILE * 48 / 32 + 8)
 struct EmitSmem {

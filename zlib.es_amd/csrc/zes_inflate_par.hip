@@ -38,7 +38,9 @@
 #define RES_W 4096u    // P4: bytes of the image resolved at a time (a multiple of PAR_THREADS and of 8)
 #define P4_SPARSE_DEP_MAX 32u  // ... of which at most this many copy from another match's bytes
 #define P4_SPARSE_MAX 1024u  // P4 (T1): a block with at most this many matches is copied match by match
+#ifndef RES_REPS
 #define RES_REPS 4u    // pointer-jumping steps between two barriers
+#endif
 #define PAR_CHUNK (ZES_BLK - 3u * RES_W)  // T2: bytes of a block's output resolved per pass over the image; behind them: room for a match record at the chunk's last byte and P4's distance array (the decode tables stay alive for the next chunk)
 #define PAR_DIST_OFF (PAR_CHUNK + 64u)
 #define PAR_MAX_OUT (1u << 27)      // T2: longest block taken (output bytes)
@@ -2028,6 +2030,7 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
       // side, one wave per match — and let one wave do the others in order.  Byte j of a match is byte (j mod D) of the
       // D bytes in front of it, overlapping or not (src/inflate.ts:287-290 copies byte by byte).
       bool sparse_done = false;
+      uint32_t nstarts = 0;  // T1: matches in the block
       if (!FOREIGN) {
         static_assert(sizeof(S.lut_l) >= P4_SPARSE_MAX * 4u && sizeof(S.lut_d) >= P4_SPARSE_MAX, "the lists lie over the dead decode tables");
         uint32_t* sp_list = S.lut_l;
@@ -2054,6 +2057,7 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
           if (k < wave) wbase2 += sm;
           nm += sm;
         }
+        nstarts = nm;
         auto rec_of = [&](uint32_t P, uint32_t& D, uint32_t& L) {
           D = ((uint32_t)S.out[P] | ((uint32_t)S.out[P + 1u] << 8)) + 1u;
           L = (uint32_t)S.out[P + 2u] + 3u;
@@ -2130,6 +2134,10 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
           __syncthreads();
         }
       }
+      // long matches (periodic data: 258 bytes each, a start every eighth word of the bitmap): most bytes would look four
+      // to nine words back for their match — the running maxima serve them in one lookup (measured: fill 197k against
+      // 70k cycles a block); text, a start every few bytes, finds it in the byte's own word or the one before
+      const bool scanmode = FOREIGN || (uint64_t)nstarts * 48u < clen;  // (uniform)
       for (uint32_t ws = 0; ws < (sparse_done ? 0u : clen); ws += RES_W) {
         const uint32_t wlen = min(RES_W, clen - ws);
         // (a) per 32 positions of the window: the last match start at or before them (matches do not overlap each
@@ -2137,7 +2145,7 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
         // (T1 looks the start up in the bitmap itself, below: a match is at most 258 bytes long, so the start that covers a
         // byte is in its own word of the bitmap or one of the nine before it — no running maxima, no barrier, and no
         // carry from window to window.  T2 overwrites the words of resolved windows with its marker flags.)
-        if (FOREIGN) {
+        if (scanmode) {
           if (tid < RES_W / 32u) {
             const uint32_t w = S.bitmap[(ws >> 5) + tid];
             uint32_t hs = w ? 32u * tid + 32u - (uint32_t)__clz(w) : 0u;  // start + 1 (window-relative), 0: none
@@ -2155,7 +2163,7 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
         // else the last one of the words before (a match that began in the window before is in res_strad) — and takes
         // that match's distance, or 0 for a literal byte.  The lane keeps its four entries in registers.
         uint32_t d[RES_W / PAR_THREADS];
-        if (!FOREIGN) {
+        if (!scanmode) {
           // (the records of the windows before are gone — their bytes have been copied over them: the one match that can
           // reach in from there, the last one to start before this window, is carried in res_strad)
           const uint32_t sEnd = S.res_strad[0], sD = S.res_strad[1];
@@ -2176,9 +2184,18 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
               w = w1[k];
               bk = 1;
             }
-            while (!w && bk < 9u && bk < wi) {
-              bk++;
-              w = S.bitmap[wi - bk];
+            // (long matches — periodic data: 258 bytes each — have their start up to nine words back: four words a read)
+            for (uint32_t stg = 0; stg < 2u && !w && wi >= 2u + 4u * stg; stg++) {
+              const uint32_t hiw = wi - 2u - 4u * stg, a = hiw >= 3u ? hiw - 3u : 0u;  // words [a, a + 3], those up to hiw count
+              uint32_t q[4];
+              __builtin_memcpy(q, &S.bitmap[a], 16);
+#pragma unroll
+              for (int t = 3; t >= 0; t--) {
+                if (!w && a + (uint32_t)t <= hiw && q[t]) {
+                  w = q[t];
+                  bk = wi - (a + (uint32_t)t);
+                }
+              }
             }
             uint32_t dv = 0, e = 0, dd = 0;
             if (w) {
