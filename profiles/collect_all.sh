@@ -1,6 +1,6 @@
 set -o pipefail
 cd $GRAFT_REPO_ROOT
-TAG=r04_g
+TAG=${1:-r04_h}
 python3 bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err; echo "[all] bench rc=$?"
 for wl in random64 text64; do bash profiles/collect.sh $TAG $wl > gpurun_out/${TAG}_collect_$wl.log 2>&1; echo "[all] collect $wl rc=$?"; done
 for wl in batch1m lowent256 lowent64 zlibtext64; do
