@@ -865,6 +865,50 @@ int launch_verify(const uint8_t* d_in, const ZesInfBuf* dbufs, uint32_t surv_cap
   return ZES_OK;
 }
 
+// ZES_DEBUG_PHASES: average shader-clock cycles per phase of the block decoder (k_inf_block_par*, k_inf_seg_block_par)
+int print_par_phases(const unsigned long long* dbg, uint64_t work) {
+    std::vector<unsigned long long> h((size_t)work * ZES_PAR_DBG_ROW);
+    HIPCHK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
+    double acc[8] = {0}, t0[3] = {0}, t15[3] = {0}, fb_lanes = 0, fb_waves = 0, hs[5] = {0}, p4[5] = {0}, why[3] = {0};
+    uint32_t cntd = 0;
+    for (uint32_t i = 0; i < work; i++) {
+      const unsigned long long* r = &h[(size_t)i * ZES_PAR_DBG_ROW];
+      if (!r[7]) continue;
+      cntd++;
+      for (int k = 1; k < 8; k++) acc[k] += (double)(r[k] - r[k - 1]);
+      for (int k = 0; k < 3; k++) {  // table-phase steps relative to the end of the header phase
+        t0[k] += (double)(r[8 + k] - r[1]);
+        t15[k] += (double)(r[12 + k] - r[1]);
+      }
+      hs[0] += (double)(r[16] - r[0]);
+      for (int k = 1; k < 5; k++) hs[k] += (double)(r[16 + k] - r[15 + k]);
+      for (int k = 0; k < 5; k++) p4[k] += (double)r[24 + k];
+      fb_lanes += (double)r[11];
+      fb_waves += (double)r[15];
+      for (int k = 0; k < 3; k++) why[k] += (double)r[29 + k];
+    }
+    fprintf(stderr, "zes phases (avg cycles over %u blocks): hdr %.0f tables %.0f compose %.0f count %.0f emit %.0f resolve %.0f flush %.0f\n",
+            cntd, acc[1] / cntd, acc[2] / cntd, acc[3] / cntd, acc[4] / cntd, acc[5] / cntd, acc[6] / cntd, acc[7] / cntd);
+    fprintf(stderr, "zes table steps, cycles since the header: first wave window %.0f landing %.0f fill %.0f | last wave %.0f %.0f %.0f\n",
+            t0[0] / cntd, t0[1] / cntd, t0[2] / cntd, t15[0] / cntd, t15[1] / cntd, t15[2] / cntd);
+    fprintf(stderr, "zes header steps (avg cycles): staging %.0f fixed fields + code-length code %.0f code lengths %.0f lit/len tables %.0f distance tables %.0f\n",
+            hs[0] / cntd, hs[1] / cntd, hs[2] / cntd, hs[3] / cntd, hs[4] / cntd);
+    fprintf(stderr, "zes resolve steps (avg cycles): carry+clear %.0f fill %.0f jumping %.0f copy %.0f | %.1f barrier rounds per block\n", p4[0] / cntd,
+            p4[1] / cntd, p4[2] / cntd, p4[3] / cntd, p4[4] / cntd);
+    {
+      double c0 = 0, c15 = 0;
+      for (uint32_t i = 0; i < work; i++) {
+        const unsigned long long* r = &h[(size_t)i * ZES_PAR_DBG_ROW];
+        if (!r[7]) continue;
+        c0 += (double)(r[22] - r[3]);
+        c15 += (double)(r[23] - r[3]);
+      }
+      fprintf(stderr, "zes count pass, cycles since its start: first wave through %.0f, last wave %.0f\n", c0 / cntd, c15 / cntd);
+    }
+    fprintf(stderr, "zes 8-bit table path: %.2f lanes in %.2f waves per block fell back to the generic construction (segment shape or list full %.2f, three positions under one token %.2f, look-back %.2f)\n", fb_lanes / cntd, fb_waves / cntd, why[0] / cntd, why[1] / cntd, why[2] / cntd);
+    return ZES_OK;
+}
+
 // T1 over a group of buffers: every launch covers all of them (scan, verify, sort, one decode work
 // item per candidate block, chain check), two host synchronisations for the whole group.  Jobs the
 // tier settles get tier = 1; the others are left for the per-buffer tiers.
@@ -1035,47 +1079,7 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
     work = ncand[0];
   }
   std::vector<ZesRes> r1(hres, hres + nbuf);
-  if (dbg) {  // average shader-clock cycles per phase of k_inf_block_par
-    std::vector<unsigned long long> h((size_t)work * ZES_PAR_DBG_ROW);
-    HIPCHK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
-    double acc[8] = {0}, t0[3] = {0}, t15[3] = {0}, fb_lanes = 0, fb_waves = 0, hs[5] = {0}, p4[5] = {0}, why[3] = {0};
-    uint32_t cntd = 0;
-    for (uint32_t i = 0; i < work; i++) {
-      const unsigned long long* r = &h[(size_t)i * ZES_PAR_DBG_ROW];
-      if (!r[7]) continue;
-      cntd++;
-      for (int k = 1; k < 8; k++) acc[k] += (double)(r[k] - r[k - 1]);
-      for (int k = 0; k < 3; k++) {  // table-phase steps relative to the end of the header phase
-        t0[k] += (double)(r[8 + k] - r[1]);
-        t15[k] += (double)(r[12 + k] - r[1]);
-      }
-      hs[0] += (double)(r[16] - r[0]);
-      for (int k = 1; k < 5; k++) hs[k] += (double)(r[16 + k] - r[15 + k]);
-      for (int k = 0; k < 5; k++) p4[k] += (double)r[24 + k];
-      fb_lanes += (double)r[11];
-      fb_waves += (double)r[15];
-      for (int k = 0; k < 3; k++) why[k] += (double)r[29 + k];
-    }
-    fprintf(stderr, "zes phases (avg cycles over %u blocks): hdr %.0f tables %.0f compose %.0f count %.0f emit %.0f resolve %.0f flush %.0f\n",
-            cntd, acc[1] / cntd, acc[2] / cntd, acc[3] / cntd, acc[4] / cntd, acc[5] / cntd, acc[6] / cntd, acc[7] / cntd);
-    fprintf(stderr, "zes table steps, cycles since the header: first wave window %.0f landing %.0f fill %.0f | last wave %.0f %.0f %.0f\n",
-            t0[0] / cntd, t0[1] / cntd, t0[2] / cntd, t15[0] / cntd, t15[1] / cntd, t15[2] / cntd);
-    fprintf(stderr, "zes header steps (avg cycles): staging %.0f fixed fields + code-length code %.0f code lengths %.0f lit/len tables %.0f distance tables %.0f\n",
-            hs[0] / cntd, hs[1] / cntd, hs[2] / cntd, hs[3] / cntd, hs[4] / cntd);
-    fprintf(stderr, "zes resolve steps (avg cycles): carry+clear %.0f fill %.0f jumping %.0f copy %.0f | %.1f barrier rounds per block\n", p4[0] / cntd,
-            p4[1] / cntd, p4[2] / cntd, p4[3] / cntd, p4[4] / cntd);
-    {
-      double c0 = 0, c15 = 0;
-      for (uint32_t i = 0; i < work; i++) {
-        const unsigned long long* r = &h[(size_t)i * ZES_PAR_DBG_ROW];
-        if (!r[7]) continue;
-        c0 += (double)(r[22] - r[3]);
-        c15 += (double)(r[23] - r[3]);
-      }
-      fprintf(stderr, "zes count pass, cycles since its start: first wave through %.0f, last wave %.0f\n", c0 / cntd, c15 / cntd);
-    }
-    fprintf(stderr, "zes 8-bit table path: %.2f lanes in %.2f waves per block fell back to the generic construction (segment shape or list full %.2f, three positions under one token %.2f, look-back %.2f)\n", fb_lanes / cntd, fb_waves / cntd, why[0] / cntd, why[1] / cntd, why[2] / cntd);
-  }
+  if (dbg && (rc = print_par_phases(dbg, work))) return rc;
   if (getenv("ZES_DEBUG")) {
     for (uint32_t i = 0, shown_b = 0; i < nbuf && shown_b < 4; i++) {
       if (r1[i].status == 0) continue;
@@ -1477,10 +1481,22 @@ int inflate_segments_run(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, cons
     fail_list = (uint32_t*)g.segfail.p;
     HIPCHK(hipMemsetAsync(fail_list, 0, 4, g.stream));
     HIPCHK(hipMemsetAsync((uint64_t*)g.symoff.p + work, 0, 8, g.stream));
-    Timed t("k_inf_seg_block_par");
-    hipLaunchKernelGGL(k_inf_seg_block_par, dim3(work), dim3(PAR_THREADS), 0, g.stream, d_in, (const ZesSegJob*)g.segjobs.p, nb, cs, (ZesSegRes*)g.sres.p,
-                       (uint32_t*)g.maps.p, (uint32_t*)g.sym16.p, ratio, fail_list, (unsigned long long*)((uint64_t*)g.symoff.p + work),
-                       (uint64_t)((share_syms / 2 + 3) & ~3ull), bump_syms, (uint64_t*)g.symoff.p);
+    unsigned long long* pdbg = nullptr;
+    if (getenv("ZES_DEBUG_PHASES")) {
+      if ((rc = ensure(g.dbg, (size_t)work * ZES_PAR_DBG_ROW * 8))) return rc;
+      HIPCHK(hipMemsetAsync(g.dbg.p, 0, (size_t)work * ZES_PAR_DBG_ROW * 8, g.stream));
+      pdbg = (unsigned long long*)g.dbg.p;
+    }
+    {
+      Timed t("k_inf_seg_block_par");
+      hipLaunchKernelGGL(k_inf_seg_block_par, dim3(work), dim3(PAR_THREADS), 0, g.stream, d_in, (const ZesSegJob*)g.segjobs.p, nb, cs, (ZesSegRes*)g.sres.p,
+                         (uint32_t*)g.maps.p, (uint32_t*)g.sym16.p, ratio, fail_list, (unsigned long long*)((uint64_t*)g.symoff.p + work),
+                         (uint64_t)((share_syms / 2 + 3) & ~3ull), bump_syms, (uint64_t*)g.symoff.p, pdbg);
+    }
+    if (pdbg) {
+      HIPCHK(hipStreamSynchronize(g.stream));
+      if ((rc = print_par_phases(pdbg, work))) return rc;
+    }
   }
   auto dump_items = [&](const char* tag) {  // ZES_T2_DBG: what every work item has come to so far
     if (!getenv("ZES_T2_DBG")) return;

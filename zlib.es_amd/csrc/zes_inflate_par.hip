@@ -2316,23 +2316,33 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
           // symbols of the window go to the symbol store, two bytes each.
           uint16_t* sym16 = reinterpret_cast<uint16_t*>(symp);
           uint32_t sy[RES_W / PAR_THREADS];
+          {
+            // (a marker's symbol comes back from the store: the lane's four reads are asked for together, clamped and
+            // unconditional — one trip to the L2 per window instead of up to four in a row: 133k of a block's 610k cycles)
+            uint32_t wd[RES_W / PAR_THREADS], vb[RES_W / PAR_THREADS], gis[RES_W / PAR_THREADS];
+            int32_t abs_[RES_W / PAR_THREADS];
+            bool fromstore[RES_W / PAR_THREADS];
 #pragma unroll
-          for (uint32_t k = 0; k < RES_W / PAR_THREADS; k++) {
-            const uint32_t b = tid + k * PAR_THREADS, P = ws + b;  // (positions inside the chunk)
-            const int32_t a = (int32_t)P - (int32_t)d[k];           // the ancestor, chunk-relative
-            const int32_t ab = a + (int32_t)clo;                    // ... block-relative
-            const uint32_t ai = a < 0 ? 0u : (uint32_t)a;
-            const bool hist = ab < 0;                               // in front of the block: a marker
-            const bool prior = !hist && a < 0;                      // in a chunk resolved before: its symbol is in the store
-            const bool mk = a >= 0 && ai < ws && ((S.bitmap[ai >> 5] >> (ai & 31u)) & 1u);
-            uint32_t v = S.out[ai];
-            if (mk || prior) {
-              const uint32_t gi = (uint32_t)ab;
-              const uint32_t wd = __hip_atomic_load(&symp[gi >> 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              v = (gi & 1u) ? wd >> 16 : wd & 0xffffu;
+            for (uint32_t k = 0; k < RES_W / PAR_THREADS; k++) {
+              const uint32_t b = tid + k * PAR_THREADS, P = ws + b;  // (positions inside the chunk)
+              const int32_t a = (int32_t)P - (int32_t)d[k];           // the ancestor, chunk-relative
+              const int32_t ab = a + (int32_t)clo;                    // ... block-relative
+              const uint32_t ai = a < 0 ? 0u : (uint32_t)a;
+              const bool hist = ab < 0;                               // in front of the block: a marker
+              const bool prior = !hist && a < 0;                      // in a chunk resolved before: its symbol is in the store
+              const bool mk = a >= 0 && ai < ws && ((S.bitmap[ai >> 5] >> (ai & 31u)) & 1u);
+              vb[k] = S.out[ai];
+              fromstore[k] = mk || prior;
+              gis[k] = fromstore[k] ? (uint32_t)ab : 0u;
+              abs_[k] = ab;
+              wd[k] = __hip_atomic_load(&symp[gis[k] >> 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            v = hist ? (uint32_t)(256 + (int32_t)ZES_WINDOW + ab) : v;
-            sy[k] = v;
+#pragma unroll
+            for (uint32_t k = 0; k < RES_W / PAR_THREADS; k++) {
+              uint32_t v = fromstore[k] ? ((gis[k] & 1u) ? wd[k] >> 16 : wd[k] & 0xffffu) : vb[k];
+              v = abs_[k] < 0 ? (uint32_t)(256 + (int32_t)ZES_WINDOW + abs_[k]) : v;
+              sy[k] = v;
+            }
           }
 #pragma unroll
           for (uint32_t k = 0; k < RES_W / PAR_THREADS; k++) {
@@ -2595,7 +2605,8 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_seg_block_par(const uint8_t
                                                                    ZesSegRes* __restrict__ sres_all, uint32_t* __restrict__ maps_all,
                                                                    uint32_t* __restrict__ sym16_all, uint32_t sym_ratio,
                                                                    uint32_t* __restrict__ fail_list, unsigned long long* __restrict__ bump,
-                                                                   uint64_t bump_base, uint64_t bump_cap, uint64_t* __restrict__ symoff) {
+                                                                   uint64_t bump_base, uint64_t bump_cap, uint64_t* __restrict__ symoff,
+                                                                   unsigned long long* __restrict__ dbg) {
   __shared__ __align__(16) ParSmem S;
   // buffer of this work item: the last one whose first work item is <= blockIdx.x
   uint32_t bi = 0;
@@ -2657,5 +2668,5 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_seg_block_par(const uint8_t
   it.ncand = ncand;
   it.fail_list = fail_list;
   it.w = blockIdx.x;  // (the list numbers items over the whole group)
-  par_body<true, true>(S, it, nullptr);
+  par_body<true, true>(S, it, dbg);
 }

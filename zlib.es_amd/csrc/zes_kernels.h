@@ -119,7 +119,7 @@ __global__ void k_inf_seg_scan(const uint8_t*, const ZesSegJob*, uint32_t, const
 __global__ void k_inf_seg_scan_short(const uint8_t*, const ZesSegJob*, uint32_t, const uint32_t*, ZesSegRes*, uint32_t*, uint32_t*, uint32_t,
                                      const uint32_t*, uint32_t*, const uint32_t*, uint64_t*);
 __global__ void k_inf_seg_block_par(const uint8_t*, const ZesSegJob*, uint32_t, const uint32_t*, ZesSegRes*, uint32_t*, uint32_t*, uint32_t, uint32_t*,
-                                    unsigned long long*, uint64_t, uint64_t, uint64_t*);
+                                    unsigned long long*, uint64_t, uint64_t, uint64_t*, unsigned long long*);
 __global__ void k_inf_seg_chain(const ZesSegJob*, const ZesSegRes*, uint32_t*, uint64_t*, ZesRes*, uint32_t*);
 __global__ void k_inf_seg_translate(uint8_t*, const ZesSegJob*, const ZesSegOut*, const uint32_t*, const ZesSegRes*, const uint32_t*, const uint64_t*,
                                     const uint8_t*, const uint32_t*, const uint64_t*, uint32_t*);
