@@ -865,6 +865,16 @@ int launch_verify(const uint8_t* d_in, const ZesInfBuf* dbufs, uint32_t surv_cap
   return ZES_OK;
 }
 
+// ZES_DEBUG_HOSTLAPS: host-side time between the synchronisation points of an inflate call (which round trips a call pays)
+void host_lap(const char* what) {
+  static const bool on = getenv("ZES_DEBUG_HOSTLAPS") != nullptr;
+  if (!on) return;
+  static thread_local std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+  const auto now = std::chrono::steady_clock::now();
+  fprintf(stderr, "zes host lap: %-34s %8.1f us\n", what, std::chrono::duration<double, std::micro>(now - last).count());
+  last = now;
+}
+
 // ZES_DEBUG_PHASES: average shader-clock cycles per phase of the block decoder (k_inf_block_par*, k_inf_seg_block_par)
 int print_par_phases(const unsigned long long* dbg, uint64_t work) {
     std::vector<unsigned long long> h((size_t)work * ZES_PAR_DBG_ROW);
@@ -1055,7 +1065,9 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
     if (one) HIPCHK(hipMemcpyAsync(hc, g.counters.p, cnt_bytes, hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipMemcpyAsync(hres, g.res.p, sizeof(ZesRes) * nbuf, hipMemcpyDeviceToHost, g.stream));
   }
+  host_lap("(work before the block-parallel tier)");
   HIPCHK(hipStreamSynchronize(g.stream));
+  host_lap("T1: search + decode + chain");
   const uint32_t nsurv = hc[0];
   if (one) {
     if (((const uint8_t*)(hc + 5))[0] & 0x40u) jobs[ids[0]].btype0 = (((const uint8_t*)(hc + 5))[0] >> 4) & 3;
@@ -1526,7 +1538,9 @@ int inflate_segments_run(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, cons
     HIPCHK(hipMemcpyAsync(hs, novf_d, (size_t)nb * 4, hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipMemcpyAsync(hres, g.res.p, sizeof(ZesRes) * nb * 2, hipMemcpyDeviceToHost, g.stream));
     if (blockpar) HIPCHK(hipMemcpyAsync(hs + nb, fail_list, 4, hipMemcpyDeviceToHost, g.stream));
+    host_lap("(host work since)");
     HIPCHK(hipStreamSynchronize(g.stream));  // (the job table upload has completed too: hj may be rewritten)
+    host_lap("T2: decode / chains");
     return ZES_OK;
   };
   // Round 3: the chains are tried on what the block decoder left BEFORE the wave decoder gets the declined items.  An
@@ -1704,7 +1718,9 @@ int inflate_segments_run(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, cons
     }
   }
   HIPCHK(hipMemcpyAsync(hs, fail_d, (size_t)nb * 4, hipMemcpyDeviceToHost, g.stream));
+  host_lap("(host work since)");
   HIPCHK(hipStreamSynchronize(g.stream));
+  host_lap("T2: windows + translate");
   for (uint32_t k = 0; k < nb; k++) {
     if (!go[k] || hs[k] != 0) continue;  // (a match behind the first byte of the stream: the serial tiers decide)
     InfJob& j = jobs[ids[k]];
@@ -1842,7 +1858,9 @@ int inflate_segments(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const st
     }
     uint32_t* hc = (uint32_t*)g.pinned;
     HIPCHK(hipMemcpyAsync(hc, cnt, (size_t)nb * 4, hipMemcpyDeviceToHost, g.stream));
+    host_lap("(host work since)");
     HIPCHK(hipStreamSynchronize(g.stream));
+    host_lap("T2: search (verify, thinning)");
     std::vector<uint32_t> nc(hc, hc + nb);
     if (getenv("ZES_T2_DBG")) {  // the candidate lists, for a comparison with a map of the stream (tools/gpu_t2_candidates.py)
       for (uint32_t k = 0; k < nb; k++) {
