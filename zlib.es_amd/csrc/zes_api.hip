@@ -2578,6 +2578,7 @@ int zes_deflate(const uint8_t* in, uint64_t n, uint8_t* out, uint64_t cap, uint6
 }
 
 int zes_inflate_dev(const uint8_t* d_in, uint64_t c, uint8_t* d_out, uint64_t cap, uint64_t* out_len, uint32_t flags) {
+  host_lap("(outside the library)");
   ROUTE_DEV(d_in, d_out);
   if (!out_len) return ZES_E_ARG;
   if ((((uintptr_t)d_in) & 15u) || (((uintptr_t)d_out) & 15u)) return ZES_E_ARG;
