@@ -2090,6 +2090,7 @@ int inflate_pieces(const uint8_t* d_in, uint8_t* d_out, InfJob& j, uint32_t flag
 // for the buffers to decode (anything else is left untouched).  firsts[i] = first byte of buffer i.
 int inflate_jobs(const uint8_t* d_in, uint8_t* d_out, std::vector<InfJob>& jobs, const uint8_t* firsts, uint32_t flags) {
   g.last_tier = 0;
+  g.sv_ok = false;  // (a survivor list serves the call that made it: the bytes behind a pointer may have changed since)
   std::vector<uint32_t> ids;
   std::vector<uint32_t> todo;
   std::vector<uint32_t> small;  // buffers T1 does not take and whose first byte is still on the device
