@@ -84,7 +84,7 @@ struct BigPool {
   // a block of at least n bytes, or nullptr (the caller falls back to malloc).  fresh = false: from inside one of the
   // library's allocator callbacks — they run under the library's lock, and a new page-locked block comes from the library
   // (zes_host_alloc takes that lock): only what the pool holds; the miss is noted and made good after the call.
-  uint8_t* take(size_t n, size_t* cap, bool fresh) {
+  uint8_t* take(size_t n, size_t* cap, bool fresh, bool note_miss = true) {
     {
       std::lock_guard<std::mutex> lk(mu);
       size_t best = free_.size();
@@ -102,7 +102,7 @@ struct BigPool {
       g_dbg_miss++;
       if (out + n > BIG_OUTSTANDING_MAX) return nullptr;
       if (!fresh) {
-        want = n > want ? n : want;
+        if (note_miss) want = n > want ? n : want;
         return nullptr;
       }
     }
@@ -354,6 +354,7 @@ void copy_parallel(uint8_t* dst, const uint8_t* src, size_t n) {
 struct SyncAlloc {
   ResultMem m;
   bool failed;
+  bool in_scratch = false;  // the early estimate was served from the scratch block: the result is copied out of it afterwards
 };
 // an early request (ZES_F_ALLOC_BOUND: an upper estimate, the bytes then come down beside the decode) is only worth
 // taking with a pooled block: downloads piece by piece into fresh malloc'd memory pay its page faults the slow way
@@ -366,9 +367,24 @@ ResultMem early_alloc(size_t n) {
 uint8_t* sync_alloc(void* user, uint32_t index, uint64_t n) {
   SyncAlloc* a = static_cast<SyncAlloc*>(user);
   result_free(a->m);  // (ZES_F_ALLOC_BOUND: a second call when the first one's estimate fell short, or the call started over)
+  a->m = ResultMem();
+  a->in_scratch = false;
   if (index & ZES_ALLOC_EARLY) {
-    a->m = early_alloc((size_t)n);
-    return a->m.p;  // (NULL: "not now" — the exact size is asked for once, later)
+    // a pooled block if the pool holds one; else the scratch block when it is long enough (grown outside the library's call,
+    // from what the calls before needed): the bytes come down beside the decode into page-locked memory, and the exact-length
+    // result is copied out by a few threads afterwards — a tight loop's results are fresh memory either way, but this way
+    // its page faults are spread over the copy's threads instead of being taken under the copy engine, and no block is
+    // page-locked for the next call (a loop over 64 MiB results alternated between 2.5 ms and 25 ms a call)
+    if (n >= BIG_MIN) a->m.p = g_big.take((size_t)n, &a->m.cap, false, false);
+    if (a->m.p) return a->m.p;
+    a->m.cap = 0;
+    if (g_sync_scratch.p && n <= g_sync_scratch.cap) {
+      a->in_scratch = true;
+      return g_sync_scratch.p;
+    }
+    if (n >= BIG_MIN) g_big.take((size_t)n, &a->m.cap, false, true);  // (notes the miss: the pool is topped up after the call)
+    a->m = ResultMem();
+    return nullptr;  // ("not now" — the exact size is asked for once, later)
   }
   a->m = result_alloc((size_t)n, false);  // (inside the library's call)
   if (!a->m.p) a->failed = true;
@@ -425,15 +441,35 @@ napi_value Inflate(napi_env env, napi_callback_info info) {
   // one call, one lock: the library decodes, then asks for the exact ArrayBuffer (the reference grows a
   // Uint8WriteStream instead, src/inflate.ts:17) and copies straight into it — nothing is kept between calls,
   // so an inflateAsync() in flight on a worker thread cannot get in between
-  SyncAlloc sa{ResultMem(), false};
+  SyncAlloc sa;
+  sa.failed = false;
   uint64_t out_len = 0;
+  // the scratch block, long enough for what the last synchronous inflate produced (a loop decodes like after like) and
+  // never shorter than the stream: grown here, outside the library's call
+  static size_t s_last_out = 0;
+  {
+    const size_t want = s_last_out > c ? s_last_out + s_last_out / 16 + (1u << 20) : 0;
+    if (want >= (4u << 20) && want <= (1024u << 20)) (void)g_sync_scratch.get(want);
+  }
   // (the pooled block is longer than the ArrayBuffer shows of it anyway: the library may ask early for an upper estimate and
   // send the bytes down while it is still decoding)
   const int rc = zes_inflate_alloc(in, c, sync_alloc, &sa, &out_len, ZES_F_ALLOC_BOUND);
-  g_big.top_up();
+  if (!sa.in_scratch) g_big.top_up();
   if (rc) {
-    result_free(sa.m);
+    if (!sa.in_scratch) result_free(sa.m);
     return throw_status(env, sa.failed ? ZES_E_ARG : rc);
+  }
+  s_last_out = (size_t)out_len;
+  if (sa.in_scratch) {  // (the estimate held: the result is the scratch block's head)
+    ResultMem m;
+    if (out_len >= BIG_MIN) m.p = g_big.take((size_t)out_len, &m.cap, false, false);
+    if (!m.p) {
+      m.cap = 0;
+      m.p = static_cast<uint8_t*>(malloc(out_len ? (size_t)out_len : 1));
+    }
+    if (!m.p) return throw_status(env, ZES_E_ARG);
+    copy_parallel(m.p, g_sync_scratch.p, (size_t)out_len);
+    return take_u8(env, m, out_len);
   }
   return take_u8(env, sa.m, out_len);
 }
