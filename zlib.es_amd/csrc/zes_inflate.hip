@@ -2437,12 +2437,33 @@ __global__ __launch_bounds__(256) void k_inf_seg_translate(uint8_t* __restrict__
   for (uint64_t g = (pre & ~7ull) + ((uint64_t)blockIdx.y * 256 + tid) * 8; g < end; g += (uint64_t)gridDim.y * 256 * 8) {
     uint32_t o2[2] = {0, 0};
     const bool whole = g >= pre && g + 8 <= end;
+    // a whole group's eight symbols: two aligned 16-byte reads and a byte shift that is the same for every group of the
+    // workgroup (g is a multiple of 8, so (g - pre) * 2 mod 16 depends on pre alone) — eight 2-byte reads, each its own
+    // instruction over 64 lanes 16 bytes apart, were most of this kernel's memory instructions
+    uint32_t sd[4] = {0, 0, 0, 0};
+    if (whole) {
+      const uintptr_t sb = reinterpret_cast<uintptr_t>(sy) + 2u * (uintptr_t)(g - pre);
+      const uint4* al = reinterpret_cast<const uint4*>(sb & ~(uintptr_t)15);
+      const uint4 lo = al[0], hi = al[1];  // (behind the last symbol: the store's slack, or the next item's share)
+      const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      const uint32_t sh = (uint32_t)(sb & 15u), wa = sh >> 2, wb = sh & 3u;  // (uniform)
+#pragma unroll
+      for (uint32_t j = 0; j < 4; j++) {
+        uint32_t x0 = 0, x1 = 0;
+#pragma unroll
+        for (uint32_t a = 0; a < 4; a++) {
+          x0 = wa == a ? w[a + j] : x0;
+          x1 = wa == a ? w[a + j + 1] : x1;
+        }
+        sd[j] = __builtin_amdgcn_alignbyte(x1, x0, wb);
+      }
+    }
 #pragma unroll
     for (uint32_t q = 0; q < 8; q++) {
       const uint64_t a = g + q;
       uint32_t b = 0;
       if (a >= pre && a < end) {
-        const uint32_t v = sy[a - pre];
+        const uint32_t v = whole ? ((sd[q >> 1] >> (16u * (q & 1u))) & 0xffffu) : (uint32_t)sy[a - pre];
         if (v >= 256u) {
           bad |= (v - 256u) < first_ok;
           b = W[(v - 256u) & (ZES_WINDOW - 1)];
