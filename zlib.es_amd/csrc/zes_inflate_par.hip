@@ -2137,7 +2137,17 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
       // long matches (periodic data: 258 bytes each, a start every eighth word of the bitmap): most bytes would look four
       // to nine words back for their match — the running maxima serve them in one lookup (measured: fill 197k against
       // 70k cycles a block); text, a start every few bytes, finds it in the byte's own word or the one before
-      const bool scanmode = FOREIGN || (uint64_t)nstarts * 48u < clen;  // (uniform)
+      if (FOREIGN) {  // (T1 has counted its matches for the sparse form above)
+        uint32_t c4 = 0;
+        for (uint32_t i = tid; i < (clen + 31u) / 32u; i += PAR_THREADS) c4 += (uint32_t)__popc(S.bitmap[i]);
+        if (tid == 0) S.sp_n = 0;
+        __syncthreads();
+        for (int dlt = 32; dlt >= 1; dlt >>= 1) c4 += (uint32_t)__shfl_xor((int)c4, dlt);
+        if (lane == 0 && c4) atomicAdd(&S.sp_n, c4);
+        __syncthreads();
+        nstarts = S.sp_n;
+      }
+      const bool scanmode = (uint64_t)nstarts * 48u < clen;  // (uniform)
       for (uint32_t ws = 0; ws < (sparse_done ? 0u : clen); ws += RES_W) {
         const uint32_t wlen = min(RES_W, clen - ws);
         // (a) per 32 positions of the window: the last match start at or before them (matches do not overlap each
@@ -2168,25 +2178,28 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
           // reach in from there, the last one to start before this window, is carried in res_strad)
           const uint32_t sEnd = S.res_strad[0], sD = S.res_strad[1];
           const uint32_t* out32 = reinterpret_cast<const uint32_t*>(S.out);
+          // (only this window's words are looked at: the words below it are no match starts any more in T2, which keeps its
+          // marker flags there, and what reaches in from below is the carried match anyway)
+          const uint32_t wlo = ws >> 5;
           uint32_t w0[RES_W / PAR_THREADS], w1[RES_W / PAR_THREADS];  // the byte's own word of the bitmap and the one before: all reads in flight
 #pragma unroll
           for (uint32_t k = 0; k < RES_W / PAR_THREADS; k++) {
             const uint32_t wi = (ws + tid + k * PAR_THREADS) >> 5;
             w0[k] = S.bitmap[wi];
-            w1[k] = S.bitmap[wi ? wi - 1u : 0u];
+            w1[k] = S.bitmap[wi > wlo ? wi - 1u : wlo];
           }
 #pragma unroll
           for (uint32_t k = 0; k < RES_W / PAR_THREADS; k++) {
             const uint32_t bpos = tid + k * PAR_THREADS, P = ws + bpos, wi = P >> 5;
             uint32_t w = w0[k] & (0xFFFFFFFFu >> (31u - (P & 31u)));  // starts at or before this byte, in its word
             uint32_t bk = 0;
-            if (!w && wi) {  // (text: a start every few bytes — the own word or the one before)
+            if (!w && wi > wlo) {  // (text: a start every few bytes — the own word or the one before)
               w = w1[k];
               bk = 1;
             }
-            // (long matches — periodic data: 258 bytes each — have their start up to nine words back: four words a read)
-            for (uint32_t stg = 0; stg < 2u && !w && wi >= 2u + 4u * stg; stg++) {
-              const uint32_t hiw = wi - 2u - 4u * stg, a = hiw >= 3u ? hiw - 3u : 0u;  // words [a, a + 3], those up to hiw count
+            // (longer matches have their start up to nine words back: four words a read)
+            for (uint32_t stg = 0; stg < 2u && !w && wi >= wlo + 2u + 4u * stg; stg++) {
+              const uint32_t hiw = wi - 2u - 4u * stg, a = hiw >= wlo + 3u ? hiw - 3u : wlo;  // words [a, a + 3], those up to hiw count
               uint32_t q[4];
               __builtin_memcpy(q, &S.bitmap[a], 16);
 #pragma unroll
@@ -2199,17 +2212,15 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
             }
             uint32_t dv = 0, e = 0, dd = 0;
             if (w) {
-              const uint32_t s = 32u * (wi - bk) + 31u - (uint32_t)__clz(w);
-              if (s >= ws) {
-                const uint32_t lo = out32[s >> 2], hi = out32[(s >> 2) + 1u];
-                const uint32_t rec = __builtin_amdgcn_alignbyte(hi, lo, s & 3u);  // distance - 1 (16 bits), length - 3 (8 bits)
-                const uint32_t D = (rec & 0xffffu) + 1u, L = ((rec >> 16) & 0xffu) + 3u;
-                dv = P < s + L ? D : 0u;
-                e = s + L;
-                dd = D;
-              } else {
-                dv = P < sEnd ? sD : 0u;
-              }
+              const uint32_t s = 32u * (wi - bk) + 31u - (uint32_t)__clz(w);  // (inside this window: its record is whole)
+              const uint32_t lo = out32[s >> 2], hi = out32[(s >> 2) + 1u];
+              const uint32_t rec = __builtin_amdgcn_alignbyte(hi, lo, s & 3u);  // distance - 1 (16 bits), length - 3 (8 bits)
+              const uint32_t D = (rec & 0xffffu) + 1u, L = ((rec >> 16) & 0xffu) + 3u;
+              dv = P < s + L ? D : 0u;
+              e = s + L;
+              dd = D;
+            } else {
+              dv = P < sEnd ? sD : 0u;  // no start in this window in front of the byte: the match carried in, if it reaches
             }
             // the match that runs past this window's end, for the next window: what the window's last byte has found
             if (bpos == RES_W - 1u) {
