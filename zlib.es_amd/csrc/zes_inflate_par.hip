@@ -747,7 +747,10 @@ __device__ __forceinline__ static void seg_table_dp(ParSmem& S, const BitSrc& sr
     stage_a(lo, 31u);
     stage_b(31u);
     stage_a(lo, 30u);
-#pragma unroll 2
+#ifndef DP_UNROLL
+#define DP_UNROLL 8
+#endif
+#pragma unroll DP_UNROLL
     for (uint32_t bb = 32u; bb-- > 0u;) {
       const uint32_t p = 32u * j + bb;
       // C(bb): what B(bb) left
