@@ -54,6 +54,7 @@ struct Ctx {
   DevBuf kraft;  // k_inf_scan's table: Kraft contribution of four 3-bit code-length fields at once
   void* pinned = nullptr;  // small pinned area for read-backs
   size_t pinned_cap = 0;
+  void* mirror = nullptr;  // one-buffer inflate: the block decoder's results as the host reads them (ZesParMirror)
   // profiling
   bool profiling = false;
   std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending;
@@ -115,6 +116,7 @@ struct UseDev {                  // a call's context for its duration (nested en
 
 // pinned staging: [0, PIN_UP) read-back area, [PIN_UP, pinned_cap) upload area for the buffer table
 constexpr size_t PIN_UP = 256 << 10;
+constexpr size_t MIRROR_ITEMS = 8192;  // work items whose results the host mirror holds (a call with a larger launch bound keeps the chain kernel)
 
 int ensure(DevBuf& b, size_t bytes) {
   if (bytes <= b.cap) return ZES_OK;
@@ -156,6 +158,10 @@ int init_locked(int device) {
   HIPCHK(hipEventCreateWithFlags(&g.ev_a1, hipEventDisableTiming));
   g.pinned_cap = 1 << 20;
   HIPCHK(hipHostMalloc(&g.pinned, g.pinned_cap, hipHostMallocDefault));
+  if (hipHostMalloc(&g.mirror, MIRROR_ITEMS * (sizeof(ZesCandRes) + 4), hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    g.mirror = nullptr;  // (the chain kernel does the work then)
+  }
   {
     // units of 2^-7, a field of 0 adds nothing; saturated at 200 so that an over-full group can never sum back to exactly 128
     uint8_t tab[4096];
@@ -1026,7 +1032,8 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
   } else {
     work = hb[1].cand_cap;  // the launch bound written into the sentinel above
   }
-  bool direct = false;
+  bool direct = false, hostchain = false;
+  ZesParMirror mir{};
   unsigned long long* dbg = nullptr;
   if (getenv("ZES_DEBUG_PHASES")) {
     if ((rc = ensure(g.dbg, (size_t)work * ZES_PAR_DBG_ROW * 8))) return rc;
@@ -1043,11 +1050,30 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
     const bool two = total_c * 10 < total_cap * 7;
     Timed t(two ? "k_inf_block_par2" : "k_inf_block_par");
     auto kern = two ? k_inf_block_par2 : k_inf_block_par;
+    // One buffer and a launch bound the mirror area holds: every work item also puts its result and its block's start bit
+    // into page-locked host memory, work item 0 the counters, and the HOST follows the chain after the one synchronisation —
+    // what k_inf_chain does, on a few hundred 16-byte records: no chain kernel behind this one (11 us + a kernel boundary of
+    // a 0.8 ms call).  Only a chain that needs the slots moved (false candidates between the blocks) still runs that kernel,
+    // for its map.
+    if (one && work <= MIRROR_ITEMS && g.mirror) {
+      void* dm = nullptr;
+      void* dp0 = nullptr;
+      if (hipHostGetDevicePointer(&dm, g.mirror, 0) == hipSuccess && hipHostGetDevicePointer(&dp0, g.pinned, 0) == hipSuccess) {
+        mir.cres_host = (ZesCandRes*)dm;
+        mir.start_host = (uint32_t*)((uint8_t*)dm + MIRROR_ITEMS * sizeof(ZesCandRes));
+        mir.counters = counters;
+        mir.counters_host = (uint32_t*)dp0;
+        mir.counter_words = (uint32_t)(cnt_bytes / 4);
+        hostchain = true;
+      } else {
+        (void)hipGetLastError();
+      }
+    }
     hipLaunchKernelGGL(kern, dim3((uint32_t)work), dim3(PAR_THREADS), 0, g.stream, d_in, d_out, dbufs, nbuf,
                        (const uint32_t*)cnt, (const uint32_t*)g.cand_sorted.p, (const uint32_t*)nullptr, (ZesCandRes*)g.cres.p, dbg, (const uint32_t*)nullptr,
-                       (const uint32_t*)g.cand.p, (uint32_t*)g.cand_sorted.p);
+                       (const uint32_t*)g.cand.p, (uint32_t*)g.cand_sorted.p, mir);
   }
-  {
+  auto device_chain = [&]() -> int {
     Timed t("k_inf_chain");
     // one buffer: the kernel puts its result and the counters straight into the page-locked read-back area (no copy
     // commands behind the kernels: ~10 us of a 0.8 ms call)
@@ -1061,14 +1087,81 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
                        (const ZesCandRes*)g.cres.p, (const uint32_t*)nullptr, (uint32_t*)g.map.p,
                        direct ? (ZesRes*)((uint8_t*)dp + 128 * 1024) : (ZesRes*)g.res.p, (const uint32_t*)counters, (uint32_t)(cnt_bytes / 4),
                        direct ? (uint32_t*)dp : (uint32_t*)nullptr);
-  }
-  if (!direct) {
-    if (one) HIPCHK(hipMemcpyAsync(hc, g.counters.p, cnt_bytes, hipMemcpyDeviceToHost, g.stream));
-    HIPCHK(hipMemcpyAsync(hres, g.res.p, sizeof(ZesRes) * nbuf, hipMemcpyDeviceToHost, g.stream));
-  }
+    if (!direct) {
+      if (one) HIPCHK(hipMemcpyAsync(hc, g.counters.p, cnt_bytes, hipMemcpyDeviceToHost, g.stream));
+      HIPCHK(hipMemcpyAsync(hres, g.res.p, sizeof(ZesRes) * nbuf, hipMemcpyDeviceToHost, g.stream));
+    }
+    return ZES_OK;
+  };
+  if (!hostchain && (rc = device_chain())) return rc;
   host_lap("(work before the block-parallel tier)");
   HIPCHK(hipStreamSynchronize(g.stream));
   host_lap("T1: search + decode + chain");
+  if (hostchain) {
+    // k_inf_chain's walk on the mirror (one buffer; start[k] = the bit candidate k's block starts at, rank order)
+    const ZesCandRes* hcr = (const ZesCandRes*)g.mirror;
+    const uint32_t* hst = (const uint32_t*)((const uint8_t*)g.mirror + MIRROR_ITEMS * sizeof(ZesCandRes));
+    ZesRes r;
+    r.status = 1;
+    r.out_len = 0;
+    r.aux = 0;
+    const uint32_t cnt0 = hc[4];
+    const uint32_t nc = std::min(cnt0, hb[0].cand_cap);
+    const uint32_t nwork = std::min<uint32_t>(nc, (uint32_t)work);
+    if (hc[0] != 0 && hc[0] <= surv_cap && nc != 0 && cnt0 <= hb[0].cand_cap && nc <= nwork && hst[0] == 16u + hb[0].start_rel) {
+      uint32_t K = 0xFFFFFFFFu;
+      for (uint32_t k = 0; k < nwork; k++)
+        if ((hcr[k].flags & 3u) == 3u) {
+          K = k;
+          break;
+        }
+      bool fast = K != 0xFFFFFFFFu;
+      uint64_t total = 0;
+      for (uint32_t k = 0; fast && k <= K; k++) {
+        const ZesCandRes& c = hcr[k];
+        if (!(c.flags & 1u)) fast = false;
+        total += c.out_len;
+        if (k < K && (c.out_len != ZES_BLK || k + 1 >= nc || (uint64_t)hst[k + 1] != c.end_bit)) fast = false;
+      }
+      if (fast) {
+        r.status = 0;
+        r.out_len = total;
+        r.aux = 1;
+      } else {  // false candidates between the blocks? follow end bit -> next start
+        uint32_t j = 0, k = 0;
+        total = 0;
+        bool ok = false;
+        for (;;) {
+          const ZesCandRes& c = hcr[j];
+          if (!(c.flags & 1u)) break;
+          k++;
+          total += c.out_len;
+          if (c.flags & 2u) {
+            ok = true;
+            break;
+          }
+          if (c.out_len != ZES_BLK) break;
+          const uint32_t* lo = std::lower_bound(hst + j + 1, hst + nc, (uint64_t)c.end_bit, [](uint32_t a, uint64_t b) { return (uint64_t)a < b; });
+          if (lo == hst + nc || (uint64_t)*lo != c.end_bit) break;
+          j = (uint32_t)(lo - hst);
+        }
+        if (ok) {  // the slots are shifted: the chain kernel's map is needed (rare)
+          if ((rc = device_chain())) return rc;
+          HIPCHK(hipStreamSynchronize(g.stream));
+          r = hres[0];
+          (void)k;
+        }
+      }
+    }
+    if (r.status != 2) hres[0] = r;
+    if (getenv("ZES_DEBUG")) {
+      fprintf(stderr, "zes T1 host chain: nsurv %u cnt %u cap %u work %llu -> status %d out_len %llu | start0 %u", hc[0], hc[4], hb[0].cand_cap,
+              (unsigned long long)work, r.status, (unsigned long long)r.out_len, hst[0]);
+      for (uint32_t k = 0; k < std::min<uint32_t>(hc[4], 10u); k++)
+        fprintf(stderr, " [%u: start %u end %llu len %u fl %u]", k, hst[k], (unsigned long long)hcr[k].end_bit, hcr[k].out_len, hcr[k].flags);
+      fprintf(stderr, "\n");
+    }
+  }
   const uint32_t nsurv = hc[0];
   if (one) {
     if (((const uint8_t*)(hc + 5))[0] & 0x40u) jobs[ids[0]].btype0 = (((const uint8_t*)(hc + 5))[0] >> 4) & 3;
@@ -1174,7 +1267,7 @@ int inflate_t1_group(const uint8_t* d_in, uint8_t* d_out, InfJob* jobs, const ui
         hipLaunchKernelGGL(k_inf_block_par, dim3(nre), dim3(PAR_THREADS), 0, g.stream, d_in, d_out, (const ZesInfBuf*)g.ibufs2.p, 1u,
                            (const uint32_t*)cnt + i, (const uint32_t*)g.cand_sorted.p, (const uint32_t*)g.map.p,
                            (ZesCandRes*)g.cres.p, (unsigned long long*)nullptr, (const uint32_t*)(dl + 3 * (size_t)nmv), (const uint32_t*)nullptr,
-                           (uint32_t*)nullptr);
+                           (uint32_t*)nullptr, ZesParMirror{});
       }
       std::vector<ZesCandRes> hcr(nre);
       for (uint32_t q = 0; q < nre; q++)
@@ -1273,7 +1366,7 @@ int inflate_t1_range(const uint8_t* d_in, uint64_t in_off, uint64_t c, uint64_t 
     Timed t("k_inf_block_par");
     hipLaunchKernelGGL((c * 10 < cap * 7) ? k_inf_block_par2 : k_inf_block_par, dim3(ncand), dim3(PAR_THREADS), 0, g.stream, d_in, d_out, dbufs, 1u, (const uint32_t*)cnt,
                        (const uint32_t*)g.cand_sorted.p, (const uint32_t*)nullptr, (ZesCandRes*)g.cres.p, (unsigned long long*)nullptr, (const uint32_t*)nullptr,
-                       (const uint32_t*)g.cand.p, (uint32_t*)g.cand_sorted.p);
+                       (const uint32_t*)g.cand.p, (uint32_t*)g.cand_sorted.p, ZesParMirror{});
   }
   {
     Timed t("k_inf_chain");
@@ -1378,7 +1471,7 @@ int range_begin(int slot, RangePend& pd, const uint8_t* d_in, uint64_t in_off, u
       Timed t("k_inf_block_par");
       hipLaunchKernelGGL(two ? k_inf_block_par2 : k_inf_block_par, dim3(pd.bound), dim3(PAR_THREADS), 0, g.stream, d_in, d_out, dbufs, 1u,
                          (const uint32_t*)cnt, (const uint32_t*)g.cand_sorted.p, (const uint32_t*)nullptr, (ZesCandRes*)g.cres.p,
-                         (unsigned long long*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)g.cand.p, (uint32_t*)g.cand_sorted.p);
+                         (unsigned long long*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)g.cand.p, (uint32_t*)g.cand_sorted.p, ZesParMirror{});
     }
     {
       Timed t("k_inf_chain");
@@ -2360,6 +2453,8 @@ static int shutdown_one(void) {
   g.kraft.cap = 0;
   if (g.pinned) (void)hipHostFree(g.pinned);
   g.pinned = nullptr;
+  if (g.mirror) (void)hipHostFree(g.mirror);
+  g.mirror = nullptr;
   g_side_up.shutdown();
   g_side_down.shutdown();
   g_up.release();

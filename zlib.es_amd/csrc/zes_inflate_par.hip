@@ -1565,6 +1565,8 @@ struct ParItem {
   uint32_t de_est, de_est2;  // end estimates: the next listed block start, the one after it (0: none)
   // T1
   ZesCandRes* cres;  // this item's result
+  ZesCandRes* cres_host;  // (one-buffer calls) a copy of it in the host's page-locked memory, or null ...
+  uint32_t* start_host;   // ... and where the block's start bit goes
   uint8_t* dst;      // its output slot
   uint64_t room;     // bytes that may be stored there
   // T2
@@ -1609,6 +1611,10 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
         r_.out_len = (TOTAL);                                         \
         r_.flags = 0;                                                 \
         *it.cres = r_;                                                \
+        if (it.cres_host) {                                           \
+          *it.cres_host = r_;                                         \
+          *it.start_host = it.start;                                  \
+        }                                                             \
       }                                                               \
     }                                                                 \
   } while (0)
@@ -2410,6 +2416,10 @@ __device__ __forceinline__ static void par_body(ParSmem& S, const ParItem& it, u
         r.out_len = total;
         r.flags = 1u | (S.bfinal ? 2u : 0u);
         *it.cres = r;
+        if (it.cres_host) {
+          *it.cres_host = r;
+          *it.start_host = it.start;
+        }
       }
     } else {
       // ---- T2: the map of the last 32 Ki symbols (in front of a shorter block: the markers themselves), the result ----
@@ -2483,7 +2493,11 @@ __device__ __forceinline__ static void block_par_t1(ParSmem& S, const uint8_t* _
                                                     const uint32_t* __restrict__ cand_all, const uint32_t* __restrict__ map_all,
                                                     ZesCandRes* __restrict__ cres_all, unsigned long long* __restrict__ dbg,
                                                     const uint32_t* __restrict__ redo, const uint32_t* __restrict__ raw_all,
-                                                    uint32_t* __restrict__ sorted_all) {
+                                                    uint32_t* __restrict__ sorted_all, const ZesParMirror& mir) {
+  // (one-buffer calls: the search's counters go to the host with this kernel — they are final — so that the host can check
+  // the chain of blocks itself after one synchronisation, without a chain kernel behind this one)
+  if (mir.counters_host && blockIdx.x == 0)
+    for (uint32_t i = threadIdx.x; i < mir.counter_words; i += PAR_THREADS) mir.counters_host[i] = mir.counters[i];
   // buffer of this work item: the last entry whose first work item is <= blockIdx.x
   uint32_t bi = 0;
   {
@@ -2546,7 +2560,19 @@ __device__ __forceinline__ static void block_par_t1(ParSmem& S, const uint8_t* _
     raw_next2 = S.wave_sum[2];
     raw_min = S.wave_sum[3];
     raw_mine = u;
-    if (threadIdx.x == 0) sorted_all[bufs[bi].cand_base + w_rank] = u;
+    if (threadIdx.x == 0) {
+      sorted_all[bufs[bi].cand_base + w_rank] = u;
+      // the host's mirror: the start of EVERY candidate and a cleared result, before anything below can leave (the list not
+      // beginning at the stream's first block: nobody decodes) — what the host reads is this launch's or nothing
+      if (mir.cres_host) {
+        ZesCandRes r0;
+        r0.end_bit = 0;
+        r0.out_len = 0;
+        r0.flags = 0;
+        mir.cres_host[w_rank] = r0;
+        mir.start_host[w_rank] = u + 16u;
+      }
+    }
     __syncthreads();  // (the words are used again further down)
   }
   // the first block of a reference-made stream starts at bit 16 and passes the candidate rules: if the sorted
@@ -2574,6 +2600,8 @@ __device__ __forceinline__ static void block_par_t1(ParSmem& S, const uint8_t* _
     it.de_est2 = ci + 2u < ncand ? cand[ci + 2u] + 16u : it.limit;
   }
   it.cres = cres_all + bufs[bi].cand_base + w;
+  it.cres_host = mir.cres_host ? mir.cres_host + w : nullptr;  // (one buffer: its candidates start at 0)
+  it.start_host = mir.cres_host ? mir.start_host + w : nullptr;
   const uint64_t slot_off = (uint64_t)w * ZES_BLK;
   it.dst = d_out + bufs[bi].out_off + slot_off;
   it.room = bufs[bi].cap > slot_off ? bufs[bi].cap - slot_off : 0;
@@ -2597,9 +2625,9 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par(const uint8_t* __
                                                                const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ cand_all,
                                                                const uint32_t* __restrict__ map_all, ZesCandRes* __restrict__ cres_all,
                                                                unsigned long long* __restrict__ dbg, const uint32_t* __restrict__ redo,
-                                                               const uint32_t* __restrict__ raw_all, uint32_t* __restrict__ sorted_all) {
+                                                               const uint32_t* __restrict__ raw_all, uint32_t* __restrict__ sorted_all, ZesParMirror mir) {
   __shared__ __align__(16) ParSmem S;
-  block_par_t1<false>(S, d_in, d_out, bufs, nbuf, cnt, cand_all, map_all, cres_all, dbg, redo, raw_all, sorted_all);
+  block_par_t1<false>(S, d_in, d_out, bufs, nbuf, cnt, cand_all, map_all, cres_all, dbg, redo, raw_all, sorted_all, mir);
 }
 // the same for compressible data (the launch's streams are shorter than 0.7 of their outputs' capacity)
 __global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par2(const uint8_t* __restrict__ d_in, uint8_t* __restrict__ d_out,
@@ -2607,9 +2635,9 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_block_par2(const uint8_t* _
                                                                 const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ cand_all,
                                                                 const uint32_t* __restrict__ map_all, ZesCandRes* __restrict__ cres_all,
                                                                 unsigned long long* __restrict__ dbg, const uint32_t* __restrict__ redo,
-                                                                const uint32_t* __restrict__ raw_all, uint32_t* __restrict__ sorted_all) {
+                                                                const uint32_t* __restrict__ raw_all, uint32_t* __restrict__ sorted_all, ZesParMirror mir) {
   __shared__ __align__(16) ParSmem S;
-  block_par_t1<true>(S, d_in, d_out, bufs, nbuf, cnt, cand_all, map_all, cres_all, dbg, redo, raw_all, sorted_all);
+  block_par_t1<true>(S, d_in, d_out, bufs, nbuf, cnt, cand_all, map_all, cres_all, dbg, redo, raw_all, sorted_all, mir);
 }
 
 // T2: one workgroup per block of another encoder's stream (work items as in k_inf_seg_scan: a buffer's item 0 starts at
@@ -2664,6 +2692,8 @@ __global__ __launch_bounds__(PAR_THREADS) void k_inf_seg_block_par(const uint8_t
   it.de_est = nx < ncand ? cand[nx] + 16u : it.limit;
   it.de_est2 = nx < ncand ? (nx + 1u < ncand ? cand[nx + 1u] + 16u : it.limit) : 0u;
   it.cres = nullptr;
+  it.cres_host = nullptr;
+  it.start_host = nullptr;
   it.dst = nullptr;
   it.room = 0;
   it.sres = sres + w;

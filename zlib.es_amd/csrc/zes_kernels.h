@@ -59,6 +59,16 @@ struct ZesCandRes {
   uint32_t flags;     // bit0 ok, bit1 bfinal
 };
 
+// k_inf_block_par*, one-buffer calls: where the results also go, in the host's page-locked memory (the host then checks
+// the chain of blocks itself; all null: nothing)
+struct ZesParMirror {
+  ZesCandRes* cres_host;        // [work] a copy of every work item's result ...
+  uint32_t* start_host;         // ... and the bit its block starts at
+  const uint32_t* counters;     // the search's counters (final when this kernel starts), copied by work item 0 ...
+  uint32_t* counters_host;      // ... to here
+  uint32_t counter_words;
+};
+
 // T2 (segment-parallel inflate): result of one work item of k_inf_seg_scan
 struct ZesSegRes {
   uint64_t end_bit;   // absolute bit where the segment stopped
@@ -130,9 +140,9 @@ __global__ void k_inf_seg_win_fin(const uint32_t*, const ZesSegJob*, const uint8
 __global__ void k_inf_seg_decode(const uint8_t*, uint64_t, uint64_t, uint8_t*, uint64_t, uint64_t, const uint32_t*, const ZesSegRes*,
                                  const uint32_t*, const uint64_t*, const uint8_t*, uint32_t*, uint32_t, uint32_t, uint32_t);
 __global__ void k_inf_block_par(const uint8_t*, uint8_t*, const ZesInfBuf*, uint32_t, const uint32_t*, const uint32_t*, const uint32_t*,
-                                ZesCandRes*, unsigned long long*, const uint32_t*, const uint32_t*, uint32_t*);
+                                ZesCandRes*, unsigned long long*, const uint32_t*, const uint32_t*, uint32_t*, ZesParMirror);
 __global__ void k_inf_block_par2(const uint8_t*, uint8_t*, const ZesInfBuf*, uint32_t, const uint32_t*, const uint32_t*, const uint32_t*,
-                                ZesCandRes*, unsigned long long*, const uint32_t*, const uint32_t*, uint32_t*);
+                                ZesCandRes*, unsigned long long*, const uint32_t*, const uint32_t*, uint32_t*, ZesParMirror);
 __global__ void k_inf_move_slots(uint8_t*, const uint8_t*, const uint32_t*, const uint32_t*, uint32_t);
 __global__ void k_inf_chain(const ZesInfBuf*, const uint32_t*, const uint32_t*, const ZesCandRes*, const uint32_t*, uint32_t*, ZesRes*, const uint32_t*, uint32_t, uint32_t*);
 __global__ void k_inf_chain_range(const ZesInfBuf*, const uint32_t*, const uint32_t*, const ZesCandRes*, ZesRes*, unsigned long long*);
